@@ -1,0 +1,170 @@
+"""ctypes binding of the CPU oracle (oracle/libsrl_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the
+product package."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from stackrl_amd.config import CConfig, MAX_BODIES
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+  subprocess.check_call(['make', '-s', '-C', _HERE])
+
+
+def lib():
+  global _LIB
+  if _LIB is None:
+    path = os.path.join(_HERE, 'libsrl_oracle.so')
+    if not os.path.isfile(path):
+      build()
+    L = ctypes.CDLL(path)
+    L.srlo_last_error.restype = ctypes.c_char_p
+    L.srlo_rng.restype = ctypes.c_uint32
+    L.srlo_rng.argtypes = [ctypes.c_uint32] * 4
+    L.srlo_acosf.restype = ctypes.c_float
+    L.srlo_acosf.argtypes = [ctypes.c_float]
+    _LIB = L
+  return _LIB
+
+
+def _p(a):
+  return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class OracleEnv(object):
+  """Batched facade over srlo_* with the same call shapes as the product's C-ABI."""
+
+  def __init__(self, cfg, pool, seed=None):
+    self.cfg = cfg
+    self.c = cfg.to_c()
+    self.L = lib()
+    self.h = ctypes.c_void_p()
+    rc = self.L.srlo_create(ctypes.byref(self.c), ctypes.byref(self.h))
+    if rc:
+      raise ValueError(self.L.srlo_last_error().decode())
+    self.n = cfg.n_envs
+    self.H, self.h_ = cfg.overhead_res, cfg.object_res
+    rc = self.L.srlo_load_meshes(self.h, _p(pool.verts), _p(pool.vert_off), _p(pool.tris),
+                                 _p(pool.tri_off), _p(pool.mass_com), ctypes.c_int32(len(pool)))
+    if rc:
+      raise ValueError(self.L.srlo_last_error().decode())
+    self.obs_map = np.zeros((self.n, self.H, self.H, 2), np.uint8)
+    self.obs_obj = np.zeros((self.n, self.h_, self.h_, 1), np.uint8)
+    self.reward = np.zeros(self.n, np.float32)
+    self.done = np.zeros(self.n, np.uint8)
+    if seed is not None:
+      self.seed(seed)
+
+  def __del__(self):
+    if getattr(self, 'h', None):
+      self.L.srlo_destroy(self.h)
+      self.h = None
+
+  def seed(self, seed):
+    self.L.srlo_seed(self.h, ctypes.c_uint32(seed % 2**32))
+
+  def set_script(self, mesh_ids, goal_rect):
+    mesh_ids = np.ascontiguousarray(mesh_ids, np.int32)
+    goal_rect = np.ascontiguousarray(goal_rect, np.int32)
+    assert mesh_ids.shape == (self.n, self.cfg.episode_length) and goal_rect.shape == (self.n, 4)
+    rc = self.L.srlo_set_script(self.h, _p(mesh_ids), _p(goal_rect))
+    if rc:
+      raise ValueError(self.L.srlo_last_error().decode())
+
+  def reset(self):
+    rc = self.L.srlo_reset(self.h, _p(self.obs_map), _p(self.obs_obj))
+    if rc:
+      raise RuntimeError(self.L.srlo_last_error().decode())
+    return (self.obs_map.copy(), self.obs_obj.copy()), np.zeros(self.n, np.float32), np.zeros(self.n, bool)
+
+  def step(self, action):
+    action = np.ascontiguousarray(action, np.int64)
+    rc = self.L.srlo_step(self.h, _p(action), _p(self.obs_map), _p(self.obs_obj), _p(self.reward), _p(self.done))
+    self.rc = rc
+    return (self.obs_map.copy(), self.obs_obj.copy()), self.reward.copy(), self.done.astype(bool)
+
+  def sample(self):
+    a = np.zeros(self.n, np.int64)
+    self.L.srlo_sample(self.h, _p(a))
+    return a
+
+  def state(self):
+    poses = np.zeros((self.n, MAX_BODIES, 8), np.float32)
+    nb = np.zeros(self.n, np.int32)
+    sub = np.zeros((self.n, 2), np.int32)
+    st = np.zeros(self.n, np.int32)
+    self.L.srlo_get_state(self.h, _p(poses), _p(nb), _p(sub), _p(st))
+    return poses, nb, sub, st
+
+  def velocities(self):
+    v = np.zeros((self.n, MAX_BODIES, 8), np.float32)
+    self.L.srlo_get_velocities(self.h, _p(v))
+    return v
+
+  def contacts(self):
+    mp = np.zeros(self.n, np.float32)
+    npts = np.zeros(self.n, np.int32)
+    self.L.srlo_get_contacts(self.h, _p(mp), _p(npts))
+    return mp, npts
+
+  def maps(self):
+    Hm = np.zeros((self.n, self.H, self.H), np.float32)
+    Om = np.zeros((self.n, self.h_, self.h_), np.float32)
+    g = np.zeros((self.n, 4), np.int32)
+    self.L.srlo_get_maps(self.h, _p(Hm), _p(Om), _p(g))
+    return Hm, Om, g
+
+  def render_heightmap(self, poses, mesh_ids):
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
+    mesh_ids = np.ascontiguousarray(mesh_ids, np.int32)
+    out = np.zeros((self.H, self.H), np.float32)
+    rc = self.L.srlo_render_heightmap(self.h, _p(poses), _p(mesh_ids), ctypes.c_int32(len(mesh_ids)), _p(out))
+    if rc:
+      raise ValueError(self.L.srlo_last_error().decode())
+    return out
+
+  def render_object(self, mesh_id):
+    out = np.zeros((self.h_, self.h_), np.float32)
+    rc = self.L.srlo_render_object(self.h, ctypes.c_int32(mesh_id), _p(out))
+    if rc:
+      raise ValueError(self.L.srlo_last_error().decode())
+    return out
+
+
+def depth_to_elevation(cfg, which, depth):
+  c = cfg.to_c()
+  depth = np.ascontiguousarray(depth, np.float32)
+  out = np.zeros_like(depth)
+  lib().srlo_depth_to_elevation(ctypes.byref(c), ctypes.c_int(which), _p(depth), _p(out))
+  return out
+
+
+def pose(cfg, H, O, u, v):
+  c = cfg.to_c()
+  H = np.ascontiguousarray(H, np.float32)
+  O = np.ascontiguousarray(O, np.float32)
+  out = np.zeros(3, np.float32)
+  lib().srlo_pose(ctypes.byref(c), _p(H), _p(O), ctypes.c_int32(u), ctypes.c_int32(v), _p(out))
+  return out
+
+
+def iou_sums(cfg, H, rect):
+  c = cfg.to_c()
+  H = np.ascontiguousarray(H, np.float32)
+  rect = np.ascontiguousarray(rect, np.int32)
+  a, b = ctypes.c_float(), ctypes.c_float()
+  lib().srlo_iou_sums(ctypes.byref(c), _p(H), _p(rect), ctypes.byref(a), ctypes.byref(b))
+  return a.value, b.value
+
+
+def goal_from_rng(cfg, key, episode):
+  c = cfg.to_c()
+  r = np.zeros(4, np.int32)
+  lib().srlo_goal_from_rng(ctypes.byref(c), ctypes.c_uint32(key), ctypes.c_uint32(episode), _p(r))
+  return r

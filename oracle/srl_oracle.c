@@ -1,0 +1,1376 @@
+/* srl_oracle.c — CPU oracle for the Stack-v0 hot path.  TEST INFRASTRUCTURE ONLY.
+ * See srl_oracle.h for scope and the parity-pinning statement.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (oracle/Makefile).  All arithmetic is
+ * IEEE binary32 with one rounding per written operation, so that an independent
+ * implementation evaluating the same expressions (the HIP kernels) is bit-identical.
+ *
+ * Plain sequential C: one env at a time, one body / pair / pixel at a time.
+ */
+#include "srl_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXB SRL_MAX_BODIES
+#define MAXV SRL_MAX_VERTS
+#define MAXT SRL_MAX_TRIS
+#define MAXSLOT 192               /* persistent body-body manifolds per env */
+#define NPAIR (MAXB * (MAXB - 1) / 2)
+#define GJK_MAXIT 32
+#define FAR_PLANE 1000.0f         /* Observer.far, observer.py:6 */
+
+static char g_err[256];
+const char* srlo_last_error(void) { return g_err; }
+static int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof g_err, "%s", msg);
+  return code;
+}
+
+/* ------------------------------------------------------------------ math */
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y, z, w; } q4;
+typedef struct { float m[9]; } m3;
+
+static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
+static inline float vdot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline v3 vcross(v3 a, v3 b) {
+  return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline v3 mmul(const m3* R, v3 a) { /* R * a */
+  return V((R->m[0] * a.x + R->m[1] * a.y) + R->m[2] * a.z,
+           (R->m[3] * a.x + R->m[4] * a.y) + R->m[5] * a.z,
+           (R->m[6] * a.x + R->m[7] * a.y) + R->m[8] * a.z);
+}
+static inline v3 mtmul(const m3* R, v3 a) { /* R^T * a */
+  return V((R->m[0] * a.x + R->m[3] * a.y) + R->m[6] * a.z,
+           (R->m[1] * a.x + R->m[4] * a.y) + R->m[7] * a.z,
+           (R->m[2] * a.x + R->m[5] * a.y) + R->m[8] * a.z);
+}
+static inline m3 quat_to_mat(q4 q) {
+  float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
+  float xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
+  float wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+  m3 R;
+  R.m[0] = 1.0f - 2.0f * (yy + zz); R.m[1] = 2.0f * (xy - wz); R.m[2] = 2.0f * (xz + wy);
+  R.m[3] = 2.0f * (xy + wz); R.m[4] = 1.0f - 2.0f * (xx + zz); R.m[5] = 2.0f * (yz - wx);
+  R.m[6] = 2.0f * (xz - wy); R.m[7] = 2.0f * (yz + wx); R.m[8] = 1.0f - 2.0f * (xx + yy);
+  return R;
+}
+/* world inverse inertia  R diag(d) R^T  (symmetric, stored full) */
+static inline m3 inv_inertia_world(const m3* R, v3 d) {
+  m3 A; /* A = R diag(d) */
+  A.m[0] = R->m[0] * d.x; A.m[1] = R->m[1] * d.y; A.m[2] = R->m[2] * d.z;
+  A.m[3] = R->m[3] * d.x; A.m[4] = R->m[4] * d.y; A.m[5] = R->m[5] * d.z;
+  A.m[6] = R->m[6] * d.x; A.m[7] = R->m[7] * d.y; A.m[8] = R->m[8] * d.z;
+  m3 I;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      I.m[3 * i + j] = (A.m[3 * i] * R->m[3 * j] + A.m[3 * i + 1] * R->m[3 * j + 1]) +
+                       A.m[3 * i + 2] * R->m[3 * j + 2];
+  return I;
+}
+/* Bullet btPlaneSpace1 restated: two unit tangents for a unit normal */
+static inline void plane_space(v3 n, v3* p, v3* q) {
+  if (fabsf(n.z) > 0.70710678f) {
+    float a = n.y * n.y + n.z * n.z;
+    float k = 1.0f / sqrtf(a);
+    *p = V(0.0f, -n.z * k, n.y * k);
+    *q = V(a * k, -n.x * p->z, n.x * p->y);
+  } else {
+    float a = n.x * n.x + n.y * n.y;
+    float k = 1.0f / sqrtf(a);
+    *p = V(-n.y * k, n.x * k, 0.0f);
+    *q = V(-n.z * p->y, n.z * p->x, a * k);
+  }
+}
+/* acos on [-1,1]: sqrt(1-|x|) * P7(|x|)  (Abramowitz & Stegun 4.4.46, |err| <= 2e-8).
+ * A private polynomial (not libm) so that CPU and GPU agree bit for bit. */
+float srlo_acosf(float x) {
+  float a = fabsf(x);
+  if (a > 1.0f) a = 1.0f;
+  float p = -0.0012624911f;
+  p = p * a + 0.0066700901f;
+  p = p * a + -0.0170881256f;
+  p = p * a + 0.0308918810f;
+  p = p * a + -0.0501743046f;
+  p = p * a + 0.0889789874f;
+  p = p * a + -0.2145988016f;
+  p = p * a + 1.5707963050f;
+  float r = sqrtf(1.0f - a) * p;
+  return x < 0.0f ? 3.14159265358979f - r : r;
+}
+
+/* ------------------------------------------------------------------ RNG */
+static inline uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+uint32_t srlo_rng(uint32_t key, uint32_t episode, uint32_t stream, uint32_t draw) {
+  uint32_t h = mix32(key + 0x9E3779B9U);
+  h = mix32(h ^ (episode + 0x85EBCA6BU));
+  h = mix32(h ^ (stream + 0xC2B2AE35U));
+  h = mix32(h ^ (draw + 0x27D4EB2FU));
+  return h;
+}
+static inline uint32_t rng_below(uint32_t r, uint32_t n) {
+  return (uint32_t)(((uint64_t)r * (uint64_t)n) >> 32);
+}
+enum { STREAM_MESH = 0, STREAM_GOAL = 1, STREAM_ACTION = 2 };
+
+/* ------------------------------------------------------------------ data */
+typedef struct {
+  int nv, nt;
+  v3 v[MAXV];           /* vertices, COM frame (link vertex - com) */
+  uint8_t tri[MAXT][3];
+  v3 com;               /* URDF inertial origin (link frame) */
+  float inv_mass;
+  v3 inv_inertia;       /* body-frame diagonal: box inertia of the AABB (Bullet's default for
+                           hull shapes when URDF inertia is not requested) */
+  float radius;         /* max |v| (COM frame) */
+} mesh_t;
+
+typedef struct {
+  v3 la, lb;            /* contact point in A / B body frames */
+  v3 n;                 /* world normal, from B towards A */
+  float dist;           /* signed distance (negative = penetration), margins removed */
+  float in, it1, it2;   /* accumulated impulses (warm start) */
+} mpoint_t;
+
+typedef struct {
+  int np;
+  mpoint_t p[4];
+  v3 axis;              /* cached GJK separating axis */
+} manifold_t;
+
+typedef struct {
+  int np;
+  int vid[8];
+  float dist[8];
+  float in[8], it1[8], it2[8];
+} gmanifold_t;
+
+typedef struct {
+  /* rigid bodies (placed) */
+  int nb;
+  int mesh[MAXB];
+  v3 x[MAXB]; q4 q[MAXB]; v3 v[MAXB]; v3 w[MAXB];
+  v3 place_x[MAXB]; q4 place_q[MAXB];
+  /* per-substep derived */
+  m3 R[MAXB]; m3 Iw[MAXB];
+  v3 wv[MAXB][MAXV];
+  v3 amin[MAXB], amax[MAXB];
+  /* contacts */
+  gmanifold_t gm[MAXB];
+  manifold_t man[MAXSLOT];
+  int16_t slot_of_pair[NPAIR];
+  int16_t pair_of_slot[MAXSLOT];    /* -1 = free */
+  uint8_t slot_a[MAXSLOT], slot_b[MAXSLOT], colour[MAXSLOT];
+  int ncolour;
+  /* episode */
+  int done;
+  uint32_t episode;
+  int ids[MAXB]; int list_pos;
+  int pending;                      /* mesh id waiting at the spawn pose, -1 = none */
+  int goal[4];                      /* u, v, h, w */
+  float prev_metric;
+  int substeps[2];
+  int status;
+  int has_script; int script_ids[MAXB]; int script_goal[4];
+  float* H;                         /* [res*res] */
+  float* O;                         /* [ores*ores] */
+} env_t;
+
+struct srlo_env {
+  srl_config c;
+  int n_mesh;
+  mesh_t* mesh;
+  env_t* env;
+  uint32_t seed;
+  uint32_t sample_counter;
+  /* derived constants */
+  float px, inv_px;
+  float lin_damp, ang_damp;
+  int max_substeps;
+  int goal_size, goal_min_h, goal_max_h, goal_min_w, goal_max_w;
+  float goal_z;
+  float scale;
+  int AW, A;
+};
+
+/* ------------------------------------------------------------------ create */
+static int derive(struct srlo_env* e) {
+  srl_config* c = &e->c;
+  if (c->n_envs < 1 || c->episode_length < 1 || c->episode_length > MAXB)
+    return fail(SRL_EINVAL, "n_envs/episode_length out of range");
+  if (c->overhead_res < c->object_res || c->object_res < 2 || c->overhead_res > 256)
+    return fail(SRL_EINVAL, "bad resolutions");
+  e->px = c->object_max_dimension / (float)c->object_res;       /* env.py:136 */
+  e->inv_px = (float)c->object_res / c->object_max_dimension;
+  e->lin_damp = (float)pow(1.0 - (double)c->linear_damping, (double)c->sim_time_step);
+  e->ang_damp = (float)pow(1.0 - (double)c->angular_damping, (double)c->sim_time_step);
+  e->max_substeps = c->max_substeps > 0 ? c->max_substeps
+                                        : (int)(300.0 / (double)c->sim_time_step); /* simulator.py:46 */
+  int H = c->overhead_res, h = c->object_res;
+  /* rewarder.py:65-80 */
+  e->goal_min_h = h; e->goal_min_w = h; e->goal_max_h = H; e->goal_max_w = H;
+  e->goal_size = (int)((double)c->goal_size_ratio * H * H);
+  if (e->goal_size <= 0) return fail(SRL_EINVAL, "goal_size_ratio must be a scalar in (0,1]");
+  if (e->goal_size / e->goal_max_w > e->goal_min_h) e->goal_min_h = e->goal_size / e->goal_max_w;
+  if (e->goal_size / e->goal_min_w < e->goal_max_h) e->goal_max_h = e->goal_size / e->goal_min_w;
+  e->goal_z = c->max_z - c->object_max_dimension;               /* observer.py:378-382 */
+  e->scale = c->reward_scale > 0.0f ? c->reward_scale : (float)c->episode_length; /* rewarder.py:97 */
+  e->AW = H - h + 1;                                            /* env.py:207-211 */
+  e->A = e->AW * e->AW;
+  return SRL_OK;
+}
+
+int srlo_create(const srl_config* cfg, srlo_env** out) {
+  struct srlo_env* e = (struct srlo_env*)calloc(1, sizeof *e);
+  if (!e) return fail(SRL_EINVAL, "oom");
+  e->c = *cfg;
+  int rc = derive(e);
+  if (rc) { free(e); return rc; }
+  e->env = (env_t*)calloc((size_t)cfg->n_envs, sizeof(env_t));
+  if (!e->env) { free(e); return fail(SRL_EINVAL, "oom"); }
+  for (int i = 0; i < cfg->n_envs; ++i) {
+    env_t* s = &e->env[i];
+    s->H = (float*)calloc((size_t)cfg->overhead_res * cfg->overhead_res, sizeof(float));
+    s->O = (float*)calloc((size_t)cfg->object_res * cfg->object_res, sizeof(float));
+    s->done = 1;                                                /* env.py:219-220 */
+    s->pending = -1;
+    for (int k = 0; k < NPAIR; ++k) s->slot_of_pair[k] = -1;
+    for (int k = 0; k < MAXSLOT; ++k) s->pair_of_slot[k] = -1;
+  }
+  *out = e;
+  return SRL_OK;
+}
+
+void srlo_destroy(srlo_env* e) {
+  if (!e) return;
+  for (int i = 0; i < e->c.n_envs; ++i) { free(e->env[i].H); free(e->env[i].O); }
+  free(e->env); free(e->mesh); free(e);
+}
+
+int srlo_load_meshes(srlo_env* e, const float* verts, const int32_t* vert_off,
+                     const int32_t* tris, const int32_t* tri_off, const float* mass_com,
+                     int32_t n_mesh) {
+  if (n_mesh < 1) return fail(SRL_EINVAL, "empty mesh pool");     /* env.py:103 */
+  free(e->mesh);
+  e->mesh = (mesh_t*)calloc((size_t)n_mesh, sizeof(mesh_t));
+  e->n_mesh = n_mesh;
+  for (int m = 0; m < n_mesh; ++m) {
+    mesh_t* M = &e->mesh[m];
+    M->nv = vert_off[m + 1] - vert_off[m];
+    M->nt = tri_off[m + 1] - tri_off[m];
+    if (M->nv < 4 || M->nv > MAXV || M->nt < 4 || M->nt > MAXT)
+      return fail(SRL_EINVAL, "mesh exceeds SRL_MAX_VERTS/SRL_MAX_TRIS");
+    float mass = mass_com[4 * m];
+    M->com = V(mass_com[4 * m + 1], mass_com[4 * m + 2], mass_com[4 * m + 3]);
+    v3 lo = V(1e30f, 1e30f, 1e30f), hi = V(-1e30f, -1e30f, -1e30f);
+    float r2 = 0.0f;
+    for (int k = 0; k < M->nv; ++k) {
+      const float* p = verts + 3 * (size_t)(vert_off[m] + k);
+      v3 a = vsub(V(p[0], p[1], p[2]), M->com);
+      M->v[k] = a;
+      lo = V(fminf(lo.x, a.x), fminf(lo.y, a.y), fminf(lo.z, a.z));
+      hi = V(fmaxf(hi.x, a.x), fmaxf(hi.y, a.y), fmaxf(hi.z, a.z));
+      float d2 = vdot(a, a);
+      if (d2 > r2) r2 = d2;
+    }
+    M->radius = sqrtf(r2);
+    for (int k = 0; k < M->nt; ++k) {
+      const int32_t* t = tris + 3 * (size_t)(tri_off[m] + k);
+      for (int j = 0; j < 3; ++j) {
+        if (t[j] < 0 || t[j] >= M->nv) return fail(SRL_EINVAL, "triangle index out of range");
+        M->tri[k][j] = (uint8_t)t[j];
+      }
+    }
+    /* Bullet btCompoundShape/btPolyhedralConvexShape::calculateLocalInertia restated:
+     * inertia of the solid box spanned by the shape's AABB (pybullet ignores the URDF
+     * inertia unless URDF_USE_INERTIA_FROM_FILE is passed; simulator.py:300 passes no flags). */
+    float lx = hi.x - lo.x, ly = hi.y - lo.y, lz = hi.z - lo.z;
+    float k12 = mass / 12.0f;
+    v3 I = V(k12 * (ly * ly + lz * lz), k12 * (lx * lx + lz * lz), k12 * (lx * lx + ly * ly));
+    M->inv_mass = 1.0f / mass;
+    M->inv_inertia = V(1.0f / I.x, 1.0f / I.y, 1.0f / I.z);
+  }
+  return SRL_OK;
+}
+
+int srlo_seed(srlo_env* e, uint32_t seed) {
+  e->seed = seed;
+  e->sample_counter = 0;
+  for (int i = 0; i < e->c.n_envs; ++i) e->env[i].episode = 0;
+  return SRL_OK;
+}
+
+int srlo_set_script(srlo_env* e, const int32_t* mesh_ids, const int32_t* goal_rect) {
+  int L = e->c.episode_length;
+  for (int i = 0; i < e->c.n_envs; ++i) {
+    env_t* s = &e->env[i];
+    for (int k = 0; k < L; ++k) {
+      int id = mesh_ids[(size_t)i * L + k];
+      if (id < 0 || id >= e->n_mesh) return fail(SRL_EINVAL, "script mesh id out of range");
+      s->script_ids[k] = id;
+    }
+    for (int k = 0; k < 4; ++k) s->script_goal[k] = goal_rect[4 * i + k];
+    s->has_script = 1;
+  }
+  return SRL_OK;
+}
+
+/* ------------------------------------------------------------------ goal (rewarder.py:211-259) */
+void srlo_goal_from_rng(const srl_config* cfg, uint32_t key, uint32_t episode, int32_t* rect) {
+  struct srlo_env tmp;
+  memset(&tmp, 0, sizeof tmp);
+  tmp.c = *cfg;
+  derive(&tmp);
+  int H = cfg->overhead_res;
+  /* b = 1 + 2*randint(2); beta(b, 4-b): Beta(1,3) = min of 3 uniforms, Beta(3,1) = max of 3 */
+  uint32_t bbit = srlo_rng(key, episode, STREAM_GOAL, 0) >> 31;
+  uint32_t u0 = srlo_rng(key, episode, STREAM_GOAL, 1) >> 8;
+  uint32_t u1 = srlo_rng(key, episode, STREAM_GOAL, 2) >> 8;
+  uint32_t u2 = srlo_rng(key, episode, STREAM_GOAL, 3) >> 8;
+  uint32_t lo = u0 < u1 ? u0 : u1; lo = lo < u2 ? lo : u2;
+  uint32_t hi = u0 > u1 ? u0 : u1; hi = hi > u2 ? hi : u2;
+  uint32_t X = bbit ? hi : lo; /* 24-bit fixed point in [0,1) */
+  int h = tmp.goal_min_h + (int)(((uint64_t)X * (uint64_t)(tmp.goal_max_h - tmp.goal_min_h)) >> 24);
+  int w = tmp.goal_size / h;
+  if (w < tmp.goal_min_w) w = tmp.goal_min_w;
+  if (w > tmp.goal_max_w) w = tmp.goal_max_w;
+  int umax = H - h, vmax = H - w;
+  int ulo = umax / 8, uhi = 7 * umax / 8 + 1;   /* margin_factor = 8, rewarder.py:16 */
+  int vlo = vmax / 8, vhi = 7 * vmax / 8 + 1;
+  int u = ulo + (int)rng_below(srlo_rng(key, episode, STREAM_GOAL, 4), (uint32_t)(uhi - ulo));
+  int v = vlo + (int)rng_below(srlo_rng(key, episode, STREAM_GOAL, 5), (uint32_t)(vhi - vlo));
+  rect[0] = u; rect[1] = v; rect[2] = h; rect[3] = w;
+}
+
+/* ------------------------------------------------------------------ depth codec */
+/* pybullet TinyRenderer depth (restated): d = far (t - near) / (t (far - near)), t = eye distance */
+static inline float depth_encode(float t, float nearp, float farp) {
+  if (t < nearp) t = nearp;
+  if (t > farp) t = farp;
+  return (farp * (t - nearp)) / (t * (farp - nearp));
+}
+/* observer.py:259-260 with numpy's float32 arithmetic (python scalars are weak) */
+static inline float elev_overhead(const srl_config* c, float d) {
+  float num = (float)((double)FAR_PLANE * ((double)FAR_PLANE - (double)c->max_z));
+  return FAR_PLANE - num / (FAR_PLANE - c->max_z * d);
+}
+/* observer.py:274-275 */
+static inline float elev_object(const srl_config* c, float d) {
+  double oz = (double)c->object_max_dimension; /* _object_z = max(_object_x,_object_y), observer.py:79-81 */
+  float c1 = (float)((double)FAR_PLANE + oz / 2);
+  float c2 = (float)((double)FAR_PLANE * (double)FAR_PLANE - (oz / 2) * (oz / 2));
+  return c1 - c2 / (FAR_PLANE + c->object_max_dimension * (0.5f - d));
+}
+void srlo_depth_to_elevation(const srl_config* c, int which, const float* depth, float* elev) {
+  if (which == 0) {
+    int n = c->overhead_res * c->overhead_res;
+    for (int i = 0; i < n; ++i) elev[i] = elev_overhead(c, depth[i]);
+  } else {
+    int r = c->object_res;
+    for (int i = 0; i < r; ++i)
+      for (int j = 0; j < r; ++j)                       /* d[:, ::-1], observer.py:277 */
+        elev[i * r + j] = elev_object(c, depth[i * r + (r - 1 - j)]);
+  }
+}
+
+/* ------------------------------------------------------------------ rasteriser */
+/* canonical edge function: antisymmetric under swapping (a,b) so shared edges are watertight */
+static inline float edge_fn(float ax, float ay, int ia, float bx, float by, int ib, float px, float py) {
+  if (ia < ib) return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+  return -((ax - bx) * (py - by) - (ay - by) * (px - bx));
+}
+/* Rasterise one triangle (xy in map coordinates, metres) into `buf` (res x res).
+ * top != 0: keep max z of up-facing triangles; top == 0: keep min z of down-facing ones. */
+static void raster_tri(float* buf, int res, float inv_px, float px, v3 a, int ia, v3 b, int ib, v3 c,
+                       int ic, int top) {
+  float area2 = (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x);
+  if (top ? !(area2 > 0.0f) : !(area2 < 0.0f)) return;
+  float xmin = fminf(a.x, fminf(b.x, c.x)), xmax = fmaxf(a.x, fmaxf(b.x, c.x));
+  float ymin = fminf(a.y, fminf(b.y, c.y)), ymax = fmaxf(a.y, fmaxf(b.y, c.y));
+  float zmin = fminf(a.z, fminf(b.z, c.z)), zmax = fmaxf(a.z, fmaxf(b.z, c.z));
+  float fi0 = ceilf(xmin * inv_px - 0.5f), fi1 = floorf(xmax * inv_px - 0.5f);
+  float fj0 = ceilf(ymin * inv_px - 0.5f), fj1 = floorf(ymax * inv_px - 0.5f);
+  if (fi0 < 0.0f) fi0 = 0.0f;
+  if (fj0 < 0.0f) fj0 = 0.0f;
+  if (fi1 > (float)(res - 1)) fi1 = (float)(res - 1);
+  if (fj1 > (float)(res - 1)) fj1 = (float)(res - 1);
+  if (fi1 < fi0 || fj1 < fj0) return;
+  int i0 = (int)fi0, i1 = (int)fi1, j0 = (int)fj0, j1 = (int)fj1;
+  /* plane z = a.z + gx (x - a.x) + gy (y - a.y) */
+  float nx = (b.y - a.y) * (c.z - a.z) - (b.z - a.z) * (c.y - a.y);
+  float ny = (b.z - a.z) * (c.x - a.x) - (b.x - a.x) * (c.z - a.z);
+  float gx = -nx / area2, gy = -ny / area2;
+  for (int i = i0; i <= i1; ++i) {
+    float x = ((float)i + 0.5f) * px;
+    for (int j = j0; j <= j1; ++j) {
+      float y = ((float)j + 0.5f) * px;
+      float e0 = edge_fn(a.x, a.y, ia, b.x, b.y, ib, x, y);
+      float e1 = edge_fn(b.x, b.y, ib, c.x, c.y, ic, x, y);
+      float e2 = edge_fn(c.x, c.y, ic, a.x, a.y, ia, x, y);
+      int inside = top ? (e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f)
+                       : (e0 <= 0.0f && e1 <= 0.0f && e2 <= 0.0f);
+      if (!inside) continue;
+      float z = a.z + ((x - a.x) * gx + (y - a.y) * gy);
+      z = fminf(fmaxf(z, zmin), zmax);
+      float* p = &buf[i * res + j];
+      if (top) { if (z > *p) *p = z; } else { if (z < *p) *p = z; }
+    }
+  }
+}
+
+/* O1: overhead height map of the placed bodies (observer.py:252-260; row <-> +x, col <-> +y) */
+static void render_heightmap(const struct srlo_env* e, int nb, const int* mesh, const v3* x,
+                             const q4* q, float* H) {
+  const srl_config* c = &e->c;
+  int res = c->overhead_res;
+  for (int k = 0; k < res * res; ++k) H[k] = 0.0f;
+  for (int b = 0; b < nb; ++b) {
+    const mesh_t* M = &e->mesh[mesh[b]];
+    m3 R = quat_to_mat(q[b]);
+    v3 wv[MAXV];
+    for (int k = 0; k < M->nv; ++k) wv[k] = vadd(x[b], mmul(&R, M->v[k]));
+    for (int t = 0; t < M->nt; ++t) {
+      int ia = M->tri[t][0], ib = M->tri[t][1], ic = M->tri[t][2];
+      raster_tri(H, res, e->inv_px, e->px, wv[ia], ia, wv[ib], ib, wv[ic], ic, 1);
+    }
+  }
+  float nearp = FAR_PLANE - c->max_z;
+  for (int k = 0; k < res * res; ++k) {
+    float d = depth_encode(FAR_PLANE - H[k], nearp, FAR_PLANE);
+    H[k] = elev_overhead(c, d);
+  }
+}
+
+/* O2: underside map of a mesh at the spawn pose (link frame at spawn, identity orientation;
+ * observer.py:262-277).  O = (z_c + oz/2) - z_underside, 0 where empty. */
+static void render_object(const struct srlo_env* e, int mesh_id, float* O) {
+  const srl_config* c = &e->c;
+  int r = c->object_res;
+  float half = c->object_max_dimension * 0.5f;
+  for (int k = 0; k < r * r; ++k) O[k] = 1e30f;
+  if (mesh_id >= 0) {
+    const mesh_t* M = &e->mesh[mesh_id];
+    v3 lv[MAXV];
+    for (int k = 0; k < M->nv; ++k) { /* back to the link frame, shifted so the map starts at 0 */
+      v3 a = vadd(M->v[k], M->com);
+      lv[k] = V(a.x + half, a.y + half, a.z);
+    }
+    for (int t = 0; t < M->nt; ++t) {
+      int ia = M->tri[t][0], ib = M->tri[t][1], ic = M->tri[t][2];
+      raster_tri(O, r, e->inv_px, e->px, lv[ia], ia, lv[ib], ib, lv[ic], ic, 0);
+    }
+  }
+  float nearp = FAR_PLANE - half, farp = FAR_PLANE + half;
+  for (int k = 0; k < r * r; ++k) {
+    float d = O[k] > 1e29f ? 1.0f : depth_encode(FAR_PLANE + O[k], nearp, farp);
+    O[k] = elev_object(c, d);
+  }
+}
+
+/* ------------------------------------------------------------------ pose (observer.py:392-421) */
+void srlo_pose(const srl_config* c, const float* H, const float* O, int32_t u, int32_t v, float* xyz) {
+  int res = c->overhead_res, r = c->object_res;
+  float px = c->object_max_dimension / (float)c->object_res;
+  float z = -1e30f; /* np.max over an empty selection raises in the reference; never empty for a real rock */
+  for (int i = 0; i < r; ++i)
+    for (int j = 0; j < r; ++j) {
+      float o = O[i * r + j];
+      if (o > 1e-4f) {
+        float s = H[(u + i) * res + (v + j)] + o;
+        if (s > z) z = s;
+      }
+    }
+  float half = ((float)r * px) * 0.5f;   /* _object_x/2 = _object_z/2 */
+  xyz[0] = (float)u * px + half;
+  xyz[1] = (float)v * px + half;
+  xyz[2] = z - half;
+}
+
+/* ------------------------------------------------------------------ reward sums (rewarder.py:297-307) */
+/* Fixed order: pixels in groups of 8 (row-major), group g accumulates into partial[g % 256],
+ * then a halving tree over the 256 partials. */
+void srlo_iou_sums(const srl_config* c, const float* H, const int32_t* g, float* inter, float* uni) {
+  int res = c->overhead_res;
+  float gz = c->max_z - c->object_max_dimension;
+  float pi[256], pu[256];
+  for (int k = 0; k < 256; ++k) { pi[k] = 0.0f; pu[k] = 0.0f; }
+  int n = res * res;
+  for (int base = 0; base < n; base += 8) {
+    int t = (base >> 3) & 255;
+    for (int k = base; k < base + 8; ++k) {
+      int i = k / res, j = k % res;
+      int in = (i >= g[0] && i < g[0] + g[2] && j >= g[1] && j < g[1] + g[3]);
+      float h = H[k];
+      if (in) {
+        pi[t] += fminf(h, gz);
+        pu[t] += fmaxf(h, gz);
+      } else {
+        pu[t] += fmaxf(h, 0.0f);
+      }
+    }
+  }
+  for (int s = 128; s >= 1; s >>= 1)
+    for (int t = 0; t < s; ++t) { pi[t] += pi[t + s]; pu[t] += pu[t + s]; }
+  *inter = pi[0];
+  *uni = pu[0];
+}
+
+/* ================================================================== physics */
+/* ---- closest point of a simplex to the origin (Ericson, Real-Time Collision Detection 5.1) */
+typedef struct {
+  v3 w[4], p[4], q[4];
+  int ia[4], ib[4];
+  int n;
+} simplex_t;
+
+static void closest_tri(v3 a, v3 b, v3 c, float* l /*3*/, int* used) {
+  v3 ab = vsub(b, a), ac = vsub(c, a), ap = vneg(a);
+  float d1 = vdot(ab, ap), d2 = vdot(ac, ap);
+  if (d1 <= 0.0f && d2 <= 0.0f) { l[0] = 1.0f; l[1] = 0.0f; l[2] = 0.0f; *used = 1; return; }
+  v3 bp = vneg(b);
+  float d3 = vdot(ab, bp), d4 = vdot(ac, bp);
+  if (d3 >= 0.0f && d4 <= d3) { l[0] = 0.0f; l[1] = 1.0f; l[2] = 0.0f; *used = 2; return; }
+  float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+    float v = d1 / (d1 - d3);
+    l[0] = 1.0f - v; l[1] = v; l[2] = 0.0f; *used = 3; return;
+  }
+  v3 cp = vneg(c);
+  float d5 = vdot(ab, cp), d6 = vdot(ac, cp);
+  if (d6 >= 0.0f && d5 <= d6) { l[0] = 0.0f; l[1] = 0.0f; l[2] = 1.0f; *used = 4; return; }
+  float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+    float w = d2 / (d2 - d6);
+    l[0] = 1.0f - w; l[1] = 0.0f; l[2] = w; *used = 5; return;
+  }
+  float va = d3 * d6 - d5 * d4;
+  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
+    float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    l[0] = 0.0f; l[1] = 1.0f - w; l[2] = w; *used = 6; return;
+  }
+  float denom = 1.0f / ((va + vb) + vc);
+  float v = vb * denom, w = vc * denom;
+  l[0] = (1.0f - v) - w; l[1] = v; l[2] = w; *used = 7;
+}
+
+/* 1: origin is on the outer side of plane abc (w.r.t. d); 0: inner side; -1: degenerate */
+static int outside_plane(v3 a, v3 b, v3 c, v3 d) {
+  v3 n = vcross(vsub(b, a), vsub(c, a));
+  float sp = vdot(vneg(a), n);
+  float sd = vdot(vsub(d, a), n);
+  if (sd * sd < 1e-24f) return -1;
+  return (sp * sd < 0.0f) ? 1 : 0;
+}
+
+/* Reduce simplex to the feature closest to the origin; lam/ v out.
+ * returns 1 ok, 0 degenerate, 2 origin enclosed (tetrahedron). */
+static int simplex_closest(simplex_t* s, float* lam, v3* vout) {
+  int used = 0;
+  float l[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (s->n == 1) {
+    l[0] = 1.0f; used = 1;
+  } else if (s->n == 2) {
+    v3 a = s->w[0], b = s->w[1];
+    v3 ab = vsub(b, a);
+    float t = vdot(vneg(a), ab);
+    if (t <= 0.0f) { l[0] = 1.0f; used = 1; }
+    else {
+      float den = vdot(ab, ab);
+      if (t >= den) { l[1] = 1.0f; used = 2; }
+      else { t = t / den; l[0] = 1.0f - t; l[1] = t; used = 3; }
+    }
+  } else if (s->n == 3) {
+    closest_tri(s->w[0], s->w[1], s->w[2], l, &used);
+  } else {
+    v3 a = s->w[0], b = s->w[1], c = s->w[2], d = s->w[3];
+    int o0 = outside_plane(a, b, c, d);
+    int o1 = outside_plane(a, c, d, b);
+    int o2 = outside_plane(a, d, b, c);
+    int o3 = outside_plane(b, d, c, a);
+    if (o0 < 0 || o1 < 0 || o2 < 0 || o3 < 0) return 0;
+    if (!o0 && !o1 && !o2 && !o3) return 2;
+    float best = 1e30f;
+    float tl[3]; int tu;
+    if (o0) {
+      closest_tri(a, b, c, tl, &tu);
+      v3 p = vadd(vadd(vscale(a, tl[0]), vscale(b, tl[1])), vscale(c, tl[2]));
+      float d2 = vdot(p, p);
+      if (d2 < best) { best = d2; l[0] = tl[0]; l[1] = tl[1]; l[2] = tl[2]; l[3] = 0.0f;
+        used = (tu & 1) | (tu & 2) | (tu & 4); }
+    }
+    if (o1) {
+      closest_tri(a, c, d, tl, &tu);
+      v3 p = vadd(vadd(vscale(a, tl[0]), vscale(c, tl[1])), vscale(d, tl[2]));
+      float d2 = vdot(p, p);
+      if (d2 < best) { best = d2; l[0] = tl[0]; l[1] = 0.0f; l[2] = tl[1]; l[3] = tl[2];
+        used = (tu & 1) | ((tu & 2) << 1) | ((tu & 4) << 1); }
+    }
+    if (o2) {
+      closest_tri(a, d, b, tl, &tu);
+      v3 p = vadd(vadd(vscale(a, tl[0]), vscale(d, tl[1])), vscale(b, tl[2]));
+      float d2 = vdot(p, p);
+      if (d2 < best) { best = d2; l[0] = tl[0]; l[1] = tl[2]; l[2] = 0.0f; l[3] = tl[1];
+        used = (tu & 1) | ((tu & 2) << 2) | ((tu & 4) >> 1); }
+    }
+    if (o3) {
+      closest_tri(b, d, c, tl, &tu);
+      v3 p = vadd(vadd(vscale(b, tl[0]), vscale(d, tl[1])), vscale(c, tl[2]));
+      float d2 = vdot(p, p);
+      if (d2 < best) { best = d2; l[0] = 0.0f; l[1] = tl[0]; l[2] = tl[2]; l[3] = tl[1];
+        used = ((tu & 1) << 1) | ((tu & 2) << 2) | (tu & 4); }
+    }
+  }
+  /* compact */
+  int m = 0;
+  v3 v = V(0.0f, 0.0f, 0.0f);
+  for (int i = 0; i < s->n; ++i) {
+    if (used & (1 << i)) {
+      s->w[m] = s->w[i]; s->p[m] = s->p[i]; s->q[m] = s->q[i];
+      s->ia[m] = s->ia[i]; s->ib[m] = s->ib[i];
+      lam[m] = l[i];
+      v = vadd(v, vscale(s->w[m], lam[m]));
+      ++m;
+    }
+  }
+  s->n = m;
+  *vout = v;
+  return 1;
+}
+
+static inline int support_max(const v3* P, int n, v3 d) {
+  int best = 0;
+  float bd = vdot(P[0], d);
+  for (int k = 1; k < n; ++k) {
+    float t = vdot(P[k], d);
+    if (t > bd) { bd = t; best = k; }
+  }
+  return best;
+}
+
+/* GJK distance between two world-space vertex clouds (convex hulls).
+ * returns 0: farther than maxdist (no contact); 1: pa/pb/n/dist valid; 2: hulls overlap */
+static int gjk_distance(const v3* VA, int na, const v3* VB, int nb, v3* axis, float maxdist,
+                        v3* pa, v3* pb, v3* nrm, float* dist) {
+  simplex_t s; s.n = 0;
+  float lam[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  v3 v = *axis;
+  float sqd = 1e30f;
+  if (!(vdot(v, v) > 1e-20f)) v = V(0.0f, 0.0f, 1.0f);
+  for (int it = 0; it < GJK_MAXIT; ++it) {
+    int ia = support_max(VA, na, vneg(v));
+    int ib = support_max(VB, nb, v);
+    v3 w = vsub(VA[ia], VB[ib]);
+    float delta = vdot(v, w);
+    if (it > 0) {
+      if (delta > 0.0f && delta * delta > sqd * (maxdist * maxdist)) return 0;
+      int dup = 0;
+      for (int k = 0; k < s.n; ++k) dup |= (s.ia[k] == ia && s.ib[k] == ib);
+      if (dup) break;
+      if (sqd - delta <= sqd * 1e-6f) break;
+    }
+    simplex_t bak = s;
+    float blam[4] = {lam[0], lam[1], lam[2], lam[3]};
+    s.w[s.n] = w; s.p[s.n] = VA[ia]; s.q[s.n] = VB[ib]; s.ia[s.n] = ia; s.ib[s.n] = ib; s.n++;
+    v3 nv;
+    int rc = simplex_closest(&s, lam, &nv);
+    if (rc == 2) return 2;
+    if (rc == 0) {
+      if (it == 0) return 0;
+      s = bak; lam[0] = blam[0]; lam[1] = blam[1]; lam[2] = blam[2]; lam[3] = blam[3];
+      break;
+    }
+    float nsq = vdot(nv, nv);
+    if (nsq < 1e-10f) return 2;
+    int stall = (it > 0) && (sqd - nsq <= 1.1920929e-7f * sqd);
+    v = nv; sqd = nsq;
+    if (stall) break;
+  }
+  v3 A = V(0.0f, 0.0f, 0.0f), B = V(0.0f, 0.0f, 0.0f);
+  for (int k = 0; k < s.n; ++k) {
+    A = vadd(A, vscale(s.p[k], lam[k]));
+    B = vadd(B, vscale(s.q[k], lam[k]));
+  }
+  float d = sqrtf(sqd);
+  if (d > maxdist) { *axis = v; return 0; }
+  *pa = A; *pb = B; *dist = d;
+  *nrm = vscale(v, 1.0f / d);
+  *axis = v;
+  return 1;
+}
+
+/* Face-normal SAT for overlapping hulls: least-penetration face axis of either body. */
+static void sat_faces(const mesh_t* MA, const v3* VA, const mesh_t* MB, const v3* VB, v3* pa, v3* pb,
+                      v3* nrm, float* dist) {
+  float best = -1e30f; int btype = 0, bvert = 0; v3 bn = V(0.0f, 0.0f, 1.0f);
+  for (int pass = 0; pass < 2; ++pass) {
+    const mesh_t* MF = pass ? MB : MA; const v3* VF = pass ? VB : VA;
+    const v3* VO = pass ? VA : VB; int no = pass ? MA->nv : MB->nv;
+    for (int t = 0; t < MF->nt; ++t) {
+      v3 a = VF[MF->tri[t][0]], b = VF[MF->tri[t][1]], c = VF[MF->tri[t][2]];
+      v3 n = vcross(vsub(b, a), vsub(c, a));
+      float l2 = vdot(n, n);
+      if (l2 < 1e-20f) continue;
+      n = vscale(n, 1.0f / sqrtf(l2));
+      float smin = 1e30f; int kmin = 0;
+      for (int k = 0; k < no; ++k) {
+        float sd = vdot(n, vsub(VO[k], a));
+        if (sd < smin) { smin = sd; kmin = k; }
+      }
+      if (smin > best) { best = smin; btype = pass; bvert = kmin; bn = n; }
+    }
+  }
+  if (btype == 0) { /* face of A, deepest vertex of B; B->A normal is -face normal */
+    *nrm = vneg(bn); *pb = VB[bvert]; *pa = vsub(VB[bvert], vscale(bn, best));
+  } else {          /* face of B, deepest vertex of A */
+    *nrm = bn; *pa = VA[bvert]; *pb = vsub(VA[bvert], vscale(bn, best));
+  }
+  *dist = best;
+}
+
+/* ---- persistent manifold (Bullet btPersistentManifold restated) */
+static void manifold_refresh(manifold_t* m, v3 xa, const m3* Ra, v3 xb, const m3* Rb, float thr) {
+  for (int i = m->np - 1; i >= 0; --i) {
+    mpoint_t* p = &m->p[i];
+    v3 wa = vadd(xa, mmul(Ra, p->la));
+    v3 wb = vadd(xb, mmul(Rb, p->lb));
+    float d = vdot(vsub(wa, wb), p->n);
+    int drop = d > thr;
+    if (!drop) {
+      v3 proj = vsub(wa, vscale(p->n, d));
+      v3 t = vsub(wb, proj);
+      drop = vdot(t, t) > thr * thr;
+    }
+    if (drop) { m->p[i] = m->p[m->np - 1]; m->np--; }
+    else p->dist = d;
+  }
+}
+
+static int manifold_sort_replace(const manifold_t* m, const mpoint_t* np_) {
+  int deep = -1; float maxpen = np_->dist;
+  for (int i = 0; i < 4; ++i) if (m->p[i].dist < maxpen) { deep = i; maxpen = m->p[i].dist; }
+  float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (deep != 0) { v3 a = vsub(np_->la, m->p[1].la), b = vsub(m->p[3].la, m->p[2].la); v3 c = vcross(a, b); res[0] = vdot(c, c); }
+  if (deep != 1) { v3 a = vsub(np_->la, m->p[0].la), b = vsub(m->p[3].la, m->p[2].la); v3 c = vcross(a, b); res[1] = vdot(c, c); }
+  if (deep != 2) { v3 a = vsub(np_->la, m->p[0].la), b = vsub(m->p[3].la, m->p[1].la); v3 c = vcross(a, b); res[2] = vdot(c, c); }
+  if (deep != 3) { v3 a = vsub(np_->la, m->p[0].la), b = vsub(m->p[2].la, m->p[1].la); v3 c = vcross(a, b); res[3] = vdot(c, c); }
+  int best = 0;
+  for (int i = 1; i < 4; ++i) if (res[i] > res[best]) best = i;
+  return best;
+}
+
+static void manifold_add(manifold_t* m, const mpoint_t* np_, float thr) {
+  float shortest = thr * thr; int near_i = -1;
+  for (int i = 0; i < m->np; ++i) {
+    v3 d = vsub(m->p[i].la, np_->la);
+    float d2 = vdot(d, d);
+    if (d2 < shortest) { shortest = d2; near_i = i; }
+  }
+  if (near_i >= 0) { /* replace geometry, keep the cached impulses */
+    mpoint_t* p = &m->p[near_i];
+    p->la = np_->la; p->lb = np_->lb; p->n = np_->n; p->dist = np_->dist;
+  } else if (m->np < 4) {
+    m->p[m->np++] = *np_;
+  } else {
+    m->p[manifold_sort_replace(m, np_)] = *np_;
+  }
+}
+
+/* ---- one sub-step (pb.stepSimulation restated; see DESIGN.md "settle solver") */
+static inline int pair_id(int i, int j) { return j * (j - 1) / 2 + i; } /* i < j */
+
+static void derive_bodies(const struct srlo_env* e, env_t* s) {
+  for (int b = 0; b < s->nb; ++b) {
+    const mesh_t* M = &e->mesh[s->mesh[b]];
+    s->R[b] = quat_to_mat(s->q[b]);
+    s->Iw[b] = inv_inertia_world(&s->R[b], M->inv_inertia);
+    v3 lo = V(1e30f, 1e30f, 1e30f), hi = V(-1e30f, -1e30f, -1e30f);
+    for (int k = 0; k < M->nv; ++k) {
+      v3 a = vadd(s->x[b], mmul(&s->R[b], M->v[k]));
+      s->wv[b][k] = a;
+      lo = V(fminf(lo.x, a.x), fminf(lo.y, a.y), fminf(lo.z, a.z));
+      hi = V(fmaxf(hi.x, a.x), fmaxf(hi.y, a.y), fmaxf(hi.z, a.z));
+    }
+    float ex = e->c.collision_margin + 0.01f * M->radius;
+    s->amin[b] = V(lo.x - ex, lo.y - ex, lo.z - ex);
+    s->amax[b] = V(hi.x + ex, hi.y + ex, hi.z + ex);
+  }
+}
+
+#define GMAXP 8   /* ground manifold: up to 8 deepest vertices within the breaking threshold */
+static void ground_manifold(const struct srlo_env* e, env_t* s, int b) {
+  const mesh_t* M = &e->mesh[s->mesh[b]];
+  float m = e->c.collision_margin, thr = 0.02f * M->radius;
+  gmanifold_t old = s->gm[b];
+  gmanifold_t* g = &s->gm[b];
+  const v3* W = s->wv[b];
+  /* selection: repeatedly take the deepest not-yet-taken vertex with dist < thr (lowest index on ties) */
+  int ns = 0;
+  float last_d = -1e30f; int last_k = -1;
+  while (ns < GMAXP) {
+    int best = -1; float bd = thr;
+    for (int k = 0; k < M->nv; ++k) {
+      float d = W[k].z - m;
+      /* strictly after (last_d, last_k) in (dist, index) order */
+      if (!(d > last_d || (d == last_d && k > last_k))) continue;
+      if (d < bd) { bd = d; best = k; }
+    }
+    if (best < 0) break;
+    g->vid[ns] = best; g->dist[ns] = bd;
+    g->in[ns] = 0.0f; g->it1[ns] = 0.0f; g->it2[ns] = 0.0f;
+    for (int j = 0; j < old.np; ++j)
+      if (old.vid[j] == best) { g->in[ns] = old.in[j]; g->it1[ns] = old.it1[j]; g->it2[ns] = old.it2[j]; }
+    last_d = bd; last_k = best;
+    ++ns;
+  }
+  g->np = ns;
+}
+
+static void update_slots(const struct srlo_env* e, env_t* s) {
+  (void)e;
+  /* broadphase over all pairs in ascending pair id; slot bookkeeping */
+  int changed = 0;
+  for (int j = 1; j < s->nb; ++j)
+    for (int i = 0; i < j; ++i) {
+      int pid = pair_id(i, j);
+      int ov = s->amin[i].x <= s->amax[j].x && s->amin[j].x <= s->amax[i].x &&
+               s->amin[i].y <= s->amax[j].y && s->amin[j].y <= s->amax[i].y &&
+               s->amin[i].z <= s->amax[j].z && s->amin[j].z <= s->amax[i].z;
+      int sl = s->slot_of_pair[pid];
+      if (!ov && sl >= 0) { s->slot_of_pair[pid] = -1; s->pair_of_slot[sl] = -1; changed = 1; }
+    }
+  for (int j = 1; j < s->nb; ++j)
+    for (int i = 0; i < j; ++i) {
+      int pid = pair_id(i, j);
+      int ov = s->amin[i].x <= s->amax[j].x && s->amin[j].x <= s->amax[i].x &&
+               s->amin[i].y <= s->amax[j].y && s->amin[j].y <= s->amax[i].y &&
+               s->amin[i].z <= s->amax[j].z && s->amin[j].z <= s->amax[i].z;
+      if (ov && s->slot_of_pair[pid] < 0) {
+        int sl = -1;
+        for (int k = 0; k < MAXSLOT; ++k) if (s->pair_of_slot[k] < 0) { sl = k; break; }
+        if (sl < 0) { s->status |= SRL_ST_PAIR_OVERFLOW; continue; }
+        s->slot_of_pair[pid] = (int16_t)sl; s->pair_of_slot[sl] = (int16_t)pid;
+        s->slot_a[sl] = (uint8_t)i; s->slot_b[sl] = (uint8_t)j;
+        s->man[sl].np = 0;
+        s->man[sl].axis = vsub(s->x[i], s->x[j]);
+        changed = 1;
+      }
+    }
+  if (changed || s->ncolour < 0) {
+    /* greedy colouring in slot order: slots of one colour share no body */
+    uint64_t used[MAXB];
+    for (int b = 0; b < MAXB; ++b) used[b] = 0;
+    int nc = 0;
+    for (int sl = 0; sl < MAXSLOT; ++sl) {
+      if (s->pair_of_slot[sl] < 0) continue;
+      uint64_t u = used[s->slot_a[sl]] | used[s->slot_b[sl]];
+      int c = 0;
+      while (u & ((uint64_t)1 << c)) ++c;
+      s->colour[sl] = (uint8_t)c;
+      used[s->slot_a[sl]] |= (uint64_t)1 << c;
+      used[s->slot_b[sl]] |= (uint64_t)1 << c;
+      if (c + 1 > nc) nc = c + 1;
+    }
+    s->ncolour = nc;
+  }
+}
+
+static void narrowphase_slot(const struct srlo_env* e, env_t* s, int sl) {
+  int a = s->slot_a[sl], b = s->slot_b[sl];
+  const mesh_t* MA = &e->mesh[s->mesh[a]];
+  const mesh_t* MB = &e->mesh[s->mesh[b]];
+  manifold_t* m = &s->man[sl];
+  float mg = e->c.collision_margin;
+  float thr = 0.02f * fminf(MA->radius, MB->radius);
+  manifold_refresh(m, s->x[a], &s->R[a], s->x[b], &s->R[b], thr);
+  v3 pa, pb, n; float d;
+  int rc = gjk_distance(s->wv[a], MA->nv, s->wv[b], MB->nv, &m->axis, (mg + mg) + thr, &pa, &pb, &n, &d);
+  if (rc == 2) { sat_faces(MA, s->wv[a], MB, s->wv[b], &pa, &pb, &n, &d); rc = 1; }
+  if (rc == 1) {
+    float dist = d - (mg + mg);
+    if (dist < thr) {
+      mpoint_t np_;
+      v3 sa = vsub(pa, vscale(n, mg));
+      v3 sb = vadd(pb, vscale(n, mg));
+      np_.la = mtmul(&s->R[a], vsub(sa, s->x[a]));
+      np_.lb = mtmul(&s->R[b], vsub(sb, s->x[b]));
+      np_.n = n; np_.dist = dist; np_.in = 0.0f; np_.it1 = 0.0f; np_.it2 = 0.0f;
+      manifold_add(m, &np_, thr);
+    }
+  }
+}
+
+/* one solver row: direction d at arms ra (body A) / rb (body B) */
+typedef struct { v3 va, wa, vb, wb; } vel4;
+
+static inline float row_solve(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float imb, const m3* Ib,
+                              vel4* u, float target, float* acc, float lo, float hi, int has_b) {
+  v3 ca = vcross(ra, d);
+  v3 aa = mmul(Ia, ca);
+  v3 cb = V(0.0f, 0.0f, 0.0f), ab = V(0.0f, 0.0f, 0.0f);
+  float k = ima + vdot(vcross(aa, ra), d);
+  float vrel = vdot(d, u->va) + vdot(ca, u->wa);
+  if (has_b) {
+    cb = vcross(rb, d);
+    ab = mmul(Ib, cb);
+    k = k + (imb + vdot(vcross(ab, rb), d));
+    vrel = vrel - (vdot(d, u->vb) + vdot(cb, u->wb));
+  }
+  float dl = (target - vrel) / k;
+  float na = *acc + dl;
+  if (na < lo) na = lo;
+  if (na > hi) na = hi;
+  dl = na - *acc;
+  *acc = na;
+  u->va = vadd(u->va, vscale(d, ima * dl));
+  u->wa = vadd(u->wa, vscale(aa, dl));
+  if (has_b) {
+    u->vb = vsub(u->vb, vscale(d, imb * dl));
+    u->wb = vsub(u->wb, vscale(ab, dl));
+  }
+  return dl;
+}
+
+static inline void row_apply(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float imb, const m3* Ib,
+                             vel4* u, float imp, int has_b) {
+  v3 aa = mmul(Ia, vcross(ra, d));
+  u->va = vadd(u->va, vscale(d, ima * imp));
+  u->wa = vadd(u->wa, vscale(aa, imp));
+  if (has_b) {
+    v3 ab = mmul(Ib, vcross(rb, d));
+    u->vb = vsub(u->vb, vscale(d, imb * imp));
+    u->wb = vsub(u->wb, vscale(ab, imp));
+  }
+}
+
+static inline float contact_target(const struct srlo_env* e, float dist) {
+  float inv_dt = 1.0f / e->c.sim_time_step;
+  /* Bullet setupContactConstraint restated: separated points may close the gap in one step,
+   * penetrating points are pushed out with erp */
+  return dist > 0.0f ? -(dist * inv_dt) : -((dist * e->c.erp) * inv_dt);
+}
+
+static void solve_ground(const struct srlo_env* e, env_t* s, int b, int warm) {
+  gmanifold_t* g = &s->gm[b];
+  if (g->np == 0) return;
+  const mesh_t* M = &e->mesh[s->mesh[b]];
+  float mu = e->c.friction_rock * e->c.friction_ground;
+  vel4 u; u.va = s->v[b]; u.wa = s->w[b]; u.vb = V(0, 0, 0); u.wb = V(0, 0, 0);
+  v3 n = V(0.0f, 0.0f, 1.0f), t1, t2;
+  plane_space(n, &t1, &t2);
+  for (int i = 0; i < g->np; ++i) {
+    v3 pw = s->wv[b][g->vid[i]];
+    v3 ra = vsub(V(pw.x, pw.y, pw.z - e->c.collision_margin), s->x[b]);
+    v3 rb = V(0, 0, 0);
+    if (warm) {
+      g->in[i] = g->in[i] * e->c.warmstart; g->it1[i] = g->it1[i] * e->c.warmstart; g->it2[i] = g->it2[i] * e->c.warmstart;
+      row_apply(n, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, g->in[i], 0);
+      row_apply(t1, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, g->it1[i], 0);
+      row_apply(t2, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, g->it2[i], 0);
+    } else {
+      row_solve(n, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, contact_target(e, g->dist[i]), &g->in[i], 0.0f, 1e30f, 0);
+      float lim = mu * g->in[i];
+      row_solve(t1, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, 0.0f, &g->it1[i], -lim, lim, 0);
+      row_solve(t2, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, 0.0f, &g->it2[i], -lim, lim, 0);
+    }
+  }
+  s->v[b] = u.va; s->w[b] = u.wa;
+}
+
+static void solve_slot(const struct srlo_env* e, env_t* s, int sl, int warm) {
+  manifold_t* m = &s->man[sl];
+  if (m->np == 0) return;
+  int a = s->slot_a[sl], b = s->slot_b[sl];
+  const mesh_t* MA = &e->mesh[s->mesh[a]];
+  const mesh_t* MB = &e->mesh[s->mesh[b]];
+  float mu = e->c.friction_rock * e->c.friction_rock;
+  vel4 u; u.va = s->v[a]; u.wa = s->w[a]; u.vb = s->v[b]; u.wb = s->w[b];
+  for (int i = 0; i < m->np; ++i) {
+    mpoint_t* p = &m->p[i];
+    v3 ra = mmul(&s->R[a], p->la);
+    v3 rb = mmul(&s->R[b], p->lb);
+    v3 t1, t2;
+    plane_space(p->n, &t1, &t2);
+    if (warm) {
+      p->in = p->in * e->c.warmstart; p->it1 = p->it1 * e->c.warmstart; p->it2 = p->it2 * e->c.warmstart;
+      row_apply(p->n, ra, rb, MA->inv_mass, &s->Iw[a], MB->inv_mass, &s->Iw[b], &u, p->in, 1);
+      row_apply(t1, ra, rb, MA->inv_mass, &s->Iw[a], MB->inv_mass, &s->Iw[b], &u, p->it1, 1);
+      row_apply(t2, ra, rb, MA->inv_mass, &s->Iw[a], MB->inv_mass, &s->Iw[b], &u, p->it2, 1);
+    } else {
+      row_solve(p->n, ra, rb, MA->inv_mass, &s->Iw[a], MB->inv_mass, &s->Iw[b], &u, contact_target(e, p->dist), &p->in, 0.0f, 1e30f, 1);
+      float lim = mu * p->in;
+      row_solve(t1, ra, rb, MA->inv_mass, &s->Iw[a], MB->inv_mass, &s->Iw[b], &u, 0.0f, &p->it1, -lim, lim, 1);
+      row_solve(t2, ra, rb, MA->inv_mass, &s->Iw[a], MB->inv_mass, &s->Iw[b], &u, 0.0f, &p->it2, -lim, lim, 1);
+    }
+  }
+  s->v[a] = u.va; s->w[a] = u.wa; s->v[b] = u.vb; s->w[b] = u.wb;
+}
+
+static void solver_sweep(const struct srlo_env* e, env_t* s, int warm) {
+  for (int b = 0; b < s->nb; ++b) solve_ground(e, s, b, warm);
+  for (int c = 0; c < s->ncolour; ++c)
+    for (int sl = 0; sl < MAXSLOT; ++sl)
+      if (s->pair_of_slot[sl] >= 0 && s->colour[sl] == c) solve_slot(e, s, sl, warm);
+}
+
+static void substep(const struct srlo_env* e, env_t* s) {
+  float dt = e->c.sim_time_step;
+  /* damping then gravity (btRigidBody::applyDamping, then the external-force impulse) */
+  for (int b = 0; b < s->nb; ++b) {
+    s->v[b] = vscale(s->v[b], e->lin_damp);
+    s->w[b] = vscale(s->w[b], e->ang_damp);
+    s->v[b].z = s->v[b].z - e->c.gravity * dt;
+  }
+  derive_bodies(e, s);
+  for (int b = 0; b < s->nb; ++b) ground_manifold(e, s, b);
+  update_slots(e, s);
+  for (int sl = 0; sl < MAXSLOT; ++sl)
+    if (s->pair_of_slot[sl] >= 0) narrowphase_slot(e, s, sl);
+  solver_sweep(e, s, 1);
+  for (int it = 0; it < e->c.solver_iterations; ++it) solver_sweep(e, s, 0);
+  /* integrate */
+  for (int b = 0; b < s->nb; ++b) {
+    s->x[b] = vadd(s->x[b], vscale(s->v[b], dt));
+    q4 q = s->q[b]; v3 w = s->w[b];
+    float hx = 0.5f * dt;
+    q4 dq;
+    dq.x = hx * ((w.x * q.w + w.y * q.z) - w.z * q.y);
+    dq.y = hx * ((w.y * q.w + w.z * q.x) - w.x * q.z);
+    dq.z = hx * ((w.z * q.w + w.x * q.y) - w.y * q.x);
+    dq.w = hx * (-((w.x * q.x + w.y * q.y) + w.z * q.z));
+    q.x += dq.x; q.y += dq.y; q.z += dq.z; q.w += dq.w;
+    float inv = 1.0f / sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w));
+    q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv;
+    s->q[b] = q;
+  }
+}
+
+/* simulator.py:322-335 (velocity criterion; angular velocity is ignored) */
+static int sim_stop(const struct srlo_env* e, const env_t* s) {
+  float thr = e->c.velocity_threshold;
+  for (int b = s->nb - 1; b >= 0; --b)
+    if (sqrtf(vdot(s->v[b], s->v[b])) > thr) return 0;
+  return 1;
+}
+static int newest_contacts(const env_t* s) {
+  int b = s->nb - 1;
+  int n = s->gm[b].np;
+  for (int sl = 0; sl < MAXSLOT; ++sl)
+    if (s->pair_of_slot[sl] >= 0 && (s->slot_a[sl] == b || s->slot_b[sl] == b)) n += s->man[sl].np;
+  return n;
+}
+/* simulator.py:337-341 */
+static int sim_drop(const struct srlo_env* e, const env_t* s) {
+  return newest_contacts(s) >= 3 || sim_stop(e, s);
+}
+
+/* Simulator.step, simulator.py:190-258 */
+static void sim_step(const struct srlo_env* e, env_t* s, v3 pos) {
+  int counter = 0;
+  if (s->pending >= 0) {             /* _place, simulator.py:310-320 */
+    int b = s->nb;
+    const mesh_t* M = &e->mesh[s->pending];
+    s->mesh[b] = s->pending;
+    /* resetBasePositionAndOrientation moves the inertial (COM) frame; loadURDF placed the link frame */
+    s->x[b] = e->c.place_at_com ? pos : vadd(pos, M->com);
+    s->q[b].x = 0.0f; s->q[b].y = 0.0f; s->q[b].z = 0.0f; s->q[b].w = 1.0f;
+    s->v[b] = V(0, 0, 0); s->w[b] = V(0, 0, 0);
+    s->gm[b].np = 0;
+    s->nb = b + 1;
+    s->pending = -1;
+    substep(e, s);
+  }
+  counter = 1;
+  if (e->c.smooth_placing) {
+    while (!sim_drop(e, s)) {
+      s->v[s->nb - 1] = V(0, 0, 0); s->w[s->nb - 1] = V(0, 0, 0);
+      substep(e, s);
+      counter++;
+      if (counter > e->max_substeps) { s->status |= SRL_ST_DIVERGED; break; }
+    }
+  }
+  s->place_x[s->nb - 1] = s->x[s->nb - 1];
+  s->place_q[s->nb - 1] = s->q[s->nb - 1];
+  s->substeps[0] = counter;
+  while (!(s->status & SRL_ST_DIVERGED) && !sim_stop(e, s)) {
+    substep(e, s);
+    counter++;
+    if (counter > e->max_substeps) { s->status |= SRL_ST_DIVERGED; break; }
+  }
+  s->substeps[1] = counter - s->substeps[0];
+}
+
+/* ------------------------------------------------------------------ reward (rewarder.py:162-179, :261-295) */
+static float metric_value(const struct srlo_env* e, env_t* s) {
+  const srl_config* c = &e->c;
+  if (c->metric == SRL_METRIC_IOU || c->metric == SRL_METRIC_OR) {
+    float inter, uni;
+    srlo_iou_sums(c, s->H, s->goal, &inter, &uni);
+    if (c->metric == SRL_METRIC_OR) return inter / ((float)(s->goal[2] * s->goal[3]) * e->goal_z);
+    return inter / uni;
+  }
+  float pmax = (float)c->object_res * e->px;     /* rewarder.py:126 */
+  float omax = 3.14159265358979f;
+  float r = 0.0f; int nout = 0;
+  for (int b = 0; b < s->nb; ++b) {
+    float fu = floorf(s->x[b].x / e->px), fv = floorf(s->x[b].y / e->px); /* xy_to_pixel: // */
+    int in = fu >= (float)s->goal[0] && fv >= (float)s->goal[1] &&
+             fu < (float)(s->goal[0] + s->goal[2]) && fv < (float)(s->goal[1] + s->goal[3]);
+    if (!in) { nout++; continue; }
+    v3 dp = vsub(s->place_x[b], s->x[b]);
+    float perr = sqrtf(vdot(dp, dp));
+    q4 a = s->place_q[b], q = s->q[b];
+    float dw = fabsf((a.x * q.x + a.y * q.y) + (a.z * q.z + a.w * q.w));
+    float oerr = 2.0f * srlo_acosf(fminf(dw, 1.0f));
+    float disc = 1.0f;
+    if (c->reward_pexp >= 0) {
+      float t = perr / pmax, pw = 1.0f;
+      for (int k = 0; k < c->reward_pexp; ++k) pw = pw * t;
+      disc = disc * fmaxf(0.0f, 1.0f - pw);
+    }
+    if (c->reward_oexp >= 0) {
+      float t = oerr / omax, pw = 1.0f;
+      for (int k = 0; k < c->reward_oexp; ++k) pw = pw * t;
+      disc = disc * fmaxf(0.0f, 1.0f - pw);
+    }
+    r = r + disc;
+  }
+  if (c->metric == SRL_METRIC_DOR) return r / (float)c->episode_length;
+  return r / (float)(c->episode_length + nout);
+}
+
+/* ------------------------------------------------------------------ episode machine */
+static void pack_obs(const struct srlo_env* e, const env_t* s, uint8_t* om, uint8_t* oo) {
+  const srl_config* c = &e->c;
+  int res = c->overhead_res, r = c->object_res;
+  float den = fmaxf(c->max_z, c->object_max_dimension);            /* env.py:171-172 */
+  for (int i = 0; i < res; ++i)
+    for (int j = 0; j < res; ++j) {
+      int in = (i >= s->goal[0] && i < s->goal[0] + s->goal[2] && j >= s->goal[1] && j < s->goal[1] + s->goal[3]);
+      float g = in ? e->goal_z : 0.0f;
+      om[(i * res + j) * 2 + 0] = (uint8_t)((s->H[i * res + j] * 255.0f) / den);
+      om[(i * res + j) * 2 + 1] = (uint8_t)((g * 255.0f) / den);
+    }
+  for (int k = 0; k < r * r; ++k) oo[k] = (uint8_t)((s->O[k] * 255.0f) / den);
+}
+
+static void env_reset(struct srlo_env* e, int i) {
+  env_t* s = &e->env[i];
+  const srl_config* c = &e->c;
+  int L = c->episode_length;
+  uint32_t key = e->seed + (uint32_t)c->env_index_offset + (uint32_t)i;   /* utils.py:433 */
+  s->episode += 1;
+  if (s->has_script) {
+    for (int k = 0; k < L; ++k) s->ids[k] = s->script_ids[k];
+    for (int k = 0; k < 4; ++k) s->goal[k] = s->script_goal[k];
+    s->has_script = 0;
+  } else {
+    /* env.py:268-272: L mesh files without replacement (with, if the pool is smaller) */
+    uint32_t draw = 0;
+    for (int k = 0; k < L; ++k) {
+      for (;;) {
+        int id = (int)rng_below(srlo_rng(key, s->episode, STREAM_MESH, draw++), (uint32_t)e->n_mesh);
+        int dup = 0;
+        if (e->n_mesh >= L) for (int j = 0; j < k; ++j) dup |= (s->ids[j] == id);
+        if (!dup) { s->ids[k] = id; break; }
+      }
+    }
+    srlo_goal_from_rng(c, key, s->episode, s->goal);
+  }
+  /* Simulator.reset: empty world + first rock pending (simulator.py:156-188) */
+  s->nb = 0;
+  for (int k = 0; k < NPAIR; ++k) s->slot_of_pair[k] = -1;
+  for (int k = 0; k < MAXSLOT; ++k) s->pair_of_slot[k] = -1;
+  s->ncolour = -1;
+  s->pending = s->ids[0];
+  s->list_pos = 1;
+  s->prev_metric = 0.0f;                                                  /* rewarder.py:191-194 */
+  s->substeps[0] = 0; s->substeps[1] = 0;
+  s->status = 0;
+  render_heightmap(e, 0, s->mesh, s->x, s->q, s->H);
+  render_object(e, s->pending, s->O);
+  s->done = 0;
+}
+
+int srlo_reset(srlo_env* e, uint8_t* obs_map, uint8_t* obs_obj) {
+  if (!e->mesh) return fail(SRL_ENOMESH, "load meshes first");
+  const srl_config* c = &e->c;
+  size_t nm = (size_t)c->overhead_res * c->overhead_res * 2, no = (size_t)c->object_res * c->object_res;
+  for (int i = 0; i < c->n_envs; ++i) {
+    env_reset(e, i);
+    pack_obs(e, &e->env[i], obs_map + nm * i, obs_obj + no * i);
+  }
+  return SRL_OK;
+}
+
+int srlo_step(srlo_env* e, const int64_t* action, uint8_t* obs_map, uint8_t* obs_obj, float* reward,
+              uint8_t* done) {
+  if (!e->mesh) return fail(SRL_ENOMESH, "load meshes first");
+  const srl_config* c = &e->c;
+  size_t nm = (size_t)c->overhead_res * c->overhead_res * 2, no = (size_t)c->object_res * c->object_res;
+  int rc = SRL_OK;
+  for (int i = 0; i < c->n_envs; ++i) {
+    env_t* s = &e->env[i];
+    if (s->done) {                                       /* env.py:235-236 */
+      env_reset(e, i);
+      reward[i] = 0.0f; done[i] = 0;
+      pack_obs(e, s, obs_map + nm * i, obs_obj + no * i);
+      continue;
+    }
+    int64_t a = action[i];
+    if (a < 0 || a >= (int64_t)e->A) {                   /* env.py:238 */
+      s->status |= SRL_ST_BAD_ACTION;
+      reward[i] = 0.0f; done[i] = 0;
+      pack_obs(e, s, obs_map + nm * i, obs_obj + no * i);
+      rc = SRL_EINVAL_ACTION;
+      continue;
+    }
+    s->status &= ~SRL_ST_BAD_ACTION;
+    int u = (int)(a / e->AW), v = (int)(a % e->AW);      /* env.py:240-241 */
+    int next = -1;
+    if (s->list_pos < c->episode_length) next = s->ids[s->list_pos++];   /* env.py:243-247 */
+    else s->done = 1;
+    float xyz[3];
+    srlo_pose(c, s->H, s->O, u, v, xyz);
+    sim_step(e, s, V(xyz[0], xyz[1], xyz[2]));
+    s->pending = next;                                   /* _load, simulator.py:258 */
+    render_heightmap(e, s->nb, s->mesh, s->x, s->q, s->H);
+    render_object(e, s->pending, s->O);
+    float mv = metric_value(e, s);
+    reward[i] = (mv - s->prev_metric) * e->scale;        /* rewarder.py:176-179 */
+    s->prev_metric = mv;
+    done[i] = (uint8_t)s->done;
+    pack_obs(e, s, obs_map + nm * i, obs_obj + no * i);
+    if ((s->status & SRL_ST_DIVERGED) && rc == SRL_OK) rc = SRL_ESIM_DIVERGED;
+  }
+  if (rc == SRL_EINVAL_ACTION) fail(rc, "Invalid action.");
+  if (rc == SRL_ESIM_DIVERGED) fail(rc, "Maximum number of simulator steps reached.");
+  return rc;
+}
+
+int srlo_sample(srlo_env* e, int64_t* action) {
+  const srl_config* c = &e->c;
+  e->sample_counter += 1;
+  for (int i = 0; i < c->n_envs; ++i) {
+    uint32_t key = e->seed + (uint32_t)c->env_index_offset + (uint32_t)i;
+    action[i] = (int64_t)rng_below(srlo_rng(key, e->sample_counter, STREAM_ACTION, 0), (uint32_t)e->A);
+  }
+  return SRL_OK;
+}
+
+/* ------------------------------------------------------------------ telemetry */
+int srlo_get_state(srlo_env* e, float* poses, int32_t* n_bodies, int32_t* substeps, int32_t* status) {
+  for (int i = 0; i < e->c.n_envs; ++i) {
+    env_t* s = &e->env[i];
+    if (poses) {
+      float* p = poses + (size_t)i * MAXB * 8;
+      memset(p, 0, sizeof(float) * MAXB * 8);
+      for (int b = 0; b < s->nb; ++b) {
+        p[b * 8 + 0] = s->x[b].x; p[b * 8 + 1] = s->x[b].y; p[b * 8 + 2] = s->x[b].z;
+        p[b * 8 + 3] = s->q[b].x; p[b * 8 + 4] = s->q[b].y; p[b * 8 + 5] = s->q[b].z; p[b * 8 + 6] = s->q[b].w;
+        p[b * 8 + 7] = (float)s->mesh[b];
+      }
+    }
+    if (n_bodies) n_bodies[i] = s->nb;
+    if (substeps) { substeps[2 * i] = s->substeps[0]; substeps[2 * i + 1] = s->substeps[1]; }
+    if (status) status[i] = s->status;
+  }
+  return SRL_OK;
+}
+
+int srlo_get_velocities(srlo_env* e, float* vel) {
+  for (int i = 0; i < e->c.n_envs; ++i) {
+    env_t* s = &e->env[i];
+    float* p = vel + (size_t)i * MAXB * 8;
+    memset(p, 0, sizeof(float) * MAXB * 8);
+    for (int b = 0; b < s->nb; ++b) {
+      p[b * 8 + 0] = s->v[b].x; p[b * 8 + 1] = s->v[b].y; p[b * 8 + 2] = s->v[b].z;
+      p[b * 8 + 4] = s->w[b].x; p[b * 8 + 5] = s->w[b].y; p[b * 8 + 6] = s->w[b].z;
+    }
+  }
+  return SRL_OK;
+}
+
+int srlo_get_contacts(srlo_env* e, float* max_pen, int32_t* n_points) {
+  for (int i = 0; i < e->c.n_envs; ++i) {
+    env_t* s = &e->env[i];
+    float mp = 0.0f; int np = 0;
+    for (int b = 0; b < s->nb; ++b)
+      for (int k = 0; k < s->gm[b].np; ++k) { np++; if (-s->gm[b].dist[k] > mp) mp = -s->gm[b].dist[k]; }
+    for (int sl = 0; sl < MAXSLOT; ++sl)
+      if (s->pair_of_slot[sl] >= 0)
+        for (int k = 0; k < s->man[sl].np; ++k) { np++; if (-s->man[sl].p[k].dist > mp) mp = -s->man[sl].p[k].dist; }
+    if (max_pen) max_pen[i] = mp;
+    if (n_points) n_points[i] = np;
+  }
+  return SRL_OK;
+}
+
+int srlo_get_maps(srlo_env* e, float* height, float* object_map, int32_t* goal_rect) {
+  const srl_config* c = &e->c;
+  size_t nh = (size_t)c->overhead_res * c->overhead_res, no = (size_t)c->object_res * c->object_res;
+  for (int i = 0; i < c->n_envs; ++i) {
+    env_t* s = &e->env[i];
+    if (height) memcpy(height + nh * i, s->H, nh * sizeof(float));
+    if (object_map) memcpy(object_map + no * i, s->O, no * sizeof(float));
+    if (goal_rect) for (int k = 0; k < 4; ++k) goal_rect[4 * i + k] = s->goal[k];
+  }
+  return SRL_OK;
+}
+
+int srlo_render_heightmap(srlo_env* e, const float* poses, const int32_t* mesh_ids, int32_t nb, float* height) {
+  if (!e->mesh) return fail(SRL_ENOMESH, "load meshes first");
+  if (nb < 0 || nb > MAXB) return fail(SRL_EINVAL, "n_bodies out of range");
+  int mesh[MAXB]; v3 x[MAXB]; q4 q[MAXB];
+  for (int b = 0; b < nb; ++b) {
+    if (mesh_ids[b] < 0 || mesh_ids[b] >= e->n_mesh) return fail(SRL_EINVAL, "mesh id out of range");
+    mesh[b] = mesh_ids[b];
+    x[b] = V(poses[7 * b], poses[7 * b + 1], poses[7 * b + 2]);
+    q[b].x = poses[7 * b + 3]; q[b].y = poses[7 * b + 4]; q[b].z = poses[7 * b + 5]; q[b].w = poses[7 * b + 6];
+  }
+  render_heightmap(e, nb, mesh, x, q, height);
+  return SRL_OK;
+}
+
+int srlo_render_object(srlo_env* e, int32_t mesh_id, float* object_map) {
+  if (!e->mesh) return fail(SRL_ENOMESH, "load meshes first");
+  if (mesh_id >= e->n_mesh) return fail(SRL_EINVAL, "mesh id out of range");
+  render_object(e, mesh_id, object_map);
+  return SRL_OK;
+}
+
+/* debug / invariant hook: run `n` raw sub-steps on env `i` (no stop criterion) */
+int srlo_debug_substeps(srlo_env* e, int32_t i, int32_t n) {
+  if (i < 0 || i >= e->c.n_envs) return fail(SRL_EINVAL, "env index");
+  for (int k = 0; k < n; ++k) substep(e, &e->env[i]);
+  return SRL_OK;
+}
+
+int srlo_debug_dump(srlo_env* e, int32_t i) {
+  env_t* s = &e->env[i];
+  for (int b = 0; b < s->nb; ++b) {
+    printf(" body %d mesh %d x=(%.5f %.5f %.5f) v=(%.5f %.5f %.5f) w=(%.4f %.4f %.4f)\n", b, s->mesh[b], s->x[b].x, s->x[b].y, s->x[b].z,
+           s->v[b].x, s->v[b].y, s->v[b].z, s->w[b].x, s->w[b].y, s->w[b].z);
+    for (int k = 0; k < s->gm[b].np; ++k)
+      printf("   ground vid %d dist %.6f in %.6f it %.6f %.6f\n", s->gm[b].vid[k], s->gm[b].dist[k], s->gm[b].in[k], s->gm[b].it1[k], s->gm[b].it2[k]);
+  }
+  for (int sl = 0; sl < MAXSLOT; ++sl) if (s->pair_of_slot[sl] >= 0) {
+    manifold_t* m = &s->man[sl];
+    printf(" slot %d (%d,%d) colour %d np %d\n", sl, s->slot_a[sl], s->slot_b[sl], s->colour[sl], m->np);
+    for (int k = 0; k < m->np; ++k)
+      printf("   dist %.6f n=(%.4f %.4f %.4f) la=(%.4f %.4f %.4f) in %.6f it %.6f %.6f\n", m->p[k].dist, m->p[k].n.x, m->p[k].n.y, m->p[k].n.z,
+             m->p[k].la.x, m->p[k].la.y, m->p[k].la.z, m->p[k].in, m->p[k].it1, m->p[k].it2);
+  }
+  fflush(stdout);
+  return 0;
+}

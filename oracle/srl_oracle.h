@@ -1,0 +1,89 @@
+/* srl_oracle.h — CPU oracle for the Stack-v0 hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or
+ * call this library; the product (stackrl_amd/) never does.
+ *
+ * It is a plain-C, single-threaded, one-env-at-a-time restatement of
+ *   stackrl/envs/stack/env.py:225-293      (episode machine, observation packing)
+ *   stackrl/envs/stack/observer.py:249-277 (depth -> elevation), :392-421 (pose)
+ *   stackrl/envs/stack/rewarder.py:144-307 (goal + 4 reward metrics)
+ *   stackrl/envs/stack/simulator.py:190-341 (place / smooth placing / settle loops)
+ * plus the build-owned definition of what pybullet does behind those calls
+ * (rasteriser, GJK + persistent manifolds + sequential impulses).
+ *
+ * PARITY PINNING: the observer arithmetic (depth->elevation, flip, pose, pixel<->xy) is
+ * pinned against golden vectors produced by the reference's own observer.py
+ * (tests/golden/observer_golden.npz).  The physics/rasteriser live in the unpinned
+ * third-party `pybullet` wheel with no reference tests: for those rows the oracle is
+ * "parity unpinned" and is the build's own definition.
+ */
+#ifndef SRL_ORACLE_H_
+#define SRL_ORACLE_H_
+
+#include "../include/srl_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct srlo_env srlo_env;
+
+int srlo_create(const srl_config* cfg, srlo_env** out);
+void srlo_destroy(srlo_env* e);
+const char* srlo_last_error(void);
+
+/* Mesh pool: OBJ-style data in the URDF link frame (data/generated/<name>.obj + .urdf).
+ * verts[vert_off[m] .. vert_off[m+1]) float xyz; tris[tri_off[m] .. tri_off[m+1]) int32 ijk
+ * (0-based, per-mesh local, outward CCW); mass_com[m] = {mass, com_x, com_y, com_z}. */
+int srlo_load_meshes(srlo_env* e, const float* verts, const int32_t* vert_off,
+                     const int32_t* tris, const int32_t* tri_off,
+                     const float* mass_com, int32_t n_mesh);
+
+int srlo_seed(srlo_env* e, uint32_t seed);
+
+/* Explicit episode scripts (parity tests drive identical scripts on both sides):
+ * mesh_ids [n_envs, L], goal_rect [n_envs, 4] = (u, v, h, w).  Used for the NEXT reset of
+ * each env and consumed by it; later episodes fall back to the counter RNG. */
+int srlo_set_script(srlo_env* e, const int32_t* mesh_ids, const int32_t* goal_rect);
+
+/* obs_map u8 [n, H, W, 2], obs_obj u8 [n, h, w, 1], reward f32 [n], done u8 [n]. */
+int srlo_reset(srlo_env* e, uint8_t* obs_map, uint8_t* obs_obj);
+int srlo_step(srlo_env* e, const int64_t* action, uint8_t* obs_map, uint8_t* obs_obj,
+              float* reward, uint8_t* done);
+int srlo_sample(srlo_env* e, int64_t* action);
+
+/* Telemetry = Simulator.poses / n_steps / Observer.state / Rewarder.goal.
+ * poses [n, SRL_MAX_BODIES, 8] = (px,py,pz, qx,qy,qz,qw, mesh_id as float); n_bodies [n];
+ * substeps [n, 2] = (S_a, S_b) of the last step (simulator.py:79-83); status [n]. */
+int srlo_get_state(srlo_env* e, float* poses, int32_t* n_bodies, int32_t* substeps,
+                   int32_t* status);
+int srlo_get_maps(srlo_env* e, float* height, float* object_map, int32_t* goal_rect);
+int srlo_get_velocities(srlo_env* e, float* vel /* [n, SRL_MAX_BODIES, 8] lin xyz0 ang xyz0 */);
+/* manifold telemetry for invariants: max penetration depth (metres, >= 0) per env */
+int srlo_get_contacts(srlo_env* e, float* max_penetration, int32_t* n_points);
+
+/* Pure functions (closed-form units) ---------------------------------------------- */
+/* Render the overhead height map for explicit poses: poses [n_bodies, 7] (COM frame),
+ * mesh_ids [n_bodies]  ->  height f32 [H*W]. */
+int srlo_render_heightmap(srlo_env* e, const float* poses, const int32_t* mesh_ids,
+                          int32_t n_bodies, float* height);
+int srlo_render_object(srlo_env* e, int32_t mesh_id, float* object_map);
+/* depth->elevation, observer.py:259-260 (which = 0) and :274-277 incl. flip (which = 1) */
+void srlo_depth_to_elevation(const srl_config* cfg, int which, const float* depth, float* elev);
+/* Observer.pose, observer.py:392-421: returns x,y,z */
+void srlo_pose(const srl_config* cfg, const float* height, const float* object_map,
+               int32_t u, int32_t v, float* xyz);
+/* Rewarder sums (rewarder.py:297-307) in the oracle's fixed summation order */
+void srlo_iou_sums(const srl_config* cfg, const float* height, const int32_t* goal_rect,
+                   float* inter, float* uni);
+/* counter RNG draw (key, episode, stream, draw) -> u32 */
+uint32_t srlo_rng(uint32_t key, uint32_t episode, uint32_t stream, uint32_t draw);
+/* goal rectangle from the counter RNG (rewarder.py:225-259 restated on integer order statistics) */
+void srlo_goal_from_rng(const srl_config* cfg, uint32_t key, uint32_t episode, int32_t* rect);
+float srlo_acosf(float x);
+int srlo_debug_substeps(srlo_env* e, int32_t env_index, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
