@@ -1,0 +1,104 @@
+/* stackrl_hip.h — C-ABI of libstackrl_hip.so, the MI355X-native batched Stack-v0 env step.
+ *
+ * This is the drop-in boundary for the reference's `stackrl.envs.make('Stack-v0', n_parallel=B)`
+ * object (stackrl/envs/utils.py:185-300 `Env`, :302-576 `ParallelEnv`): one handle owns B
+ * independent envs on one GPU; `srl_step` replaces the `conn.send((STEP, a))` / `conn.recv()`
+ * fan-out (utils.py:468-486, :540-543, :554-566) plus everything each worker process runs for it
+ * (`StackEnv.step` env.py:233-264 -> `Observer.pose` observer.py:392-421 -> `Simulator.step`
+ * simulator.py:190-258 -> `Observer.__call__` observer.py:249-277 -> `Rewarder.__call__`
+ * rewarder.py:144-179 -> `StackEnv.observation` env.py:225-231).
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in the signatures; `stream` is a hipStream_t passed as void*
+ *    (NULL = the null stream).
+ *  - "dev" pointers are device memory owned by the caller; "host" pointers are host memory.
+ *  - every function returns an SRL_* code (include/srl_types.h); `srl_last_error()` gives the
+ *    message of the calling thread's last failure.
+ *  - `srl_reset/srl_step/srl_sample` only enqueue work on `stream` and return; the caller's
+ *    buffers are valid when the stream reaches that point.  No allocation happens in them.
+ *  - a handle is not thread-safe; distinct handles are independent.
+ */
+#ifndef STACKRL_HIP_H_
+#define STACKRL_HIP_H_
+
+#include "srl_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct srl_env srl_env;
+
+/* Stack-v0 defaults: env.py:28-51 under the registry kwargs of envs/stack/__init__.py:4-8. */
+int srl_config_default(srl_config* cfg);
+
+/* `envs.make(...)` / `ParallelEnv.__init__` + `start` (utils.py:311-448): allocates all device state
+ * for cfg->n_envs envs on the current HIP device. */
+int srl_create(const srl_config* cfg, srl_env** out);
+/* `ParallelEnv.terminate` (utils.py:450-466). */
+void srl_destroy(srl_env* env);
+const char* srl_last_error(void);
+
+/* Mesh pool = the URDF list `data.generated(name='[5-9]?')` (envs/data/__init__.py:39-83) preloaded
+ * once instead of `loadURDF` per step (simulator.py:297-308).  Host pointers, OBJ/URDF link frame:
+ * verts float[vert_off[n_mesh]][3]; tris int32[tri_off[n_mesh]][3] per-mesh local, outward CCW;
+ * mass_com float[n_mesh][4] = mass, inertial origin xyz (template.urdf:8-9). */
+int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, const int32_t* tris,
+                    const int32_t* tri_off, const float* mass_com, int32_t n_mesh);
+
+/* `ParallelEnv.seed` (utils.py:522-532) / `StackEnv.seed` (env.py:341-346): env i uses
+ * seed + env_index_offset + i (mod 2^32) as the key of its counter RNG; episode counters restart. */
+int srl_seed(srl_env* env, uint32_t seed);
+
+/* Explicit episode script for the NEXT reset of every env (host pointers): mesh_ids int32[n][L],
+ * goal_rect int32[n][4] = (u, v, h, w).  Stands in for the reference's RNG streams
+ * (env.py:268-272, rewarder.py:211-259), which are gym-version dependent. */
+int srl_set_script(srl_env* env, const int32_t* mesh_ids, const int32_t* goal_rect);
+
+/* `ParallelEnv.reset` (utils.py:488-503, :545-552): obs_map u8[n][H][W][2], obs_obj u8[n][h][w][1]. */
+int srl_reset(srl_env* env, void* obs_map_dev, void* obs_obj_dev, void* stream);
+
+/* `ParallelEnv.step` (utils.py:468-486): action int64[n]; reward float[n]; done uint8[n].
+ * Auto-reset semantics of env.py:235-236 are kept: a step on a finished env returns the reset
+ * observation, reward 0, done 0. */
+int srl_step(srl_env* env, const int64_t* action_dev, void* obs_map_dev, void* obs_obj_dev,
+             float* reward_dev, uint8_t* done_dev, void* stream);
+
+/* `ParallelEnv.sample` (utils.py:534-538): uniform actions in [0, A), int64[n] on the device. */
+int srl_sample(srl_env* env, int64_t* action_dev, void* stream);
+
+/* Blocks until `stream` is idle and reports what the reference would have raised during the steps
+ * since the last call: SRL_EINVAL_ACTION ("Invalid action.", env.py:238), SRL_ESIM_DIVERGED
+ * (simulator.py:221-224 / :242-245), else SRL_OK. */
+int srl_sync_status(srl_env* env, void* stream);
+
+/* Telemetry (host pointers, synchronises the device; any pointer may be NULL):
+ * `Simulator.poses` (simulator.py:90-93) as float[n][SRL_MAX_BODIES][8] = pos xyz, quat xyzw, mesh id;
+ * n_bodies int32[n]; `Simulator.n_steps` (simulator.py:79-83) int32[n][2]; status bits int32[n]. */
+int srl_get_state(srl_env* env, float* poses, int32_t* n_bodies, int32_t* substeps, int32_t* status);
+/* `Observer.state` (observer.py:365-368) float[n][H*W], float[n][h*w]; `Rewarder` goal rect int32[n][4]. */
+int srl_get_maps(srl_env* env, float* height, float* object_map, int32_t* goal_rect);
+/* velocities float[n][SRL_MAX_BODIES][8] = lin xyz 0, ang xyz 0 */
+int srl_get_velocities(srl_env* env, float* vel);
+/* contact telemetry: deepest penetration (m) and number of manifold points per env */
+int srl_get_contacts(srl_env* env, float* max_penetration, int32_t* n_points);
+
+/* Renderer on explicit poses (test / profiling hook for the O1 row, observer.py:252-260):
+ * poses_dev float[n][SRL_MAX_BODIES][7] (COM frame), mesh_ids_dev int32[n][SRL_MAX_BODIES],
+ * n_bodies_dev int32[n] -> height_dev float[n][H*W]. */
+int srl_render_heightmap(srl_env* env, const float* poses_dev, const int32_t* mesh_ids_dev,
+                         const int32_t* n_bodies_dev, float* height_dev, void* stream);
+/* O2 row: underside map of one mesh (observer.py:262-277), host output float[h*w]. */
+int srl_get_object_map(srl_env* env, int32_t mesh_id, float* object_map);
+
+/* Per-kernel HIP-event timing (bench.py's roofline leg).  enable != 0 brackets every kernel launch of
+ * srl_reset/srl_step with events on the launch stream; srl_get_kernel_times synchronises and returns the
+ * accumulated milliseconds and launch counts since the last call: index 0 = settle (K1+K4),
+ * 1 = render (K2+K5+obs pack), 2 = reserved. */
+int srl_set_profiling(srl_env* env, int32_t enable);
+int srl_get_kernel_times(srl_env* env, float* ms3, int32_t* launches3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STACKRL_HIP_H_ */

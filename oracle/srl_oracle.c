@@ -1076,7 +1076,7 @@ static int sim_drop(const struct srlo_env* e, const env_t* s) {
 
 /* Simulator.step, simulator.py:190-258 */
 static void sim_step(const struct srlo_env* e, env_t* s, v3 pos) {
-  int counter = 0;
+  int counter = 0, diverged = 0;
   if (s->pending >= 0) {             /* _place, simulator.py:310-320 */
     int b = s->nb;
     const mesh_t* M = &e->mesh[s->pending];
@@ -1096,18 +1096,21 @@ static void sim_step(const struct srlo_env* e, env_t* s, v3 pos) {
       s->v[s->nb - 1] = V(0, 0, 0); s->w[s->nb - 1] = V(0, 0, 0);
       substep(e, s);
       counter++;
-      if (counter > e->max_substeps) { s->status |= SRL_ST_DIVERGED; break; }
+      if (counter > e->max_substeps) { diverged = 1; break; }
     }
   }
   s->place_x[s->nb - 1] = s->x[s->nb - 1];
   s->place_q[s->nb - 1] = s->q[s->nb - 1];
   s->substeps[0] = counter;
-  while (!(s->status & SRL_ST_DIVERGED) && !sim_stop(e, s)) {
+  while (!diverged && !sim_stop(e, s)) {
     substep(e, s);
     counter++;
-    if (counter > e->max_substeps) { s->status |= SRL_ST_DIVERGED; break; }
+    if (counter > e->max_substeps) { diverged = 1; break; }
   }
   s->substeps[1] = counter - s->substeps[0];
+  /* the reference raises RuntimeError here (simulator.py:221-224, :242-245); the flag stays set
+   * until the next reset so the caller can see which env it was */
+  if (diverged) s->status |= SRL_ST_DIVERGED;
 }
 
 /* ------------------------------------------------------------------ reward (rewarder.py:162-179, :261-295) */

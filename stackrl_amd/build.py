@@ -1,0 +1,36 @@
+"""Builds libstackrl_hip.so in-tree with hipcc for gfx950 (no JIT cache: the .so travels with the tree)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libstackrl_hip.so')
+SOURCES = ['stackrl_hip.hip']
+DEPS = ['stackrl_hip.hip', 'settle.hip', 'render.hip', 'srl_device.h', 'srl_kernels.h',
+        os.path.join('..', '..', 'include', 'stackrl_hip.h'), os.path.join('..', '..', 'include', 'srl_types.h')]
+# -ffp-contract=off: the solver/rasteriser definition is "one IEEE rounding per written operation"
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+         '-fno-fast-math', '-Wall', '-Wno-unused-function', '-Wno-unused-value', '-Wno-unused-result']
+
+
+def stale():
+  if not os.path.isfile(LIB):
+    return True
+  t = os.path.getmtime(LIB)
+  return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+  if not force and not stale():
+    return LIB
+  hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+  cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
+  if verbose:
+    print(' '.join(cmd), file=sys.stderr)
+  subprocess.check_call(cmd)
+  return LIB
+
+
+if __name__ == '__main__':
+  build(force='-f' in sys.argv, verbose=True)

@@ -1,0 +1,708 @@
+// settle.hip — K1 (place / smooth placing / settle) + K4 (Observer.pose) + the episode machine.
+//
+// One workgroup per env.  The env's whole persistent state ("blob": poses, velocities, ground and
+// body-body manifolds with their warm-start impulses, slot tables) is loaded into LDS once, every
+// sub-step runs out of LDS, and the blob is written back once — HBM traffic per env step is
+// 2 x BLOB words regardless of how many sub-steps the stop criterion takes.
+//
+// Work mapping per sub-step (DESIGN.md "settle solver"):
+//   lane = body   damping+gravity, rotation, world vertices, AABB, ground manifold, integration
+//   lane = pair   AABB broadphase over all i<j pairs, slot release
+//   lane = slot   manifold refresh, GJK closest points, manifold insert, sequential impulses
+// Sequential-impulse sweeps visit "ground" then the contact-graph colours in order; slots of one
+// colour touch disjoint bodies, so a sweep is order-independent inside a phase and the result is
+// the same as the sequential definition.
+//
+// Reference call sites restated: simulator.py:190-258 (step), :310-341 (_place/_stop/_drop),
+// observer.py:392-421 (pose), env.py:233-247 (action unflatten, episode list), env.py:266-293 (reset).
+#include "srl_device.h"
+#include "srl_kernels.h"
+
+__constant__ uint8_t c_pair_i[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
+__constant__ uint8_t c_pair_j[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
+
+// misc words in LDS
+enum { M_MODE = 0, M_U, M_V, M_NEXT, M_ZMAX, M_FLAGS, M_NCOL, M_CNT, M_NB, M_PENDING, M_STATUS, M_DONE, M_WORDS = 16 };
+
+struct Lds {
+  float* sm;
+  const DevParams* P;
+  __device__ __forceinline__ float* X(int b) const { return sm + P->OFF_X + 3 * b; }
+  __device__ __forceinline__ float* Q(int b) const { return sm + P->OFF_Q + 4 * b; }
+  __device__ __forceinline__ float* Vl(int b) const { return sm + P->OFF_V + 3 * b; }
+  __device__ __forceinline__ float* Wl(int b) const { return sm + P->OFF_W + 3 * b; }
+  __device__ __forceinline__ float* PX(int b) const { return sm + P->OFF_PX + 3 * b; }
+  __device__ __forceinline__ float* PQ(int b) const { return sm + P->OFF_PQ + 4 * b; }
+  __device__ __forceinline__ int* MESH() const { return (int*)(sm + P->OFF_MESH); }
+  __device__ __forceinline__ float* GM(int b) const { return sm + P->OFF_GM + SRL_GM_WORDS * b; }
+  __device__ __forceinline__ float* MAN(int s) const { return sm + P->OFF_MAN + SRL_MAN_WORDS * s; }
+  __device__ __forceinline__ int* SOP() const { return (int*)(sm + P->OFF_SOP); }
+  __device__ __forceinline__ int* POS() const { return (int*)(sm + P->OFF_POS); }
+  __device__ __forceinline__ int* COL() const { return (int*)(sm + P->OFF_COL); }
+  __device__ __forceinline__ float* R(int b) const { return sm + P->BLOB + P->S_R + 9 * b; }
+  __device__ __forceinline__ float* IW(int b) const { return sm + P->BLOB + P->S_IW + 9 * b; }
+  __device__ __forceinline__ float* AMIN(int b) const { return sm + P->BLOB + P->S_AMIN + 3 * b; }
+  __device__ __forceinline__ float* AMAX(int b) const { return sm + P->BLOB + P->S_AMAX + 3 * b; }
+  __device__ __forceinline__ float* BC(int b) const { return sm + P->BLOB + P->S_BC + 8 * b; }  // inv_mass, ii xyz, radius, nv, vo, mesh
+  __device__ __forceinline__ float* WV(int b) const { return sm + P->BLOB + P->S_WV + 3 * P->VS * b; }
+  __device__ __forceinline__ int* MISC() const { return (int*)(sm + P->BLOB + P->S_MISC); }
+};
+
+// ------------------------------------------------------------------ episode reset (env.py:266-293)
+__device__ void goal_from_rng(const DevParams& P, uint32_t key, uint32_t episode, int32_t* rect) {
+  int H = P.c.overhead_res;
+  uint32_t bbit = srl_rng(key, episode, SRL_STREAM_GOAL, 0) >> 31;
+  uint32_t u0 = srl_rng(key, episode, SRL_STREAM_GOAL, 1) >> 8;
+  uint32_t u1 = srl_rng(key, episode, SRL_STREAM_GOAL, 2) >> 8;
+  uint32_t u2 = srl_rng(key, episode, SRL_STREAM_GOAL, 3) >> 8;
+  uint32_t lo = u0 < u1 ? u0 : u1; lo = lo < u2 ? lo : u2;
+  uint32_t hi = u0 > u1 ? u0 : u1; hi = hi > u2 ? hi : u2;
+  uint32_t X = bbit ? hi : lo;   // Beta(3,1) = max of 3 uniforms, Beta(1,3) = min of 3 (rewarder.py:227-231)
+  int h = P.goal_min_h + (int)(((uint64_t)X * (uint64_t)(P.goal_max_h - P.goal_min_h)) >> 24);
+  int w = P.goal_size / h;
+  if (w < P.goal_min_w) w = P.goal_min_w;
+  if (w > P.goal_max_w) w = P.goal_max_w;
+  int umax = H - h, vmax = H - w;
+  int ulo = umax / 8, uhi = 7 * umax / 8 + 1;
+  int vlo = vmax / 8, vhi = 7 * vmax / 8 + 1;
+  rect[0] = ulo + (int)srl_rng_below(srl_rng(key, episode, SRL_STREAM_GOAL, 4), (uint32_t)(uhi - ulo));
+  rect[1] = vlo + (int)srl_rng_below(srl_rng(key, episode, SRL_STREAM_GOAL, 5), (uint32_t)(vhi - vlo));
+  rect[2] = h; rect[3] = w;
+}
+
+__device__ void env_reset(const DevParams& P, EnvHdr* h, int e) {
+  int L = P.c.episode_length;
+  uint32_t key = P.seed + (uint32_t)P.c.env_index_offset + (uint32_t)e;   // utils.py:433
+  h->episode += 1;
+  if (h->has_script) {
+    for (int k = 0; k < L; ++k) h->ids[k] = h->script_ids[k];
+    for (int k = 0; k < 4; ++k) h->goal[k] = h->script_goal[k];
+    h->has_script = 0;
+  } else {
+    uint32_t draw = 0;
+    for (int k = 0; k < L; ++k) {
+      for (;;) {   // env.py:268-272: without replacement unless the pool is smaller than L
+        int id = (int)srl_rng_below(srl_rng(key, h->episode, SRL_STREAM_MESH, draw++), (uint32_t)P.n_mesh);
+        int dup = 0;
+        if (P.n_mesh >= L) for (int j = 0; j < k; ++j) dup |= (h->ids[j] == id);
+        if (!dup) { h->ids[k] = id; break; }
+      }
+    }
+    goal_from_rng(P, key, h->episode, h->goal);
+  }
+  h->nb = 0;
+  h->ncolour = -1;
+  h->pending = h->ids[0];
+  h->list_pos = 1;
+  h->prev_metric = 0.0f;   // rewarder.py:191-194
+  h->substeps[0] = 0; h->substeps[1] = 0;
+  h->status = 0;
+  h->done = 0;
+}
+
+// ------------------------------------------------------------------ per-body derived state + ground manifold
+__device__ void body_phase(const Lds& L, int b, bool dyn) {
+  const DevParams& P = *L.P;
+  float dt = P.c.sim_time_step;
+  if (dyn) {   // btRigidBody::applyDamping, then the gravity impulse
+    v3 v = ld3(L.Vl(b)) * P.lin_damp;
+    v3 w = ld3(L.Wl(b)) * P.ang_damp;
+    v.z = v.z - P.c.gravity * dt;
+    st3(L.Vl(b), v); st3(L.Wl(b), w);
+  }
+  const float* bc = L.BC(b);
+  int nv = __float_as_int(bc[5]), vo = __float_as_int(bc[6]);
+  float radius = bc[4];
+  q4 q; q.x = L.Q(b)[0]; q.y = L.Q(b)[1]; q.z = L.Q(b)[2]; q.w = L.Q(b)[3];
+  m3 R = quat_to_mat(q);
+  m3 I = inv_inertia_world(R, V(bc[1], bc[2], bc[3]));
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { L.R(b)[i] = R.m[i]; L.IW(b)[i] = I.m[i]; }
+  v3 x = ld3(L.X(b));
+  v3 lo = V(1e30f, 1e30f, 1e30f), hi = V(-1e30f, -1e30f, -1e30f);
+  float* W = L.WV(b);
+  for (int k = 0; k < nv; ++k) {
+    float4 lv = P.mv[vo + k];
+    v3 a = x + mmul(R, V(lv.x, lv.y, lv.z));
+    st3(W + 3 * k, a);
+    lo = V(fminf(lo.x, a.x), fminf(lo.y, a.y), fminf(lo.z, a.z));
+    hi = V(fmaxf(hi.x, a.x), fmaxf(hi.y, a.y), fmaxf(hi.z, a.z));
+  }
+  float ex = P.c.collision_margin + 0.01f * radius;
+  st3(L.AMIN(b), V(lo.x - ex, lo.y - ex, lo.z - ex));
+  st3(L.AMAX(b), V(hi.x + ex, hi.y + ex, hi.z + ex));
+  // ground manifold: up to 8 deepest vertices within the breaking threshold, in (dist, index) order;
+  // warm-start impulses carried over by vertex id
+  float m = P.c.collision_margin, thr = 0.02f * radius;
+  float* g = L.GM(b);
+  int onp = __float_as_int(g[0]);
+  int ovid[SRL_GMAXP]; float oin[SRL_GMAXP], ot1[SRL_GMAXP], ot2[SRL_GMAXP];
+#pragma unroll
+  for (int j = 0; j < SRL_GMAXP; ++j) {
+    ovid[j] = j < onp ? __float_as_int(g[1 + j]) : -1;
+    oin[j] = g[17 + j]; ot1[j] = g[25 + j]; ot2[j] = g[33 + j];
+  }
+  int ns = 0;
+  float last_d = -1e30f; int last_k = -1;
+  while (ns < SRL_GMAXP) {
+    int best = -1; float bd = thr;
+    for (int k = 0; k < nv; ++k) {
+      float d = W[3 * k + 2] - m;
+      if (!(d > last_d || (d == last_d && k > last_k))) continue;
+      if (d < bd) { bd = d; best = k; }
+    }
+    if (best < 0) break;
+    float in = 0.0f, t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < SRL_GMAXP; ++j)
+      if (ovid[j] == best) { in = oin[j]; t1 = ot1[j]; t2 = ot2[j]; }
+    g[1 + ns] = __int_as_float(best); g[9 + ns] = bd;
+    g[17 + ns] = in; g[25 + ns] = t1; g[33 + ns] = t2;
+    last_d = bd; last_k = best;
+    ++ns;
+  }
+  g[0] = __int_as_float(ns);
+}
+
+// ------------------------------------------------------------------ persistent manifold (lane = slot)
+__device__ void manifold_refresh(float* mp, v3 xa, const m3& Ra, v3 xb, const m3& Rb, float thr) {
+  int np = __float_as_int(mp[0]);
+  for (int i = np - 1; i >= 0; --i) {
+    float* p = mp + 4 + SRL_MP_WORDS * i;
+    v3 n = ld3(p + 6);
+    v3 wa = xa + mmul(Ra, ld3(p));
+    v3 wb = xb + mmul(Rb, ld3(p + 3));
+    float d = dot(wa - wb, n);
+    bool drop = d > thr;
+    if (!drop) {
+      v3 proj = wa - n * d;
+      v3 t = wb - proj;
+      drop = dot(t, t) > thr * thr;
+    }
+    if (drop) {
+      const float* last = mp + 4 + SRL_MP_WORDS * (np - 1);
+      for (int k = 0; k < SRL_MP_WORDS; ++k) p[k] = last[k];
+      np--;
+    } else {
+      p[9] = d;
+    }
+  }
+  mp[0] = __int_as_float(np);
+}
+
+__device__ int manifold_sort_replace(const float* mp, v3 nla, float ndist) {
+  int deep = -1; float maxpen = ndist;
+  for (int i = 0; i < 4; ++i) {
+    float d = mp[4 + SRL_MP_WORDS * i + 9];
+    if (d < maxpen) { deep = i; maxpen = d; }
+  }
+  v3 l0 = ld3(mp + 4), l1 = ld3(mp + 4 + SRL_MP_WORDS), l2 = ld3(mp + 4 + 2 * SRL_MP_WORDS), l3 = ld3(mp + 4 + 3 * SRL_MP_WORDS);
+  float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (deep != 0) { v3 c = cross(nla - l1, l3 - l2); res[0] = dot(c, c); }
+  if (deep != 1) { v3 c = cross(nla - l0, l3 - l2); res[1] = dot(c, c); }
+  if (deep != 2) { v3 c = cross(nla - l0, l3 - l1); res[2] = dot(c, c); }
+  if (deep != 3) { v3 c = cross(nla - l0, l2 - l1); res[3] = dot(c, c); }
+  int best = 0; float br = res[0];
+  if (res[1] > br) { br = res[1]; best = 1; }
+  if (res[2] > br) { br = res[2]; best = 2; }
+  if (res[3] > br) { br = res[3]; best = 3; }
+  return best;
+}
+
+__device__ void manifold_add(float* mp, v3 la, v3 lb, v3 n, float dist, float thr) {
+  int np = __float_as_int(mp[0]);
+  float shortest = thr * thr; int near_i = -1;
+  for (int i = 0; i < np; ++i) {
+    v3 d = ld3(mp + 4 + SRL_MP_WORDS * i) - la;
+    float d2 = dot(d, d);
+    if (d2 < shortest) { shortest = d2; near_i = i; }
+  }
+  float* p;
+  bool keep_impulses = false;
+  if (near_i >= 0) { p = mp + 4 + SRL_MP_WORDS * near_i; keep_impulses = true; }
+  else if (np < 4) { p = mp + 4 + SRL_MP_WORDS * np; mp[0] = __int_as_float(np + 1); }
+  else p = mp + 4 + SRL_MP_WORDS * manifold_sort_replace(mp, la, dist);
+  st3(p, la); st3(p + 3, lb); st3(p + 6, n); p[9] = dist;
+  if (!keep_impulses) { p[10] = 0.0f; p[11] = 0.0f; p[12] = 0.0f; }
+}
+
+// least-penetration face axis for overlapping hulls
+__device__ void sat_faces(const DevParams& P, int mesh_a, const float* VA, int na, int mesh_b, const float* VB, int nb,
+                          v3& pa, v3& pb, v3& nrm, float& dist) {
+  float best = -1e30f; int btype = 0, bvert = 0; v3 bn = V(0.0f, 0.0f, 1.0f);
+  for (int pass = 0; pass < 2; ++pass) {
+    const MeshHdr mh = P.mh[pass ? mesh_b : mesh_a];
+    const float* VF = pass ? VB : VA;
+    const float* VO = pass ? VA : VB;
+    int no = pass ? na : nb;
+    for (int t = 0; t < mh.nt; ++t) {
+      uchar4 tr = P.mt[mh.to + t];
+      v3 a = ld3(VF + 3 * tr.x), b = ld3(VF + 3 * tr.y), c = ld3(VF + 3 * tr.z);
+      v3 n = cross(b - a, c - a);
+      float l2 = dot(n, n);
+      if (l2 < 1e-20f) continue;
+      n = n * (1.0f / sqrtf(l2));
+      float smin = 1e30f; int kmin = 0;
+      for (int k = 0; k < no; ++k) {
+        float sd = dot(n, ld3(VO + 3 * k) - a);
+        if (sd < smin) { smin = sd; kmin = k; }
+      }
+      if (smin > best) { best = smin; btype = pass; bvert = kmin; bn = n; }
+    }
+  }
+  if (btype == 0) { nrm = neg(bn); pb = ld3(VB + 3 * bvert); pa = pb - bn * best; }
+  else { nrm = bn; pa = ld3(VA + 3 * bvert); pb = pa - bn * best; }
+  dist = best;
+}
+
+__device__ void narrowphase_slot(const Lds& L, int sl) {
+  const DevParams& P = *L.P;
+  int pid = L.POS()[sl];
+  int a = c_pair_i[pid], b = c_pair_j[pid];
+  const float* bca = L.BC(a);
+  const float* bcb = L.BC(b);
+  int na = __float_as_int(bca[5]), nb = __float_as_int(bcb[5]);
+  float* mp = L.MAN(sl);
+  float mg = P.c.collision_margin;
+  float thr = 0.02f * fminf(bca[4], bcb[4]);
+  v3 xa = ld3(L.X(a)), xb = ld3(L.X(b));
+  m3 Ra = ldm(L.R(a)), Rb = ldm(L.R(b));
+  manifold_refresh(mp, xa, Ra, xb, Rb, thr);
+  v3 axis = ld3(mp + 1);
+  v3 pa, pb, n; float d;
+  int rc = gjk_distance(L.WV(a), na, L.WV(b), nb, axis, (mg + mg) + thr, pa, pb, n, d);
+  if (rc == 2) {
+    sat_faces(P, __float_as_int(bca[7]), L.WV(a), na, __float_as_int(bcb[7]), L.WV(b), nb, pa, pb, n, d);
+    rc = 1;
+  } else {
+    st3(mp + 1, axis);
+  }
+  if (rc == 1) {
+    float dist = d - (mg + mg);
+    if (dist < thr) {
+      v3 sa = pa - n * mg;
+      v3 sb = pb + n * mg;
+      manifold_add(mp, mtmul(Ra, sa - xa), mtmul(Rb, sb - xb), n, dist, thr);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ sequential impulses
+struct Vel4 { v3 va, wa, vb, wb; };
+
+template <bool HAS_B>
+__device__ __forceinline__ void row_solve(v3 d, v3 ra, v3 rb, float ima, const m3& Ia, float imb, const m3& Ib, Vel4& u,
+                                          float target, float& acc, float lo, float hi) {
+  v3 ca = cross(ra, d);
+  v3 aa = mmul(Ia, ca);
+  v3 cb = V(0.0f, 0.0f, 0.0f), ab = V(0.0f, 0.0f, 0.0f);
+  float k = ima + dot(cross(aa, ra), d);
+  float vrel = dot(d, u.va) + dot(ca, u.wa);
+  if (HAS_B) {
+    cb = cross(rb, d);
+    ab = mmul(Ib, cb);
+    k = k + (imb + dot(cross(ab, rb), d));
+    vrel = vrel - (dot(d, u.vb) + dot(cb, u.wb));
+  }
+  float dl = (target - vrel) / k;
+  float na = acc + dl;
+  if (na < lo) na = lo;
+  if (na > hi) na = hi;
+  dl = na - acc;
+  acc = na;
+  u.va = u.va + d * (ima * dl);
+  u.wa = u.wa + aa * dl;
+  if (HAS_B) {
+    u.vb = u.vb - d * (imb * dl);
+    u.wb = u.wb - ab * dl;
+  }
+}
+
+template <bool HAS_B>
+__device__ __forceinline__ void row_apply(v3 d, v3 ra, v3 rb, float ima, const m3& Ia, float imb, const m3& Ib, Vel4& u,
+                                          float imp) {
+  v3 aa = mmul(Ia, cross(ra, d));
+  u.va = u.va + d * (ima * imp);
+  u.wa = u.wa + aa * imp;
+  if (HAS_B) {
+    v3 ab = mmul(Ib, cross(rb, d));
+    u.vb = u.vb - d * (imb * imp);
+    u.wb = u.wb - ab * imp;
+  }
+}
+
+__device__ __forceinline__ float contact_target(const DevParams& P, float dist) {
+  float inv_dt = 1.0f / P.c.sim_time_step;
+  return dist > 0.0f ? -(dist * inv_dt) : -((dist * P.c.erp) * inv_dt);
+}
+
+template <bool WARM>
+__device__ void solve_ground(const Lds& L, int b) {
+  const DevParams& P = *L.P;
+  float* g = L.GM(b);
+  int np = __float_as_int(g[0]);
+  if (np == 0) return;
+  const float* bc = L.BC(b);
+  float ima = bc[0];
+  float mu = P.c.friction_rock * P.c.friction_ground;
+  m3 Ia = ldm(L.IW(b));
+  m3 Iz;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Iz.m[i] = 0.0f;
+  Vel4 u; u.va = ld3(L.Vl(b)); u.wa = ld3(L.Wl(b)); u.vb = V(0, 0, 0); u.wb = V(0, 0, 0);
+  v3 x = ld3(L.X(b));
+  v3 n = V(0.0f, 0.0f, 1.0f), t1, t2;
+  plane_space(n, t1, t2);
+  const float* W = L.WV(b);
+  v3 rb0 = V(0, 0, 0);
+  for (int i = 0; i < np; ++i) {
+    int vid = __float_as_int(g[1 + i]);
+    v3 pw = ld3(W + 3 * vid);
+    v3 ra = V(pw.x, pw.y, pw.z - P.c.collision_margin) - x;
+    if (WARM) {
+      float in = g[17 + i] * P.c.warmstart, i1 = g[25 + i] * P.c.warmstart, i2 = g[33 + i] * P.c.warmstart;
+      g[17 + i] = in; g[25 + i] = i1; g[33 + i] = i2;
+      row_apply<false>(n, ra, rb0, ima, Ia, 0.0f, Iz, u, in);
+      row_apply<false>(t1, ra, rb0, ima, Ia, 0.0f, Iz, u, i1);
+      row_apply<false>(t2, ra, rb0, ima, Ia, 0.0f, Iz, u, i2);
+    } else {
+      float in = g[17 + i], i1 = g[25 + i], i2 = g[33 + i];
+      row_solve<false>(n, ra, rb0, ima, Ia, 0.0f, Iz, u, contact_target(P, g[9 + i]), in, 0.0f, 1e30f);
+      float lim = mu * in;
+      row_solve<false>(t1, ra, rb0, ima, Ia, 0.0f, Iz, u, 0.0f, i1, -lim, lim);
+      row_solve<false>(t2, ra, rb0, ima, Ia, 0.0f, Iz, u, 0.0f, i2, -lim, lim);
+      g[17 + i] = in; g[25 + i] = i1; g[33 + i] = i2;
+    }
+  }
+  st3(L.Vl(b), u.va); st3(L.Wl(b), u.wa);
+}
+
+template <bool WARM>
+__device__ void solve_slot(const Lds& L, int sl) {
+  const DevParams& P = *L.P;
+  float* mp = L.MAN(sl);
+  int np = __float_as_int(mp[0]);
+  if (np == 0) return;
+  int pid = L.POS()[sl];
+  int a = c_pair_i[pid], b = c_pair_j[pid];
+  float ima = L.BC(a)[0], imb = L.BC(b)[0];
+  float mu = P.c.friction_rock * P.c.friction_rock;
+  m3 Ra = ldm(L.R(a)), Rb = ldm(L.R(b));
+  m3 Ia = ldm(L.IW(a)), Ib = ldm(L.IW(b));
+  Vel4 u; u.va = ld3(L.Vl(a)); u.wa = ld3(L.Wl(a)); u.vb = ld3(L.Vl(b)); u.wb = ld3(L.Wl(b));
+  for (int i = 0; i < np; ++i) {
+    float* p = mp + 4 + SRL_MP_WORDS * i;
+    v3 ra = mmul(Ra, ld3(p));
+    v3 rb = mmul(Rb, ld3(p + 3));
+    v3 n = ld3(p + 6), t1, t2;
+    plane_space(n, t1, t2);
+    if (WARM) {
+      float in = p[10] * P.c.warmstart, i1 = p[11] * P.c.warmstart, i2 = p[12] * P.c.warmstart;
+      p[10] = in; p[11] = i1; p[12] = i2;
+      row_apply<true>(n, ra, rb, ima, Ia, imb, Ib, u, in);
+      row_apply<true>(t1, ra, rb, ima, Ia, imb, Ib, u, i1);
+      row_apply<true>(t2, ra, rb, ima, Ia, imb, Ib, u, i2);
+    } else {
+      float in = p[10], i1 = p[11], i2 = p[12];
+      row_solve<true>(n, ra, rb, ima, Ia, imb, Ib, u, contact_target(P, p[9]), in, 0.0f, 1e30f);
+      float lim = mu * in;
+      row_solve<true>(t1, ra, rb, ima, Ia, imb, Ib, u, 0.0f, i1, -lim, lim);
+      row_solve<true>(t2, ra, rb, ima, Ia, imb, Ib, u, 0.0f, i2, -lim, lim);
+      p[10] = in; p[11] = i1; p[12] = i2;
+    }
+  }
+  st3(L.Vl(a), u.va); st3(L.Wl(a), u.wa); st3(L.Vl(b), u.vb); st3(L.Wl(b), u.wb);
+}
+
+template <bool WARM>
+__device__ void solver_sweep(const Lds& L, int nb, int ncol, int tid, int T) {
+  const DevParams& P = *L.P;
+  for (int b = tid; b < nb; b += T) solve_ground<WARM>(L, b);
+  __syncthreads();
+  for (int c = 0; c < ncol; ++c) {
+    for (int sl = tid; sl < P.NS; sl += T)
+      if (L.POS()[sl] >= 0 && L.COL()[sl] == c) solve_slot<WARM>(L, sl);
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ one sub-step (block-wide)
+__device__ void substep(const Lds& L, int nb, int tid, int T) {
+  const DevParams& P = *L.P;
+  int* misc = L.MISC();
+  for (int b = tid; b < nb; b += T) body_phase(L, b, true);
+  if (tid == 0) misc[M_FLAGS] = 0;
+  __syncthreads();
+  // broadphase: AABB overlap for every pair; release slots of pairs that separated
+  int npair = nb * (nb - 1) / 2;
+  int fl = 0;
+  for (int pid = tid; pid < npair; pid += T) {
+    int i = c_pair_i[pid], j = c_pair_j[pid];
+    v3 ai = ld3(L.AMIN(i)), bi = ld3(L.AMAX(i)), aj = ld3(L.AMIN(j)), bj = ld3(L.AMAX(j));
+    bool ov = ai.x <= bj.x && aj.x <= bi.x && ai.y <= bj.y && aj.y <= bi.y && ai.z <= bj.z && aj.z <= bi.z;
+    int sl = L.SOP()[pid];
+    if (!ov && sl >= 0) { L.SOP()[pid] = -1; L.POS()[sl] = -1; fl |= 1; }
+    if (ov && sl < 0) fl |= 2;
+  }
+  if (fl) atomicOr(&misc[M_FLAGS], fl);
+  __syncthreads();
+  const int flags = misc[M_FLAGS], ncol0 = misc[M_NCOL];
+  if (flags || ncol0 < 0) {
+    __syncthreads();   // every thread has taken its snapshot before thread 0 rewrites the words
+    if (tid == 0) {
+      if (flags & 2) {   // allocate slots for newly close pairs: ascending pair id, lowest free slot first
+        for (int pid = 0; pid < npair; ++pid) {
+          if (L.SOP()[pid] >= 0) continue;
+          int i = c_pair_i[pid], j = c_pair_j[pid];
+          v3 ai = ld3(L.AMIN(i)), bi = ld3(L.AMAX(i)), aj = ld3(L.AMIN(j)), bj = ld3(L.AMAX(j));
+          bool ov = ai.x <= bj.x && aj.x <= bi.x && ai.y <= bj.y && aj.y <= bi.y && ai.z <= bj.z && aj.z <= bi.z;
+          if (!ov) continue;
+          int sl = -1;
+          for (int k = 0; k < P.NS; ++k) if (L.POS()[k] < 0) { sl = k; break; }
+          if (sl < 0) { misc[M_STATUS] |= SRL_ST_PAIR_OVERFLOW; continue; }
+          L.SOP()[pid] = sl; L.POS()[sl] = pid;
+          float* mp = L.MAN(sl);
+          mp[0] = __int_as_float(0);
+          st3(mp + 1, ld3(L.X(i)) - ld3(L.X(j)));
+        }
+      }
+      // greedy colouring in slot order
+      uint64_t used[SRL_MAX_BODIES];
+      for (int b = 0; b < SRL_MAX_BODIES; ++b) used[b] = 0;
+      int nc = 0;
+      for (int sl = 0; sl < P.NS; ++sl) {
+        int pid = L.POS()[sl];
+        if (pid < 0) continue;
+        int i = c_pair_i[pid], j = c_pair_j[pid];
+        uint64_t u = used[i] | used[j];
+        int c = __ffsll((long long)~u) - 1;
+        L.COL()[sl] = c;
+        used[i] |= (uint64_t)1 << c;
+        used[j] |= (uint64_t)1 << c;
+        if (c + 1 > nc) nc = c + 1;
+      }
+      misc[M_NCOL] = nc;
+    }
+    __syncthreads();
+  }
+  int ncol = misc[M_NCOL];
+  for (int sl = tid; sl < P.NS; sl += T)
+    if (L.POS()[sl] >= 0) narrowphase_slot(L, sl);
+  __syncthreads();
+  solver_sweep<true>(L, nb, ncol, tid, T);
+  for (int it = 0; it < P.c.solver_iterations; ++it) solver_sweep<false>(L, nb, ncol, tid, T);
+  // integrate
+  float dt = P.c.sim_time_step;
+  for (int b = tid; b < nb; b += T) {
+    v3 v = ld3(L.Vl(b)), w = ld3(L.Wl(b));
+    st3(L.X(b), ld3(L.X(b)) + v * dt);
+    float* Q = L.Q(b);
+    q4 q; q.x = Q[0]; q.y = Q[1]; q.z = Q[2]; q.w = Q[3];
+    float hx = 0.5f * dt;
+    q4 dq;
+    dq.x = hx * ((w.x * q.w + w.y * q.z) - w.z * q.y);
+    dq.y = hx * ((w.y * q.w + w.z * q.x) - w.x * q.z);
+    dq.z = hx * ((w.z * q.w + w.x * q.y) - w.y * q.x);
+    dq.w = hx * (-((w.x * q.x + w.y * q.y) + w.z * q.z));
+    q.x += dq.x; q.y += dq.y; q.z += dq.z; q.w += dq.w;
+    float inv = 1.0f / sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w));
+    Q[0] = q.x * inv; Q[1] = q.y * inv; Q[2] = q.z * inv; Q[3] = q.w * inv;
+  }
+  __syncthreads();
+}
+
+// simulator.py:322-335: every body's linear speed <= threshold
+__device__ __forceinline__ bool sim_stop(const Lds& L, int nb, int tid) {
+  bool moving = false;
+  if (tid < nb) {
+    v3 v = ld3(L.Vl(tid));
+    moving = sqrtf(dot(v, v)) > L.P->c.velocity_threshold;
+  }
+  return !__syncthreads_or(moving ? 1 : 0);
+}
+
+// number of manifold points on the newest body (getContactPoints, simulator.py:340)
+__device__ int newest_contacts(const Lds& L, int nb, int tid, int T) {
+  int* misc = L.MISC();
+  if (tid == 0) misc[M_CNT] = __float_as_int(L.GM(nb - 1)[0]);
+  __syncthreads();
+  int n = 0;
+  for (int sl = tid; sl < L.P->NS; sl += T) {
+    int pid = L.POS()[sl];
+    if (pid >= 0 && (c_pair_i[pid] == nb - 1 || c_pair_j[pid] == nb - 1)) n += __float_as_int(L.MAN(sl)[0]);
+  }
+  if (n) atomicAdd(&misc[M_CNT], n);
+  __syncthreads();
+  int r = misc[M_CNT];
+  __syncthreads();
+  return r;
+}
+
+// ------------------------------------------------------------------ K1 + K4 + episode machine
+extern "C" __global__ void __launch_bounds__(256) srl_k_step(DevParams P, const int64_t* __restrict__ action) {
+  extern __shared__ float sm[];
+  const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  Lds L; L.sm = sm; L.P = &P;
+  int* misc = L.MISC();
+  EnvHdr* h = &P.hdr[e];
+  float* gblob = P.blob + (size_t)e * P.BLOB;
+
+  if (tid == 0) {
+    int mode;
+    if (P.force_reset || h->done) {          // env.py:235-236 auto-reset
+      env_reset(P, h, e);
+      mode = 1;
+    } else {
+      int64_t a = action[e];
+      if (a < 0 || a >= (int64_t)P.A) {       // env.py:238
+        h->status |= SRL_ST_BAD_ACTION;
+        atomicOr(P.flags, 1);
+        mode = 2;
+      } else {
+        h->status &= ~SRL_ST_BAD_ACTION;
+        mode = 0;
+        misc[M_U] = (int)(a / P.AW);          // env.py:240-241
+        misc[M_V] = (int)(a % P.AW);
+        int next = -1;
+        if (h->list_pos < P.c.episode_length) next = h->ids[h->list_pos++];   // env.py:243-247
+        else h->done = 1;
+        misc[M_NEXT] = next;
+        misc[M_NB] = h->nb;
+        misc[M_PENDING] = h->pending;
+        misc[M_NCOL] = h->ncolour;
+        misc[M_STATUS] = h->status;
+        misc[M_ZMAX] = (int)f2o(-1e30f);
+      }
+    }
+    h->mode = mode;
+    misc[M_MODE] = mode;
+  }
+  __syncthreads();
+  const int mode = misc[M_MODE];
+  if (mode == 1) {   // Simulator.reset: empty world (simulator.py:156-188)
+    int* gi = (int*)gblob;
+    for (int k = tid; k < P.NP; k += T) gi[P.OFF_SOP + k] = -1;
+    for (int k = tid; k < P.NS; k += T) gi[P.OFF_POS + k] = -1;
+    return;
+  }
+  if (mode == 2) return;
+
+  // ---- load the persistent blob into LDS
+  for (int k = tid; k < P.BLOB; k += T) sm[k] = gblob[k];
+  __syncthreads();
+
+  // ---- K4: Observer.pose (observer.py:392-421): z = max(H[window] + O | O > 1e-4) - oz/2
+  const int u = misc[M_U], v = misc[M_V], pending = misc[M_PENDING];
+  int nb = misc[M_NB];
+  {
+    const int res = P.c.overhead_res, r = P.c.object_res;
+    const float* Hm = P.H + (size_t)e * res * res;
+    const float* Om = P.objmap + (size_t)pending * r * r;
+    uint32_t best = f2o(-1e30f);
+    for (int k = tid; k < r * r; k += T) {
+      int i = k / r, j = k % r;
+      float o = Om[k];
+      if (o > 1e-4f) {
+        uint32_t s = f2o(Hm[(u + i) * res + (v + j)] + o);
+        best = s > best ? s : best;
+      }
+    }
+    atomicMax((uint32_t*)&misc[M_ZMAX], best);
+  }
+  __syncthreads();
+  if (tid == 0) {   // _place (simulator.py:310-320): teleport the pending rock, zero velocity
+    float z = o2f((uint32_t)misc[M_ZMAX]);
+    float half = ((float)P.c.object_res * P.px) * 0.5f;
+    v3 pos = V((float)u * P.px + half, (float)v * P.px + half, z - half);
+    const MeshHdr mh = P.mh[pending];
+    int b = nb;
+    L.MESH()[b] = pending;
+    // resetBasePositionAndOrientation moves the inertial (COM) frame; loadURDF had placed the link frame
+    st3(L.X(b), P.c.place_at_com ? pos : pos + V(mh.cx, mh.cy, mh.cz));
+    L.Q(b)[0] = 0.0f; L.Q(b)[1] = 0.0f; L.Q(b)[2] = 0.0f; L.Q(b)[3] = 1.0f;
+    st3(L.Vl(b), V(0, 0, 0)); st3(L.Wl(b), V(0, 0, 0));
+    L.GM(b)[0] = __int_as_float(0);
+  }
+  nb += 1;
+  __syncthreads();
+  for (int b = tid; b < nb; b += T) {
+    int m = L.MESH()[b];
+    const MeshHdr mh = P.mh[m];
+    float* bc = L.BC(b);
+    bc[0] = mh.inv_mass; bc[1] = mh.iix; bc[2] = mh.iiy; bc[3] = mh.iiz; bc[4] = mh.radius;
+    bc[5] = __int_as_float(mh.nv); bc[6] = __int_as_float(mh.vo); bc[7] = __int_as_float(m);
+  }
+  __syncthreads();
+
+  // ---- Simulator.step (simulator.py:190-258)
+  int counter = 0;
+  bool diverged = false;
+  substep(L, nb, tid, T);
+  counter = 1;
+  if (P.c.smooth_placing) {
+    for (;;) {
+      bool drop = newest_contacts(L, nb, tid, T) >= 3;   // _drop, simulator.py:337-341
+      bool stop = sim_stop(L, nb, tid);
+      if (drop || stop) break;
+      if (tid == 0) { st3(L.Vl(nb - 1), V(0, 0, 0)); st3(L.Wl(nb - 1), V(0, 0, 0)); }   // resetBaseVelocity
+      __syncthreads();
+      substep(L, nb, tid, T);
+      counter++;
+      if (counter > P.max_substeps) { diverged = true; break; }
+    }
+  }
+  if (tid == 0) {
+    st3(L.PX(nb - 1), ld3(L.X(nb - 1)));
+    for (int k = 0; k < 4; ++k) L.PQ(nb - 1)[k] = L.Q(nb - 1)[k];
+  }
+  const int s_a = counter;
+  while (!diverged && !sim_stop(L, nb, tid)) {
+    substep(L, nb, tid, T);
+    counter++;
+    if (counter > P.max_substeps) { diverged = true; break; }
+  }
+  __syncthreads();
+
+  // ---- write back
+  for (int k = tid; k < P.BLOB; k += T) gblob[k] = sm[k];
+  if (tid == 0) {
+    h->nb = nb;
+    h->pending = misc[M_NEXT];   // _load, simulator.py:258
+    h->ncolour = misc[M_NCOL];
+    h->substeps[0] = s_a;
+    h->substeps[1] = counter - s_a;
+    int st = misc[M_STATUS] | (diverged ? SRL_ST_DIVERGED : 0);
+    h->status = st;
+    if (diverged) atomicOr(P.flags, 2);
+  }
+}
+
+// ------------------------------------------------------------------ ParallelEnv.sample (utils.py:534-538)
+extern "C" __global__ void srl_k_sample(DevParams P, int64_t* __restrict__ action) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.c.n_envs) return;
+  uint32_t key = P.seed + (uint32_t)P.c.env_index_offset + (uint32_t)i;
+  action[i] = (int64_t)srl_rng_below(srl_rng(key, P.sample_counter, SRL_STREAM_ACTION, 0), (uint32_t)P.A);
+}
+
+// ------------------------------------------------------------------ telemetry reduction
+extern "C" __global__ void srl_k_contacts(DevParams P, float* __restrict__ max_pen, int32_t* __restrict__ n_points) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P.c.n_envs) return;
+  const float* gb = P.blob + (size_t)e * P.BLOB;
+  const int* gi = (const int*)gb;
+  int nb = P.hdr[e].nb;
+  float mp = 0.0f; int np = 0;
+  for (int b = 0; b < nb; ++b) {
+    const float* g = gb + P.OFF_GM + SRL_GM_WORDS * b;
+    int n = __float_as_int(g[0]);
+    for (int k = 0; k < n; ++k) { np++; if (-g[9 + k] > mp) mp = -g[9 + k]; }
+  }
+  for (int sl = 0; sl < P.NS; ++sl) {
+    if (gi[P.OFF_POS + sl] < 0) continue;
+    const float* m = gb + P.OFF_MAN + SRL_MAN_WORDS * sl;
+    int n = __float_as_int(m[0]);
+    for (int k = 0; k < n; ++k) { np++; float d = m[4 + SRL_MP_WORDS * k + 9]; if (-d > mp) mp = -d; }
+  }
+  max_pen[e] = mp; n_points[e] = np;
+}

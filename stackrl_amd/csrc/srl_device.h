@@ -1,0 +1,377 @@
+// srl_device.h — device-side building blocks of libstackrl_hip (gfx950 only).
+//
+// All arithmetic is IEEE binary32 with one rounding per written operation (the library is built
+// with -ffp-contract=off): the kernels evaluate exactly the expression trees of the solver /
+// rasteriser definition in DESIGN.md, so results do not depend on how work is spread over lanes.
+//
+// Reference rows implemented here (paths relative to menezesandre/stackrl):
+//   observer.py:259-260, :274-277   depth -> elevation (elev_overhead / elev_object)
+//   rewarder.py:225-259             goal rectangle (goal_from_rng)
+//   simulator.py:190-341            place / smooth placing / settle (settle.hip uses these pieces)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SRL_FAR 1000.0f      // Observer.far, observer.py:6
+#define SRL_GMAXP 8          // ground manifold points per body
+#define SRL_NSLOT_MAX 192    // persistent body-body manifolds per env
+#define SRL_MP_WORDS 13      // manifold point: la3 lb3 n3 dist in it1 it2
+#define SRL_MAN_WORDS 56     // np, axis3, 4 points
+#define SRL_GM_WORDS 41      // np, vid8, dist8, in8, it1 8, it2 8
+#define SRL_GJK_MAXIT 32
+
+struct v3 { float x, y, z; };
+struct q4 { float x, y, z, w; };
+struct m3 { float m[9]; };
+
+__device__ __forceinline__ v3 V(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ v3 neg(v3 a) { return V(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ v3 cross(v3 a, v3 b) {
+  return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
+__device__ __forceinline__ void st3(float* p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+__device__ __forceinline__ m3 ldm(const float* p) {
+  m3 R;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R.m[i] = p[i];
+  return R;
+}
+__device__ __forceinline__ v3 mmul(const m3& R, v3 a) {
+  return V((R.m[0] * a.x + R.m[1] * a.y) + R.m[2] * a.z, (R.m[3] * a.x + R.m[4] * a.y) + R.m[5] * a.z,
+           (R.m[6] * a.x + R.m[7] * a.y) + R.m[8] * a.z);
+}
+__device__ __forceinline__ v3 mtmul(const m3& R, v3 a) {
+  return V((R.m[0] * a.x + R.m[3] * a.y) + R.m[6] * a.z, (R.m[1] * a.x + R.m[4] * a.y) + R.m[7] * a.z,
+           (R.m[2] * a.x + R.m[5] * a.y) + R.m[8] * a.z);
+}
+__device__ __forceinline__ m3 quat_to_mat(q4 q) {
+  float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
+  float xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
+  float wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+  m3 R;
+  R.m[0] = 1.0f - 2.0f * (yy + zz); R.m[1] = 2.0f * (xy - wz); R.m[2] = 2.0f * (xz + wy);
+  R.m[3] = 2.0f * (xy + wz); R.m[4] = 1.0f - 2.0f * (xx + zz); R.m[5] = 2.0f * (yz - wx);
+  R.m[6] = 2.0f * (xz - wy); R.m[7] = 2.0f * (yz + wx); R.m[8] = 1.0f - 2.0f * (xx + yy);
+  return R;
+}
+// world inverse inertia R diag(d) R^T
+__device__ __forceinline__ m3 inv_inertia_world(const m3& R, v3 d) {
+  m3 A;
+  A.m[0] = R.m[0] * d.x; A.m[1] = R.m[1] * d.y; A.m[2] = R.m[2] * d.z;
+  A.m[3] = R.m[3] * d.x; A.m[4] = R.m[4] * d.y; A.m[5] = R.m[5] * d.z;
+  A.m[6] = R.m[6] * d.x; A.m[7] = R.m[7] * d.y; A.m[8] = R.m[8] * d.z;
+  m3 I;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      I.m[3 * i + j] = (A.m[3 * i] * R.m[3 * j] + A.m[3 * i + 1] * R.m[3 * j + 1]) + A.m[3 * i + 2] * R.m[3 * j + 2];
+  return I;
+}
+// Bullet btPlaneSpace1 restated
+__device__ __forceinline__ void plane_space(v3 n, v3& p, v3& q) {
+  if (fabsf(n.z) > 0.70710678f) {
+    float a = n.y * n.y + n.z * n.z;
+    float k = 1.0f / sqrtf(a);
+    p = V(0.0f, -n.z * k, n.y * k);
+    q = V(a * k, -n.x * p.z, n.x * p.y);
+  } else {
+    float a = n.x * n.x + n.y * n.y;
+    float k = 1.0f / sqrtf(a);
+    p = V(-n.y * k, n.x * k, 0.0f);
+    q = V(-n.z * p.y, n.z * p.x, a * k);
+  }
+}
+// private acos polynomial (A&S 4.4.46): bit-identical on host and device
+__device__ __forceinline__ float srl_acosf(float x) {
+  float a = fabsf(x);
+  if (a > 1.0f) a = 1.0f;
+  float p = -0.0012624911f;
+  p = p * a + 0.0066700901f;
+  p = p * a + -0.0170881256f;
+  p = p * a + 0.0308918810f;
+  p = p * a + -0.0501743046f;
+  p = p * a + 0.0889789874f;
+  p = p * a + -0.2145988016f;
+  p = p * a + 1.5707963050f;
+  float r = sqrtf(1.0f - a) * p;
+  return x < 0.0f ? 3.14159265358979f - r : r;
+}
+
+// ---------------------------------------------------------------- ordered-int view of floats
+__device__ __forceinline__ uint32_t f2o(float f) {
+  uint32_t u = __float_as_uint(f);
+  return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float o2f(uint32_t o) {
+  uint32_t u = o ^ (((o >> 31) - 1u) | 0x80000000u);
+  return __uint_as_float(u);
+}
+
+// ---------------------------------------------------------------- counter RNG
+__host__ __device__ __forceinline__ uint32_t srl_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t srl_rng(uint32_t key, uint32_t episode, uint32_t stream, uint32_t draw) {
+  uint32_t h = srl_mix32(key + 0x9E3779B9U);
+  h = srl_mix32(h ^ (episode + 0x85EBCA6BU));
+  h = srl_mix32(h ^ (stream + 0xC2B2AE35U));
+  h = srl_mix32(h ^ (draw + 0x27D4EB2FU));
+  return h;
+}
+__host__ __device__ __forceinline__ uint32_t srl_rng_below(uint32_t r, uint32_t n) {
+  return (uint32_t)(((uint64_t)r * (uint64_t)n) >> 32);
+}
+enum { SRL_STREAM_MESH = 0, SRL_STREAM_GOAL = 1, SRL_STREAM_ACTION = 2 };
+
+// ---------------------------------------------------------------- depth codec
+// pybullet TinyRenderer depth restated: d = far (t - near) / (t (far - near))
+__device__ __forceinline__ float depth_encode(float t, float nearp, float farp) {
+  if (t < nearp) t = nearp;
+  if (t > farp) t = farp;
+  return (farp * (t - nearp)) / (t * (farp - nearp));
+}
+
+// ---------------------------------------------------------------- rasteriser
+// canonical (antisymmetric) edge function: shared edges are watertight
+__device__ __forceinline__ float edge_fn(float ax, float ay, int ia, float bx, float by, int ib, float px, float py) {
+  if (ia < ib) return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+  return -((ax - bx) * (py - by) - (ay - by) * (px - bx));
+}
+
+// Rasterise one triangle into an LDS tile of ordered-uint heights.
+// TOP: keep max z of up-facing triangles (only z > 0 can win over the 0 floor);
+// !TOP: keep min z of down-facing triangles.
+template <bool TOP>
+__device__ __forceinline__ void raster_tri(uint32_t* tile, int res, float inv_px, float px, v3 a, int ia, v3 b, int ib,
+                                           v3 c, int ic) {
+  float area2 = (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x);
+  if (TOP ? !(area2 > 0.0f) : !(area2 < 0.0f)) return;
+  float xmin = fminf(a.x, fminf(b.x, c.x)), xmax = fmaxf(a.x, fmaxf(b.x, c.x));
+  float ymin = fminf(a.y, fminf(b.y, c.y)), ymax = fmaxf(a.y, fmaxf(b.y, c.y));
+  float zmin = fminf(a.z, fminf(b.z, c.z)), zmax = fmaxf(a.z, fmaxf(b.z, c.z));
+  float fi0 = ceilf(xmin * inv_px - 0.5f), fi1 = floorf(xmax * inv_px - 0.5f);
+  float fj0 = ceilf(ymin * inv_px - 0.5f), fj1 = floorf(ymax * inv_px - 0.5f);
+  if (fi0 < 0.0f) fi0 = 0.0f;
+  if (fj0 < 0.0f) fj0 = 0.0f;
+  if (fi1 > (float)(res - 1)) fi1 = (float)(res - 1);
+  if (fj1 > (float)(res - 1)) fj1 = (float)(res - 1);
+  if (fi1 < fi0 || fj1 < fj0) return;
+  int i0 = (int)fi0, i1 = (int)fi1, j0 = (int)fj0, j1 = (int)fj1;
+  float nx = (b.y - a.y) * (c.z - a.z) - (b.z - a.z) * (c.y - a.y);
+  float ny = (b.z - a.z) * (c.x - a.x) - (b.x - a.x) * (c.z - a.z);
+  float gx = -nx / area2, gy = -ny / area2;
+  for (int i = i0; i <= i1; ++i) {
+    float x = ((float)i + 0.5f) * px;
+    for (int j = j0; j <= j1; ++j) {
+      float y = ((float)j + 0.5f) * px;
+      float e0 = edge_fn(a.x, a.y, ia, b.x, b.y, ib, x, y);
+      float e1 = edge_fn(b.x, b.y, ib, c.x, c.y, ic, x, y);
+      float e2 = edge_fn(c.x, c.y, ic, a.x, a.y, ia, x, y);
+      bool inside = TOP ? (e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) : (e0 <= 0.0f && e1 <= 0.0f && e2 <= 0.0f);
+      if (!inside) continue;
+      float z = a.z + ((x - a.x) * gx + (y - a.y) * gy);
+      z = fminf(fmaxf(z, zmin), zmax);
+      if (TOP) atomicMax(&tile[i * res + j], f2o(z));
+      else atomicMin(&tile[i * res + j], f2o(z));
+    }
+  }
+}
+
+// ---------------------------------------------------------------- GJK (Ericson closest-point sub-algorithms)
+__device__ __forceinline__ void closest_tri(v3 a, v3 b, v3 c, float& l0, float& l1, float& l2, int& used) {
+  v3 ab = b - a, ac = c - a, ap = neg(a);
+  float d1 = dot(ab, ap), d2 = dot(ac, ap);
+  if (d1 <= 0.0f && d2 <= 0.0f) { l0 = 1.0f; l1 = 0.0f; l2 = 0.0f; used = 1; return; }
+  v3 bp = neg(b);
+  float d3 = dot(ab, bp), d4 = dot(ac, bp);
+  if (d3 >= 0.0f && d4 <= d3) { l0 = 0.0f; l1 = 1.0f; l2 = 0.0f; used = 2; return; }
+  float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+    float v = d1 / (d1 - d3);
+    l0 = 1.0f - v; l1 = v; l2 = 0.0f; used = 3; return;
+  }
+  v3 cp = neg(c);
+  float d5 = dot(ab, cp), d6 = dot(ac, cp);
+  if (d6 >= 0.0f && d5 <= d6) { l0 = 0.0f; l1 = 0.0f; l2 = 1.0f; used = 4; return; }
+  float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+    float w = d2 / (d2 - d6);
+    l0 = 1.0f - w; l1 = 0.0f; l2 = w; used = 5; return;
+  }
+  float va = d3 * d6 - d5 * d4;
+  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
+    float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    l0 = 0.0f; l1 = 1.0f - w; l2 = w; used = 6; return;
+  }
+  float denom = 1.0f / ((va + vb) + vc);
+  float v = vb * denom, w = vc * denom;
+  l0 = (1.0f - v) - w; l1 = v; l2 = w; used = 7;
+}
+
+__device__ __forceinline__ int outside_plane(v3 a, v3 b, v3 c, v3 d) {
+  v3 n = cross(b - a, c - a);
+  float sp = dot(neg(a), n);
+  float sd = dot(d - a, n);
+  if (sd * sd < 1e-24f) return -1;
+  return (sp * sd < 0.0f) ? 1 : 0;
+}
+
+struct Simplex {
+  v3 w[4], p[4], q[4];
+  int ia[4], ib[4];
+  float lam[4];
+  int n;
+};
+
+// all indexing below is static after unrolling (no scratch)
+__device__ __forceinline__ void simplex_push(Simplex& s, v3 w, v3 p, v3 q, int ia, int ib) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (s.n == i) { s.w[i] = w; s.p[i] = p; s.q[i] = q; s.ia[i] = ia; s.ib[i] = ib; }
+  s.n += 1;
+}
+
+// returns 1 ok (simplex reduced, lam + v valid), 0 degenerate (nothing modified), 2 origin enclosed
+__device__ __forceinline__ int simplex_closest(Simplex& s, v3& vout) {
+  int used = 0;
+  float l[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (s.n == 1) {
+    l[0] = 1.0f; used = 1;
+  } else if (s.n == 2) {
+    v3 a = s.w[0], b = s.w[1];
+    v3 ab = b - a;
+    float t = dot(neg(a), ab);
+    if (t <= 0.0f) { l[0] = 1.0f; used = 1; }
+    else {
+      float den = dot(ab, ab);
+      if (t >= den) { l[1] = 1.0f; used = 2; }
+      else { t = t / den; l[0] = 1.0f - t; l[1] = t; used = 3; }
+    }
+  } else if (s.n == 3) {
+    closest_tri(s.w[0], s.w[1], s.w[2], l[0], l[1], l[2], used);
+  } else {
+    v3 a = s.w[0], b = s.w[1], c = s.w[2], d = s.w[3];
+    int o0 = outside_plane(a, b, c, d);
+    int o1 = outside_plane(a, c, d, b);
+    int o2 = outside_plane(a, d, b, c);
+    int o3 = outside_plane(b, d, c, a);
+    if (o0 < 0 || o1 < 0 || o2 < 0 || o3 < 0) return 0;
+    if (!o0 && !o1 && !o2 && !o3) return 2;
+    float best = 1e30f;
+    float t0, t1, t2; int tu;
+    if (o0) {
+      closest_tri(a, b, c, t0, t1, t2, tu);
+      v3 p = (a * t0 + b * t1) + c * t2;
+      float d2 = dot(p, p);
+      if (d2 < best) { best = d2; l[0] = t0; l[1] = t1; l[2] = t2; l[3] = 0.0f; used = (tu & 1) | (tu & 2) | (tu & 4); }
+    }
+    if (o1) {
+      closest_tri(a, c, d, t0, t1, t2, tu);
+      v3 p = (a * t0 + c * t1) + d * t2;
+      float d2 = dot(p, p);
+      if (d2 < best) { best = d2; l[0] = t0; l[1] = 0.0f; l[2] = t1; l[3] = t2; used = (tu & 1) | ((tu & 2) << 1) | ((tu & 4) << 1); }
+    }
+    if (o2) {
+      closest_tri(a, d, b, t0, t1, t2, tu);
+      v3 p = (a * t0 + d * t1) + b * t2;
+      float d2 = dot(p, p);
+      if (d2 < best) { best = d2; l[0] = t0; l[1] = t2; l[2] = 0.0f; l[3] = t1; used = (tu & 1) | ((tu & 2) << 2) | ((tu & 4) >> 1); }
+    }
+    if (o3) {
+      closest_tri(b, d, c, t0, t1, t2, tu);
+      v3 p = (b * t0 + d * t1) + c * t2;
+      float d2 = dot(p, p);
+      if (d2 < best) { best = d2; l[0] = 0.0f; l[1] = t0; l[2] = t2; l[3] = t1; used = ((tu & 1) << 1) | ((tu & 2) << 2) | (tu & 4); }
+    }
+  }
+  // compaction, dropping unused vertices from the highest index down (keeps ascending order)
+#define SRL_SHIFT(i)                                                                                 \
+  if (!(used & (1 << (i)))) {                                                                        \
+    _Pragma("unroll") for (int k = (i); k < 3; ++k) {                                                \
+      s.w[k] = s.w[k + 1]; s.p[k] = s.p[k + 1]; s.q[k] = s.q[k + 1];                                  \
+      s.ia[k] = s.ia[k + 1]; s.ib[k] = s.ib[k + 1]; l[k] = l[k + 1];                                  \
+    }                                                                                                \
+  }
+  SRL_SHIFT(3) SRL_SHIFT(2) SRL_SHIFT(1) SRL_SHIFT(0)
+#undef SRL_SHIFT
+  int m = __popc((unsigned)used & ((1u << s.n) - 1u));
+  v3 v = V(0.0f, 0.0f, 0.0f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < m) { s.lam[k] = l[k]; v = v + s.w[k] * l[k]; }
+  s.n = m;
+  vout = v;
+  return 1;
+}
+
+__device__ __forceinline__ int support_max(const float* P, int n, v3 d) {
+  int best = 0;
+  float bd = dot(ld3(P), d);
+  for (int k = 1; k < n; ++k) {
+    float t = dot(ld3(P + 3 * k), d);
+    if (t > bd) { bd = t; best = k; }
+  }
+  return best;
+}
+
+// GJK distance between two world-space vertex clouds held in LDS (float triples).
+// 0: farther than maxdist; 1: pa/pb/n/dist valid; 2: hulls overlap.
+__device__ __forceinline__ int gjk_distance(const float* VA, int na, const float* VB, int nb, v3& axis, float maxdist,
+                                            v3& pa, v3& pb, v3& nrm, float& dist) {
+  Simplex s;
+  s.n = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    s.lam[k] = 0.0f; s.ia[k] = -1; s.ib[k] = -1;
+    s.w[k] = V(0.0f, 0.0f, 0.0f); s.p[k] = V(0.0f, 0.0f, 0.0f); s.q[k] = V(0.0f, 0.0f, 0.0f);
+  }
+  v3 v = axis;
+  float sqd = 1e30f;
+  if (!(dot(v, v) > 1e-20f)) v = V(0.0f, 0.0f, 1.0f);
+  for (int it = 0; it < SRL_GJK_MAXIT; ++it) {
+    int ia = support_max(VA, na, neg(v));
+    int ib = support_max(VB, nb, v);
+    v3 a = ld3(VA + 3 * ia), b = ld3(VB + 3 * ib);
+    v3 w = a - b;
+    float delta = dot(v, w);
+    if (it > 0) {
+      if (delta > 0.0f && delta * delta > sqd * (maxdist * maxdist)) return 0;
+      int dup = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dup |= (k < s.n && s.ia[k] == ia && s.ib[k] == ib);
+      if (dup) break;
+      if (sqd - delta <= sqd * 1e-6f) break;
+    }
+    simplex_push(s, w, a, b, ia, ib);
+    v3 nv;
+    int rc = simplex_closest(s, nv);
+    if (rc == 2) return 2;
+    if (rc == 0) {
+      if (it == 0) return 0;
+      s.n -= 1;   // drop the vertex just pushed; lam still describes the previous simplex
+      break;
+    }
+    float nsq = dot(nv, nv);
+    if (nsq < 1e-10f) return 2;
+    bool stall = (it > 0) && (sqd - nsq <= 1.1920929e-7f * sqd);
+    v = nv; sqd = nsq;
+    if (stall) break;
+  }
+  v3 A = V(0.0f, 0.0f, 0.0f), B = V(0.0f, 0.0f, 0.0f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < s.n) { A = A + s.p[k] * s.lam[k]; B = B + s.q[k] * s.lam[k]; }
+  float d = sqrtf(sqd);
+  if (d > maxdist) { axis = v; return 0; }
+  pa = A; pb = B; dist = d;
+  nrm = v * (1.0f / d);
+  axis = v;
+  return 1;
+}

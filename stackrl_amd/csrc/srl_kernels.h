@@ -1,0 +1,56 @@
+// srl_kernels.h — shared host/device parameter blocks of libstackrl_hip.
+#pragma once
+#include <stdint.h>
+#include "../../include/srl_types.h"
+
+// Per-mesh header in the device mesh table.
+struct MeshHdr {
+  int32_t vo, nv, to, nt;       // offsets/counts into mesh_verts (float4) / mesh_tris (uchar4)
+  float inv_mass;
+  float iix, iiy, iiz;          // inverse inertia diagonal (body frame): box inertia of the AABB
+  float radius;                 // bounding radius about the centre of mass
+  float cx, cy, cz;             // centre of mass in the URDF link frame
+};
+
+// Per-env scalar state (global memory).
+struct EnvHdr {
+  int32_t nb;                   // placed bodies
+  int32_t done;                 // StackEnv._done (env.py:219-220)
+  uint32_t episode;             // episode counter (RNG key part)
+  int32_t list_pos;             // next index into ids (episode_list.pop, env.py:243-247)
+  int32_t pending;              // mesh id waiting at the spawn pose, -1 = none (Simulator._new)
+  int32_t mode;                 // what the last step did: 0 placement, 1 reset, 2 rejected action
+  int32_t goal[4];              // u, v, h, w (rewarder.py:255-257)
+  float prev_metric;            // Rewarder._memory[metric]
+  int32_t substeps[2];          // Simulator.n_steps
+  int32_t status;               // SRL_ST_* bits
+  int32_t ncolour;              // contact-graph colours, -1 = recolour
+  int32_t has_script;
+  int32_t ids[SRL_MAX_BODIES];
+  int32_t script_ids[SRL_MAX_BODIES];
+  int32_t script_goal[4];
+};
+
+// Everything a kernel needs, passed by value.
+struct DevParams {
+  srl_config c;
+  // derived scalars (computed once on the host in double, rounded to float like the oracle does)
+  float px, inv_px, lin_damp, ang_damp, goal_z, scale, elev_num, obj_c1, obj_c2;
+  int32_t max_substeps, goal_size, goal_min_h, goal_max_h, goal_min_w, goal_max_w, AW, A;
+  int32_t n_mesh, VS /*vertex stride*/, NS /*manifold slots*/, NP /*body pairs*/;
+  uint32_t seed, sample_counter;
+  int32_t force_reset;
+  // persistent blob layout (32-bit words)
+  int32_t OFF_X, OFF_Q, OFF_V, OFF_W, OFF_PX, OFF_PQ, OFF_MESH, OFF_GM, OFF_MAN, OFF_SOP, OFF_POS, OFF_COL, BLOB;
+  // scratch layout (words, after the blob in LDS)
+  int32_t S_R, S_IW, S_AMIN, S_AMAX, S_BC, S_WV, S_MISC, LDS_WORDS;
+  // device pointers
+  EnvHdr* hdr;
+  float* blob;            // [n_envs][BLOB]
+  float* H;               // [n_envs][res*res]
+  const MeshHdr* mh;
+  const float4* mv;       // mesh vertices, COM frame
+  const uchar4* mt;       // triangles
+  const float* objmap;    // [n_mesh][ores*ores] underside maps (O2)
+  int32_t* flags;         // [1] accumulated error bits since the last srl_sync_status
+};

@@ -1,0 +1,510 @@
+// stackrl_hip.hip — C-ABI of libstackrl_hip.so (include/stackrl_hip.h): host side.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC (see stackrl_amd/build.py).
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/stackrl_hip.h"
+#include "settle.hip"
+#include "render.hip"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* arg = "") {
+  snprintf(g_err, sizeof g_err, fmt, arg);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      snprintf(g_err, sizeof g_err, "%s: %s", #expr, hipGetErrorString(_e));             \
+      return SRL_EHIP;                                                                   \
+    }                                                                                    \
+  } while (0)
+
+struct EventPair { hipEvent_t a, b; int which; };
+
+}  // namespace
+
+struct srl_env {
+  DevParams P;
+  MeshHdr* d_mh = nullptr;
+  float4* d_mv = nullptr;
+  uchar4* d_mt = nullptr;
+  float* d_objmap = nullptr;
+  int step_threads = 64;
+  size_t step_lds = 0, render_lds = 0, objmap_lds = 0;
+  bool profiling = false;
+  std::vector<EventPair> pending;
+  std::vector<hipEvent_t> pool;
+  float acc_ms[3] = {0, 0, 0};
+  int acc_n[3] = {0, 0, 0};
+};
+
+namespace {
+
+int nslots(int L) {
+  int np = L * (L - 1) / 2;
+  if (np < 1) np = 1;
+  return np < SRL_NSLOT_MAX ? np : SRL_NSLOT_MAX;
+}
+
+// derived constants: identical expressions to the oracle's derive() so both sides round alike
+int derive(DevParams& P) {
+  srl_config& c = P.c;
+  if (c.n_envs < 1 || c.episode_length < 1 || c.episode_length > SRL_MAX_BODIES)
+    return fail(SRL_EINVAL, "n_envs/episode_length out of range");
+  if (c.overhead_res < c.object_res || c.object_res < 2 || c.overhead_res > 256 || (c.overhead_res % 8) != 0)
+    return fail(SRL_EINVAL, "bad resolutions (overhead_res must be a multiple of 8, <= 256)");
+  if (c.metric < 0 || c.metric > 3) return fail(SRL_EINVAL, "Invalid value for argument metric");
+  P.px = c.object_max_dimension / (float)c.object_res;
+  P.inv_px = (float)c.object_res / c.object_max_dimension;
+  P.lin_damp = (float)pow(1.0 - (double)c.linear_damping, (double)c.sim_time_step);
+  P.ang_damp = (float)pow(1.0 - (double)c.angular_damping, (double)c.sim_time_step);
+  P.max_substeps = c.max_substeps > 0 ? c.max_substeps : (int)(300.0 / (double)c.sim_time_step);   // simulator.py:46
+  int H = c.overhead_res, h = c.object_res;
+  P.goal_min_h = h; P.goal_min_w = h; P.goal_max_h = H; P.goal_max_w = H;   // rewarder.py:65-80
+  P.goal_size = (int)((double)c.goal_size_ratio * H * H);
+  if (P.goal_size <= 0) return fail(SRL_EINVAL, "goal_size_ratio must be a scalar in (0,1]");
+  if (P.goal_size / P.goal_max_w > P.goal_min_h) P.goal_min_h = P.goal_size / P.goal_max_w;
+  if (P.goal_size / P.goal_min_w < P.goal_max_h) P.goal_max_h = P.goal_size / P.goal_min_w;
+  P.goal_z = c.max_z - c.object_max_dimension;                                 // observer.py:378-382
+  P.scale = c.reward_scale > 0.0f ? c.reward_scale : (float)c.episode_length;  // rewarder.py:97
+  P.AW = H - h + 1;                                                            // env.py:207-211
+  P.A = P.AW * P.AW;
+  // observer.py:259-260 / :274-275 constants, rounded to float32 the way numpy rounds python scalars
+  double oz = (double)c.object_max_dimension;
+  P.elev_num = (float)((double)SRL_FAR * ((double)SRL_FAR - (double)c.max_z));
+  P.obj_c1 = (float)((double)SRL_FAR + oz / 2);
+  P.obj_c2 = (float)((double)SRL_FAR * (double)SRL_FAR - (oz / 2) * (oz / 2));
+  return SRL_OK;
+}
+
+void layout(DevParams& P) {
+  int L = P.c.episode_length;
+  P.NS = nslots(L);
+  P.NP = L * (L - 1) / 2 > 0 ? L * (L - 1) / 2 : 1;
+  int o = 0;
+  P.OFF_X = o; o += 3 * L;
+  P.OFF_Q = o; o += 4 * L;
+  P.OFF_V = o; o += 3 * L;
+  P.OFF_W = o; o += 3 * L;
+  P.OFF_PX = o; o += 3 * L;
+  P.OFF_PQ = o; o += 4 * L;
+  P.OFF_MESH = o; o += L;
+  P.OFF_GM = o; o += SRL_GM_WORDS * L;
+  P.OFF_MAN = o; o += SRL_MAN_WORDS * P.NS;
+  P.OFF_SOP = o; o += P.NP;
+  P.OFF_POS = o; o += P.NS;
+  P.OFF_COL = o; o += P.NS;
+  P.BLOB = (o + 3) & ~3;
+  int s = 0;
+  P.S_R = s; s += 9 * L;
+  P.S_IW = s; s += 9 * L;
+  P.S_AMIN = s; s += 3 * L;
+  P.S_AMAX = s; s += 3 * L;
+  P.S_BC = s; s += 8 * L;
+  P.S_WV = s; s += 3 * P.VS * L;
+  P.S_MISC = s; s += M_WORDS;
+  P.LDS_WORDS = P.BLOB + s;
+}
+
+hipEvent_t get_event(srl_env* env) {
+  if (!env->pool.empty()) { hipEvent_t e = env->pool.back(); env->pool.pop_back(); return e; }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+void prof_begin(srl_env* env, hipStream_t st, int which) {
+  if (!env->profiling) return;
+  EventPair p; p.a = get_event(env); p.b = get_event(env); p.which = which;
+  hipEventRecord(p.a, st);
+  env->pending.push_back(p);
+}
+void prof_end(srl_env* env, hipStream_t st) {
+  if (!env->profiling) return;
+  hipEventRecord(env->pending.back().b, st);
+}
+
+int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void* obs_obj, float* reward, uint8_t* done,
+                       hipStream_t st, int force_reset) {
+  if (!env->d_mh) return fail(SRL_ENOMESH, "srl_load_meshes must be called first");
+  DevParams P = env->P;
+  P.force_reset = force_reset;
+  const int n = P.c.n_envs;
+  prof_begin(env, st, 0);
+  hipLaunchKernelGGL(srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, P, action);
+  prof_end(env, st);
+  prof_begin(env, st, 1);
+  hipLaunchKernelGGL(srl_k_render, dim3(n), dim3(256), env->render_lds, st, P, (uint8_t*)obs_map, (uint8_t*)obs_obj,
+                     reward, done, (const float*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr,
+                     (float*)nullptr);
+  prof_end(env, st);
+  HIP_TRY(hipGetLastError());
+  return SRL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* srl_last_error(void) { return g_err; }
+
+int srl_config_default(srl_config* c) {
+  if (!c) return fail(SRL_EINVAL, "null config");
+  memset(c, 0, sizeof *c);
+  c->n_envs = 1;
+  c->episode_length = 30;            // DEFAULT_EPISODE_LENGTH, env.py:20
+  c->overhead_res = 128; c->object_res = 32;
+  c->object_max_dimension = 0.125f; c->max_z = 0.375f;
+  c->sim_time_step = 0.01f; c->gravity = 9.8f; c->velocity_threshold = 0.01f;
+  c->smooth_placing = 1; c->max_substeps = 0;
+  c->metric = SRL_METRIC_IOU; c->goal_size_ratio = 0.25f; c->reward_scale = 1.0f;
+  c->reward_pexp = 2; c->reward_oexp = 2;   // Stack-v0 registry: reward_params=2
+  c->solver_iterations = 10; c->collision_margin = 0.001f; c->erp = 0.2f;
+  c->friction_rock = 0.6f; c->friction_ground = 0.5f;
+  c->linear_damping = 0.04f; c->angular_damping = 0.04f; c->warmstart = 0.85f;
+  c->place_at_com = 1;
+  return SRL_OK;
+}
+
+int srl_create(const srl_config* cfg, srl_env** out) {
+  if (!cfg || !out) return fail(SRL_EINVAL, "null argument");
+  srl_env* env = new srl_env();
+  memset(&env->P, 0, sizeof env->P);
+  env->P.c = *cfg;
+  int rc = derive(env->P);
+  if (rc) { delete env; return rc; }
+  env->P.VS = 4;
+  layout(env->P);
+  DevParams& P = env->P;
+  const int n = P.c.n_envs, res = P.c.overhead_res;
+  // pair tables
+  {
+    uint8_t pi[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2], pj[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
+    for (int j = 1; j < SRL_MAX_BODIES; ++j)
+      for (int i = 0; i < j; ++i) { pi[j * (j - 1) / 2 + i] = (uint8_t)i; pj[j * (j - 1) / 2 + i] = (uint8_t)j; }
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_i), pi, sizeof pi));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_j), pj, sizeof pj));
+  }
+  HIP_TRY(hipMalloc((void**)&P.hdr, sizeof(EnvHdr) * (size_t)n));
+  HIP_TRY(hipMalloc((void**)&P.blob, sizeof(float) * (size_t)n * P.BLOB));
+  HIP_TRY(hipMalloc((void**)&P.H, sizeof(float) * (size_t)n * res * res));
+  HIP_TRY(hipMalloc((void**)&P.flags, sizeof(int32_t)));
+  HIP_TRY(hipMemset(P.blob, 0, sizeof(float) * (size_t)n * P.BLOB));
+  HIP_TRY(hipMemset(P.H, 0, sizeof(float) * (size_t)n * res * res));
+  HIP_TRY(hipMemset(P.flags, 0, sizeof(int32_t)));
+  {
+    std::vector<EnvHdr> h((size_t)n);
+    memset(h.data(), 0, sizeof(EnvHdr) * (size_t)n);
+    for (int i = 0; i < n; ++i) { h[i].done = 1; h[i].pending = -1; h[i].ncolour = -1; }   // env.py:219-220
+    HIP_TRY(hipMemcpy(P.hdr, h.data(), sizeof(EnvHdr) * (size_t)n, hipMemcpyHostToDevice));
+  }
+  *out = env;
+  return SRL_OK;
+}
+
+void srl_destroy(srl_env* env) {
+  if (!env) return;
+  (void)hipDeviceSynchronize();
+  for (auto& p : env->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto& e : env->pool) hipEventDestroy(e);
+  hipFree(env->P.hdr); hipFree(env->P.blob); hipFree(env->P.H); hipFree(env->P.flags);
+  hipFree(env->d_mh); hipFree(env->d_mv); hipFree(env->d_mt); hipFree(env->d_objmap);
+  delete env;
+}
+
+int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, const int32_t* tris,
+                    const int32_t* tri_off, const float* mass_com, int32_t n_mesh) {
+  if (!env || !verts || !vert_off || !tris || !tri_off || !mass_com) return fail(SRL_EINVAL, "null argument");
+  if (n_mesh < 1) return fail(SRL_EINVAL, "List of object descriptor files is empty.");   // env.py:103
+  DevParams& P = env->P;
+  std::vector<MeshHdr> mh((size_t)n_mesh);
+  std::vector<float4> mv((size_t)vert_off[n_mesh]);
+  std::vector<uchar4> mt((size_t)tri_off[n_mesh]);
+  int vs = 4;
+  for (int m = 0; m < n_mesh; ++m) {
+    MeshHdr& M = mh[m];
+    M.vo = vert_off[m]; M.nv = vert_off[m + 1] - vert_off[m];
+    M.to = tri_off[m]; M.nt = tri_off[m + 1] - tri_off[m];
+    if (M.nv < 4 || M.nv > SRL_MAX_VERTS || M.nt < 4 || M.nt > SRL_MAX_TRIS)
+      return fail(SRL_EINVAL, "mesh exceeds SRL_MAX_VERTS/SRL_MAX_TRIS");
+    if (M.nv > vs) vs = M.nv;
+    float mass = mass_com[4 * m];
+    M.cx = mass_com[4 * m + 1]; M.cy = mass_com[4 * m + 2]; M.cz = mass_com[4 * m + 3];
+    float lox = 1e30f, loy = 1e30f, loz = 1e30f, hix = -1e30f, hiy = -1e30f, hiz = -1e30f, r2 = 0.0f;
+    for (int k = 0; k < M.nv; ++k) {
+      const float* p = verts + 3 * (size_t)(M.vo + k);
+      float ax = p[0] - M.cx, ay = p[1] - M.cy, az = p[2] - M.cz;   // COM frame
+      mv[(size_t)M.vo + k] = make_float4(ax, ay, az, 0.0f);
+      lox = fminf(lox, ax); loy = fminf(loy, ay); loz = fminf(loz, az);
+      hix = fmaxf(hix, ax); hiy = fmaxf(hiy, ay); hiz = fmaxf(hiz, az);
+      float d2 = (ax * ax + ay * ay) + az * az;
+      if (d2 > r2) r2 = d2;
+    }
+    M.radius = sqrtf(r2);
+    for (int k = 0; k < M.nt; ++k) {
+      const int32_t* t = tris + 3 * (size_t)(M.to + k);
+      for (int j = 0; j < 3; ++j)
+        if (t[j] < 0 || t[j] >= M.nv) return fail(SRL_EINVAL, "triangle index out of range");
+      mt[(size_t)M.to + k] = make_uchar4((unsigned char)t[0], (unsigned char)t[1], (unsigned char)t[2], 0);
+    }
+    // Bullet's default for hull shapes when the URDF inertia is not requested (simulator.py:300 passes no
+    // flags): inertia of the solid box spanned by the AABB (btCompoundShape::calculateLocalInertia restated)
+    float lx = hix - lox, ly = hiy - loy, lz = hiz - loz;
+    float k12 = mass / 12.0f;
+    float Ix = k12 * (ly * ly + lz * lz), Iy = k12 * (lx * lx + lz * lz), Iz = k12 * (lx * lx + ly * ly);
+    M.inv_mass = 1.0f / mass;
+    M.iix = 1.0f / Ix; M.iiy = 1.0f / Iy; M.iiz = 1.0f / Iz;
+  }
+  hipFree(env->d_mh); hipFree(env->d_mv); hipFree(env->d_mt); hipFree(env->d_objmap);
+  env->d_mh = nullptr; env->d_mv = nullptr; env->d_mt = nullptr; env->d_objmap = nullptr;
+  const int r = P.c.object_res;
+  HIP_TRY(hipMalloc((void**)&env->d_mh, sizeof(MeshHdr) * mh.size()));
+  HIP_TRY(hipMalloc((void**)&env->d_mv, sizeof(float4) * mv.size()));
+  HIP_TRY(hipMalloc((void**)&env->d_mt, sizeof(uchar4) * mt.size()));
+  HIP_TRY(hipMalloc((void**)&env->d_objmap, sizeof(float) * (size_t)n_mesh * r * r));
+  HIP_TRY(hipMemcpy(env->d_mh, mh.data(), sizeof(MeshHdr) * mh.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(env->d_mv, mv.data(), sizeof(float4) * mv.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(env->d_mt, mt.data(), sizeof(uchar4) * mt.size(), hipMemcpyHostToDevice));
+  P.mh = env->d_mh; P.mv = env->d_mv; P.mt = env->d_mt; P.objmap = env->d_objmap;
+  P.n_mesh = n_mesh;
+  P.VS = vs;
+  int old_blob = P.BLOB;
+  layout(P);
+  if (P.BLOB != old_blob) return fail(SRL_EINVAL, "internal: blob layout changed");
+  env->step_lds = sizeof(float) * (size_t)P.LDS_WORDS;
+  if (env->step_lds > 160 * 1024) return fail(SRL_EINVAL, "episode_length x mesh size exceeds the 160 KB LDS budget");
+  int need = P.NS > P.c.episode_length ? P.NS : P.c.episode_length;
+  env->step_threads = ((need + 63) / 64) * 64;
+  if (env->step_threads > 256) env->step_threads = 256;
+  const int res = P.c.overhead_res;
+  env->render_lds = sizeof(uint32_t) * (size_t)res * res +
+                    sizeof(float) * (3 * SRL_MAX_BODIES + 9 * SRL_MAX_BODIES + SRL_MAX_BODIES + SRL_MAX_BODIES + 1 + 512);
+  env->objmap_lds = sizeof(uint32_t) * (size_t)r * r;
+  HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)srl_k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->render_lds));
+  // K3: object maps of the whole pool, once
+  hipLaunchKernelGGL(srl_k_objmap, dim3(n_mesh), dim3(256), env->objmap_lds, 0, P, env->d_objmap);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  if (n_mesh < P.c.episode_length) { /* sampled with replacement, env.py:104-106 */ }
+  return SRL_OK;
+}
+
+int srl_seed(srl_env* env, uint32_t seed) {
+  if (!env) return fail(SRL_EINVAL, "null env");
+  env->P.seed = seed;
+  env->P.sample_counter = 0;
+  HIP_TRY(hipDeviceSynchronize());
+  const int n = env->P.c.n_envs;
+  std::vector<uint32_t> z((size_t)n, 0u);
+  HIP_TRY(hipMemcpy2D(&env->P.hdr[0].episode, sizeof(EnvHdr), z.data(), sizeof(uint32_t), sizeof(uint32_t), (size_t)n,
+                      hipMemcpyHostToDevice));
+  return SRL_OK;
+}
+
+int srl_set_script(srl_env* env, const int32_t* mesh_ids, const int32_t* goal_rect) {
+  if (!env || !mesh_ids || !goal_rect) return fail(SRL_EINVAL, "null argument");
+  const DevParams& P = env->P;
+  const int n = P.c.n_envs, L = P.c.episode_length;
+  for (size_t k = 0; k < (size_t)n * L; ++k)
+    if (mesh_ids[k] < 0 || mesh_ids[k] >= P.n_mesh) return fail(SRL_EINVAL, "script mesh id out of range");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy2D(&P.hdr[0].script_ids[0], sizeof(EnvHdr), mesh_ids, sizeof(int32_t) * L, sizeof(int32_t) * L,
+                      (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy2D(&P.hdr[0].script_goal[0], sizeof(EnvHdr), goal_rect, sizeof(int32_t) * 4, sizeof(int32_t) * 4,
+                      (size_t)n, hipMemcpyHostToDevice));
+  std::vector<int32_t> ones((size_t)n, 1);
+  HIP_TRY(hipMemcpy2D(&P.hdr[0].has_script, sizeof(EnvHdr), ones.data(), sizeof(int32_t), sizeof(int32_t), (size_t)n,
+                      hipMemcpyHostToDevice));
+  return SRL_OK;
+}
+
+int srl_reset(srl_env* env, void* obs_map, void* obs_obj, void* stream) {
+  if (!env || !obs_map || !obs_obj) return fail(SRL_EINVAL, "null argument");
+  // reward/done of a reset are zeros (utils.py:545-552); the kernels still need somewhere to write them
+  static thread_local float* scratch_r = nullptr;
+  static thread_local uint8_t* scratch_d = nullptr;
+  static thread_local int scratch_n = 0;
+  const int n = env->P.c.n_envs;
+  if (scratch_n < n) {
+    hipFree(scratch_r); hipFree(scratch_d);
+    HIP_TRY(hipMalloc((void**)&scratch_r, sizeof(float) * (size_t)n));
+    HIP_TRY(hipMalloc((void**)&scratch_d, (size_t)n));
+    scratch_n = n;
+  }
+  return launch_step_render(env, nullptr, obs_map, obs_obj, scratch_r, scratch_d, (hipStream_t)stream, 1);
+}
+
+int srl_step(srl_env* env, const int64_t* action, void* obs_map, void* obs_obj, float* reward, uint8_t* done,
+             void* stream) {
+  if (!env || !action || !obs_map || !obs_obj || !reward || !done) return fail(SRL_EINVAL, "null argument");
+  return launch_step_render(env, action, obs_map, obs_obj, reward, done, (hipStream_t)stream, 0);
+}
+
+int srl_sample(srl_env* env, int64_t* action, void* stream) {
+  if (!env || !action) return fail(SRL_EINVAL, "null argument");
+  env->P.sample_counter += 1;
+  const int n = env->P.c.n_envs;
+  hipLaunchKernelGGL(srl_k_sample, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, env->P, action);
+  HIP_TRY(hipGetLastError());
+  return SRL_OK;
+}
+
+int srl_sync_status(srl_env* env, void* stream) {
+  if (!env) return fail(SRL_EINVAL, "null env");
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  int32_t f = 0;
+  HIP_TRY(hipMemcpy(&f, env->P.flags, sizeof f, hipMemcpyDeviceToHost));
+  if (f) HIP_TRY(hipMemset(env->P.flags, 0, sizeof f));
+  if (f & 1) return fail(SRL_EINVAL_ACTION, "Invalid action.");
+  if (f & 2) return fail(SRL_ESIM_DIVERGED, "Maximum number of simulator steps reached. This may be caused by incorrect behaviour due to a large time step value");
+  return SRL_OK;
+}
+
+int srl_get_state(srl_env* env, float* poses, int32_t* n_bodies, int32_t* substeps, int32_t* status) {
+  if (!env) return fail(SRL_EINVAL, "null env");
+  const DevParams& P = env->P;
+  const int n = P.c.n_envs;
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<EnvHdr> h((size_t)n);
+  HIP_TRY(hipMemcpy(h.data(), P.hdr, sizeof(EnvHdr) * (size_t)n, hipMemcpyDeviceToHost));
+  std::vector<float> blob;
+  if (poses) {
+    blob.resize((size_t)n * P.BLOB);
+    HIP_TRY(hipMemcpy(blob.data(), P.blob, sizeof(float) * blob.size(), hipMemcpyDeviceToHost));
+    memset(poses, 0, sizeof(float) * (size_t)n * SRL_MAX_BODIES * 8);
+  }
+  for (int i = 0; i < n; ++i) {
+    if (poses) {
+      const float* gb = blob.data() + (size_t)i * P.BLOB;
+      float* p = poses + (size_t)i * SRL_MAX_BODIES * 8;
+      for (int b = 0; b < h[i].nb; ++b) {
+        for (int k = 0; k < 3; ++k) p[b * 8 + k] = gb[P.OFF_X + 3 * b + k];
+        for (int k = 0; k < 4; ++k) p[b * 8 + 3 + k] = gb[P.OFF_Q + 4 * b + k];
+        p[b * 8 + 7] = (float)((const int32_t*)gb)[P.OFF_MESH + b];
+      }
+    }
+    if (n_bodies) n_bodies[i] = h[i].nb;
+    if (substeps) { substeps[2 * i] = h[i].substeps[0]; substeps[2 * i + 1] = h[i].substeps[1]; }
+    if (status) status[i] = h[i].status;
+  }
+  return SRL_OK;
+}
+
+int srl_get_velocities(srl_env* env, float* vel) {
+  if (!env || !vel) return fail(SRL_EINVAL, "null argument");
+  const DevParams& P = env->P;
+  const int n = P.c.n_envs;
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<EnvHdr> h((size_t)n);
+  HIP_TRY(hipMemcpy(h.data(), P.hdr, sizeof(EnvHdr) * (size_t)n, hipMemcpyDeviceToHost));
+  std::vector<float> blob((size_t)n * P.BLOB);
+  HIP_TRY(hipMemcpy(blob.data(), P.blob, sizeof(float) * blob.size(), hipMemcpyDeviceToHost));
+  memset(vel, 0, sizeof(float) * (size_t)n * SRL_MAX_BODIES * 8);
+  for (int i = 0; i < n; ++i) {
+    const float* gb = blob.data() + (size_t)i * P.BLOB;
+    float* p = vel + (size_t)i * SRL_MAX_BODIES * 8;
+    for (int b = 0; b < h[i].nb; ++b)
+      for (int k = 0; k < 3; ++k) { p[b * 8 + k] = gb[P.OFF_V + 3 * b + k]; p[b * 8 + 4 + k] = gb[P.OFF_W + 3 * b + k]; }
+  }
+  return SRL_OK;
+}
+
+int srl_get_contacts(srl_env* env, float* max_penetration, int32_t* n_points) {
+  if (!env || !max_penetration || !n_points) return fail(SRL_EINVAL, "null argument");
+  const int n = env->P.c.n_envs;
+  float* d_mp = nullptr; int32_t* d_np = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_mp, sizeof(float) * (size_t)n));
+  HIP_TRY(hipMalloc((void**)&d_np, sizeof(int32_t) * (size_t)n));
+  hipLaunchKernelGGL(srl_k_contacts, dim3((n + 63) / 64), dim3(64), 0, 0, env->P, d_mp, d_np);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(max_penetration, d_mp, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(n_points, d_np, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+  hipFree(d_mp); hipFree(d_np);
+  return SRL_OK;
+}
+
+int srl_get_maps(srl_env* env, float* height, float* object_map, int32_t* goal_rect) {
+  if (!env) return fail(SRL_EINVAL, "null env");
+  const DevParams& P = env->P;
+  const int n = P.c.n_envs, res = P.c.overhead_res, r = P.c.object_res;
+  HIP_TRY(hipDeviceSynchronize());
+  if (height) HIP_TRY(hipMemcpy(height, P.H, sizeof(float) * (size_t)n * res * res, hipMemcpyDeviceToHost));
+  if (object_map || goal_rect) {
+    std::vector<EnvHdr> h((size_t)n);
+    HIP_TRY(hipMemcpy(h.data(), P.hdr, sizeof(EnvHdr) * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+      if (goal_rect) for (int k = 0; k < 4; ++k) goal_rect[4 * i + k] = h[i].goal[k];
+      if (object_map) {
+        float* o = object_map + (size_t)i * r * r;
+        if (h[i].pending >= 0) {
+          HIP_TRY(hipMemcpy(o, env->d_objmap + (size_t)h[i].pending * r * r, sizeof(float) * r * r, hipMemcpyDeviceToHost));
+        } else {
+          // empty map = elev_object(1.0), evaluated like the kernel does
+          float e0 = P.obj_c1 - P.obj_c2 / (SRL_FAR + P.c.object_max_dimension * (0.5f - 1.0f));
+          for (int k = 0; k < r * r; ++k) o[k] = e0;
+        }
+      }
+    }
+  }
+  return SRL_OK;
+}
+
+int srl_get_object_map(srl_env* env, int32_t mesh_id, float* object_map) {
+  if (!env || !object_map) return fail(SRL_EINVAL, "null argument");
+  if (!env->d_objmap) return fail(SRL_ENOMESH, "srl_load_meshes must be called first");
+  if (mesh_id < 0 || mesh_id >= env->P.n_mesh) return fail(SRL_EINVAL, "mesh id out of range");
+  const int r = env->P.c.object_res;
+  HIP_TRY(hipMemcpy(object_map, env->d_objmap + (size_t)mesh_id * r * r, sizeof(float) * r * r, hipMemcpyDeviceToHost));
+  return SRL_OK;
+}
+
+int srl_render_heightmap(srl_env* env, const float* poses, const int32_t* mesh_ids, const int32_t* n_bodies,
+                         float* height, void* stream) {
+  if (!env || !poses || !mesh_ids || !n_bodies || !height) return fail(SRL_EINVAL, "null argument");
+  if (!env->d_mh) return fail(SRL_ENOMESH, "srl_load_meshes must be called first");
+  hipStream_t st = (hipStream_t)stream;
+  prof_begin(env, st, 1);
+  hipLaunchKernelGGL(srl_k_render, dim3(env->P.c.n_envs), dim3(256), env->render_lds, st, env->P, (uint8_t*)nullptr,
+                     (uint8_t*)nullptr, (float*)nullptr, (uint8_t*)nullptr, poses, mesh_ids, n_bodies, height);
+  prof_end(env, st);
+  HIP_TRY(hipGetLastError());
+  return SRL_OK;
+}
+
+int srl_set_profiling(srl_env* env, int32_t enable) {
+  if (!env) return fail(SRL_EINVAL, "null env");
+  env->profiling = enable != 0;
+  return SRL_OK;
+}
+
+int srl_get_kernel_times(srl_env* env, float* ms3, int32_t* launches3) {
+  if (!env) return fail(SRL_EINVAL, "null env");
+  HIP_TRY(hipDeviceSynchronize());
+  for (auto& p : env->pending) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { env->acc_ms[p.which] += ms; env->acc_n[p.which] += 1; }
+    env->pool.push_back(p.a); env->pool.push_back(p.b);
+  }
+  env->pending.clear();
+  for (int k = 0; k < 3; ++k) {
+    if (ms3) ms3[k] = env->acc_ms[k];
+    if (launches3) launches3[k] = env->acc_n[k];
+    env->acc_ms[k] = 0.0f; env->acc_n[k] = 0;
+  }
+  return SRL_OK;
+}
+
+}  // extern "C"

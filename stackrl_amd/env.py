@@ -1,0 +1,239 @@
+"""Host-side mirror of the reference's batched env interface over the HIP C-ABI.
+
+`VecStackEnv` is what `stackrl.envs.make('Stack-v0', n_parallel=B, seed=s, **kwargs)` returns in
+the reference (`stackrl/envs/utils.py:44-141` -> `ParallelEnv`, `:302-576`): same method and property
+names (`step/reset/sample/seed/close/__call__`, `batch_size`, `observation_spec`, `action_spec`,
+`multiprocessing`), same argument meaning, same tuple layout
+`((u8[B,H,W,2], u8[B,h,w,1]), f32[B], bool[B])`, same non-blocking default (a callable that yields the
+time step, `utils.py:468-486`), same exception types.  Tensors are torch (ROCm) instead of tf.
+
+All arithmetic happens in libstackrl_hip.so; torch only owns device memory and streams.
+"""
+import collections
+import ctypes
+
+import numpy as np
+import torch
+
+from stackrl_amd import assets as _assets
+from stackrl_amd import lib as _lib
+from stackrl_amd import config as _config
+from stackrl_amd.config import StackConfig
+
+TensorSpec = collections.namedtuple('TensorSpec', ['shape', 'dtype'])
+
+
+def _check(rc):
+  if rc == _config.OK:
+    return
+  msg = _lib.last_error()
+  if rc == _config.EINVAL_ACTION:
+    raise AssertionError(msg)             # env.py:238
+  if rc == _config.ESIM_DIVERGED:
+    raise RuntimeError(msg)               # simulator.py:221-224
+  if rc in (_config.EINVAL, _config.ENOMESH):
+    raise ValueError(msg)
+  raise RuntimeError('HIP error: ' + msg)
+
+
+def _np_ptr(a):
+  return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class VecStackEnv(object):
+  """B independent Stack-v0 envs on one GPU (drop-in for `ParallelEnv`, utils.py:302)."""
+
+  def __init__(self, n_parallel=None, block=None, seed=None, pool=None, device=None,
+               env_index_offset=0, **kwargs):
+    """
+    Args:
+      n_parallel: number of environments B (utils.py:324).
+      block: whether step/reset block by default; None -> False (utils.py:326-327).
+      seed: env i uses (seed + env_index_offset + i) % 2**32 (utils.py:433).
+      pool: `assets.MeshPool` (the urdf list of env.py:92-103); None -> synthetic default pool.
+      device: torch device (defaults to the current cuda device).
+      env_index_offset: global index of env 0 when the batch is sharded over ranks.
+      kwargs: StackEnv arguments (env.py:28-51), e.g. episode_length, sim_time_step, rewarder.
+    """
+    if not torch.cuda.is_available():
+      raise RuntimeError('VecStackEnv needs a HIP device: there is no CPU fallback in the product path.')
+    self._lib = _lib.load()
+    self._device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    self.config = StackConfig(n_envs=int(n_parallel or 1), env_index_offset=int(env_index_offset), **kwargs)
+    self._block = block
+    self._c = self.config.to_c()
+    self._h = ctypes.c_void_p()
+    with torch.cuda.device(self._device):
+      _check(self._lib.srl_create(ctypes.byref(self._c), ctypes.byref(self._h)))
+      self.pool = pool if pool is not None else _assets.default_pool()
+      p = self.pool
+      _check(self._lib.srl_load_meshes(self._h, _np_ptr(p.verts), _np_ptr(p.vert_off), _np_ptr(p.tris),
+                                       _np_ptr(p.tri_off), _np_ptr(p.mass_com), len(p)))
+    B, H, h = self.config.n_envs, self.config.overhead_res, self.config.object_res
+    self._observation_spec = (TensorSpec((H, H, 2), torch.uint8), TensorSpec((h, h, 1), torch.uint8))
+    self._action_spec = TensorSpec((), torch.int64)
+    self._B, self._H, self._hh = B, H, h
+    self._closed = False
+    self.seed(seed if seed is not None else 0)
+
+  # ---- properties (utils.py:270-281, :417-422)
+  @property
+  def multiprocessing(self):
+    return False
+
+  @property
+  def batch_size(self):
+    return self._B
+
+  @property
+  def observation_spec(self):
+    return self._observation_spec
+
+  @property
+  def action_spec(self):
+    return self._action_spec
+
+  @property
+  def n_actions(self):
+    return self.config.n_actions
+
+  def __call__(self, *args, **kwargs):
+    return self.step(*args, **kwargs)
+
+  def __del__(self):
+    try:
+      self.terminate()
+    except Exception:
+      pass
+
+  # ---- lifecycle
+  def terminate(self):
+    if getattr(self, '_h', None) and not self._closed:
+      self._closed = True
+      self._lib.srl_destroy(self._h)
+      self._h = None
+
+  def close(self):
+    self.terminate()
+
+  def seed(self, seed):
+    """utils.py:522-532: returns the list of per-env seeds."""
+    seed = int(seed) % 2**32
+    _check(self._lib.srl_seed(self._h, seed))
+    off = self.config.env_index_offset
+    return [[(seed + off + i) % 2**32] for i in range(self._B)]
+
+  def set_script(self, mesh_ids, goal_rect):
+    """Explicit episode script for the next reset (parity harness)."""
+    mesh_ids = np.ascontiguousarray(mesh_ids, np.int32)
+    goal_rect = np.ascontiguousarray(goal_rect, np.int32)
+    if mesh_ids.shape != (self._B, self.config.episode_length) or goal_rect.shape != (self._B, 4):
+      raise ValueError('script shapes must be [B, L] and [B, 4]')
+    _check(self._lib.srl_set_script(self._h, _np_ptr(mesh_ids), _np_ptr(goal_rect)))
+
+  # ---- stepping
+  def _stream(self):
+    return ctypes.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+
+  def _new_obs(self):
+    return (torch.empty((self._B, self._H, self._H, 2), dtype=torch.uint8, device=self._device),
+            torch.empty((self._B, self._hh, self._hh, 1), dtype=torch.uint8, device=self._device))
+
+  def _finish(self, out):
+    def wait():
+      _check(self._lib.srl_sync_status(self._h, self._stream()))
+      return out
+    return wait
+
+  def reset(self, block=None):
+    om, oo = self._new_obs()
+    with torch.cuda.device(self._device):
+      _check(self._lib.srl_reset(self._h, om.data_ptr(), oo.data_ptr(), self._stream()))
+    out = ((om, oo), torch.zeros(self._B, dtype=torch.float32, device=self._device),
+           torch.zeros(self._B, dtype=torch.bool, device=self._device))     # utils.py:545-552
+    wait = self._finish(out)
+    block = self._block if block is None else block
+    return wait() if block else wait
+
+  def step(self, action, block=None):
+    if not torch.is_tensor(action):
+      action = torch.as_tensor(action)
+    action = action.to(device=self._device, dtype=torch.int64).contiguous()
+    if action.shape != (self._B,):
+      raise ValueError('action must have shape [{}]'.format(self._B))
+    om, oo = self._new_obs()
+    reward = torch.empty(self._B, dtype=torch.float32, device=self._device)
+    done = torch.empty(self._B, dtype=torch.uint8, device=self._device)
+    with torch.cuda.device(self._device):
+      _check(self._lib.srl_step(self._h, action.data_ptr(), om.data_ptr(), oo.data_ptr(), reward.data_ptr(),
+                                done.data_ptr(), self._stream()))
+    out = ((om, oo), reward, done.view(torch.bool))
+    self._keep = action   # keep the action tensor alive until the kernels consumed it
+    wait = self._finish(out)
+    block = self._block if block is None else block
+    return wait() if block else wait
+
+  def sample(self):
+    """utils.py:534-538: a batch of uniform random actions."""
+    a = torch.empty(self._B, dtype=torch.int64, device=self._device)
+    with torch.cuda.device(self._device):
+      _check(self._lib.srl_sample(self._h, a.data_ptr(), self._stream()))
+    return a
+
+  # ---- telemetry (Simulator.poses / n_steps, Observer.state, Rewarder.goal)
+  def state(self):
+    B = self._B
+    poses = np.zeros((B, _config.MAX_BODIES, 8), np.float32)
+    nb = np.zeros(B, np.int32)
+    sub = np.zeros((B, 2), np.int32)
+    st = np.zeros(B, np.int32)
+    _check(self._lib.srl_get_state(self._h, _np_ptr(poses), _np_ptr(nb), _np_ptr(sub), _np_ptr(st)))
+    return poses, nb, sub, st
+
+  def velocities(self):
+    v = np.zeros((self._B, _config.MAX_BODIES, 8), np.float32)
+    _check(self._lib.srl_get_velocities(self._h, _np_ptr(v)))
+    return v
+
+  def contacts(self):
+    mp = np.zeros(self._B, np.float32)
+    npts = np.zeros(self._B, np.int32)
+    _check(self._lib.srl_get_contacts(self._h, _np_ptr(mp), _np_ptr(npts)))
+    return mp, npts
+
+  def maps(self):
+    Hm = np.zeros((self._B, self._H, self._H), np.float32)
+    Om = np.zeros((self._B, self._hh, self._hh), np.float32)
+    g = np.zeros((self._B, 4), np.int32)
+    _check(self._lib.srl_get_maps(self._h, _np_ptr(Hm), _np_ptr(Om), _np_ptr(g)))
+    return Hm, Om, g
+
+  def object_map(self, mesh_id):
+    o = np.zeros((self._hh, self._hh), np.float32)
+    _check(self._lib.srl_get_object_map(self._h, int(mesh_id), _np_ptr(o)))
+    return o
+
+  def render_heightmap(self, poses, mesh_ids, n_bodies, out=None):
+    """O1 on explicit poses: poses f32[B,32,7], mesh_ids i32[B,32], n_bodies i32[B] (device tensors)."""
+    if out is None:
+      out = torch.empty((self._B, self._H, self._H), dtype=torch.float32, device=self._device)
+    with torch.cuda.device(self._device):
+      _check(self._lib.srl_render_heightmap(self._h, poses.data_ptr(), mesh_ids.data_ptr(), n_bodies.data_ptr(),
+                                            out.data_ptr(), self._stream()))
+    return out
+
+  def set_profiling(self, enable=True):
+    _check(self._lib.srl_set_profiling(self._h, int(bool(enable))))
+
+  def kernel_times(self):
+    ms = np.zeros(3, np.float32)
+    n = np.zeros(3, np.int32)
+    _check(self._lib.srl_get_kernel_times(self._h, _np_ptr(ms), _np_ptr(n)))
+    return ms, n
+
+
+def make(env='Stack-v0', n_parallel=None, block=None, seed=None, **kwargs):
+  """`stackrl.envs.make` (utils.py:44-141) for the one registered id this build implements."""
+  if env != 'Stack-v0':
+    raise ValueError("Only 'Stack-v0' is implemented (Stack-v1/v2 are out of scope, SURVEY.md section 2).")
+  return VecStackEnv(n_parallel=n_parallel or 1, block=block, seed=seed, **kwargs)

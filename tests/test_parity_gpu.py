@@ -1,0 +1,137 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on identical inputs.
+
+Bar: integer / index / byte outputs bit-exact; float state compared with atol 1e-6 m (the solver
+definition is evaluated with identical IEEE operations on both sides, so the observed difference is 0;
+the stated tolerance of the contract is 1e-4 m / 1e-3 rad, SURVEY.md section 8c tier C).
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+pytestmark = pytest.mark.gpu
+
+POSE_ATOL = 1e-6
+
+
+def _mk(ref_pool, oracle_mod, n, L, seed=11, **kw):
+  from stackrl_amd import env as envs
+  from stackrl_amd.config import StackConfig
+  g = envs.VecStackEnv(n_parallel=n, seed=seed, pool=ref_pool, block=True, episode_length=L, **kw)
+  o = oracle_mod.OracleEnv(StackConfig(n_envs=n, episode_length=L, **kw), ref_pool, seed=seed)
+  return g, o
+
+
+def _cmp_step(g, o, gout, oout, tag):
+  (gm, go), gr, gd = gout
+  (om, oo), orr, od = oout
+  assert np.array_equal(gm.cpu().numpy(), om), tag + ': obs_map differs'
+  assert np.array_equal(go.cpu().numpy(), oo), tag + ': obs_obj differs'
+  assert np.array_equal(gd.cpu().numpy(), od), tag + ': done differs'
+  np.testing.assert_allclose(gr.cpu().numpy(), orr, rtol=0, atol=1e-7, err_msg=tag + ': reward')
+  gp, gnb, gsub, gst = g.state()
+  op, onb, osub, ost = o.state()
+  assert np.array_equal(gnb, onb), tag
+  assert np.array_equal(gsub, osub), tag + ': sub-step counts differ {} vs {}'.format(gsub[:4], osub[:4])
+  assert np.array_equal(gst, ost), tag
+  np.testing.assert_allclose(gp, op, rtol=0, atol=POSE_ATOL, err_msg=tag + ': poses')
+  gH, gO, gg = g.maps()
+  oH, oO, og = o.maps()
+  assert np.array_equal(gg, og), tag + ': goal rect'
+  np.testing.assert_allclose(gH, oH, rtol=0, atol=1.2e-4, err_msg=tag + ': height map')
+  np.testing.assert_allclose(gO, oO, rtol=0, atol=1.2e-4, err_msg=tag + ': object map')
+  return float(np.abs(gp - op).max()), float(np.abs(gH - oH).max())
+
+
+def test_object_maps_bit_exact(ref_pool, oracle_mod):
+  g, o = _mk(ref_pool, oracle_mod, 1, 8)
+  for m in range(len(ref_pool)):
+    assert np.array_equal(g.object_map(m), o.render_object(m)), 'mesh {}'.format(m)
+
+
+def test_render_explicit_poses(ref_pool, oracle_mod):
+  n = 16
+  g, o = _mk(ref_pool, oracle_mod, n, 8)
+  rng = np.random.RandomState(3)
+  poses = np.zeros((n, 32, 7), np.float32)
+  mesh = np.zeros((n, 32), np.int32)
+  nb = rng.randint(0, 9, size=n).astype(np.int32)
+  nb[0] = 0
+  for i in range(n):
+    for b in range(nb[i]):
+      q = rng.normal(size=4); q /= np.linalg.norm(q)
+      poses[i, b] = [rng.uniform(-0.02, 0.52), rng.uniform(-0.02, 0.52), rng.uniform(0.0, 0.3), *q]
+      mesh[i, b] = rng.randint(len(ref_pool))
+  out = g.render_heightmap(torch.from_numpy(poses).cuda(), torch.from_numpy(mesh).cuda(),
+                           torch.from_numpy(nb).cuda()).cpu().numpy()
+  for i in range(n):
+    ref = o.render_heightmap(poses[i, :nb[i]], mesh[i, :nb[i]])
+    assert np.array_equal(out[i], ref), 'env {} max diff {}'.format(i, np.abs(out[i] - ref).max())
+
+
+@pytest.mark.parametrize('L,n,kw', [
+  (8, 32, {}),
+  (8, 8, dict(sim_time_step=0.0125, rewarder='dor', reward_scale=None)),   # root config.gin env overrides
+  (16, 8, dict(rewarder='diou')),
+  (4, 4, dict(rewarder='or', smooth_placing=False)),
+])
+def test_scripted_episodes(ref_pool, oracle_mod, L, n, kw):
+  g, o = _mk(ref_pool, oracle_mod, n, L, **kw)
+  rng = np.random.RandomState(5)
+  ids = np.stack([rng.choice(len(ref_pool), size=L, replace=False) for _ in range(n)]).astype(np.int32)
+  rect = np.stack([[rng.randint(8, 40), rng.randint(8, 40), 64, 64] for _ in range(n)]).astype(np.int32)
+  g.set_script(ids, rect); o.set_script(ids, rect)
+  gout, oout = g.reset(), o.reset()
+  assert np.array_equal(gout[0][0].cpu().numpy(), oout[0][0])
+  assert np.array_equal(gout[0][1].cpu().numpy(), oout[0][1])
+  A = g.n_actions
+  worst = 0.0
+  for k in range(L + 2):       # runs through done and the auto-reset step (env.py:235-236)
+    a = rng.randint(0, A, size=n).astype(np.int64)
+    gout = g.step(torch.from_numpy(a).cuda())
+    oout = o.step(a)
+    dp, dh = _cmp_step(g, o, gout, oout, 'step {}'.format(k))
+    worst = max(worst, dp)
+    if k == L - 1:
+      assert oout[2].all() and gout[2].all()
+    if k == L:
+      assert not oout[2].any() and float(gout[1].abs().max()) == 0.0
+  print('max pose diff', worst)
+
+
+def test_rng_driven_episodes_and_sample(ref_pool, oracle_mod):
+  n, L = 64, 8
+  g, o = _mk(ref_pool, oracle_mod, n, L, seed=123)
+  gout, oout = g.reset(), o.reset()
+  assert np.array_equal(gout[0][0].cpu().numpy(), oout[0][0])
+  for k in range(2 * (L + 1)):
+    ga = g.sample()
+    oa = o.sample()
+    assert np.array_equal(ga.cpu().numpy(), oa)
+    _cmp_step(g, o, g.step(ga), o.step(oa), 'step {}'.format(k))
+
+
+def test_invalid_action_raises(ref_pool, oracle_mod):
+  g, o = _mk(ref_pool, oracle_mod, 4, 4)
+  g.reset()
+  a = torch.tensor([0, 5, g.n_actions, 7], dtype=torch.int64).cuda()
+  with pytest.raises(AssertionError, match='Invalid action'):
+    g.step(a)
+  # state of the offending env is untouched, the others stepped
+  _, nb, _, st = g.state()
+  assert nb.tolist() == [1, 1, 0, 1] and st[2] & 4
+
+
+def test_nonblocking_step_returns_callable(ref_pool, oracle_mod):
+  from stackrl_amd import env as envs
+  g = envs.make('Stack-v0', n_parallel=8, seed=1, pool=ref_pool, episode_length=4)
+  step = g.reset()
+  assert callable(step)
+  (om, oo), r, d = step()
+  assert om.shape == (8, 128, 128, 2) and oo.shape == (8, 32, 32, 1) and om.dtype == torch.uint8
+  assert r.dtype == torch.float32 and d.dtype == torch.bool and not d.any()
+  nxt = g.step(g.sample())
+  assert callable(nxt)
+  (om, oo), r, d = nxt()
+  assert g.batch_size == 8 and not g.multiprocessing
+  assert g.observation_spec[0].shape == (128, 128, 2) and g.action_spec.dtype == torch.int64
