@@ -94,6 +94,8 @@ class StackConfig:
       raise ValueError('Only flat_action=True (Stack-v0) is implemented.')
     if not (1 <= self.episode_length <= MAX_BODIES):
       raise ValueError('episode_length must be in [1, {}].'.format(MAX_BODIES))
+    self.exponents()   # rewarder.py:129-142 argument checks
+    self.metric_id     # rewarder.py:116-121
 
   @property
   def object_res(self):
