@@ -129,6 +129,7 @@ typedef struct {
   int nv, nt;
   v3 v[MAXV];           /* vertices, COM frame (link vertex - com) */
   uint8_t tri[MAXT][3];
+  float pl[MAXT][4];    /* face planes, COM frame: unit normal xyz, offset d (n.p <= d inside) */
   v3 com;               /* URDF inertial origin (link frame) */
   float inv_mass;
   v3 inv_inertia;       /* body-frame diagonal: box inertia of the AABB (Bullet's default for
@@ -291,6 +292,12 @@ int srlo_load_meshes(srlo_env* e, const float* verts, const int32_t* vert_off,
         if (t[j] < 0 || t[j] >= M->nv) return fail(SRL_EINVAL, "triangle index out of range");
         M->tri[k][j] = (uint8_t)t[j];
       }
+      v3 a = M->v[t[0]], b = M->v[t[1]], c = M->v[t[2]];
+      v3 n = vcross(vsub(b, a), vsub(c, a));
+      float len = sqrtf(vdot(n, n));
+      if (!(len > 0.0f)) return fail(SRL_EINVAL, "degenerate triangle");
+      n = vscale(n, 1.0f / len);
+      M->pl[k][0] = n.x; M->pl[k][1] = n.y; M->pl[k][2] = n.z; M->pl[k][3] = vdot(n, a);
     }
     /* Bullet btCompoundShape/btPolyhedralConvexShape::calculateLocalInertia restated:
      * inertia of the solid box spanned by the shape's AABB (pybullet ignores the URDF
@@ -384,49 +391,48 @@ void srlo_depth_to_elevation(const srl_config* c, int which, const float* depth,
   }
 }
 
-/* ------------------------------------------------------------------ rasteriser */
-/* canonical edge function: antisymmetric under swapping (a,b) so shared edges are watertight */
-static inline float edge_fn(float ax, float ay, int ia, float bx, float by, int ib, float px, float py) {
-  if (ia < ib) return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
-  return -((ax - bx) * (py - by) - (ay - by) * (px - bx));
-}
-/* Rasterise one triangle (xy in map coordinates, metres) into `buf` (res x res).
- * top != 0: keep max z of up-facing triangles; top == 0: keep min z of down-facing ones. */
-static void raster_tri(float* buf, int res, float inv_px, float px, v3 a, int ia, v3 b, int ib, v3 c,
-                       int ic, int top) {
-  float area2 = (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x);
-  if (top ? !(area2 > 0.0f) : !(area2 < 0.0f)) return;
-  float xmin = fminf(a.x, fminf(b.x, c.x)), xmax = fmaxf(a.x, fmaxf(b.x, c.x));
-  float ymin = fminf(a.y, fminf(b.y, c.y)), ymax = fmaxf(a.y, fmaxf(b.y, c.y));
-  float zmin = fminf(a.z, fminf(b.z, c.z)), zmax = fmaxf(a.z, fmaxf(b.z, c.z));
-  float fi0 = ceilf(xmin * inv_px - 0.5f), fi1 = floorf(xmax * inv_px - 0.5f);
-  float fj0 = ceilf(ymin * inv_px - 0.5f), fj1 = floorf(ymax * inv_px - 0.5f);
-  if (fi0 < 0.0f) fi0 = 0.0f;
-  if (fj0 < 0.0f) fj0 = 0.0f;
-  if (fi1 > (float)(res - 1)) fi1 = (float)(res - 1);
-  if (fj1 > (float)(res - 1)) fj1 = (float)(res - 1);
-  if (fi1 < fi0 || fj1 < fj0) return;
-  int i0 = (int)fi0, i1 = (int)fi1, j0 = (int)fj0, j1 = (int)fj1;
-  /* plane z = a.z + gx (x - a.x) + gy (y - a.y) */
-  float nx = (b.y - a.y) * (c.z - a.z) - (b.z - a.z) * (c.y - a.y);
-  float ny = (b.z - a.z) * (c.x - a.x) - (b.x - a.x) * (c.z - a.z);
-  float gx = -nx / area2, gy = -ny / area2;
-  for (int i = i0; i <= i1; ++i) {
-    float x = ((float)i + 0.5f) * px;
-    for (int j = j0; j <= j1; ++j) {
-      float y = ((float)j + 0.5f) * px;
-      float e0 = edge_fn(a.x, a.y, ia, b.x, b.y, ib, x, y);
-      float e1 = edge_fn(b.x, b.y, ib, c.x, c.y, ic, x, y);
-      float e2 = edge_fn(c.x, c.y, ic, a.x, a.y, ia, x, y);
-      int inside = top ? (e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f)
-                       : (e0 <= 0.0f && e1 <= 0.0f && e2 <= 0.0f);
-      if (!inside) continue;
-      float z = a.z + ((x - a.x) * gx + (y - a.y) * gy);
-      z = fminf(fmaxf(z, zmin), zmax);
-      float* p = &buf[i * res + j];
-      if (top) { if (z > *p) *p = z; } else { if (z < *p) *p = z; }
-    }
+/* ------------------------------------------------------------------ renderer (convex ray cast) */
+/* A rock is the intersection of its face half-spaces.  Along the vertical line through a pixel centre
+ * the hull spans [z_lo, z_hi]: z_hi = min over up-facing planes (n_z >= 0), z_lo = max over down-facing
+ * planes (n_z < 0).  |n_z| is clamped to >= 1e-6, so a vertical face acts as an up/down plane of enormous
+ * slope: it never limits z on its inner side and empties the interval on its outer side.  The overhead
+ * camera sees z_hi, the object camera (from below) sees z_lo; a pixel is hit iff z_lo <= z_hi. */
+typedef struct { float a, b, c; int type; } rplane_t;   /* z = a x + b y + c; type 0 up, 1 down */
+
+static int make_rplanes(const mesh_t* M, const m3* R, v3 x, rplane_t* out) {
+  for (int t = 0; t < M->nt; ++t) {
+    v3 nw = mmul(R, V(M->pl[t][0], M->pl[t][1], M->pl[t][2]));
+    float dw = M->pl[t][3] + vdot(nw, x);
+    rplane_t p;
+    float nz = nw.z;
+    if (nz >= 0.0f) { if (nz < 1e-6f) nz = 1e-6f; p.type = 0; }
+    else { if (nz > -1e-6f) nz = -1e-6f; p.type = 1; }
+    p.a = -nw.x / nz; p.b = -nw.y / nz; p.c = dw / nz;
+    out[t] = p;
   }
+  return M->nt;
+}
+
+/* returns 1 and [zlo, zhi] if the vertical line through (px, py) meets the hull */
+static inline int ray_cast(const rplane_t* pl, int n, float px, float py, float* zlo, float* zhi) {
+  float hi = 1e30f, lo = -1e30f;
+  for (int t = 0; t < n; ++t) {   /* fused multiply-adds: part of the definition (the kernel uses v_fma_f32) */
+    float z = fmaf(pl[t].a, px, fmaf(pl[t].b, py, pl[t].c));
+    if (pl[t].type == 0) hi = fminf(hi, z);
+    else lo = fmaxf(lo, z);
+  }
+  *zlo = lo; *zhi = hi;
+  return lo <= hi;
+}
+
+/* pixel range [i0, i1] whose centres lie in [lo, hi] (clipped to the map) */
+static inline int pixel_range(float lo, float hi, float inv_px, int res, int* i0, int* i1) {
+  float f0 = ceilf(lo * inv_px - 0.5f), f1 = floorf(hi * inv_px - 0.5f);
+  if (f0 < 0.0f) f0 = 0.0f;
+  if (f1 > (float)(res - 1)) f1 = (float)(res - 1);
+  if (f1 < f0) return 0;
+  *i0 = (int)f0; *i1 = (int)f1;
+  return 1;
 }
 
 /* O1: overhead height map of the placed bodies (observer.py:252-260; row <-> +x, col <-> +y) */
@@ -438,11 +444,24 @@ static void render_heightmap(const struct srlo_env* e, int nb, const int* mesh, 
   for (int b = 0; b < nb; ++b) {
     const mesh_t* M = &e->mesh[mesh[b]];
     m3 R = quat_to_mat(q[b]);
-    v3 wv[MAXV];
-    for (int k = 0; k < M->nv; ++k) wv[k] = vadd(x[b], mmul(&R, M->v[k]));
-    for (int t = 0; t < M->nt; ++t) {
-      int ia = M->tri[t][0], ib = M->tri[t][1], ic = M->tri[t][2];
-      raster_tri(H, res, e->inv_px, e->px, wv[ia], ia, wv[ib], ib, wv[ic], ic, 1);
+    float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+    for (int k = 0; k < M->nv; ++k) {
+      v3 a = vadd(x[b], mmul(&R, M->v[k]));
+      xmin = fminf(xmin, a.x); xmax = fmaxf(xmax, a.x);
+      ymin = fminf(ymin, a.y); ymax = fmaxf(ymax, a.y);
+    }
+    int i0, i1, j0, j1;
+    if (!pixel_range(xmin, xmax, e->inv_px, res, &i0, &i1)) continue;
+    if (!pixel_range(ymin, ymax, e->inv_px, res, &j0, &j1)) continue;
+    rplane_t pl[MAXT];
+    int np = make_rplanes(M, &R, x[b], pl);
+    for (int i = i0; i <= i1; ++i) {
+      float px = ((float)i + 0.5f) * e->px;
+      for (int j = j0; j <= j1; ++j) {
+        float py = ((float)j + 0.5f) * e->px;
+        float lo, hi;
+        if (ray_cast(pl, np, px, py, &lo, &hi) && hi > H[i * res + j]) H[i * res + j] = hi;
+      }
     }
   }
   float nearp = FAR_PLANE - c->max_z;
@@ -461,14 +480,18 @@ static void render_object(const struct srlo_env* e, int mesh_id, float* O) {
   for (int k = 0; k < r * r; ++k) O[k] = 1e30f;
   if (mesh_id >= 0) {
     const mesh_t* M = &e->mesh[mesh_id];
-    v3 lv[MAXV];
-    for (int k = 0; k < M->nv; ++k) { /* back to the link frame, shifted so the map starts at 0 */
-      v3 a = vadd(M->v[k], M->com);
-      lv[k] = V(a.x + half, a.y + half, a.z);
-    }
-    for (int t = 0; t < M->nt; ++t) {
-      int ia = M->tri[t][0], ib = M->tri[t][1], ic = M->tri[t][2];
-      raster_tri(O, r, e->inv_px, e->px, lv[ia], ia, lv[ib], ib, lv[ic], ic, 0);
+    m3 I; for (int k = 0; k < 9; ++k) I.m[k] = (k % 4 == 0) ? 1.0f : 0.0f;
+    /* map coordinates: link frame shifted so that the map starts at 0 */
+    v3 xs = V(M->com.x + half, M->com.y + half, M->com.z);
+    rplane_t pl[MAXT];
+    int np = make_rplanes(M, &I, xs, pl);
+    for (int i = 0; i < r; ++i) {
+      float px = ((float)i + 0.5f) * e->px;
+      for (int j = 0; j < r; ++j) {
+        float py = ((float)j + 0.5f) * e->px;
+        float lo, hi;
+        if (ray_cast(pl, np, px, py, &lo, &hi)) O[i * r + j] = lo;
+      }
     }
   }
   float nearp = FAR_PLANE - half, farp = FAR_PLANE + half;
@@ -498,17 +521,18 @@ void srlo_pose(const srl_config* c, const float* H, const float* O, int32_t u, i
 }
 
 /* ------------------------------------------------------------------ reward sums (rewarder.py:297-307) */
-/* Fixed order: pixels in groups of 8 (row-major), group g accumulates into partial[g % 256],
- * then a halving tree over the 256 partials. */
+/* Fixed order: pixels in groups of 4 (row-major), group g accumulates into partial[g % 512],
+ * then a halving tree over the 512 partials. */
+#define NPART 512
 void srlo_iou_sums(const srl_config* c, const float* H, const int32_t* g, float* inter, float* uni) {
   int res = c->overhead_res;
   float gz = c->max_z - c->object_max_dimension;
-  float pi[256], pu[256];
-  for (int k = 0; k < 256; ++k) { pi[k] = 0.0f; pu[k] = 0.0f; }
+  float pi[NPART], pu[NPART];
+  for (int k = 0; k < NPART; ++k) { pi[k] = 0.0f; pu[k] = 0.0f; }
   int n = res * res;
-  for (int base = 0; base < n; base += 8) {
-    int t = (base >> 3) & 255;
-    for (int k = base; k < base + 8; ++k) {
+  for (int base = 0; base < n; base += 4) {
+    int t = (base >> 2) & (NPART - 1);
+    for (int k = base; k < base + 4; ++k) {
       int i = k / res, j = k % res;
       int in = (i >= g[0] && i < g[0] + g[2] && j >= g[1] && j < g[1] + g[3]);
       float h = H[k];
@@ -520,7 +544,7 @@ void srlo_iou_sums(const srl_config* c, const float* H, const int32_t* g, float*
       }
     }
   }
-  for (int s = 128; s >= 1; s >>= 1)
+  for (int s = NPART / 2; s >= 1; s >>= 1)
     for (int t = 0; t < s; ++t) { pi[t] += pi[t + s]; pu[t] += pu[t + s]; }
   *inter = pi[0];
   *uni = pu[0];

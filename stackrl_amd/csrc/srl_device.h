@@ -138,52 +138,6 @@ __device__ __forceinline__ float depth_encode(float t, float nearp, float farp) 
   return (farp * (t - nearp)) / (t * (farp - nearp));
 }
 
-// ---------------------------------------------------------------- rasteriser
-// canonical (antisymmetric) edge function: shared edges are watertight
-__device__ __forceinline__ float edge_fn(float ax, float ay, int ia, float bx, float by, int ib, float px, float py) {
-  if (ia < ib) return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
-  return -((ax - bx) * (py - by) - (ay - by) * (px - bx));
-}
-
-// Rasterise one triangle into an LDS tile of ordered-uint heights.
-// TOP: keep max z of up-facing triangles (only z > 0 can win over the 0 floor);
-// !TOP: keep min z of down-facing triangles.
-template <bool TOP>
-__device__ __forceinline__ void raster_tri(uint32_t* tile, int res, float inv_px, float px, v3 a, int ia, v3 b, int ib,
-                                           v3 c, int ic) {
-  float area2 = (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x);
-  if (TOP ? !(area2 > 0.0f) : !(area2 < 0.0f)) return;
-  float xmin = fminf(a.x, fminf(b.x, c.x)), xmax = fmaxf(a.x, fmaxf(b.x, c.x));
-  float ymin = fminf(a.y, fminf(b.y, c.y)), ymax = fmaxf(a.y, fmaxf(b.y, c.y));
-  float zmin = fminf(a.z, fminf(b.z, c.z)), zmax = fmaxf(a.z, fmaxf(b.z, c.z));
-  float fi0 = ceilf(xmin * inv_px - 0.5f), fi1 = floorf(xmax * inv_px - 0.5f);
-  float fj0 = ceilf(ymin * inv_px - 0.5f), fj1 = floorf(ymax * inv_px - 0.5f);
-  if (fi0 < 0.0f) fi0 = 0.0f;
-  if (fj0 < 0.0f) fj0 = 0.0f;
-  if (fi1 > (float)(res - 1)) fi1 = (float)(res - 1);
-  if (fj1 > (float)(res - 1)) fj1 = (float)(res - 1);
-  if (fi1 < fi0 || fj1 < fj0) return;
-  int i0 = (int)fi0, i1 = (int)fi1, j0 = (int)fj0, j1 = (int)fj1;
-  float nx = (b.y - a.y) * (c.z - a.z) - (b.z - a.z) * (c.y - a.y);
-  float ny = (b.z - a.z) * (c.x - a.x) - (b.x - a.x) * (c.z - a.z);
-  float gx = -nx / area2, gy = -ny / area2;
-  for (int i = i0; i <= i1; ++i) {
-    float x = ((float)i + 0.5f) * px;
-    for (int j = j0; j <= j1; ++j) {
-      float y = ((float)j + 0.5f) * px;
-      float e0 = edge_fn(a.x, a.y, ia, b.x, b.y, ib, x, y);
-      float e1 = edge_fn(b.x, b.y, ib, c.x, c.y, ic, x, y);
-      float e2 = edge_fn(c.x, c.y, ic, a.x, a.y, ia, x, y);
-      bool inside = TOP ? (e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) : (e0 <= 0.0f && e1 <= 0.0f && e2 <= 0.0f);
-      if (!inside) continue;
-      float z = a.z + ((x - a.x) * gx + (y - a.y) * gy);
-      z = fminf(fmaxf(z, zmin), zmax);
-      if (TOP) atomicMax(&tile[i * res + j], f2o(z));
-      else atomicMin(&tile[i * res + j], f2o(z));
-    }
-  }
-}
-
 // ---------------------------------------------------------------- GJK (Ericson closest-point sub-algorithms)
 __device__ __forceinline__ void closest_tri(v3 a, v3 b, v3 c, float& l0, float& l1, float& l2, int& used) {
   v3 ab = b - a, ac = c - a, ap = neg(a);

@@ -51,6 +51,7 @@ struct DevParams {
   const MeshHdr* mh;
   const float4* mv;       // mesh vertices, COM frame
   const uchar4* mt;       // triangles
+  const float4* mp;       // face planes, COM frame: unit normal xyz, offset d
   const float* objmap;    // [n_mesh][ores*ores] underside maps (O2)
   int32_t* flags;         // [1] accumulated error bits since the last srl_sync_status
 };

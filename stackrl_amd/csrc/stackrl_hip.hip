@@ -40,6 +40,7 @@ struct srl_env {
   MeshHdr* d_mh = nullptr;
   float4* d_mv = nullptr;
   uchar4* d_mt = nullptr;
+  float4* d_mp = nullptr;
   float* d_objmap = nullptr;
   int step_threads = 64;
   size_t step_lds = 0, render_lds = 0, objmap_lds = 0;
@@ -146,7 +147,7 @@ int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void*
   hipLaunchKernelGGL(srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, P, action);
   prof_end(env, st);
   prof_begin(env, st, 1);
-  hipLaunchKernelGGL(srl_k_render, dim3(n), dim3(256), env->render_lds, st, P, (uint8_t*)obs_map, (uint8_t*)obs_obj,
+  hipLaunchKernelGGL(srl_k_render, dim3(n), dim3(SRL_RENDER_THREADS), env->render_lds, st, P, (uint8_t*)obs_map, (uint8_t*)obs_obj,
                      reward, done, (const float*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr,
                      (float*)nullptr);
   prof_end(env, st);
@@ -220,7 +221,7 @@ void srl_destroy(srl_env* env) {
   for (auto& p : env->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& e : env->pool) hipEventDestroy(e);
   hipFree(env->P.hdr); hipFree(env->P.blob); hipFree(env->P.H); hipFree(env->P.flags);
-  hipFree(env->d_mh); hipFree(env->d_mv); hipFree(env->d_mt); hipFree(env->d_objmap);
+  hipFree(env->d_mh); hipFree(env->d_mv); hipFree(env->d_mt); hipFree(env->d_mp); hipFree(env->d_objmap);
   delete env;
 }
 
@@ -232,6 +233,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   std::vector<MeshHdr> mh((size_t)n_mesh);
   std::vector<float4> mv((size_t)vert_off[n_mesh]);
   std::vector<uchar4> mt((size_t)tri_off[n_mesh]);
+  std::vector<float4> mp((size_t)tri_off[n_mesh]);
   int vs = 4;
   for (int m = 0; m < n_mesh; ++m) {
     MeshHdr& M = mh[m];
@@ -258,6 +260,15 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
       for (int j = 0; j < 3; ++j)
         if (t[j] < 0 || t[j] >= M.nv) return fail(SRL_EINVAL, "triangle index out of range");
       mt[(size_t)M.to + k] = make_uchar4((unsigned char)t[0], (unsigned char)t[1], (unsigned char)t[2], 0);
+      // face plane in the COM frame: unit normal and offset (same expression order as the solver's dot/cross)
+      const float4 a = mv[(size_t)M.vo + t[0]], b = mv[(size_t)M.vo + t[1]], c = mv[(size_t)M.vo + t[2]];
+      float ux = b.x - a.x, uy = b.y - a.y, uz = b.z - a.z, wx = c.x - a.x, wy = c.y - a.y, wz = c.z - a.z;
+      float nx = uy * wz - uz * wy, ny = uz * wx - ux * wz, nz = ux * wy - uy * wx;
+      float len = sqrtf((nx * nx + ny * ny) + nz * nz);
+      if (!(len > 0.0f)) return fail(SRL_EINVAL, "degenerate triangle");
+      float il = 1.0f / len;
+      nx = nx * il; ny = ny * il; nz = nz * il;
+      mp[(size_t)M.to + k] = make_float4(nx, ny, nz, (nx * a.x + ny * a.y) + nz * a.z);
     }
     // Bullet's default for hull shapes when the URDF inertia is not requested (simulator.py:300 passes no
     // flags): inertia of the solid box spanned by the AABB (btCompoundShape::calculateLocalInertia restated)
@@ -267,17 +278,19 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
     M.inv_mass = 1.0f / mass;
     M.iix = 1.0f / Ix; M.iiy = 1.0f / Iy; M.iiz = 1.0f / Iz;
   }
-  hipFree(env->d_mh); hipFree(env->d_mv); hipFree(env->d_mt); hipFree(env->d_objmap);
-  env->d_mh = nullptr; env->d_mv = nullptr; env->d_mt = nullptr; env->d_objmap = nullptr;
+  hipFree(env->d_mh); hipFree(env->d_mv); hipFree(env->d_mt); hipFree(env->d_mp); hipFree(env->d_objmap);
+  env->d_mh = nullptr; env->d_mv = nullptr; env->d_mt = nullptr; env->d_mp = nullptr; env->d_objmap = nullptr;
   const int r = P.c.object_res;
   HIP_TRY(hipMalloc((void**)&env->d_mh, sizeof(MeshHdr) * mh.size()));
   HIP_TRY(hipMalloc((void**)&env->d_mv, sizeof(float4) * mv.size()));
   HIP_TRY(hipMalloc((void**)&env->d_mt, sizeof(uchar4) * mt.size()));
+  HIP_TRY(hipMalloc((void**)&env->d_mp, sizeof(float4) * mp.size()));
   HIP_TRY(hipMalloc((void**)&env->d_objmap, sizeof(float) * (size_t)n_mesh * r * r));
   HIP_TRY(hipMemcpy(env->d_mh, mh.data(), sizeof(MeshHdr) * mh.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(env->d_mv, mv.data(), sizeof(float4) * mv.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(env->d_mt, mt.data(), sizeof(uchar4) * mt.size(), hipMemcpyHostToDevice));
-  P.mh = env->d_mh; P.mv = env->d_mv; P.mt = env->d_mt; P.objmap = env->d_objmap;
+  HIP_TRY(hipMemcpy(env->d_mp, mp.data(), sizeof(float4) * mp.size(), hipMemcpyHostToDevice));
+  P.mh = env->d_mh; P.mv = env->d_mv; P.mt = env->d_mt; P.mp = env->d_mp; P.objmap = env->d_objmap;
   P.n_mesh = n_mesh;
   P.VS = vs;
   int old_blob = P.BLOB;
@@ -289,9 +302,8 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   env->step_threads = ((need + 63) / 64) * 64;
   if (env->step_threads > 256) env->step_threads = 256;
   const int res = P.c.overhead_res;
-  env->render_lds = sizeof(uint32_t) * (size_t)res * res +
-                    sizeof(float) * (3 * SRL_MAX_BODIES + 9 * SRL_MAX_BODIES + SRL_MAX_BODIES + SRL_MAX_BODIES + 1 + 512);
-  env->objmap_lds = sizeof(uint32_t) * (size_t)r * r;
+  env->render_lds = render_lds_bytes(res);
+  env->objmap_lds = 0;
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->render_lds));
   // K3: object maps of the whole pool, once
@@ -477,7 +489,7 @@ int srl_render_heightmap(srl_env* env, const float* poses, const int32_t* mesh_i
   if (!env->d_mh) return fail(SRL_ENOMESH, "srl_load_meshes must be called first");
   hipStream_t st = (hipStream_t)stream;
   prof_begin(env, st, 1);
-  hipLaunchKernelGGL(srl_k_render, dim3(env->P.c.n_envs), dim3(256), env->render_lds, st, env->P, (uint8_t*)nullptr,
+  hipLaunchKernelGGL(srl_k_render, dim3(env->P.c.n_envs), dim3(SRL_RENDER_THREADS), env->render_lds, st, env->P, (uint8_t*)nullptr,
                      (uint8_t*)nullptr, (float*)nullptr, (uint8_t*)nullptr, poses, mesh_ids, n_bodies, height);
   prof_end(env, st);
   HIP_TRY(hipGetLastError());
