@@ -1,22 +1,31 @@
 // settle.hip — K1 (place / smooth placing / settle) + K4 (Observer.pose) + the episode machine.
 //
-// One workgroup per env.  The env's whole persistent state ("blob": poses, velocities, ground and
-// body-body manifolds with their warm-start impulses, slot tables) is loaded into LDS once, every
-// sub-step runs out of LDS, and the blob is written back once — HBM traffic per env step is
-// 2 x BLOB words regardless of how many sub-steps the stop criterion takes.
+// One 256-thread workgroup (4 waves) per env.  The env's whole persistent state ("blob": poses,
+// velocities, ground and body-body manifolds with their warm-start impulses, slot tables) is loaded into
+// LDS once, every sub-step runs out of LDS, and the blob is written back once — HBM traffic per env step
+// is 2 x BLOB words regardless of how many sub-steps the stop criterion takes.
 //
-// Work mapping per sub-step (DESIGN.md "settle solver"):
-//   lane = body   damping+gravity, rotation, world vertices, AABB, ground manifold, integration
-//   lane = pair   AABB broadphase over all i<j pairs, slot release
-//   lane = slot   manifold refresh, GJK closest points, manifold insert, sequential impulses
-// Sequential-impulse sweeps visit "ground" then the contact-graph colours in order; slots of one
-// colour touch disjoint bodies, so a sweep is order-independent inside a phase and the result is
-// the same as the sequential definition.
+// At the batch sizes of the reference workloads (1,024 - 4,096 envs per GPU) there are about as many envs
+// as SIMDs, and a launch lasts as long as its slowest env (stop criterion simulator.py:322-335), so the
+// kernel is organised for the LATENCY of one env's sub-step, not for throughput per lane:
+//   lane = (body, vertex)   world vertices from an LDS copy of the local ones (one pass, no loops)
+//   lane = body             damping + gravity, rotation, inertia, AABB, ground manifold, integration
+//   lane = pair             AABB broadphase over all i<j pairs, slot release
+//   16 lanes = slot         GJK closest points: the support scans are split over the 16 lanes and combined
+//                           with xor shuffles; manifold refresh / insert by the group's first lane
+//   lane = contact point    sequential impulses: each lane keeps the constants of its three rows (normal +
+//                           two friction) in registers for all sweeps; body velocities live in LDS
+// A sweep visits "ground" then the contact-graph colours in order (block barrier between phases); inside a
+// phase the points of one manifold are consecutive lanes of one wave and take turns in index order
+// (wave-synchronous, no barrier), manifolds of one colour share no body — so the parallel sweep is exactly
+// the sequential definition (DESIGN.md "settle solver") and results are bit-identical to the CPU oracle.
 //
 // Reference call sites restated: simulator.py:190-258 (step), :310-341 (_place/_stop/_drop),
 // observer.py:392-421 (pose), env.py:233-247 (action unflatten, episode list), env.py:266-293 (reset).
 #include "srl_device.h"
 #include "srl_kernels.h"
+
+#define SRL_GJK_GROUP 16
 
 __constant__ uint8_t c_pair_i[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
 __constant__ uint8_t c_pair_j[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
@@ -45,6 +54,7 @@ struct Lds {
   __device__ __forceinline__ float* AMAX(int b) const { return sm + P->BLOB + P->S_AMAX + 3 * b; }
   __device__ __forceinline__ float* BC(int b) const { return sm + P->BLOB + P->S_BC + 8 * b; }  // inv_mass, ii xyz, radius, nv, vo, mesh
   __device__ __forceinline__ float* WV(int b) const { return sm + P->BLOB + P->S_WV + 3 * P->VS * b; }
+  __device__ __forceinline__ float* LV(int b) const { return sm + P->BLOB + P->S_LV + 3 * P->VS * b; }
   __device__ __forceinline__ int* MISC() const { return (int*)(sm + P->BLOB + P->S_MISC); }
 };
 
@@ -100,66 +110,81 @@ __device__ void env_reset(const DevParams& P, EnvHdr* h, int e) {
   h->done = 0;
 }
 
-// ------------------------------------------------------------------ per-body derived state + ground manifold
-__device__ void body_phase(const Lds& L, int b, bool dyn) {
+// ------------------------------------------------------------------ per-body derived state
+// lane = body: damping then gravity (btRigidBody::applyDamping, then the external-force impulse), rotation
+// matrix and world inverse inertia
+__device__ void body_frame(const Lds& L, int b) {
   const DevParams& P = *L.P;
-  float dt = P.c.sim_time_step;
-  if (dyn) {   // btRigidBody::applyDamping, then the gravity impulse
-    v3 v = ld3(L.Vl(b)) * P.lin_damp;
-    v3 w = ld3(L.Wl(b)) * P.ang_damp;
-    v.z = v.z - P.c.gravity * dt;
-    st3(L.Vl(b), v); st3(L.Wl(b), w);
-  }
+  const float dt = P.c.sim_time_step;
+  v3 v = ld3(L.Vl(b)) * P.lin_damp;
+  v3 w = ld3(L.Wl(b)) * P.ang_damp;
+  v.z = v.z - P.c.gravity * dt;
+  st3(L.Vl(b), v); st3(L.Wl(b), w);
   const float* bc = L.BC(b);
-  int nv = __float_as_int(bc[5]), vo = __float_as_int(bc[6]);
-  float radius = bc[4];
   q4 q; q.x = L.Q(b)[0]; q.y = L.Q(b)[1]; q.z = L.Q(b)[2]; q.w = L.Q(b)[3];
   m3 R = quat_to_mat(q);
   m3 I = inv_inertia_world(R, V(bc[1], bc[2], bc[3]));
 #pragma unroll
   for (int i = 0; i < 9; ++i) { L.R(b)[i] = R.m[i]; L.IW(b)[i] = I.m[i]; }
-  v3 x = ld3(L.X(b));
+}
+
+// lane = body: AABB of the world vertices + ground manifold (up to 8 deepest vertices within the breaking
+// threshold in (dist, index) order; warm-start impulses carried over by vertex id)
+__device__ void body_bounds_ground(const Lds& L, int b) {
+  const DevParams& P = *L.P;
+  const float* bc = L.BC(b);
+  const int nv = __float_as_int(bc[5]);
+  const float radius = bc[4];
+  const float m = P.c.collision_margin, thr = 0.02f * radius;
+  const float* W = L.WV(b);
   v3 lo = V(1e30f, 1e30f, 1e30f), hi = V(-1e30f, -1e30f, -1e30f);
-  float* W = L.WV(b);
+  float sd[SRL_GMAXP]; int sk[SRL_GMAXP];
+#pragma unroll
+  for (int j = 0; j < SRL_GMAXP; ++j) { sd[j] = 0.0f; sk[j] = -1; }
+  int ns = 0;
   for (int k = 0; k < nv; ++k) {
-    float4 lv = P.mv[vo + k];
-    v3 a = x + mmul(R, V(lv.x, lv.y, lv.z));
-    st3(W + 3 * k, a);
+    v3 a = ld3(W + 3 * k);
     lo = V(fminf(lo.x, a.x), fminf(lo.y, a.y), fminf(lo.z, a.z));
     hi = V(fmaxf(hi.x, a.x), fmaxf(hi.y, a.y), fmaxf(hi.z, a.z));
+    float cd = a.z - m;
+    if (cd < thr) {   // sorted insertion, static register indexing
+      int ck = k;
+      bool placed = false;
+#pragma unroll
+      for (int j = 0; j < SRL_GMAXP; ++j) {
+        if (!placed) {
+          if (j < ns) {
+            if (cd < sd[j] || (cd == sd[j] && ck < sk[j])) {
+              float td = sd[j]; sd[j] = cd; cd = td;
+              int tk = sk[j]; sk[j] = ck; ck = tk;
+            }
+          } else { sd[j] = cd; sk[j] = ck; placed = true; }
+        }
+      }
+      if (placed) ns++;
+    }
   }
-  float ex = P.c.collision_margin + 0.01f * radius;
+  const float ex = P.c.collision_margin + 0.01f * radius;
   st3(L.AMIN(b), V(lo.x - ex, lo.y - ex, lo.z - ex));
   st3(L.AMAX(b), V(hi.x + ex, hi.y + ex, hi.z + ex));
-  // ground manifold: up to 8 deepest vertices within the breaking threshold, in (dist, index) order;
-  // warm-start impulses carried over by vertex id
-  float m = P.c.collision_margin, thr = 0.02f * radius;
   float* g = L.GM(b);
-  int onp = __float_as_int(g[0]);
+  const int onp = __float_as_int(g[0]);
   int ovid[SRL_GMAXP]; float oin[SRL_GMAXP], ot1[SRL_GMAXP], ot2[SRL_GMAXP];
 #pragma unroll
   for (int j = 0; j < SRL_GMAXP; ++j) {
     ovid[j] = j < onp ? __float_as_int(g[1 + j]) : -1;
     oin[j] = g[17 + j]; ot1[j] = g[25 + j]; ot2[j] = g[33 + j];
   }
-  int ns = 0;
-  float last_d = -1e30f; int last_k = -1;
-  while (ns < SRL_GMAXP) {
-    int best = -1; float bd = thr;
-    for (int k = 0; k < nv; ++k) {
-      float d = W[3 * k + 2] - m;
-      if (!(d > last_d || (d == last_d && k > last_k))) continue;
-      if (d < bd) { bd = d; best = k; }
-    }
-    if (best < 0) break;
-    float in = 0.0f, t1 = 0.0f, t2 = 0.0f;
 #pragma unroll
-    for (int j = 0; j < SRL_GMAXP; ++j)
-      if (ovid[j] == best) { in = oin[j]; t1 = ot1[j]; t2 = ot2[j]; }
-    g[1 + ns] = __int_as_float(best); g[9 + ns] = bd;
-    g[17 + ns] = in; g[25 + ns] = t1; g[33 + ns] = t2;
-    last_d = bd; last_k = best;
-    ++ns;
+  for (int i = 0; i < SRL_GMAXP; ++i) {
+    if (i < ns) {
+      float in = 0.0f, t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+      for (int j = 0; j < SRL_GMAXP; ++j)
+        if (ovid[j] == sk[i]) { in = oin[j]; t1 = ot1[j]; t2 = ot2[j]; }
+      g[1 + i] = __int_as_float(sk[i]); g[9 + i] = sd[i];
+      g[17 + i] = in; g[25 + i] = t1; g[33 + i] = t2;
+    }
   }
   g[0] = __int_as_float(ns);
 }
@@ -255,7 +280,9 @@ __device__ void sat_faces(const DevParams& P, int mesh_a, const float* VA, int n
   dist = best;
 }
 
-__device__ void narrowphase_slot(const Lds& L, int sl) {
+// 16 lanes per slot: GJK runs in lock step on all of them (support scans split), the first lane maintains
+// the manifold
+__device__ void narrowphase_slot(const Lds& L, int sl, int gl) {
   const DevParams& P = *L.P;
   int pid = L.POS()[sl];
   int a = c_pair_i[pid], b = c_pair_j[pid];
@@ -267,10 +294,11 @@ __device__ void narrowphase_slot(const Lds& L, int sl) {
   float thr = 0.02f * fminf(bca[4], bcb[4]);
   v3 xa = ld3(L.X(a)), xb = ld3(L.X(b));
   m3 Ra = ldm(L.R(a)), Rb = ldm(L.R(b));
-  manifold_refresh(mp, xa, Ra, xb, Rb, thr);
+  if (gl == 0) manifold_refresh(mp, xa, Ra, xb, Rb, thr);
   v3 axis = ld3(mp + 1);
   v3 pa, pb, n; float d;
-  int rc = gjk_distance(L.WV(a), na, L.WV(b), nb, axis, (mg + mg) + thr, pa, pb, n, d);
+  int rc = gjk_distance<SRL_GJK_GROUP>(L.WV(a), na, L.WV(b), nb, axis, (mg + mg) + thr, pa, pb, n, d, gl);
+  if (gl != 0) return;
   if (rc == 2) {
     sat_faces(P, __float_as_int(bca[7]), L.WV(a), na, __float_as_int(bcb[7]), L.WV(b), nb, pa, pb, n, d);
     rc = 1;
@@ -287,47 +315,54 @@ __device__ void narrowphase_slot(const Lds& L, int sl) {
   }
 }
 
-// ------------------------------------------------------------------ sequential impulses
+// ------------------------------------------------------------------ sequential impulses (lane = contact point)
+// One solver row in precomputed form: direction d, ca = ra x d, aa = Ia ca (and cb, ab for body B),
+// k = effective mass denominator.  Same expression trees as the sequential definition.
+struct Row { v3 d, ca, aa, cb, ab; float k; };
 struct Vel4 { v3 va, wa, vb, wb; };
 
 template <bool HAS_B>
-__device__ __forceinline__ void row_solve(v3 d, v3 ra, v3 rb, float ima, const m3& Ia, float imb, const m3& Ib, Vel4& u,
-                                          float target, float& acc, float lo, float hi) {
-  v3 ca = cross(ra, d);
-  v3 aa = mmul(Ia, ca);
-  v3 cb = V(0.0f, 0.0f, 0.0f), ab = V(0.0f, 0.0f, 0.0f);
-  float k = ima + dot(cross(aa, ra), d);
-  float vrel = dot(d, u.va) + dot(ca, u.wa);
+__device__ __forceinline__ Row make_row(v3 d, v3 ra, v3 rb, float ima, const m3& Ia, float imb, const m3& Ib) {
+  Row r;
+  r.d = d;
+  r.ca = cross(ra, d);
+  r.aa = mmul(Ia, r.ca);
+  r.cb = V(0.0f, 0.0f, 0.0f); r.ab = V(0.0f, 0.0f, 0.0f);
+  r.k = ima + dot(cross(r.aa, ra), d);
   if (HAS_B) {
-    cb = cross(rb, d);
-    ab = mmul(Ib, cb);
-    k = k + (imb + dot(cross(ab, rb), d));
-    vrel = vrel - (dot(d, u.vb) + dot(cb, u.wb));
+    r.cb = cross(rb, d);
+    r.ab = mmul(Ib, r.cb);
+    r.k = r.k + (imb + dot(cross(r.ab, rb), d));
   }
-  float dl = (target - vrel) / k;
+  return r;
+}
+
+template <bool HAS_B>
+__device__ __forceinline__ void row_solve(const Row& r, float ima, float imb, Vel4& u, float target, float& acc,
+                                          float lo, float hi) {
+  float vrel = dot(r.d, u.va) + dot(r.ca, u.wa);
+  if (HAS_B) vrel = vrel - (dot(r.d, u.vb) + dot(r.cb, u.wb));
+  float dl = (target - vrel) / r.k;
   float na = acc + dl;
   if (na < lo) na = lo;
   if (na > hi) na = hi;
   dl = na - acc;
   acc = na;
-  u.va = u.va + d * (ima * dl);
-  u.wa = u.wa + aa * dl;
+  u.va = u.va + r.d * (ima * dl);
+  u.wa = u.wa + r.aa * dl;
   if (HAS_B) {
-    u.vb = u.vb - d * (imb * dl);
-    u.wb = u.wb - ab * dl;
+    u.vb = u.vb - r.d * (imb * dl);
+    u.wb = u.wb - r.ab * dl;
   }
 }
 
 template <bool HAS_B>
-__device__ __forceinline__ void row_apply(v3 d, v3 ra, v3 rb, float ima, const m3& Ia, float imb, const m3& Ib, Vel4& u,
-                                          float imp) {
-  v3 aa = mmul(Ia, cross(ra, d));
-  u.va = u.va + d * (ima * imp);
-  u.wa = u.wa + aa * imp;
+__device__ __forceinline__ void row_apply(const Row& r, float ima, float imb, Vel4& u, float imp) {
+  u.va = u.va + r.d * (ima * imp);
+  u.wa = u.wa + r.aa * imp;
   if (HAS_B) {
-    v3 ab = mmul(Ib, cross(rb, d));
-    u.vb = u.vb - d * (imb * imp);
-    u.wb = u.wb - ab * imp;
+    u.vb = u.vb - r.d * (imb * imp);
+    u.wb = u.wb - r.ab * imp;
   }
 }
 
@@ -336,105 +371,142 @@ __device__ __forceinline__ float contact_target(const DevParams& P, float dist) 
   return dist > 0.0f ? -(dist * inv_dt) : -((dist * P.c.erp) * inv_dt);
 }
 
-template <bool WARM>
-__device__ void solve_ground(const Lds& L, int b) {
+// A contact point owned by one lane for the duration of a sub-step's solve
+struct Point {
+  Row n, t1, t2;
+  float target, in, i1, i2, ima, imb, mu;
+  int a, b;        // bodies (b < 0: ground)
+  int colour;      // -1 = ground phase
+  int idx;         // position inside its manifold (turn order)
+  bool valid;
+};
+
+__device__ __forceinline__ Point make_ground_point(const Lds& L, int b, int i) {
   const DevParams& P = *L.P;
-  float* g = L.GM(b);
-  int np = __float_as_int(g[0]);
-  if (np == 0) return;
-  const float* bc = L.BC(b);
-  float ima = bc[0];
-  float mu = P.c.friction_rock * P.c.friction_ground;
-  m3 Ia = ldm(L.IW(b));
+  Point p;
+  p.valid = false; p.a = b; p.b = -1; p.colour = -1; p.idx = i;
+  p.in = 0.0f; p.i1 = 0.0f; p.i2 = 0.0f; p.target = 0.0f; p.ima = 0.0f; p.imb = 0.0f; p.mu = 0.0f;
+  const float* g = L.GM(b);
+  if (i >= __float_as_int(g[0])) return p;
+  p.valid = true;
+  p.ima = L.BC(b)[0];
+  p.mu = P.c.friction_rock * P.c.friction_ground;
+  const m3 Ia = ldm(L.IW(b));
   m3 Iz;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) Iz.m[i] = 0.0f;
-  Vel4 u; u.va = ld3(L.Vl(b)); u.wa = ld3(L.Wl(b)); u.vb = V(0, 0, 0); u.wb = V(0, 0, 0);
-  v3 x = ld3(L.X(b));
+  for (int k = 0; k < 9; ++k) Iz.m[k] = 0.0f;
+  const int vid = __float_as_int(g[1 + i]);
+  const v3 pw = ld3(L.WV(b) + 3 * vid);
+  const v3 ra = V(pw.x, pw.y, pw.z - P.c.collision_margin) - ld3(L.X(b));
+  const v3 rb0 = V(0.0f, 0.0f, 0.0f);
   v3 n = V(0.0f, 0.0f, 1.0f), t1, t2;
   plane_space(n, t1, t2);
-  const float* W = L.WV(b);
-  v3 rb0 = V(0, 0, 0);
-  for (int i = 0; i < np; ++i) {
-    int vid = __float_as_int(g[1 + i]);
-    v3 pw = ld3(W + 3 * vid);
-    v3 ra = V(pw.x, pw.y, pw.z - P.c.collision_margin) - x;
-    if (WARM) {
-      float in = g[17 + i] * P.c.warmstart, i1 = g[25 + i] * P.c.warmstart, i2 = g[33 + i] * P.c.warmstart;
-      g[17 + i] = in; g[25 + i] = i1; g[33 + i] = i2;
-      row_apply<false>(n, ra, rb0, ima, Ia, 0.0f, Iz, u, in);
-      row_apply<false>(t1, ra, rb0, ima, Ia, 0.0f, Iz, u, i1);
-      row_apply<false>(t2, ra, rb0, ima, Ia, 0.0f, Iz, u, i2);
-    } else {
-      float in = g[17 + i], i1 = g[25 + i], i2 = g[33 + i];
-      row_solve<false>(n, ra, rb0, ima, Ia, 0.0f, Iz, u, contact_target(P, g[9 + i]), in, 0.0f, 1e30f);
-      float lim = mu * in;
-      row_solve<false>(t1, ra, rb0, ima, Ia, 0.0f, Iz, u, 0.0f, i1, -lim, lim);
-      row_solve<false>(t2, ra, rb0, ima, Ia, 0.0f, Iz, u, 0.0f, i2, -lim, lim);
-      g[17 + i] = in; g[25 + i] = i1; g[33 + i] = i2;
-    }
-  }
-  st3(L.Vl(b), u.va); st3(L.Wl(b), u.wa);
+  p.n = make_row<false>(n, ra, rb0, p.ima, Ia, 0.0f, Iz);
+  p.t1 = make_row<false>(t1, ra, rb0, p.ima, Ia, 0.0f, Iz);
+  p.t2 = make_row<false>(t2, ra, rb0, p.ima, Ia, 0.0f, Iz);
+  p.target = contact_target(P, g[9 + i]);
+  p.in = g[17 + i]; p.i1 = g[25 + i]; p.i2 = g[33 + i];
+  return p;
 }
 
-template <bool WARM>
-__device__ void solve_slot(const Lds& L, int sl) {
+__device__ __forceinline__ Point make_pair_point(const Lds& L, int sl, int i) {
   const DevParams& P = *L.P;
-  float* mp = L.MAN(sl);
-  int np = __float_as_int(mp[0]);
-  if (np == 0) return;
-  int pid = L.POS()[sl];
-  int a = c_pair_i[pid], b = c_pair_j[pid];
-  float ima = L.BC(a)[0], imb = L.BC(b)[0];
-  float mu = P.c.friction_rock * P.c.friction_rock;
-  m3 Ra = ldm(L.R(a)), Rb = ldm(L.R(b));
-  m3 Ia = ldm(L.IW(a)), Ib = ldm(L.IW(b));
-  Vel4 u; u.va = ld3(L.Vl(a)); u.wa = ld3(L.Wl(a)); u.vb = ld3(L.Vl(b)); u.wb = ld3(L.Wl(b));
-  for (int i = 0; i < np; ++i) {
-    float* p = mp + 4 + SRL_MP_WORDS * i;
-    v3 ra = mmul(Ra, ld3(p));
-    v3 rb = mmul(Rb, ld3(p + 3));
-    v3 n = ld3(p + 6), t1, t2;
-    plane_space(n, t1, t2);
-    if (WARM) {
-      float in = p[10] * P.c.warmstart, i1 = p[11] * P.c.warmstart, i2 = p[12] * P.c.warmstart;
-      p[10] = in; p[11] = i1; p[12] = i2;
-      row_apply<true>(n, ra, rb, ima, Ia, imb, Ib, u, in);
-      row_apply<true>(t1, ra, rb, ima, Ia, imb, Ib, u, i1);
-      row_apply<true>(t2, ra, rb, ima, Ia, imb, Ib, u, i2);
-    } else {
-      float in = p[10], i1 = p[11], i2 = p[12];
-      row_solve<true>(n, ra, rb, ima, Ia, imb, Ib, u, contact_target(P, p[9]), in, 0.0f, 1e30f);
-      float lim = mu * in;
-      row_solve<true>(t1, ra, rb, ima, Ia, imb, Ib, u, 0.0f, i1, -lim, lim);
-      row_solve<true>(t2, ra, rb, ima, Ia, imb, Ib, u, 0.0f, i2, -lim, lim);
-      p[10] = in; p[11] = i1; p[12] = i2;
-    }
-  }
-  st3(L.Vl(a), u.va); st3(L.Wl(a), u.wa); st3(L.Vl(b), u.vb); st3(L.Wl(b), u.wb);
+  Point p;
+  p.valid = false; p.a = 0; p.b = 0; p.colour = 0; p.idx = i;
+  p.in = 0.0f; p.i1 = 0.0f; p.i2 = 0.0f; p.target = 0.0f; p.ima = 0.0f; p.imb = 0.0f; p.mu = 0.0f;
+  if (sl >= P.NS) return p;
+  const int pid = L.POS()[sl];
+  if (pid < 0) return p;
+  const float* mp = L.MAN(sl);
+  if (i >= __float_as_int(mp[0])) return p;
+  p.valid = true;
+  p.a = c_pair_i[pid]; p.b = c_pair_j[pid];
+  p.colour = L.COL()[sl];
+  p.ima = L.BC(p.a)[0]; p.imb = L.BC(p.b)[0];
+  p.mu = P.c.friction_rock * P.c.friction_rock;
+  const float* q = mp + 4 + SRL_MP_WORDS * i;
+  const m3 Ra = ldm(L.R(p.a)), Rb = ldm(L.R(p.b));
+  const m3 Ia = ldm(L.IW(p.a)), Ib = ldm(L.IW(p.b));
+  const v3 ra = mmul(Ra, ld3(q));
+  const v3 rb = mmul(Rb, ld3(q + 3));
+  v3 n = ld3(q + 6), t1, t2;
+  plane_space(n, t1, t2);
+  p.n = make_row<true>(n, ra, rb, p.ima, Ia, p.imb, Ib);
+  p.t1 = make_row<true>(t1, ra, rb, p.ima, Ia, p.imb, Ib);
+  p.t2 = make_row<true>(t2, ra, rb, p.ima, Ia, p.imb, Ib);
+  p.target = contact_target(P, q[9]);
+  p.in = q[10]; p.i1 = q[11]; p.i2 = q[12];
+  return p;
 }
 
-template <bool WARM>
-__device__ void solver_sweep(const Lds& L, int nb, int ncol, int tid, int T) {
-  const DevParams& P = *L.P;
-  for (int b = tid; b < nb; b += T) solve_ground<WARM>(L, b);
+// one turn of a point: read the velocities of its bodies, three rows, write them back
+template <bool WARM, bool HAS_B>
+__device__ __forceinline__ void point_turn(const Lds& L, Point& p) {
+  const float ws = L.P->c.warmstart;
+  Vel4 u;
+  u.va = ld3(L.Vl(p.a)); u.wa = ld3(L.Wl(p.a));
+  if (HAS_B) { u.vb = ld3(L.Vl(p.b)); u.wb = ld3(L.Wl(p.b)); }
+  else { u.vb = V(0.0f, 0.0f, 0.0f); u.wb = V(0.0f, 0.0f, 0.0f); }
+  if (WARM) {
+    p.in = p.in * ws; p.i1 = p.i1 * ws; p.i2 = p.i2 * ws;
+    row_apply<HAS_B>(p.n, p.ima, p.imb, u, p.in);
+    row_apply<HAS_B>(p.t1, p.ima, p.imb, u, p.i1);
+    row_apply<HAS_B>(p.t2, p.ima, p.imb, u, p.i2);
+  } else {
+    row_solve<HAS_B>(p.n, p.ima, p.imb, u, p.target, p.in, 0.0f, 1e30f);
+    const float lim = p.mu * p.in;
+    row_solve<HAS_B>(p.t1, p.ima, p.imb, u, 0.0f, p.i1, -lim, lim);
+    row_solve<HAS_B>(p.t2, p.ima, p.imb, u, 0.0f, p.i2, -lim, lim);
+  }
+  st3(L.Vl(p.a), u.va); st3(L.Wl(p.a), u.wa);
+  if (HAS_B) { st3(L.Vl(p.b), u.vb); st3(L.Wl(p.b), u.wb); }
+}
+
+template <bool WARM, int PP>
+__device__ __forceinline__ void solver_sweep(const Lds& L, Point& gp, Point (&pp)[PP], int ncol) {
+  // ground phase: the (up to 8) points of one body are consecutive lanes of one wave and take turns
+#pragma unroll 1
+  for (int i = 0; i < SRL_GMAXP; ++i) {
+    if (gp.valid && gp.idx == i) point_turn<WARM, false>(L, gp);
+    __builtin_amdgcn_wave_barrier();
+  }
   __syncthreads();
+#pragma unroll 1
   for (int c = 0; c < ncol; ++c) {
-    for (int sl = tid; sl < P.NS; sl += T)
-      if (L.POS()[sl] >= 0 && L.COL()[sl] == c) solve_slot<WARM>(L, sl);
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < PP; ++r)
+        if (pp[r].valid && pp[r].colour == c && pp[r].idx == i) point_turn<WARM, true>(L, pp[r]);
+      __builtin_amdgcn_wave_barrier();
+    }
     __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------ one sub-step (block-wide)
-__device__ void substep(const Lds& L, int nb, int tid, int T) {
+template <int T, int PP>
+__device__ void substep(const Lds& L, int nb, int tid) {
   const DevParams& P = *L.P;
   int* misc = L.MISC();
-  for (int b = tid; b < nb; b += T) body_phase(L, b, true);
+  // (1) lane = body: damping, gravity, frame
+  if (tid < nb) body_frame(L, tid);
   if (tid == 0) misc[M_FLAGS] = 0;
   __syncthreads();
-  // broadphase: AABB overlap for every pair; release slots of pairs that separated
-  int npair = nb * (nb - 1) / 2;
+  // (2) lane = (body, vertex): world vertices
+  for (int it = tid; it < nb * P.VS; it += T) {
+    const int b = it / P.VS, k = it - b * P.VS;
+    if (k < __float_as_int(L.BC(b)[5])) {
+      const m3 R = ldm(L.R(b));
+      st3(L.WV(b) + 3 * k, ld3(L.X(b)) + mmul(R, ld3(L.LV(b) + 3 * k)));
+    }
+  }
+  __syncthreads();
+  // (3) lane = body: AABB + ground manifold
+  if (tid < nb) body_bounds_ground(L, tid);
+  __syncthreads();
+  // (4) broadphase: AABB overlap for every pair; release slots of pairs that separated
+  const int npair = nb * (nb - 1) / 2;
   int fl = 0;
   for (int pid = tid; pid < npair; pid += T) {
     int i = c_pair_i[pid], j = c_pair_j[pid];
@@ -467,7 +539,7 @@ __device__ void substep(const Lds& L, int nb, int tid, int T) {
         }
       }
       // greedy colouring in slot order
-      uint64_t used[SRL_MAX_BODIES];
+      uint64_t* used = (uint64_t*)(L.sm + P.BLOB + P.S_USED);   // LDS scratch, 8-byte aligned
       for (int b = 0; b < SRL_MAX_BODIES; ++b) used[b] = 0;
       int nc = 0;
       for (int sl = 0; sl < P.NS; ++sl) {
@@ -485,15 +557,37 @@ __device__ void substep(const Lds& L, int nb, int tid, int T) {
     }
     __syncthreads();
   }
-  int ncol = misc[M_NCOL];
-  for (int sl = tid; sl < P.NS; sl += T)
-    if (L.POS()[sl] >= 0) narrowphase_slot(L, sl);
+  const int ncol = misc[M_NCOL];
+  // (5) narrowphase: 16 lanes per slot
+  {
+    const int gl = tid & (SRL_GJK_GROUP - 1);
+    for (int sl = tid / SRL_GJK_GROUP; sl < P.NS; sl += T / SRL_GJK_GROUP)
+      if (L.POS()[sl] >= 0) narrowphase_slot(L, sl, gl);
+  }
   __syncthreads();
-  solver_sweep<true>(L, nb, ncol, tid, T);
-  for (int it = 0; it < P.c.solver_iterations; ++it) solver_sweep<false>(L, nb, ncol, tid, T);
-  // integrate
-  float dt = P.c.sim_time_step;
-  for (int b = tid; b < nb; b += T) {
+  // (6) sequential impulses: lane = contact point, row constants in registers for all sweeps
+  {
+    Point gp = make_ground_point(L, tid >> 3, tid & 7);
+    if ((tid >> 3) >= nb) gp.valid = false;
+    Point pp[PP];
+#pragma unroll
+    for (int r = 0; r < PP; ++r) pp[r] = make_pair_point(L, (tid + r * T) >> 2, tid & 3);
+    __syncthreads();   // every lane has read the pre-solve velocities' companions (R, Iw, manifolds)
+    solver_sweep<true, PP>(L, gp, pp, ncol);
+    for (int it = 0; it < P.c.solver_iterations; ++it) solver_sweep<false, PP>(L, gp, pp, ncol);
+    // accumulated impulses back to the manifolds (warm start of the next sub-step)
+    if (gp.valid) { float* g = L.GM(gp.a); g[17 + gp.idx] = gp.in; g[25 + gp.idx] = gp.i1; g[33 + gp.idx] = gp.i2; }
+#pragma unroll
+    for (int r = 0; r < PP; ++r)
+      if (pp[r].valid) {
+        float* q = L.MAN((tid + r * T) >> 2) + 4 + SRL_MP_WORDS * pp[r].idx;
+        q[10] = pp[r].in; q[11] = pp[r].i1; q[12] = pp[r].i2;
+      }
+  }
+  // (7) integrate (the last solver phase ended with a barrier)
+  const float dt = P.c.sim_time_step;
+  if (tid < nb) {
+    const int b = tid;
     v3 v = ld3(L.Vl(b)), w = ld3(L.Wl(b));
     st3(L.X(b), ld3(L.X(b)) + v * dt);
     float* Q = L.Q(b);
@@ -539,9 +633,10 @@ __device__ int newest_contacts(const Lds& L, int nb, int tid, int T) {
 }
 
 // ------------------------------------------------------------------ K1 + K4 + episode machine
-extern "C" __global__ void __launch_bounds__(256) srl_k_step(DevParams P, const int64_t* __restrict__ action) {
+template <int T, int PP>
+__device__ __forceinline__ void step_body(const DevParams& P, const int64_t* __restrict__ action) {
   extern __shared__ float sm[];
-  const int e = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const int e = blockIdx.x, tid = threadIdx.x;
   Lds L; L.sm = sm; L.P = &P;
   int* misc = L.MISC();
   EnvHdr* h = &P.hdr[e];
@@ -633,11 +728,21 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_step(DevParams P, const 
     bc[5] = __int_as_float(mh.nv); bc[6] = __int_as_float(mh.vo); bc[7] = __int_as_float(m);
   }
   __syncthreads();
+  // local (COM-frame) vertices of every body into LDS, once per step
+  for (int it = tid; it < nb * P.VS; it += T) {
+    const int b = it / P.VS, k = it - b * P.VS;
+    const float* bc = L.BC(b);
+    if (k < __float_as_int(bc[5])) {
+      float4 lv = P.mv[__float_as_int(bc[6]) + k];
+      st3(L.LV(b) + 3 * k, V(lv.x, lv.y, lv.z));
+    }
+  }
+  __syncthreads();
 
   // ---- Simulator.step (simulator.py:190-258)
   int counter = 0;
   bool diverged = false;
-  substep(L, nb, tid, T);
+  substep<T, PP>(L, nb, tid);
   counter = 1;
   if (P.c.smooth_placing) {
     for (;;) {
@@ -646,7 +751,7 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_step(DevParams P, const 
       if (drop || stop) break;
       if (tid == 0) { st3(L.Vl(nb - 1), V(0, 0, 0)); st3(L.Wl(nb - 1), V(0, 0, 0)); }   // resetBaseVelocity
       __syncthreads();
-      substep(L, nb, tid, T);
+      substep<T, PP>(L, nb, tid);
       counter++;
       if (counter > P.max_substeps) { diverged = true; break; }
     }
@@ -657,7 +762,7 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_step(DevParams P, const 
   }
   const int s_a = counter;
   while (!diverged && !sim_stop(L, nb, tid)) {
-    substep(L, nb, tid, T);
+    substep<T, PP>(L, nb, tid);
     counter++;
     if (counter > P.max_substeps) { diverged = true; break; }
   }
@@ -675,6 +780,22 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_step(DevParams P, const 
     h->status = st;
     if (diverged) atomicOr(P.flags, 2);
   }
+}
+
+// Variants: T threads per env, PP contact points of body-body manifolds per thread (4 NS <= T PP).
+// L <= 8 runs two waves per env so that four envs per CU (1,024 envs per GPU) are resident together with up to
+// 256 VGPRs per lane; longer episodes use four waves.
+extern "C" __global__ void __launch_bounds__(128, 2) srl_k_step(DevParams P, const int64_t* __restrict__ action) {
+  step_body<128, 1>(P, action);
+}
+extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp1(DevParams P, const int64_t* __restrict__ action) {
+  step_body<256, 1>(P, action);
+}
+extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp2(DevParams P, const int64_t* __restrict__ action) {
+  step_body<256, 2>(P, action);
+}
+extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp3(DevParams P, const int64_t* __restrict__ action) {
+  step_body<256, 3>(P, action);
 }
 
 // ------------------------------------------------------------------ ParallelEnv.sample (utils.py:534-538)

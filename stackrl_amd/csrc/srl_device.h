@@ -265,20 +265,33 @@ __device__ __forceinline__ int simplex_closest(Simplex& s, v3& vout) {
   return 1;
 }
 
-__device__ __forceinline__ int support_max(const float* P, int n, v3 d) {
-  int best = 0;
-  float bd = dot(ld3(P), d);
-  for (int k = 1; k < n; ++k) {
+// Support vertex (arg max of P[k] . d, lowest index on ties) computed by a group of G adjacent lanes:
+// each lane scans the vertices k = gl, gl + G, ... and the group combines with xor shuffles.
+// G = 1 is the plain sequential scan.  The dot products are the same on every mapping, so the index
+// returned does not depend on G.
+template <int G>
+__device__ __forceinline__ int support_max(const float* P, int n, v3 d, int gl) {
+  int best = 0x7fffffff;
+  float bd = -3.0e38f;
+  for (int k = gl; k < n; k += G) {
     float t = dot(ld3(P + 3 * k), d);
     if (t > bd) { bd = t; best = k; }
+  }
+#pragma unroll
+  for (int m = 1; m < G; m <<= 1) {
+    float ot = __shfl_xor(bd, m, G);
+    int ok = __shfl_xor(best, m, G);
+    if (ot > bd || (ot == bd && ok < best)) { bd = ot; best = ok; }
   }
   return best;
 }
 
-// GJK distance between two world-space vertex clouds held in LDS (float triples).
+// GJK distance between two world-space vertex clouds held in LDS (float triples), run by a group of G
+// lanes that all follow the same control flow (only the support scans are split).
 // 0: farther than maxdist; 1: pa/pb/n/dist valid; 2: hulls overlap.
+template <int G>
 __device__ __forceinline__ int gjk_distance(const float* VA, int na, const float* VB, int nb, v3& axis, float maxdist,
-                                            v3& pa, v3& pb, v3& nrm, float& dist) {
+                                            v3& pa, v3& pb, v3& nrm, float& dist, int gl) {
   Simplex s;
   s.n = 0;
 #pragma unroll
@@ -290,8 +303,8 @@ __device__ __forceinline__ int gjk_distance(const float* VA, int na, const float
   float sqd = 1e30f;
   if (!(dot(v, v) > 1e-20f)) v = V(0.0f, 0.0f, 1.0f);
   for (int it = 0; it < SRL_GJK_MAXIT; ++it) {
-    int ia = support_max(VA, na, neg(v));
-    int ib = support_max(VB, nb, v);
+    int ia = support_max<G>(VA, na, neg(v), gl);
+    int ib = support_max<G>(VB, nb, v, gl);
     v3 a = ld3(VA + 3 * ia), b = ld3(VB + 3 * ib);
     v3 w = a - b;
     float delta = dot(v, w);

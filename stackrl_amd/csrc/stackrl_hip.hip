@@ -42,7 +42,8 @@ struct srl_env {
   uchar4* d_mt = nullptr;
   float4* d_mp = nullptr;
   float* d_objmap = nullptr;
-  int step_threads = 64;
+  int step_threads = 256;
+  int step_pp = 1;
   size_t step_lds = 0, render_lds = 0, objmap_lds = 0;
   bool profiling = false;
   std::vector<EventPair> pending;
@@ -115,6 +116,9 @@ void layout(DevParams& P) {
   P.S_AMAX = s; s += 3 * L;
   P.S_BC = s; s += 8 * L;
   P.S_WV = s; s += 3 * P.VS * L;
+  P.S_LV = s; s += 3 * P.VS * L;
+  s = (s + 1) & ~1;
+  P.S_USED = s; s += 2 * SRL_MAX_BODIES;   // colouring scratch (uint64 per body); BLOB is a multiple of 4 words
   P.S_MISC = s; s += M_WORDS;
   P.LDS_WORDS = P.BLOB + s;
 }
@@ -144,7 +148,10 @@ int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void*
   P.force_reset = force_reset;
   const int n = P.c.n_envs;
   prof_begin(env, st, 0);
-  hipLaunchKernelGGL(srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, P, action);
+  if (env->step_pp == 0) hipLaunchKernelGGL(srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, P, action);
+  else if (env->step_pp == 1) hipLaunchKernelGGL(srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, P, action);
+  else if (env->step_pp == 2) hipLaunchKernelGGL(srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, P, action);
+  else hipLaunchKernelGGL(srl_k_step_pp3, dim3(n), dim3(env->step_threads), env->step_lds, st, P, action);
   prof_end(env, st);
   prof_begin(env, st, 1);
   hipLaunchKernelGGL(srl_k_render, dim3(n), dim3(SRL_RENDER_THREADS), env->render_lds, st, P, (uint8_t*)obs_map, (uint8_t*)obs_obj,
@@ -298,13 +305,16 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   if (P.BLOB != old_blob) return fail(SRL_EINVAL, "internal: blob layout changed");
   env->step_lds = sizeof(float) * (size_t)P.LDS_WORDS;
   if (env->step_lds > 160 * 1024) return fail(SRL_EINVAL, "episode_length x mesh size exceeds the 160 KB LDS budget");
-  int need = P.NS > P.c.episode_length ? P.NS : P.c.episode_length;
-  env->step_threads = ((need + 63) / 64) * 64;
-  if (env->step_threads > 256) env->step_threads = 256;
+  // threads per env / pair-manifold points per thread (settle.hip "Variants")
+  if (4 * P.NS <= 128 && 8 * P.c.episode_length <= 128) { env->step_threads = 128; env->step_pp = 0; }
+  else { env->step_threads = 256; env->step_pp = (4 * P.NS + 255) / 256; }
   const int res = P.c.overhead_res;
   env->render_lds = render_lds_bytes(res);
   env->objmap_lds = 0;
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->render_lds));
   // K3: object maps of the whole pool, once
   hipLaunchKernelGGL(srl_k_objmap, dim3(n_mesh), dim3(256), env->objmap_lds, 0, P, env->d_objmap);
