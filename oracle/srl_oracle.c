@@ -39,19 +39,29 @@ static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
 static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
-static inline float vdot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+/* The vector kernels below are DEFINED with fused multiply-adds (one rounding per fmaf): the HIP side
+ * issues v_fma_f32 for exactly these expressions. */
+static inline float vdot(v3 a, v3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 static inline v3 vcross(v3 a, v3 b) {
-  return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+  return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+static inline v3 vmadd(v3 a, v3 b, float s) { /* a + b * s */
+  return V(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z));
 }
 static inline v3 mmul(const m3* R, v3 a) { /* R * a */
-  return V((R->m[0] * a.x + R->m[1] * a.y) + R->m[2] * a.z,
-           (R->m[3] * a.x + R->m[4] * a.y) + R->m[5] * a.z,
-           (R->m[6] * a.x + R->m[7] * a.y) + R->m[8] * a.z);
+  return V(fmaf(R->m[0], a.x, fmaf(R->m[1], a.y, R->m[2] * a.z)),
+           fmaf(R->m[3], a.x, fmaf(R->m[4], a.y, R->m[5] * a.z)),
+           fmaf(R->m[6], a.x, fmaf(R->m[7], a.y, R->m[8] * a.z)));
+}
+static inline v3 mmul_add(const m3* R, v3 a, v3 x) { /* x + R * a */
+  return V(fmaf(R->m[0], a.x, fmaf(R->m[1], a.y, fmaf(R->m[2], a.z, x.x))),
+           fmaf(R->m[3], a.x, fmaf(R->m[4], a.y, fmaf(R->m[5], a.z, x.y))),
+           fmaf(R->m[6], a.x, fmaf(R->m[7], a.y, fmaf(R->m[8], a.z, x.z))));
 }
 static inline v3 mtmul(const m3* R, v3 a) { /* R^T * a */
-  return V((R->m[0] * a.x + R->m[3] * a.y) + R->m[6] * a.z,
-           (R->m[1] * a.x + R->m[4] * a.y) + R->m[7] * a.z,
-           (R->m[2] * a.x + R->m[5] * a.y) + R->m[8] * a.z);
+  return V(fmaf(R->m[0], a.x, fmaf(R->m[3], a.y, R->m[6] * a.z)),
+           fmaf(R->m[1], a.x, fmaf(R->m[4], a.y, R->m[7] * a.z)),
+           fmaf(R->m[2], a.x, fmaf(R->m[5], a.y, R->m[8] * a.z)));
 }
 static inline m3 quat_to_mat(q4 q) {
   float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
@@ -446,7 +456,7 @@ static void render_heightmap(const struct srlo_env* e, int nb, const int* mesh, 
     m3 R = quat_to_mat(q[b]);
     float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
     for (int k = 0; k < M->nv; ++k) {
-      v3 a = vadd(x[b], mmul(&R, M->v[k]));
+      v3 a = mmul_add(&R, M->v[k], x[b]);
       xmin = fminf(xmin, a.x); xmax = fmaxf(xmax, a.x);
       ymin = fminf(ymin, a.y); ymax = fmaxf(ymax, a.y);
     }
@@ -628,28 +638,28 @@ static int simplex_closest(simplex_t* s, float* lam, v3* vout) {
     float tl[3]; int tu;
     if (o0) {
       closest_tri(a, b, c, tl, &tu);
-      v3 p = vadd(vadd(vscale(a, tl[0]), vscale(b, tl[1])), vscale(c, tl[2]));
+      v3 p = vmadd(vmadd(vscale(a, tl[0]), b, tl[1]), c, tl[2]);
       float d2 = vdot(p, p);
       if (d2 < best) { best = d2; l[0] = tl[0]; l[1] = tl[1]; l[2] = tl[2]; l[3] = 0.0f;
         used = (tu & 1) | (tu & 2) | (tu & 4); }
     }
     if (o1) {
       closest_tri(a, c, d, tl, &tu);
-      v3 p = vadd(vadd(vscale(a, tl[0]), vscale(c, tl[1])), vscale(d, tl[2]));
+      v3 p = vmadd(vmadd(vscale(a, tl[0]), c, tl[1]), d, tl[2]);
       float d2 = vdot(p, p);
       if (d2 < best) { best = d2; l[0] = tl[0]; l[1] = 0.0f; l[2] = tl[1]; l[3] = tl[2];
         used = (tu & 1) | ((tu & 2) << 1) | ((tu & 4) << 1); }
     }
     if (o2) {
       closest_tri(a, d, b, tl, &tu);
-      v3 p = vadd(vadd(vscale(a, tl[0]), vscale(d, tl[1])), vscale(b, tl[2]));
+      v3 p = vmadd(vmadd(vscale(a, tl[0]), d, tl[1]), b, tl[2]);
       float d2 = vdot(p, p);
       if (d2 < best) { best = d2; l[0] = tl[0]; l[1] = tl[2]; l[2] = 0.0f; l[3] = tl[1];
         used = (tu & 1) | ((tu & 2) << 2) | ((tu & 4) >> 1); }
     }
     if (o3) {
       closest_tri(b, d, c, tl, &tu);
-      v3 p = vadd(vadd(vscale(b, tl[0]), vscale(d, tl[1])), vscale(c, tl[2]));
+      v3 p = vmadd(vmadd(vscale(b, tl[0]), d, tl[1]), c, tl[2]);
       float d2 = vdot(p, p);
       if (d2 < best) { best = d2; l[0] = 0.0f; l[1] = tl[0]; l[2] = tl[2]; l[3] = tl[1];
         used = ((tu & 1) << 1) | ((tu & 2) << 2) | (tu & 4); }
@@ -663,7 +673,7 @@ static int simplex_closest(simplex_t* s, float* lam, v3* vout) {
       s->w[m] = s->w[i]; s->p[m] = s->p[i]; s->q[m] = s->q[i];
       s->ia[m] = s->ia[i]; s->ib[m] = s->ib[i];
       lam[m] = l[i];
-      v = vadd(v, vscale(s->w[m], lam[m]));
+      v = vmadd(v, s->w[m], lam[m]);
       ++m;
     }
   }
@@ -722,8 +732,8 @@ static int gjk_distance(const v3* VA, int na, const v3* VB, int nb, v3* axis, fl
   }
   v3 A = V(0.0f, 0.0f, 0.0f), B = V(0.0f, 0.0f, 0.0f);
   for (int k = 0; k < s.n; ++k) {
-    A = vadd(A, vscale(s.p[k], lam[k]));
-    B = vadd(B, vscale(s.q[k], lam[k]));
+    A = vmadd(A, s.p[k], lam[k]);
+    B = vmadd(B, s.q[k], lam[k]);
   }
   float d = sqrtf(sqd);
   if (d > maxdist) { *axis = v; return 0; }
@@ -755,9 +765,9 @@ static void sat_faces(const mesh_t* MA, const v3* VA, const mesh_t* MB, const v3
     }
   }
   if (btype == 0) { /* face of A, deepest vertex of B; B->A normal is -face normal */
-    *nrm = vneg(bn); *pb = VB[bvert]; *pa = vsub(VB[bvert], vscale(bn, best));
+    *nrm = vneg(bn); *pb = VB[bvert]; *pa = vmadd(VB[bvert], bn, -best);
   } else {          /* face of B, deepest vertex of A */
-    *nrm = bn; *pa = VA[bvert]; *pb = vsub(VA[bvert], vscale(bn, best));
+    *nrm = bn; *pa = VA[bvert]; *pb = vmadd(VA[bvert], bn, -best);
   }
   *dist = best;
 }
@@ -766,12 +776,12 @@ static void sat_faces(const mesh_t* MA, const v3* VA, const mesh_t* MB, const v3
 static void manifold_refresh(manifold_t* m, v3 xa, const m3* Ra, v3 xb, const m3* Rb, float thr) {
   for (int i = m->np - 1; i >= 0; --i) {
     mpoint_t* p = &m->p[i];
-    v3 wa = vadd(xa, mmul(Ra, p->la));
-    v3 wb = vadd(xb, mmul(Rb, p->lb));
+    v3 wa = mmul_add(Ra, p->la, xa);
+    v3 wb = mmul_add(Rb, p->lb, xb);
     float d = vdot(vsub(wa, wb), p->n);
     int drop = d > thr;
     if (!drop) {
-      v3 proj = vsub(wa, vscale(p->n, d));
+      v3 proj = vmadd(wa, p->n, -d);
       v3 t = vsub(wb, proj);
       drop = vdot(t, t) > thr * thr;
     }
@@ -820,7 +830,7 @@ static void derive_bodies(const struct srlo_env* e, env_t* s) {
     s->Iw[b] = inv_inertia_world(&s->R[b], M->inv_inertia);
     v3 lo = V(1e30f, 1e30f, 1e30f), hi = V(-1e30f, -1e30f, -1e30f);
     for (int k = 0; k < M->nv; ++k) {
-      v3 a = vadd(s->x[b], mmul(&s->R[b], M->v[k]));
+      v3 a = mmul_add(&s->R[b], M->v[k], s->x[b]);
       s->wv[b][k] = a;
       lo = V(fminf(lo.x, a.x), fminf(lo.y, a.y), fminf(lo.z, a.z));
       hi = V(fmaxf(hi.x, a.x), fmaxf(hi.y, a.y), fmaxf(hi.z, a.z));
@@ -924,8 +934,8 @@ static void narrowphase_slot(const struct srlo_env* e, env_t* s, int sl) {
     float dist = d - (mg + mg);
     if (dist < thr) {
       mpoint_t np_;
-      v3 sa = vsub(pa, vscale(n, mg));
-      v3 sb = vadd(pb, vscale(n, mg));
+      v3 sa = vmadd(pa, n, -mg);
+      v3 sb = vmadd(pb, n, mg);
       np_.la = mtmul(&s->R[a], vsub(sa, s->x[a]));
       np_.lb = mtmul(&s->R[b], vsub(sb, s->x[b]));
       np_.n = n; np_.dist = dist; np_.in = 0.0f; np_.it1 = 0.0f; np_.it2 = 0.0f;
@@ -956,11 +966,11 @@ static inline float row_solve(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float
   if (na > hi) na = hi;
   dl = na - *acc;
   *acc = na;
-  u->va = vadd(u->va, vscale(d, ima * dl));
-  u->wa = vadd(u->wa, vscale(aa, dl));
+  u->va = vmadd(u->va, d, ima * dl);
+  u->wa = vmadd(u->wa, aa, dl);
   if (has_b) {
-    u->vb = vsub(u->vb, vscale(d, imb * dl));
-    u->wb = vsub(u->wb, vscale(ab, dl));
+    u->vb = vmadd(u->vb, d, -(imb * dl));
+    u->wb = vmadd(u->wb, ab, -dl);
   }
   return dl;
 }
@@ -968,12 +978,12 @@ static inline float row_solve(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float
 static inline void row_apply(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float imb, const m3* Ib,
                              vel4* u, float imp, int has_b) {
   v3 aa = mmul(Ia, vcross(ra, d));
-  u->va = vadd(u->va, vscale(d, ima * imp));
-  u->wa = vadd(u->wa, vscale(aa, imp));
+  u->va = vmadd(u->va, d, ima * imp);
+  u->wa = vmadd(u->wa, aa, imp);
   if (has_b) {
     v3 ab = mmul(Ib, vcross(rb, d));
-    u->vb = vsub(u->vb, vscale(d, imb * imp));
-    u->wb = vsub(u->wb, vscale(ab, imp));
+    u->vb = vmadd(u->vb, d, -(imb * imp));
+    u->wb = vmadd(u->wb, ab, -imp);
   }
 }
 
@@ -1064,7 +1074,7 @@ static void substep(const struct srlo_env* e, env_t* s) {
   for (int it = 0; it < e->c.solver_iterations; ++it) solver_sweep(e, s, 0);
   /* integrate */
   for (int b = 0; b < s->nb; ++b) {
-    s->x[b] = vadd(s->x[b], vscale(s->v[b], dt));
+    s->x[b] = vmadd(s->x[b], s->v[b], dt);
     q4 q = s->q[b]; v3 w = s->w[b];
     float hx = 0.5f * dt;
     q4 dq;

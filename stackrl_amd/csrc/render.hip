@@ -228,7 +228,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       if (b >= nb) break;
       m3 R = ldm(L.sR + 9 * b);
       float4 lv = P.mv[L.mhdr[4 * b + 0] + (it - vs)];
-      v3 a = ld3(L.sx + 3 * b) + mmul(R, V(lv.x, lv.y, lv.z));
+      v3 a = mmul_add(R, V(lv.x, lv.y, lv.z), ld3(L.sx + 3 * b));
       atomicMin(&L.bbox[4 * b + 0], f2o(a.x)); atomicMax(&L.bbox[4 * b + 1], f2o(a.x));
       atomicMin(&L.bbox[4 * b + 2], f2o(a.y)); atomicMax(&L.bbox[4 * b + 3], f2o(a.y));
     }

@@ -128,9 +128,10 @@ __device__ void body_frame(const Lds& L, int b) {
   for (int i = 0; i < 9; ++i) { L.R(b)[i] = R.m[i]; L.IW(b)[i] = I.m[i]; }
 }
 
-// lane = body: AABB of the world vertices + ground manifold (up to 8 deepest vertices within the breaking
-// threshold in (dist, index) order; warm-start impulses carried over by vertex id)
-__device__ void body_bounds_ground(const Lds& L, int b) {
+// 16 lanes = body: AABB of the world vertices + ground manifold (up to 8 deepest vertices within the breaking
+// threshold in (dist, index) order; warm-start impulses carried over by vertex id).  Each lane owns the
+// vertices gl, gl + 16, ...; the group repeatedly extracts the minimum (dist, index) with xor shuffles.
+__device__ void body_bounds_ground(const Lds& L, int b, int gl) {
   const DevParams& P = *L.P;
   const float* bc = L.BC(b);
   const int nv = __float_as_int(bc[5]);
@@ -138,32 +139,49 @@ __device__ void body_bounds_ground(const Lds& L, int b) {
   const float m = P.c.collision_margin, thr = 0.02f * radius;
   const float* W = L.WV(b);
   v3 lo = V(1e30f, 1e30f, 1e30f), hi = V(-1e30f, -1e30f, -1e30f);
-  float sd[SRL_GMAXP]; int sk[SRL_GMAXP];
+  float cd[SRL_MAX_VERTS / 16];   // this lane's candidate distances (+inf: not a candidate / already taken)
 #pragma unroll
-  for (int j = 0; j < SRL_GMAXP; ++j) { sd[j] = 0.0f; sk[j] = -1; }
-  int ns = 0;
-  for (int k = 0; k < nv; ++k) {
-    v3 a = ld3(W + 3 * k);
-    lo = V(fminf(lo.x, a.x), fminf(lo.y, a.y), fminf(lo.z, a.z));
-    hi = V(fmaxf(hi.x, a.x), fmaxf(hi.y, a.y), fmaxf(hi.z, a.z));
-    float cd = a.z - m;
-    if (cd < thr) {   // sorted insertion, static register indexing
-      int ck = k;
-      bool placed = false;
-#pragma unroll
-      for (int j = 0; j < SRL_GMAXP; ++j) {
-        if (!placed) {
-          if (j < ns) {
-            if (cd < sd[j] || (cd == sd[j] && ck < sk[j])) {
-              float td = sd[j]; sd[j] = cd; cd = td;
-              int tk = sk[j]; sk[j] = ck; ck = tk;
-            }
-          } else { sd[j] = cd; sk[j] = ck; placed = true; }
-        }
-      }
-      if (placed) ns++;
+  for (int j = 0; j < SRL_MAX_VERTS / 16; ++j) {
+    const int k = gl + 16 * j;
+    cd[j] = 3.0e38f;
+    if (k < nv) {
+      v3 a = ld3(W + 3 * k);
+      lo = V(fminf(lo.x, a.x), fminf(lo.y, a.y), fminf(lo.z, a.z));
+      hi = V(fmaxf(hi.x, a.x), fmaxf(hi.y, a.y), fmaxf(hi.z, a.z));
+      const float d = a.z - m;
+      if (d < thr) cd[j] = d;
     }
   }
+#pragma unroll
+  for (int s = 1; s < 16; s <<= 1) {
+    lo = V(fminf(lo.x, __shfl_xor(lo.x, s, 16)), fminf(lo.y, __shfl_xor(lo.y, s, 16)), fminf(lo.z, __shfl_xor(lo.z, s, 16)));
+    hi = V(fmaxf(hi.x, __shfl_xor(hi.x, s, 16)), fmaxf(hi.y, __shfl_xor(hi.y, s, 16)), fmaxf(hi.z, __shfl_xor(hi.z, s, 16)));
+  }
+  float sd[SRL_GMAXP]; int sk[SRL_GMAXP];
+  int ns = 0;
+#pragma unroll
+  for (int r = 0; r < SRL_GMAXP; ++r) {
+    sd[r] = 0.0f; sk[r] = -1;
+    if (ns == r) {   // group-uniform: previous round found a candidate
+      float bd = 3.0e38f; int bk = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < SRL_MAX_VERTS / 16; ++j)
+        if (cd[j] < bd) { bd = cd[j]; bk = gl + 16 * j; }   // ascending k: lowest index wins ties
+#pragma unroll
+      for (int s = 1; s < 16; s <<= 1) {
+        const float od = __shfl_xor(bd, s, 16);
+        const int ok = __shfl_xor(bk, s, 16);
+        if (od < bd || (od == bd && ok < bk)) { bd = od; bk = ok; }
+      }
+      if (bd < 3.0e38f) {
+        sd[r] = bd; sk[r] = bk; ns = r + 1;
+#pragma unroll
+        for (int j = 0; j < SRL_MAX_VERTS / 16; ++j)
+          if (gl + 16 * j == bk) cd[j] = 3.0e38f;
+      }
+    }
+  }
+  if (gl != 0) return;
   const float ex = P.c.collision_margin + 0.01f * radius;
   st3(L.AMIN(b), V(lo.x - ex, lo.y - ex, lo.z - ex));
   st3(L.AMAX(b), V(hi.x + ex, hi.y + ex, hi.z + ex));
@@ -195,12 +213,12 @@ __device__ void manifold_refresh(float* mp, v3 xa, const m3& Ra, v3 xb, const m3
   for (int i = np - 1; i >= 0; --i) {
     float* p = mp + 4 + SRL_MP_WORDS * i;
     v3 n = ld3(p + 6);
-    v3 wa = xa + mmul(Ra, ld3(p));
-    v3 wb = xb + mmul(Rb, ld3(p + 3));
+    v3 wa = mmul_add(Ra, ld3(p), xa);
+    v3 wb = mmul_add(Rb, ld3(p + 3), xb);
     float d = dot(wa - wb, n);
     bool drop = d > thr;
     if (!drop) {
-      v3 proj = wa - n * d;
+      v3 proj = madd(wa, n, -d);
       v3 t = wb - proj;
       drop = dot(t, t) > thr * thr;
     }
@@ -275,8 +293,8 @@ __device__ void sat_faces(const DevParams& P, int mesh_a, const float* VA, int n
       if (smin > best) { best = smin; btype = pass; bvert = kmin; bn = n; }
     }
   }
-  if (btype == 0) { nrm = neg(bn); pb = ld3(VB + 3 * bvert); pa = pb - bn * best; }
-  else { nrm = bn; pa = ld3(VA + 3 * bvert); pb = pa - bn * best; }
+  if (btype == 0) { nrm = neg(bn); pb = ld3(VB + 3 * bvert); pa = madd(pb, bn, -best); }
+  else { nrm = bn; pa = ld3(VA + 3 * bvert); pb = madd(pa, bn, -best); }
   dist = best;
 }
 
@@ -308,8 +326,8 @@ __device__ void narrowphase_slot(const Lds& L, int sl, int gl) {
   if (rc == 1) {
     float dist = d - (mg + mg);
     if (dist < thr) {
-      v3 sa = pa - n * mg;
-      v3 sb = pb + n * mg;
+      v3 sa = madd(pa, n, -mg);
+      v3 sb = madd(pb, n, mg);
       manifold_add(mp, mtmul(Ra, sa - xa), mtmul(Rb, sb - xb), n, dist, thr);
     }
   }
@@ -348,21 +366,21 @@ __device__ __forceinline__ void row_solve(const Row& r, float ima, float imb, Ve
   if (na > hi) na = hi;
   dl = na - acc;
   acc = na;
-  u.va = u.va + r.d * (ima * dl);
-  u.wa = u.wa + r.aa * dl;
+  u.va = madd(u.va, r.d, ima * dl);
+  u.wa = madd(u.wa, r.aa, dl);
   if (HAS_B) {
-    u.vb = u.vb - r.d * (imb * dl);
-    u.wb = u.wb - r.ab * dl;
+    u.vb = madd(u.vb, r.d, -(imb * dl));
+    u.wb = madd(u.wb, r.ab, -dl);
   }
 }
 
 template <bool HAS_B>
 __device__ __forceinline__ void row_apply(const Row& r, float ima, float imb, Vel4& u, float imp) {
-  u.va = u.va + r.d * (ima * imp);
-  u.wa = u.wa + r.aa * imp;
+  u.va = madd(u.va, r.d, ima * imp);
+  u.wa = madd(u.wa, r.aa, imp);
   if (HAS_B) {
-    u.vb = u.vb - r.d * (imb * imp);
-    u.wb = u.wb - r.ab * imp;
+    u.vb = madd(u.vb, r.d, -(imb * imp));
+    u.wb = madd(u.wb, r.ab, -imp);
   }
 }
 
@@ -485,26 +503,38 @@ __device__ __forceinline__ void solver_sweep(const Lds& L, Point& gp, Point (&pp
 }
 
 // ------------------------------------------------------------------ one sub-step (block-wide)
+#ifdef SRL_STAMPS
+#define STAMP(k) do { if (tid == 0) { long long _t = wall_clock64(); L.P->hdr[blockIdx.x].stamps[k] += _t - _t0; _t0 = _t; } } while (0)
+#else
+#define STAMP(k)
+#endif
+
 template <int T, int PP>
 __device__ void substep(const Lds& L, int nb, int tid) {
   const DevParams& P = *L.P;
+#ifdef SRL_STAMPS
+  long long _t0 = wall_clock64();
+#endif
   int* misc = L.MISC();
   // (1) lane = body: damping, gravity, frame
   if (tid < nb) body_frame(L, tid);
   if (tid == 0) misc[M_FLAGS] = 0;
   __syncthreads();
+  STAMP(0);
   // (2) lane = (body, vertex): world vertices
   for (int it = tid; it < nb * P.VS; it += T) {
     const int b = it / P.VS, k = it - b * P.VS;
     if (k < __float_as_int(L.BC(b)[5])) {
       const m3 R = ldm(L.R(b));
-      st3(L.WV(b) + 3 * k, ld3(L.X(b)) + mmul(R, ld3(L.LV(b) + 3 * k)));
+      st3(L.WV(b) + 3 * k, mmul_add(R, ld3(L.LV(b) + 3 * k), ld3(L.X(b))));
     }
   }
   __syncthreads();
-  // (3) lane = body: AABB + ground manifold
-  if (tid < nb) body_bounds_ground(L, tid);
+  STAMP(1);
+  // (3) 16 lanes = body: AABB + ground manifold
+  for (int b = tid >> 4; b < nb; b += T >> 4) body_bounds_ground(L, b, tid & 15);
   __syncthreads();
+  STAMP(2);
   // (4) broadphase: AABB overlap for every pair; release slots of pairs that separated
   const int npair = nb * (nb - 1) / 2;
   int fl = 0;
@@ -558,6 +588,7 @@ __device__ void substep(const Lds& L, int nb, int tid) {
     __syncthreads();
   }
   const int ncol = misc[M_NCOL];
+  STAMP(3);
   // (5) narrowphase: 16 lanes per slot
   {
     const int gl = tid & (SRL_GJK_GROUP - 1);
@@ -565,6 +596,7 @@ __device__ void substep(const Lds& L, int nb, int tid) {
       if (L.POS()[sl] >= 0) narrowphase_slot(L, sl, gl);
   }
   __syncthreads();
+  STAMP(4);
   // (6) sequential impulses: lane = contact point, row constants in registers for all sweeps
   {
     Point gp = make_ground_point(L, tid >> 3, tid & 7);
@@ -573,6 +605,7 @@ __device__ void substep(const Lds& L, int nb, int tid) {
 #pragma unroll
     for (int r = 0; r < PP; ++r) pp[r] = make_pair_point(L, (tid + r * T) >> 2, tid & 3);
     __syncthreads();   // every lane has read the pre-solve velocities' companions (R, Iw, manifolds)
+    STAMP(5);
     solver_sweep<true, PP>(L, gp, pp, ncol);
     for (int it = 0; it < P.c.solver_iterations; ++it) solver_sweep<false, PP>(L, gp, pp, ncol);
     // accumulated impulses back to the manifolds (warm start of the next sub-step)
@@ -584,12 +617,13 @@ __device__ void substep(const Lds& L, int nb, int tid) {
         q[10] = pp[r].in; q[11] = pp[r].i1; q[12] = pp[r].i2;
       }
   }
+  STAMP(6);
   // (7) integrate (the last solver phase ended with a barrier)
   const float dt = P.c.sim_time_step;
   if (tid < nb) {
     const int b = tid;
     v3 v = ld3(L.Vl(b)), w = ld3(L.Wl(b));
-    st3(L.X(b), ld3(L.X(b)) + v * dt);
+    st3(L.X(b), madd(ld3(L.X(b)), v, dt));
     float* Q = L.Q(b);
     q4 q; q.x = Q[0]; q.y = Q[1]; q.z = Q[2]; q.w = Q[3];
     float hx = 0.5f * dt;
@@ -603,6 +637,7 @@ __device__ void substep(const Lds& L, int nb, int tid) {
     Q[0] = q.x * inv; Q[1] = q.y * inv; Q[2] = q.z * inv; Q[3] = q.w * inv;
   }
   __syncthreads();
+  STAMP(7);
 }
 
 // simulator.py:322-335: every body's linear speed <= threshold
@@ -633,18 +668,22 @@ __device__ int newest_contacts(const Lds& L, int nb, int tid, int T) {
 }
 
 // ------------------------------------------------------------------ K1 + K4 + episode machine
+// Pp points to the handle's DevParams in device memory: every field access is a scalar load.  (A by-value
+// kernel argument whose address is taken is copied to scratch and every access becomes a scratch load.)
 template <int T, int PP>
-__device__ __forceinline__ void step_body(const DevParams& P, const int64_t* __restrict__ action) {
+__device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, const int64_t* __restrict__ action,
+                                          int force_reset) {
+  const DevParams& P = *Pp;
   extern __shared__ float sm[];
   const int e = blockIdx.x, tid = threadIdx.x;
-  Lds L; L.sm = sm; L.P = &P;
+  Lds L; L.sm = sm; L.P = Pp;
   int* misc = L.MISC();
   EnvHdr* h = &P.hdr[e];
   float* gblob = P.blob + (size_t)e * P.BLOB;
 
   if (tid == 0) {
     int mode;
-    if (P.force_reset || h->done) {          // env.py:235-236 auto-reset
+    if (force_reset || h->done) {            // env.py:235-236 auto-reset
       env_reset(P, h, e);
       mode = 1;
     } else {
@@ -785,17 +824,21 @@ __device__ __forceinline__ void step_body(const DevParams& P, const int64_t* __r
 // Variants: T threads per env, PP contact points of body-body manifolds per thread (4 NS <= T PP).
 // L <= 8 runs two waves per env so that four envs per CU (1,024 envs per GPU) are resident together with up to
 // 256 VGPRs per lane; longer episodes use four waves.
-extern "C" __global__ void __launch_bounds__(128, 2) srl_k_step(DevParams P, const int64_t* __restrict__ action) {
-  step_body<128, 1>(P, action);
+extern "C" __global__ void __launch_bounds__(128, 2) srl_k_step(const DevParams* __restrict__ Pp,
+    const int64_t* __restrict__ action, int force_reset) {
+  step_body<128, 1>(Pp, action, force_reset);
 }
-extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp1(DevParams P, const int64_t* __restrict__ action) {
-  step_body<256, 1>(P, action);
+extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp1(const DevParams* __restrict__ Pp,
+    const int64_t* __restrict__ action, int force_reset) {
+  step_body<256, 1>(Pp, action, force_reset);
 }
-extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp2(DevParams P, const int64_t* __restrict__ action) {
-  step_body<256, 2>(P, action);
+extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp2(const DevParams* __restrict__ Pp,
+    const int64_t* __restrict__ action, int force_reset) {
+  step_body<256, 2>(Pp, action, force_reset);
 }
-extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp3(DevParams P, const int64_t* __restrict__ action) {
-  step_body<256, 3>(P, action);
+extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp3(const DevParams* __restrict__ Pp,
+    const int64_t* __restrict__ action, int force_reset) {
+  step_body<256, 3>(Pp, action, force_reset);
 }
 
 // ------------------------------------------------------------------ ParallelEnv.sample (utils.py:534-538)

@@ -29,9 +29,13 @@ __device__ __forceinline__ v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + 
 __device__ __forceinline__ v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ v3 operator*(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
 __device__ __forceinline__ v3 neg(v3 a) { return V(-a.x, -a.y, -a.z); }
-__device__ __forceinline__ float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// The vector kernels are DEFINED with fused multiply-adds (one rounding per fmaf), mirrored by the oracle.
+__device__ __forceinline__ float dot(v3 a, v3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 __device__ __forceinline__ v3 cross(v3 a, v3 b) {
-  return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+  return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+__device__ __forceinline__ v3 madd(v3 a, v3 b, float s) {   // a + b * s
+  return V(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z));
 }
 __device__ __forceinline__ v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
 __device__ __forceinline__ void st3(float* p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
@@ -42,12 +46,17 @@ __device__ __forceinline__ m3 ldm(const float* p) {
   return R;
 }
 __device__ __forceinline__ v3 mmul(const m3& R, v3 a) {
-  return V((R.m[0] * a.x + R.m[1] * a.y) + R.m[2] * a.z, (R.m[3] * a.x + R.m[4] * a.y) + R.m[5] * a.z,
-           (R.m[6] * a.x + R.m[7] * a.y) + R.m[8] * a.z);
+  return V(fmaf(R.m[0], a.x, fmaf(R.m[1], a.y, R.m[2] * a.z)), fmaf(R.m[3], a.x, fmaf(R.m[4], a.y, R.m[5] * a.z)),
+           fmaf(R.m[6], a.x, fmaf(R.m[7], a.y, R.m[8] * a.z)));
+}
+__device__ __forceinline__ v3 mmul_add(const m3& R, v3 a, v3 x) {   // x + R * a
+  return V(fmaf(R.m[0], a.x, fmaf(R.m[1], a.y, fmaf(R.m[2], a.z, x.x))),
+           fmaf(R.m[3], a.x, fmaf(R.m[4], a.y, fmaf(R.m[5], a.z, x.y))),
+           fmaf(R.m[6], a.x, fmaf(R.m[7], a.y, fmaf(R.m[8], a.z, x.z))));
 }
 __device__ __forceinline__ v3 mtmul(const m3& R, v3 a) {
-  return V((R.m[0] * a.x + R.m[3] * a.y) + R.m[6] * a.z, (R.m[1] * a.x + R.m[4] * a.y) + R.m[7] * a.z,
-           (R.m[2] * a.x + R.m[5] * a.y) + R.m[8] * a.z);
+  return V(fmaf(R.m[0], a.x, fmaf(R.m[3], a.y, R.m[6] * a.z)), fmaf(R.m[1], a.x, fmaf(R.m[4], a.y, R.m[7] * a.z)),
+           fmaf(R.m[2], a.x, fmaf(R.m[5], a.y, R.m[8] * a.z)));
 }
 __device__ __forceinline__ m3 quat_to_mat(q4 q) {
   float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
@@ -222,25 +231,25 @@ __device__ __forceinline__ int simplex_closest(Simplex& s, v3& vout) {
     float t0, t1, t2; int tu;
     if (o0) {
       closest_tri(a, b, c, t0, t1, t2, tu);
-      v3 p = (a * t0 + b * t1) + c * t2;
+      v3 p = madd(madd(a * t0, b, t1), c, t2);
       float d2 = dot(p, p);
       if (d2 < best) { best = d2; l[0] = t0; l[1] = t1; l[2] = t2; l[3] = 0.0f; used = (tu & 1) | (tu & 2) | (tu & 4); }
     }
     if (o1) {
       closest_tri(a, c, d, t0, t1, t2, tu);
-      v3 p = (a * t0 + c * t1) + d * t2;
+      v3 p = madd(madd(a * t0, c, t1), d, t2);
       float d2 = dot(p, p);
       if (d2 < best) { best = d2; l[0] = t0; l[1] = 0.0f; l[2] = t1; l[3] = t2; used = (tu & 1) | ((tu & 2) << 1) | ((tu & 4) << 1); }
     }
     if (o2) {
       closest_tri(a, d, b, t0, t1, t2, tu);
-      v3 p = (a * t0 + d * t1) + b * t2;
+      v3 p = madd(madd(a * t0, d, t1), b, t2);
       float d2 = dot(p, p);
       if (d2 < best) { best = d2; l[0] = t0; l[1] = t2; l[2] = 0.0f; l[3] = t1; used = (tu & 1) | ((tu & 2) << 2) | ((tu & 4) >> 1); }
     }
     if (o3) {
       closest_tri(b, d, c, t0, t1, t2, tu);
-      v3 p = (b * t0 + d * t1) + c * t2;
+      v3 p = madd(madd(b * t0, d, t1), c, t2);
       float d2 = dot(p, p);
       if (d2 < best) { best = d2; l[0] = 0.0f; l[1] = t0; l[2] = t2; l[3] = t1; used = ((tu & 1) << 1) | ((tu & 2) << 2) | (tu & 4); }
     }
@@ -259,7 +268,7 @@ __device__ __forceinline__ int simplex_closest(Simplex& s, v3& vout) {
   v3 v = V(0.0f, 0.0f, 0.0f);
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (k < m) { s.lam[k] = l[k]; v = v + s.w[k] * l[k]; }
+    if (k < m) { s.lam[k] = l[k]; v = madd(v, s.w[k], l[k]); }
   s.n = m;
   vout = v;
   return 1;
@@ -334,7 +343,7 @@ __device__ __forceinline__ int gjk_distance(const float* VA, int na, const float
   v3 A = V(0.0f, 0.0f, 0.0f), B = V(0.0f, 0.0f, 0.0f);
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (k < s.n) { A = A + s.p[k] * s.lam[k]; B = B + s.q[k] * s.lam[k]; }
+    if (k < s.n) { A = madd(A, s.p[k], s.lam[k]); B = madd(B, s.q[k], s.lam[k]); }
   float d = sqrtf(sqd);
   if (d > maxdist) { axis = v; return 0; }
   pa = A; pb = B; dist = d;

@@ -29,6 +29,9 @@ struct EnvHdr {
   int32_t ids[SRL_MAX_BODIES];
   int32_t script_ids[SRL_MAX_BODIES];
   int32_t script_goal[4];
+#ifdef SRL_STAMPS
+  long long stamps[8];          // diagnostic build only: accumulated wall-clock ticks per sub-step phase
+#endif
 };
 
 // Everything a kernel needs, passed by value.

@@ -41,6 +41,8 @@ struct srl_env {
   float4* d_mv = nullptr;
   uchar4* d_mt = nullptr;
   float4* d_mp = nullptr;
+  DevParams* d_P = nullptr;   // device copy of P for the settle kernel (re-uploaded whenever P changes)
+  bool P_dirty = true;
   float* d_objmap = nullptr;
   int step_threads = 256;
   int step_pp = 1;
@@ -144,14 +146,18 @@ void prof_end(srl_env* env, hipStream_t st) {
 int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void* obs_obj, float* reward, uint8_t* done,
                        hipStream_t st, int force_reset) {
   if (!env->d_mh) return fail(SRL_ENOMESH, "srl_load_meshes must be called first");
-  DevParams P = env->P;
-  P.force_reset = force_reset;
+  const DevParams& P = env->P;
   const int n = P.c.n_envs;
+  if (env->P_dirty) {   // only after create / load_meshes / seed, never in steady state
+    HIP_TRY(hipMemcpyAsync(env->d_P, &env->P, sizeof(DevParams), hipMemcpyHostToDevice, st));
+    env->P_dirty = false;
+  }
+  const DevParams* dP = env->d_P;
   prof_begin(env, st, 0);
-  if (env->step_pp == 0) hipLaunchKernelGGL(srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, P, action);
-  else if (env->step_pp == 1) hipLaunchKernelGGL(srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, P, action);
-  else if (env->step_pp == 2) hipLaunchKernelGGL(srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, P, action);
-  else hipLaunchKernelGGL(srl_k_step_pp3, dim3(n), dim3(env->step_threads), env->step_lds, st, P, action);
+  if (env->step_pp == 0) hipLaunchKernelGGL(srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
+  else if (env->step_pp == 1) hipLaunchKernelGGL(srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
+  else if (env->step_pp == 2) hipLaunchKernelGGL(srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
+  else hipLaunchKernelGGL(srl_k_step_pp3, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
   prof_end(env, st);
   prof_begin(env, st, 1);
   hipLaunchKernelGGL(srl_k_render, dim3(n), dim3(SRL_RENDER_THREADS), env->render_lds, st, P, (uint8_t*)obs_map, (uint8_t*)obs_obj,
@@ -209,6 +215,7 @@ int srl_create(const srl_config* cfg, srl_env** out) {
   HIP_TRY(hipMalloc((void**)&P.blob, sizeof(float) * (size_t)n * P.BLOB));
   HIP_TRY(hipMalloc((void**)&P.H, sizeof(float) * (size_t)n * res * res));
   HIP_TRY(hipMalloc((void**)&P.flags, sizeof(int32_t)));
+  HIP_TRY(hipMalloc((void**)&env->d_P, sizeof(DevParams)));
   HIP_TRY(hipMemset(P.blob, 0, sizeof(float) * (size_t)n * P.BLOB));
   HIP_TRY(hipMemset(P.H, 0, sizeof(float) * (size_t)n * res * res));
   HIP_TRY(hipMemset(P.flags, 0, sizeof(int32_t)));
@@ -227,7 +234,7 @@ void srl_destroy(srl_env* env) {
   (void)hipDeviceSynchronize();
   for (auto& p : env->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& e : env->pool) hipEventDestroy(e);
-  hipFree(env->P.hdr); hipFree(env->P.blob); hipFree(env->P.H); hipFree(env->P.flags);
+  hipFree(env->P.hdr); hipFree(env->P.blob); hipFree(env->P.H); hipFree(env->P.flags); hipFree(env->d_P);
   hipFree(env->d_mh); hipFree(env->d_mv); hipFree(env->d_mt); hipFree(env->d_mp); hipFree(env->d_objmap);
   delete env;
 }
@@ -258,7 +265,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
       mv[(size_t)M.vo + k] = make_float4(ax, ay, az, 0.0f);
       lox = fminf(lox, ax); loy = fminf(loy, ay); loz = fminf(loz, az);
       hix = fmaxf(hix, ax); hiy = fmaxf(hiy, ay); hiz = fmaxf(hiz, az);
-      float d2 = (ax * ax + ay * ay) + az * az;
+      float d2 = fmaf(ax, ax, fmaf(ay, ay, az * az));   // dot(a, a) as the kernels define it
       if (d2 > r2) r2 = d2;
     }
     M.radius = sqrtf(r2);
@@ -270,12 +277,12 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
       // face plane in the COM frame: unit normal and offset (same expression order as the solver's dot/cross)
       const float4 a = mv[(size_t)M.vo + t[0]], b = mv[(size_t)M.vo + t[1]], c = mv[(size_t)M.vo + t[2]];
       float ux = b.x - a.x, uy = b.y - a.y, uz = b.z - a.z, wx = c.x - a.x, wy = c.y - a.y, wz = c.z - a.z;
-      float nx = uy * wz - uz * wy, ny = uz * wx - ux * wz, nz = ux * wy - uy * wx;
-      float len = sqrtf((nx * nx + ny * ny) + nz * nz);
+      float nx = fmaf(uy, wz, -(uz * wy)), ny = fmaf(uz, wx, -(ux * wz)), nz = fmaf(ux, wy, -(uy * wx));   // cross
+      float len = sqrtf(fmaf(nx, nx, fmaf(ny, ny, nz * nz)));
       if (!(len > 0.0f)) return fail(SRL_EINVAL, "degenerate triangle");
       float il = 1.0f / len;
       nx = nx * il; ny = ny * il; nz = nz * il;
-      mp[(size_t)M.to + k] = make_float4(nx, ny, nz, (nx * a.x + ny * a.y) + nz * a.z);
+      mp[(size_t)M.to + k] = make_float4(nx, ny, nz, fmaf(nx, a.x, fmaf(ny, a.y, nz * a.z)));
     }
     // Bullet's default for hull shapes when the URDF inertia is not requested (simulator.py:300 passes no
     // flags): inertia of the solid box spanned by the AABB (btCompoundShape::calculateLocalInertia restated)
@@ -300,6 +307,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   P.mh = env->d_mh; P.mv = env->d_mv; P.mt = env->d_mt; P.mp = env->d_mp; P.objmap = env->d_objmap;
   P.n_mesh = n_mesh;
   P.VS = vs;
+  env->P_dirty = true;
   int old_blob = P.BLOB;
   layout(P);
   if (P.BLOB != old_blob) return fail(SRL_EINVAL, "internal: blob layout changed");
@@ -328,6 +336,7 @@ int srl_seed(srl_env* env, uint32_t seed) {
   if (!env) return fail(SRL_EINVAL, "null env");
   env->P.seed = seed;
   env->P.sample_counter = 0;
+  env->P_dirty = true;
   HIP_TRY(hipDeviceSynchronize());
   const int n = env->P.c.n_envs;
   std::vector<uint32_t> z((size_t)n, 0u);
@@ -505,6 +514,18 @@ int srl_render_heightmap(srl_env* env, const float* poses, const int32_t* mesh_i
   HIP_TRY(hipGetLastError());
   return SRL_OK;
 }
+
+#ifdef SRL_STAMPS
+// diagnostic build only: per-env accumulated phase ticks (100 MHz wall clock), host array [n][8]
+int srl_debug_stamps(srl_env* env, long long* out) {
+  const int n = env->P.c.n_envs;
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<EnvHdr> h((size_t)n);
+  HIP_TRY(hipMemcpy(h.data(), env->P.hdr, sizeof(EnvHdr) * (size_t)n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i) for (int k = 0; k < 8; ++k) out[8 * i + k] = h[i].stamps[k];
+  return SRL_OK;
+}
+#endif
 
 int srl_set_profiling(srl_env* env, int32_t enable) {
   if (!env) return fail(SRL_EINVAL, "null env");

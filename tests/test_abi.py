@@ -57,15 +57,15 @@ def test_config_validation_mirrors_reference_errors():
 
 
 def test_product_has_no_oracle_dependency():
-  """The product package must not import or link anything under oracle/."""
+  """The product package must not import, include, link or call anything under oracle/."""
   pkg = os.path.join(ROOT, 'stackrl_amd')
+  bad = re.compile(r'(import\s+oracle|from\s+oracle|oracle/|oracle\.py|srlo_|libsrl_oracle|srl_oracle)')
   for dirpath, _, files in os.walk(pkg):
     for f in files:
       if f.endswith(('.py', '.hip', '.h')):
         with open(os.path.join(dirpath, f)) as fh:
           src = fh.read()
-        assert 'oracle' not in src.replace('the oracle', '').replace("oracle's", '').replace('like the oracle', ''), \
-          os.path.join(dirpath, f)
+        assert not bad.search(src), os.path.join(dirpath, f)
 
 
 def test_env_requires_gpu_loudly():
