@@ -158,6 +158,8 @@ typedef struct {
   int np;
   mpoint_t p[4];
   v3 axis;              /* cached GJK separating axis */
+  int sn;               /* cached GJK simplex: number of vertex pairs, then (ia, ib) per pair */
+  int sia[4], sib[4];
 } manifold_t;
 
 typedef struct {
@@ -694,20 +696,42 @@ static inline int support_max(const v3* P, int n, v3 d) {
 
 /* GJK distance between two world-space vertex clouds (convex hulls).
  * returns 0: farther than maxdist (no contact); 1: pa/pb/n/dist valid; 2: hulls overlap */
-static int gjk_distance(const v3* VA, int na, const v3* VB, int nb, v3* axis, float maxdist,
-                        v3* pa, v3* pb, v3* nrm, float* dist) {
+static void simplex_store(const simplex_t* s, int* sn, int* sia, int* sib) {
+  *sn = s->n;
+  for (int k = 0; k < 4; ++k) { sia[k] = k < s->n ? s->ia[k] : 0; sib[k] = k < s->n ? s->ib[k] : 0; }
+}
+
+/* GJK with a cached simplex: the vertex pairs that spanned the closest feature last time are re-evaluated at
+ * the current poses and used as the starting simplex (a resting contact then converges in one iteration);
+ * if that simplex is degenerate or encloses the origin the search restarts from the cached axis. */
+static int gjk_distance(const v3* VA, int na, const v3* VB, int nb, v3* axis, int* sn, int* sia, int* sib,
+                        float maxdist, v3* pa, v3* pb, v3* nrm, float* dist) {
   simplex_t s; s.n = 0;
   float lam[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   v3 v = *axis;
   float sqd = 1e30f;
+  int warm = 0;
+  if (*sn > 0) {
+    s.n = *sn;
+    for (int k = 0; k < s.n; ++k) {
+      s.ia[k] = sia[k]; s.ib[k] = sib[k];
+      s.p[k] = VA[sia[k]]; s.q[k] = VB[sib[k]];
+      s.w[k] = vsub(s.p[k], s.q[k]);
+    }
+    v3 nv;
+    int rc = simplex_closest(&s, lam, &nv);
+    float nsq = vdot(nv, nv);
+    if (rc == 1 && !(nsq < 1e-10f)) { v = nv; sqd = nsq; warm = 1; }
+    else { s.n = 0; lam[0] = 0.0f; lam[1] = 0.0f; lam[2] = 0.0f; lam[3] = 0.0f; }
+  }
   if (!(vdot(v, v) > 1e-20f)) v = V(0.0f, 0.0f, 1.0f);
   for (int it = 0; it < GJK_MAXIT; ++it) {
     int ia = support_max(VA, na, vneg(v));
     int ib = support_max(VB, nb, v);
     v3 w = vsub(VA[ia], VB[ib]);
     float delta = vdot(v, w);
-    if (it > 0) {
-      if (delta > 0.0f && delta * delta > sqd * (maxdist * maxdist)) return 0;
+    if (it > 0 || warm) {
+      if (delta > 0.0f && delta * delta > sqd * (maxdist * maxdist)) { simplex_store(&s, sn, sia, sib); return 0; }
       int dup = 0;
       for (int k = 0; k < s.n; ++k) dup |= (s.ia[k] == ia && s.ib[k] == ib);
       if (dup) break;
@@ -718,18 +742,19 @@ static int gjk_distance(const v3* VA, int na, const v3* VB, int nb, v3* axis, fl
     s.w[s.n] = w; s.p[s.n] = VA[ia]; s.q[s.n] = VB[ib]; s.ia[s.n] = ia; s.ib[s.n] = ib; s.n++;
     v3 nv;
     int rc = simplex_closest(&s, lam, &nv);
-    if (rc == 2) return 2;
+    if (rc == 2) { *sn = 0; return 2; }
     if (rc == 0) {
-      if (it == 0) return 0;
+      if (it == 0 && !warm) { *sn = 0; return 0; }
       s = bak; lam[0] = blam[0]; lam[1] = blam[1]; lam[2] = blam[2]; lam[3] = blam[3];
       break;
     }
     float nsq = vdot(nv, nv);
-    if (nsq < 1e-10f) return 2;
-    int stall = (it > 0) && (sqd - nsq <= 1.1920929e-7f * sqd);
+    if (nsq < 1e-10f) { *sn = 0; return 2; }
+    int stall = (it > 0 || warm) && (sqd - nsq <= 1.1920929e-7f * sqd);
     v = nv; sqd = nsq;
     if (stall) break;
   }
+  simplex_store(&s, sn, sia, sib);
   v3 A = V(0.0f, 0.0f, 0.0f), B = V(0.0f, 0.0f, 0.0f);
   for (int k = 0; k < s.n; ++k) {
     A = vmadd(A, s.p[k], lam[k]);
@@ -896,6 +921,7 @@ static void update_slots(const struct srlo_env* e, env_t* s) {
         s->slot_of_pair[pid] = (int16_t)sl; s->pair_of_slot[sl] = (int16_t)pid;
         s->slot_a[sl] = (uint8_t)i; s->slot_b[sl] = (uint8_t)j;
         s->man[sl].np = 0;
+        s->man[sl].sn = 0;
         s->man[sl].axis = vsub(s->x[i], s->x[j]);
         changed = 1;
       }
@@ -928,7 +954,7 @@ static void narrowphase_slot(const struct srlo_env* e, env_t* s, int sl) {
   float thr = 0.02f * fminf(MA->radius, MB->radius);
   manifold_refresh(m, s->x[a], &s->R[a], s->x[b], &s->R[b], thr);
   v3 pa, pb, n; float d;
-  int rc = gjk_distance(s->wv[a], MA->nv, s->wv[b], MB->nv, &m->axis, (mg + mg) + thr, &pa, &pb, &n, &d);
+  int rc = gjk_distance(s->wv[a], MA->nv, s->wv[b], MB->nv, &m->axis, &m->sn, m->sia, m->sib, (mg + mg) + thr, &pa, &pb, &n, &d);
   if (rc == 2) { sat_faces(MA, s->wv[a], MB, s->wv[b], &pa, &pb, &n, &d); rc = 1; }
   if (rc == 1) {
     float dist = d - (mg + mg);

@@ -315,8 +315,11 @@ __device__ void narrowphase_slot(const Lds& L, int sl, int gl) {
   if (gl == 0) manifold_refresh(mp, xa, Ra, xb, Rb, thr);
   v3 axis = ld3(mp + 1);
   v3 pa, pb, n; float d;
-  int rc = gjk_distance<SRL_GJK_GROUP>(L.WV(a), na, L.WV(b), nb, axis, (mg + mg) + thr, pa, pb, n, d, gl);
+  int cache[3];
+  cache[0] = __float_as_int(mp[56]); cache[1] = __float_as_int(mp[57]); cache[2] = __float_as_int(mp[58]);
+  int rc = gjk_distance<SRL_GJK_GROUP>(L.WV(a), na, L.WV(b), nb, axis, cache, (mg + mg) + thr, pa, pb, n, d, gl);
   if (gl != 0) return;
+  mp[56] = __int_as_float(cache[0]); mp[57] = __int_as_float(cache[1]); mp[58] = __int_as_float(cache[2]);
   if (rc == 2) {
     sat_faces(P, __float_as_int(bca[7]), L.WV(a), na, __float_as_int(bcb[7]), L.WV(b), nb, pa, pb, n, d);
     rc = 1;
@@ -565,6 +568,7 @@ __device__ void substep(const Lds& L, int nb, int tid) {
           L.SOP()[pid] = sl; L.POS()[sl] = pid;
           float* mp = L.MAN(sl);
           mp[0] = __int_as_float(0);
+          mp[56] = __int_as_float(0);   // no cached simplex
           st3(mp + 1, ld3(L.X(i)) - ld3(L.X(j)));
         }
       }

@@ -16,7 +16,7 @@
 #define SRL_GMAXP 8          // ground manifold points per body
 #define SRL_NSLOT_MAX 192    // persistent body-body manifolds per env
 #define SRL_MP_WORDS 13      // manifold point: la3 lb3 n3 dist in it1 it2
-#define SRL_MAN_WORDS 56     // np, axis3, 4 points
+#define SRL_MAN_WORDS 60     // np, axis3, 4 points, cached GJK simplex: n, 3 words of packed (ia, ib) pairs
 #define SRL_GM_WORDS 41      // np, vid8, dist8, in8, it1 8, it2 8
 #define SRL_GJK_MAXIT 32
 
@@ -274,33 +274,40 @@ __device__ __forceinline__ int simplex_closest(Simplex& s, v3& vout) {
   return 1;
 }
 
-// Support vertex (arg max of P[k] . d, lowest index on ties) computed by a group of G adjacent lanes:
-// each lane scans the vertices k = gl, gl + G, ... and the group combines with xor shuffles.
-// G = 1 is the plain sequential scan.  The dot products are the same on every mapping, so the index
-// returned does not depend on G.
+// Support vertices of A in direction -v and of B in direction +v (arg max of P[k] . d, lowest index on ties),
+// computed by a group of G adjacent lanes: each lane scans the vertices k = gl, gl + G, ... of both clouds and the
+// group combines both results in the same xor-shuffle rounds.  G = 1 is the plain sequential scan.  The dot
+// products are the same on every mapping, so the indices returned do not depend on G.
 template <int G>
-__device__ __forceinline__ int support_max(const float* P, int n, v3 d, int gl) {
-  int best = 0x7fffffff;
-  float bd = -3.0e38f;
+__device__ __forceinline__ void support_pair(const float* VA, int na, const float* VB, int nb, v3 v, int gl, int& ia,
+                                             int& ib) {
+  const v3 nv = neg(v);
+  int ba = 0x7fffffff, bb = 0x7fffffff;
+  float da = -3.0e38f, db = -3.0e38f;
+  const int n = na > nb ? na : nb;
   for (int k = gl; k < n; k += G) {
-    float t = dot(ld3(P + 3 * k), d);
-    if (t > bd) { bd = t; best = k; }
+    if (k < na) { float t = dot(ld3(VA + 3 * k), nv); if (t > da) { da = t; ba = k; } }
+    if (k < nb) { float t = dot(ld3(VB + 3 * k), v); if (t > db) { db = t; bb = k; } }
   }
 #pragma unroll
   for (int m = 1; m < G; m <<= 1) {
-    float ot = __shfl_xor(bd, m, G);
-    int ok = __shfl_xor(best, m, G);
-    if (ot > bd || (ot == bd && ok < best)) { bd = ot; best = ok; }
+    float oa = __shfl_xor(da, m, G), ob = __shfl_xor(db, m, G);
+    int ka = __shfl_xor(ba, m, G), kb = __shfl_xor(bb, m, G);
+    if (oa > da || (oa == da && ka < ba)) { da = oa; ba = ka; }
+    if (ob > db || (ob == db && kb < bb)) { db = ob; bb = kb; }
   }
-  return best;
+  ia = ba; ib = bb;
 }
 
-// GJK distance between two world-space vertex clouds held in LDS (float triples), run by a group of G
-// lanes that all follow the same control flow (only the support scans are split).
+// GJK distance between two world-space vertex clouds held in LDS (float triples), run by a group of G lanes that
+// all follow the same control flow (only the support scans are split).  `cache` (4 words: n, then the (ia, ib)
+// pairs packed two per word) holds the simplex of the previous call: re-evaluated at the current poses it is the
+// starting simplex, so a resting contact converges in one iteration; a degenerate or enclosing cached simplex
+// restarts from the cached axis.
 // 0: farther than maxdist; 1: pa/pb/n/dist valid; 2: hulls overlap.
 template <int G>
-__device__ __forceinline__ int gjk_distance(const float* VA, int na, const float* VB, int nb, v3& axis, float maxdist,
-                                            v3& pa, v3& pb, v3& nrm, float& dist, int gl) {
+__device__ __forceinline__ int gjk_distance(const float* VA, int na, const float* VB, int nb, v3& axis, int* cache,
+                                            float maxdist, v3& pa, v3& pb, v3& nrm, float& dist, int gl) {
   Simplex s;
   s.n = 0;
 #pragma unroll
@@ -310,15 +317,40 @@ __device__ __forceinline__ int gjk_distance(const float* VA, int na, const float
   }
   v3 v = axis;
   float sqd = 1e30f;
+  bool warm = false;
+  const int cn = cache[0];
+  if (cn > 0) {
+    const int c1 = cache[1], c2 = cache[2];
+    s.n = cn;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < cn) {
+        const int pr = ((k < 2 ? c1 : c2) >> (16 * (k & 1))) & 0xffff;
+        s.ia[k] = pr & 0xff; s.ib[k] = pr >> 8;
+        s.p[k] = ld3(VA + 3 * s.ia[k]); s.q[k] = ld3(VB + 3 * s.ib[k]);
+        s.w[k] = s.p[k] - s.q[k];
+      }
+    }
+    v3 nv0;
+    int rc = simplex_closest(s, nv0);
+    float nsq = dot(nv0, nv0);
+    if (rc == 1 && !(nsq < 1e-10f)) { v = nv0; sqd = nsq; warm = true; }
+    else {
+      s.n = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s.lam[k] = 0.0f;
+    }
+  }
   if (!(dot(v, v) > 1e-20f)) v = V(0.0f, 0.0f, 1.0f);
+  int result = -1;
   for (int it = 0; it < SRL_GJK_MAXIT; ++it) {
-    int ia = support_max<G>(VA, na, neg(v), gl);
-    int ib = support_max<G>(VB, nb, v, gl);
+    int ia, ib;
+    support_pair<G>(VA, na, VB, nb, v, gl, ia, ib);
     v3 a = ld3(VA + 3 * ia), b = ld3(VB + 3 * ib);
     v3 w = a - b;
     float delta = dot(v, w);
-    if (it > 0) {
-      if (delta > 0.0f && delta * delta > sqd * (maxdist * maxdist)) return 0;
+    if (it > 0 || warm) {
+      if (delta > 0.0f && delta * delta > sqd * (maxdist * maxdist)) { result = 0; break; }
       int dup = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) dup |= (k < s.n && s.ia[k] == ia && s.ib[k] == ib);
@@ -328,18 +360,25 @@ __device__ __forceinline__ int gjk_distance(const float* VA, int na, const float
     simplex_push(s, w, a, b, ia, ib);
     v3 nv;
     int rc = simplex_closest(s, nv);
-    if (rc == 2) return 2;
+    if (rc == 2) { cache[0] = 0; return 2; }
     if (rc == 0) {
-      if (it == 0) return 0;
+      if (it == 0 && !warm) { cache[0] = 0; return 0; }
       s.n -= 1;   // drop the vertex just pushed; lam still describes the previous simplex
       break;
     }
     float nsq = dot(nv, nv);
-    if (nsq < 1e-10f) return 2;
-    bool stall = (it > 0) && (sqd - nsq <= 1.1920929e-7f * sqd);
+    if (nsq < 1e-10f) { cache[0] = 0; return 2; }
+    bool stall = (it > 0 || warm) && (sqd - nsq <= 1.1920929e-7f * sqd);
     v = nv; sqd = nsq;
     if (stall) break;
   }
+  {   // store the simplex for the next call
+    int pk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pk[k] = k < s.n ? ((s.ia[k] & 0xff) | ((s.ib[k] & 0xff) << 8)) : 0;
+    cache[0] = s.n; cache[1] = pk[0] | (pk[1] << 16); cache[2] = pk[2] | (pk[3] << 16);
+  }
+  if (result == 0) return 0;
   v3 A = V(0.0f, 0.0f, 0.0f), B = V(0.0f, 0.0f, 0.0f);
 #pragma unroll
   for (int k = 0; k < 4; ++k)
