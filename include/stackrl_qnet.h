@@ -1,0 +1,37 @@
+/* stackrl_qnet.h — C-ABI of libstackrl_qnet.so: the hand-written pieces of the Q-network rollout path.
+ *
+ * The reference evaluates `DeepQSiamFCN` (stackrl/nets/models.py:106-201) with stock TensorFlow ops.  Plain
+ * convolutions stay library calls (MIOpen through PyTorch-ROCm); the two ops below are the ones written by hand:
+ *
+ *  srl_xcorr_forward  = `layers.correlation` (stackrl/nets/layers.py:21-38): per-sample VALID cross-correlation
+ *                       `tf.map_fn(tf.nn.conv2d)` of the left features x[b] (C,H,W) with the right features
+ *                       w[b] (C,kh,kw) as the kernel, summed over channels -> out[b] (H-kh+1, W-kw+1).
+ *  srl_policy_head    = the epsilon-greedy head of `DQN.policy` (stackrl/agents/dqn.py:334-348) on the advantage
+ *                       map: argmax_a Q(s,a) == argmax_a A(s,a) (the dueling mean and value are per-row constants,
+ *                       models.py:188-192), ties to the lowest index, then `where(u > eps, argmax, random)`.
+ *
+ * Plain C, device pointers owned by the caller, `stream` is a hipStream_t as void*; returns 0 on success.
+ */
+#ifndef STACKRL_QNET_H_
+#define STACKRL_QNET_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* x float32 [B][C][H][W], w float32 [B][C][kh][kw] (kw in {16, 32}), out float32 [B][H-kh+1][W-kw+1]; contiguous */
+int srl_xcorr_forward(const float* x_dev, const float* w_dev, float* out_dev, int32_t B, int32_t C, int32_t H,
+                      int32_t W, int32_t kh, int32_t kw, void* stream);
+
+/* adv float32 [B][A]; u float32 [B] uniform(0,1); rnd int64 [B] uniform {0..A-1}; actions int64 [B] */
+int srl_policy_head(const float* adv_dev, const float* u_dev, const int64_t* rnd_dev, float epsilon,
+                    int64_t* actions_dev, int32_t B, int32_t A, void* stream);
+
+const char* srl_qnet_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

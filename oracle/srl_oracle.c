@@ -1437,3 +1437,12 @@ int srlo_debug_dump(srlo_env* e, int32_t i) {
   fflush(stdout);
   return 0;
 }
+
+/* debug: slot statistics of env i: active slots, slots with contact points, total points, colours */
+int srlo_debug_slots(srlo_env* e, int32_t i, int32_t* out4) {
+  env_t* s = &e->env[i];
+  int act = 0, con = 0, pts = 0;
+  for (int sl = 0; sl < MAXSLOT; ++sl) if (s->pair_of_slot[sl] >= 0) { act++; if (s->man[sl].np > 0) con++; pts += s->man[sl].np; }
+  out4[0] = act; out4[1] = con; out4[2] = pts; out4[3] = s->ncolour;
+  return 0;
+}

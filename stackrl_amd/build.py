@@ -21,14 +21,32 @@ def stale():
   return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
+QLIB = os.path.join(HERE, 'libstackrl_qnet.so')
+QDEPS = ['qnet.hip', os.path.join('..', '..', 'include', 'stackrl_qnet.h')]
+# the Q-net ops are ordinary fp32 kernels compared against a torch fp32 reference with a stated tolerance
+QFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wall', '-Wno-unused-function',
+          '-Wno-unused-value', '-Wno-unused-result']
+
+
+def qstale():
+  if not os.path.isfile(QLIB):
+    return True
+  t = os.path.getmtime(QLIB)
+  return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in QDEPS)
+
+
 def build(force=False, verbose=False):
-  if not force and not stale():
-    return LIB
   hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-  cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
-  if verbose:
-    print(' '.join(cmd), file=sys.stderr)
-  subprocess.check_call(cmd)
+  if force or stale():
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
+    if verbose:
+      print(' '.join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+  if force or qstale():
+    cmd = [hipcc] + QFLAGS + [os.path.join(CSRC, 'qnet.hip'), '-o', QLIB]
+    if verbose:
+      print(' '.join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
   return LIB
 
 

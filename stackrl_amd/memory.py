@@ -1,0 +1,159 @@
+"""Replay memory of the DQN update path: `ReplayMemory` (stackrl/agents/memory.py:9-361) on device tensors.
+
+Partitioned circular buffer (one partition per env, memory.py:52-62), prioritised sampling without replacement
+by Gumbel-top-k (memory.py:220-223), importance-sampling weights (memory.py:257-260), incremental min/max
+logit tracking (memory.py:163-179, :278-316).  The reference pins its variables to the CPU (memory.py:49) and
+ships every minibatch to the GPU; here everything stays in HBM (a B = 4,096, 64-slot memory is 8.9 GB).
+
+Reference quirks, restated deliberately:
+  * memory.py:239-242 computes the next index as `(i + n) % L + i // L` — for partition p > 0 that is
+    `(k + n) % L + p`, a slot of partition 0, not of p (correct only for a single env).  The intended
+    "stay inside the partition" arithmetic `(k + n) % L + p * L` is the default here;
+    `reference_next_index=True` reproduces the literal formula (tests pin both).
+  * memory.py:169-172 / :306-309 mask with `logits * float(!isinf)`, i.e. -inf * 0 = NaN; the intent (minimum over
+    the finite logits) is what is implemented.
+  * `alpha * logits` with alpha = 0 gives NaN for unsampleable slots (memory.py:223); they are kept at -inf.
+"""
+import math
+
+import torch
+
+
+class ReplayMemory(object):
+  def __init__(self, state_spec, max_length, alpha=None, beta=None, iters_counter=None, n_steps=None,
+               epsilon=1e-3, seed=None, device=None, reference_next_index=False):
+    """state_spec: sequence of (shape-with-batch, dtype), e.g. (((B,128,128,2), uint8), ((B,32,32,1), uint8)).
+    alpha / beta: scalars or callables of the iteration count (memory.py:64-78)."""
+    self.device = torch.device(device) if device is not None else torch.device('cpu')
+    self._n_parts = int(state_spec[0][0][0])                       # memory.py:52
+    max_length -= max_length % self._n_parts                       # memory.py:54
+    self._max_length = max_length // self._n_parts                 # memory.py:56
+    self._size = max_length
+    self._offsets = torch.arange(self._n_parts, dtype=torch.int64, device=self.device) * self._max_length
+    if (callable(alpha) or callable(beta)) and iters_counter is None:
+      raise ValueError('iters_counter must be provided with a callable alpha/beta')   # memory.py:66-73
+    self._alpha = alpha if callable(alpha) else float(alpha or 0.)
+    self._beta = beta if callable(beta) else float(1. if beta is None else beta)
+    self._iters_counter = iters_counter
+    self._n_steps = int(n_steps or 1)
+    self._n_range = torch.arange(1, self._n_steps + 1, dtype=torch.int64, device=self.device)
+    assert self._max_length > self._n_steps                        # memory.py:86
+    if epsilon <= 0:
+      raise ValueError('epsilon must be greater than 0')           # memory.py:88-89
+    self.epsilon = float(epsilon)
+    self._gen = torch.Generator(device=self.device)
+    if seed is not None:
+      self._gen.manual_seed(int(seed))
+    self._reference_next_index = bool(reference_next_index)
+    self._states = [torch.zeros((max_length,) + tuple(shape[1:]), dtype=dtype, device=self.device)
+                    for shape, dtype in state_spec]
+    self._rewards = torch.zeros(max_length, dtype=torch.float32, device=self.device)
+    self._terminal = torch.ones(max_length, dtype=torch.bool, device=self.device)      # memory.py:105-108
+    self._actions = torch.zeros(max_length, dtype=torch.int64, device=self.device)
+    self._logits = torch.full((max_length,), -math.inf, dtype=torch.float32, device=self.device)
+    self._insert_index = 0
+    self._max_logit = 0.0
+    self._max_logit_index = 0
+    self._min_logit = 0.0
+    self._min_logit_index = 0
+
+  def __len__(self):
+    return int(torch.isfinite(self._logits).sum())                 # memory.py:129-132
+
+  @property
+  def max_length(self):
+    return self._max_length
+
+  @property
+  def alpha(self):
+    return float(self._alpha(self._iters_counter())) if callable(self._alpha) else self._alpha
+
+  @property
+  def beta(self):
+    return float(self._beta(self._iters_counter())) if callable(self._beta) else self._beta
+
+  # ------------------------------------------------------------------ add (memory.py:151-196)
+  def _recompute_max(self):
+    idx = int(torch.argmax(self._logits))
+    self._max_logit_index, self._max_logit = idx, float(self._logits[idx])
+
+  def _recompute_min(self):
+    finite = torch.isfinite(self._logits)
+    if not bool(finite.any()):
+      raise FloatingPointError('No sampleable transition (failed to compute min logit)')   # memory.py:174-177
+    masked = torch.where(finite, self._logits, torch.full_like(self._logits, math.inf))
+    idx = int(torch.argmin(masked))
+    self._min_logit_index, self._min_logit = idx, float(self._logits[idx])
+
+  def add(self, state, reward, terminal, action):
+    L = self._max_length
+    idx = self._offsets + self._insert_index % L                   # memory.py:153
+    for var, upd in zip(self._states, state):
+      var.index_copy_(0, idx, upd.to(var.dtype))
+    self._rewards.index_copy_(0, idx, reward.to(torch.float32))
+    self._terminal.index_copy_(0, idx, terminal.to(torch.bool))
+    self._actions.index_copy_(0, idx, action.to(torch.int64))
+    self._logits.index_fill_(0, idx, -math.inf)                    # unsampleable until the next state exists
+    if self._insert_index > 0:
+      slot = self._insert_index % L
+      if self._max_logit_index % L == slot:                        # tf.reduce_any(index == indexes), memory.py:164
+        self._recompute_max()
+      if self._min_logit_index % L == slot:
+        self._recompute_min()
+    # the transition n steps back becomes sampleable unless an episode boundary lies in between (memory.py:181-194)
+    back = self._offsets[:, None] + ((self._insert_index - self._n_range) % L)[None, :]      # [B, n]
+    boundary = self._terminal[back].any(dim=-1)
+    val = torch.where(boundary, torch.full((), -math.inf, device=self.device),
+                      torch.full((), self._max_logit, device=self.device))
+    self._logits.index_copy_(0, back[:, -1], val.to(torch.float32))
+    self._insert_index += 1
+
+  def set_terminal(self):
+    """memory.py:199-203: mark the latest transition terminal (explicit reset after a non-terminal state)."""
+    idx = self._offsets + (self._insert_index - 1) % self._max_length
+    self._terminal.index_fill_(0, idx, True)
+
+  # ------------------------------------------------------------------ sample (memory.py:206-263)
+  def next_indexes(self, indexes, steps):
+    L = self._max_length
+    if self._reference_next_index:
+      return (indexes + steps) % L + indexes // L                  # literal memory.py:239-242
+    return (indexes % L + steps) % L + (indexes // L) * L
+
+  def sample(self, minibatch_size, get_weights=False):
+    alpha = self.alpha
+    u = torch.rand(self._logits.shape, generator=self._gen, device=self.device, dtype=torch.float32)
+    z = -torch.log(-torch.log(u))                                  # Gumbel-max trick, memory.py:220-222
+    keys = torch.where(torch.isinf(self._logits), self._logits, alpha * self._logits) + z
+    values, indexes = torch.topk(keys, minibatch_size)
+    if not bool(torch.isfinite(values).all()):
+      raise FloatingPointError('Not enough elements to sample')    # memory.py:227-230
+    states = tuple(s[indexes] for s in self._states)
+    actions = self._actions[indexes]
+    nxt = self.next_indexes(indexes, self._n_steps)
+    next_states = tuple(s[nxt] for s in self._states)
+    terminal = self._terminal[nxt]
+    if self._n_steps != 1:                                          # memory.py:251-254
+      nxt = self.next_indexes(indexes[:, None], self._n_range[None, :])
+    rewards = self._rewards[nxt]
+    if get_weights:
+      weights = torch.exp(self.beta * alpha * (self._min_logit - self._logits[indexes]))   # memory.py:257-260
+      return indexes, weights, (states, actions, rewards, next_states, terminal)
+    return states, actions, rewards, next_states, terminal
+
+  # ------------------------------------------------------------------ update_priorities (memory.py:266-316)
+  def update_priorities(self, indexes, deltas):
+    logits = torch.log(deltas.to(torch.float32) + self.epsilon)    # memory.py:272
+    self._logits.index_copy_(0, indexes, logits)
+    amax = int(torch.argmax(logits)); amin = int(torch.argmin(logits))
+    max_logit, min_logit = float(logits[amax]), float(logits[amin])
+    hit_max = bool((indexes == self._max_logit_index).any())
+    hit_min = bool((indexes == self._min_logit_index).any())
+    if max_logit >= self._max_logit:
+      self._max_logit_index, self._max_logit = int(indexes[amax]), max_logit
+    elif hit_max:
+      self._recompute_max()
+    if min_logit <= self._min_logit:
+      self._min_logit_index, self._min_logit = int(indexes[amin]), min_logit
+    elif hit_min:
+      self._recompute_min()

@@ -1,0 +1,281 @@
+"""CPU tests of the learner rows (N1, A1, A2, M1, T1) against the numpy/pure-Python oracle (oracle/dqn_oracle.py)
+and closed forms, plus the world_size-2 `gloo` test of the gradient all-reduce."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+from oracle import dqn_oracle as O
+from stackrl_amd import nets
+from stackrl_amd.dqn import DQN, PolynomialDecay
+from stackrl_amd.memory import ReplayMemory
+
+
+def _small_net(seed=3):
+  return nets.DeepQSiamFCN(input_spec=((16, 16, 2), (4, 4, 1)), left_filters=2, left_depth=2, pos_filters=2,
+                           dueling_units=8, seed=seed)
+
+
+def test_net_matches_reference_architecture():
+  net = nets.DeepQSiamFCN(seed=1)
+  parts = {k: sum(p.numel() for p in getattr(net, k).parameters()) for k in ['left', 'right', 'value', 'pos']}
+  # ~2.13 M parameters (left 1.94 M, right 0.12 M, dueling 0.066 M, pos 2.5 K)
+  assert parts == {'left': 1940944, 'right': 116736, 'value': 66049, 'pos': 2497}
+  assert nets.count_parameters(net) == 2126226
+  m = nets.forward_macs()
+  assert abs(sum(m.values()) - 957e6) < 2e6 and abs(m['xcorr'] - 154e6) < 1e6     # 1.91 GFLOP forward
+  assert net.n_actions == 9409 and net.out_hw == (97, 97)
+  # same seed -> same weights (seed chain models.py:149-153), different seed -> different
+  a, b, c = nets.DeepQSiamFCN(seed=1), nets.DeepQSiamFCN(seed=1), nets.DeepQSiamFCN(seed=2)
+  assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
+  assert not all(torch.equal(p, q) for p, q in zip(a.parameters(), c.parameters()))
+  w = a.left.down[1][0].weight                       # he_normal: std = sqrt(2/fan_in), truncated at 2 sigma
+  fan_in = w[0].numel()
+  w = w.detach()
+  assert abs(float(w.std()) - math.sqrt(2 / fan_in)) < 0.1 * math.sqrt(2 / fan_in)
+  assert float(w.abs().max()) <= 2 * math.sqrt(2 / fan_in) / .8796 + 1e-6
+
+
+def test_forward_shapes_scaling_and_dueling():
+  net = _small_net()
+  x = torch.randint(0, 256, (3, 16, 16, 2), dtype=torch.uint8)
+  w = torch.randint(0, 256, (3, 4, 4, 1), dtype=torch.uint8)
+  q = net((x, w))
+  assert q.shape == (3, 13 * 13) and q.dtype == torch.float32
+  # uint8 inputs are scaled by 1/255 (models.py:144-147): same result as float inputs already divided
+  q2 = net((x.float() / 255, w.float() / 255))
+  assert torch.allclose(q, q2, atol=1e-5)
+  # dueling: Q = A - mean(A) + V  (models.py:188-192)
+  xf, x0, wf = net.features((x, w))
+  a = net.pos(nets.correlation_reference(xf, wf)).flatten(1)
+  v = net.value(x0.mean(dim=(2, 3)))
+  assert torch.allclose(q, a - a.mean(-1, keepdim=True) + v, atol=1e-5)
+  assert torch.equal(q.argmax(-1), a.argmax(-1))       # what the fused policy head relies on
+
+
+def test_correlation_against_loops():
+  rng = np.random.RandomState(0)
+  x = rng.normal(size=(2, 3, 9, 10)).astype(np.float32)
+  w = rng.normal(size=(2, 3, 4, 5)).astype(np.float32)
+  got = nets.correlation_reference(torch.from_numpy(x), torch.from_numpy(w)).numpy()
+  np.testing.assert_allclose(got, O.xcorr(x, w), rtol=1e-5, atol=1e-5)
+
+
+def test_polynomial_decay_matches_config_gin():
+  eps = PolynomialDecay(1.0, 400000, .1, 1.0)          # config.gin:73-76
+  assert eps(0) == 1.0 and abs(eps(200000) - 0.55) < 1e-12 and eps(400000) == eps(10 ** 7) == .1
+  beta = PolynomialDecay(0.4, 400000, 1.0, 1.0)        # config.gin:78-81
+  assert beta(0) == 0.4 and abs(beta(100000) - 0.55) < 1e-12 and beta(400000) == 1.0
+
+
+@pytest.mark.parametrize('P,L,n,literal', [(1, 7, 1, False), (3, 5, 1, False), (3, 5, 1, True), (2, 9, 3, False)])
+def test_replay_memory_against_restatement(P, L, n, literal):
+  """Every add / set_terminal / update_priorities step leaves the same logits, flags and min/max trackers as the
+  list-based restatement of memory.py, and the transition returned for each sampleable index is identical."""
+  rng = np.random.RandomState(P * 100 + L)
+  spec = (((P, 2, 2, 1), torch.uint8),)
+  mem = ReplayMemory(spec, P * L, alpha=0.6, beta=0.5, n_steps=n, seed=0, reference_next_index=literal)
+  ref = O.RefMemory(P, P * L, n_steps=n, literal_next_index=literal)
+  assert mem.max_length == ref.L
+  for t in range(4 * L):
+    s = rng.randint(0, 255, size=(P, 2, 2, 1)).astype(np.uint8)
+    r = rng.normal(size=P).astype(np.float32)
+    term = rng.uniform(size=P) < (0.25 if n == 1 else 0.08)
+    a = rng.randint(0, 50, size=P)
+    # with nothing sampleable left when the slot holding the min logit is overwritten the reference asserts
+    # ("No sampleable transition", memory.py:174-177): both sides must fail at the same step
+    try:
+      mem.add((torch.from_numpy(s),), torch.from_numpy(r), torch.from_numpy(term), torch.from_numpy(a))
+      failed = False
+    except FloatingPointError:
+      failed = True
+    try:
+      ref.add(s, r, term, a)
+      assert not failed
+    except AssertionError:
+      assert failed
+      return
+    if t % 7 == 6:
+      mem.set_terminal(); ref.set_terminal()
+    lg = mem._logits.numpy()
+    assert np.array_equal(np.isfinite(lg), np.isfinite(np.array(ref.logits))), t
+    fin = np.isfinite(lg)
+    np.testing.assert_allclose(lg[fin], np.array(ref.logits)[fin], rtol=1e-6)
+    assert np.array_equal(mem._terminal.numpy(), np.array(ref.terminal))
+    assert mem._insert_index == ref.insert and len(mem) == int(fin.sum())
+    idx = np.where(fin)[0]
+    if len(idx) >= 2 and t % 3 == 2:
+      pick = rng.choice(idx, size=min(3, len(idx)), replace=False)
+      d = rng.uniform(0, 2, size=len(pick)).astype(np.float32)
+      mem.update_priorities(torch.from_numpy(pick), torch.from_numpy(d))
+      ref.update_priorities([int(i) for i in pick], d)
+      assert mem._max_logit_index == ref.max_idx and mem._min_logit_index == ref.min_idx
+      assert abs(mem._max_logit - ref.max_logit) < 1e-6 and abs(mem._min_logit - ref.min_logit) < 1e-6
+    # index arithmetic (bit-exact) and gathered transition for every sampleable slot
+    for i in idx:
+      nxt = int(mem.next_indexes(torch.tensor(int(i)), n))
+      assert nxt == ref.next_index(int(i), n)
+      if not literal:
+        assert nxt // L == int(i) // L                         # stays inside the env's partition
+      st, ac, rew, nst, te = ref.transition(int(i))
+      assert int(mem._actions[i]) == ac and bool(mem._terminal[nxt]) == te
+      assert np.array_equal(mem._states[0][i].numpy(), st)
+      if nst is not None:                                      # (the literal formula can point at a never-written slot)
+        assert np.array_equal(mem._states[0][nxt].numpy(), nst)
+  # sampling: without replacement, only sampleable slots, weights = exp(beta*alpha*(min_logit - logit))
+  k = min(4, len(mem))
+  if k:
+    indexes, weights, (states, actions, rewards, next_states, terminal) = mem.sample(k, get_weights=True)
+    ii = indexes.tolist()
+    assert len(set(ii)) == k and all(math.isfinite(ref.logits[i]) for i in ii)
+    for i, wgt in zip(ii, weights.tolist()):
+      assert abs(wgt - ref.weight(i, 0.6, 0.5)) < 1e-5
+    if n > 1:
+      assert rewards.shape == (k, n)
+      for row, i in zip(rewards.tolist(), ii):
+        assert np.allclose(row, ref.transition(i)[2])
+  with pytest.raises(FloatingPointError, match='Not enough elements'):       # memory.py:227-230
+    mem.sample(len(mem) + 1)
+
+
+def test_literal_next_index_leaves_partition():
+  """The reference formula (memory.py:239-242) points into partition 0 for every other env: documented quirk."""
+  mem = ReplayMemory((((4, 1, 1, 1), torch.uint8),), 40, reference_next_index=True)
+  i = torch.tensor([3, 13, 29])
+  assert mem.next_indexes(i, 1).tolist() == [4, 5, 2]          # (i+1)%10 + i//10
+  mem2 = ReplayMemory((((4, 1, 1, 1), torch.uint8),), 40)
+  assert mem2.next_indexes(i, 1).tolist() == [4, 14, 20]
+
+
+@pytest.mark.parametrize('double,prioritized', [(True, True), (False, False)])
+def test_dqn_update_math_against_numpy(double, prioritized):
+  torch.manual_seed(0)
+  net = _small_net()
+  agent = DQN(net, learning_rate=1e-3, minibatch_size=6, replay_memory_size=4 * 12, discount_factor=.966667,
+              collect_batch_size=4, exploration=0.5, prioritization=0.6 if prioritized else None,
+              priority_bias_compensation=0.4 if prioritized else None, double=double, seed=5,
+              target_update_period=3, adam_betas=(0.95, 0.95))
+  rng = np.random.RandomState(1)
+  for t in range(11):
+    s = (torch.from_numpy(rng.randint(0, 256, (4, 16, 16, 2)).astype(np.uint8)),
+         torch.from_numpy(rng.randint(0, 256, (4, 4, 4, 1)).astype(np.uint8)))
+    agent.observe(s, torch.from_numpy(rng.normal(size=4).astype(np.float32)), torch.from_numpy(rng.uniform(size=4) < .2),
+                  torch.from_numpy(rng.randint(0, net.n_actions, 4)))
+  # make the target net differ from the online net
+  with torch.no_grad():
+    for p in agent._target_q_net.parameters():
+      p.add_(0.01 * torch.randn_like(p))
+  mem = agent._replay_memory
+  state = mem._gen.get_state()
+  if prioritized:
+    idx, wts, (st, ac, rw, ns, te) = mem.sample(6, get_weights=True)
+  else:
+    st, ac, rw, ns, te = mem.sample(6); wts = None
+  mem._gen.set_state(state)                      # train() will draw the same minibatch
+  with torch.no_grad():
+    q, qo, qt = agent._q_net(st), agent._q_net(ns), agent._target_q_net(ns)
+  ref_loss, ref_mtd, ref_td = O.dqn_targets(q.numpy(), qo.numpy(), qt.numpy(), ac.numpy(), rw.numpy(), te.numpy(),
+                                            .966667, double=double, weights=None if wts is None else wts.numpy())
+  before = [p.detach().clone() for p in agent._params]
+  loss, mtd = agent.train()
+  assert abs(float(loss) - ref_loss) <= 1e-5 * max(1, abs(ref_loss)) and abs(float(mtd) - ref_mtd) <= 1e-5 * max(1, abs(ref_mtd))
+  assert agent.iterations == 1 and any(not torch.equal(a, b) for a, b in zip(before, agent._params))
+  if prioritized:                                # priorities <- log(|td| + 1e-3), memory.py:272
+    np.testing.assert_allclose(mem._logits[idx].numpy(), np.log(ref_td + 1e-3), rtol=1e-4, atol=1e-5)
+  # hard target sync every `target_update_period` iterations (dqn.py:478-484)
+  agent.train()
+  assert not all(torch.equal(a, b) for a, b in zip(agent._q_net.state_dict().values(), agent._target_q_net.state_dict().values()))
+  agent.train()
+  assert agent.iterations == 3
+  assert all(torch.equal(a, b) for a, b in zip(agent._q_net.state_dict().values(), agent._target_q_net.state_dict().values()))
+
+
+def test_policy_modes_and_argument_checks():
+  net = _small_net()
+  s = (torch.randint(0, 256, (5, 16, 16, 2), dtype=torch.uint8), torch.randint(0, 256, (5, 4, 4, 1), dtype=torch.uint8))
+  a = DQN(net, exploration=0.0, collect_batch_size=5, replay_memory_size=50, seed=1)
+  g, q = a.policy(s, values=True)
+  assert torch.equal(g, q.argmax(-1)) and torch.equal(a.policy(s, exploration=True), g)      # eps = 0 -> greedy
+  b = DQN(net, exploration=1.0, collect_batch_size=5, replay_memory_size=50, seed=1)
+  acts = torch.stack([b.policy(s, exploration=True) for _ in range(20)])
+  assert acts.min() >= 0 and acts.max() < net.n_actions and len(torch.unique(acts)) > 20     # eps = 1 -> uniform
+  c = DQN(net, exploration_mode='boltzmann', exploration=1e-6, collect_batch_size=5, replay_memory_size=50, seed=1)
+  assert torch.equal(c.policy(s, exploration=True), g)                                       # T -> 0 is greedy
+  assert abs(DQN(net, exploration_mode=1, exploration=2.0, collect_batch_size=5, replay_memory_size=50).epsilon - math.exp(-.5)) < 1e-12
+  with pytest.raises(ValueError, match=r'Must be in \[0,1\]'):
+    DQN(net, exploration=1.5)                                                                # dqn.py:166-169
+  with pytest.raises(ValueError, match='greater than 0'):
+    DQN(net, exploration_mode='boltzmann', exploration=0.0)                                  # dqn.py:177-180
+  with pytest.raises(TypeError):
+    DQN('not a net')                                                                         # dqn.py:122-125
+  sched = DQN(net, exploration=PolynomialDecay(1.0, 10, .1), collect_batch_size=5, replay_memory_size=50)
+  assert sched.epsilon == 1.0
+
+
+def _rank_main(rank, world, port, out):
+  import torch.distributed as dist
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  torch.manual_seed(0)
+  net = _small_net(seed=7)                                     # identical replicas
+  agent = DQN(net, learning_rate=1e-2, minibatch_size=4, replay_memory_size=2 * 10, collect_batch_size=2, exploration=0.3,
+              double=True, seed=100 + rank)                    # rank-local replay shard and sampling stream
+  rng = np.random.RandomState(50 + rank)                       # rank-local env shard
+  for t in range(9):
+    s = (torch.from_numpy(rng.randint(0, 256, (2, 16, 16, 2)).astype(np.uint8)),
+         torch.from_numpy(rng.randint(0, 256, (2, 4, 4, 1)).astype(np.uint8)))
+    agent.observe(s, torch.from_numpy(rng.normal(size=2).astype(np.float32)), torch.zeros(2, dtype=torch.bool),
+                  torch.from_numpy(rng.randint(0, net.n_actions, 2)))
+  # local gradient of this rank's minibatch, computed without the collective
+  st = agent._replay_memory._gen.get_state()
+  states, actions, rewards, next_states, terminal = agent._replay_memory.sample(4)
+  agent._replay_memory._gen.set_state(st)
+  y = agent.td_targets(rewards, next_states, terminal)
+  q = agent._q_net(states).gather(1, actions[:, None])[:, 0]
+  agent._flat_grad.zero_()
+  agent.loss_from_td((q - y).abs()).backward()
+  local = agent._flat_grad.clone()
+  gathered = [torch.zeros_like(local) for _ in range(world)]
+  dist.all_gather(gathered, local)
+  expect = torch.stack(gathered).mean(0)
+  agent.train()                                                # all-reduce + identical Adam step on every replica
+  flat = torch.cat([p.detach().flatten() for p in agent._params])
+  allp = [torch.zeros_like(flat) for _ in range(world)]
+  dist.all_gather(allp, flat)
+  if rank == 0:
+    torch.save({'grad_ok': bool(torch.allclose(agent._flat_grad, expect, atol=1e-7)),
+                'replicas_equal': bool(torch.equal(allp[0], allp[1])),
+                'grads_differ_across_ranks': bool(not torch.allclose(gathered[0], gathered[1]))}, out)
+  dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world_size_2_gloo(tmp_path):
+  import torch.multiprocessing as mp
+  out = str(tmp_path / 'res.pt')
+  port = 29000 + os.getpid() % 2000
+  mp.spawn(_rank_main, args=(2, port, out), nprocs=2, join=True)
+  res = torch.load(out)
+  assert res == {'grad_ok': True, 'replicas_equal': True, 'grads_differ_across_ranks': True}
+
+
+def test_env_shards_equal_one_batch(oracle_mod, ref_pool):
+  """Multi-GPU sharding of the env path: rank g owns envs [g*B/G, (g+1)*B/G) with keys seed + offset + i
+  (utils.py:433), no data exchange.  Two shards stepped separately give exactly the unsharded batch."""
+  from stackrl_amd.config import StackConfig
+  L = 4
+  full = oracle_mod.OracleEnv(StackConfig(n_envs=6, episode_length=L), ref_pool, seed=21)
+  lo = oracle_mod.OracleEnv(StackConfig(n_envs=3, episode_length=L, env_index_offset=0), ref_pool, seed=21)
+  hi = oracle_mod.OracleEnv(StackConfig(n_envs=3, episode_length=L, env_index_offset=3), ref_pool, seed=21)
+  (fm, fo), _, _ = full.reset()
+  (lm, _), _, _ = lo.reset(); (hm, _), _, _ = hi.reset()
+  assert np.array_equal(fm, np.concatenate([lm, hm]))
+  for _ in range(L + 1):
+    a = full.sample()
+    assert np.array_equal(a, np.concatenate([lo.sample(), hi.sample()]))
+    (fm, fo), fr, fd = full.step(a)
+    (lm, lo_), lr, ld = lo.step(a[:3]); (hm, ho_), hr, hd = hi.step(a[3:])
+    assert np.array_equal(fm, np.concatenate([lm, hm])) and np.array_equal(fo, np.concatenate([lo_, ho_]))
+    assert np.array_equal(fr, np.concatenate([lr, hr])) and np.array_equal(fd, np.concatenate([ld, hd]))

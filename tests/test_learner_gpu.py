@@ -1,0 +1,78 @@
+"""GPU tests of the learner rows: the hand-written Q-net ops against a plain PyTorch fp32 reference, the fused
+rollout policy against `DQN.policy`, and an end-to-end collect -> step -> train loop on the HIP env."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('B,C,H,h', [(3, 16, 128, 32), (2, 16, 64, 16), (1, 5, 40, 32)])
+def test_xcorr_hip_matches_torch_fp32(B, C, H, h):
+  from stackrl_amd import nets, qops
+  g = torch.Generator(device='cuda').manual_seed(B * 7 + C)
+  x = torch.rand((B, C, H, H), generator=g, device='cuda')          # post-ReLU features are non-negative
+  w = torch.rand((B, C, h, h), generator=g, device='cuda') - 0.3
+  got = qops.xcorr_forward(x, w)
+  ref = nets.correlation_reference(x.double(), w.double()).float()  # fp64 accumulate reference
+  assert got.shape == ref.shape == (B, 1, H - h + 1, H - h + 1)
+  # fp32 accumulation of C*h*h <= 16,384 products: stated tolerance 2e-5 relative to the result scale
+  scale = float(ref.abs().max())
+  assert float((got - ref).abs().max()) <= 2e-5 * scale
+  ref32 = nets.correlation_reference(x, w)
+  assert float((got - ref32).abs().max()) <= 5e-5 * scale
+
+
+def test_policy_head_matches_torch():
+  from stackrl_amd import qops
+  g = torch.Generator(device='cuda').manual_seed(3)
+  adv = torch.randn((257, 9409), generator=g, device='cuda')
+  adv[5, 100] = adv[5, 7000] = adv[5].max() + 1.0                   # tie -> lowest index (tf.argmax)
+  u = torch.rand(257, generator=g, device='cuda')
+  rnd = torch.randint(9409, (257,), generator=g, device='cuda')
+  for eps in (0.0, 0.3, 1.0):
+    got = qops.policy_head(adv, u, rnd, eps)
+    ref = torch.where(u > eps, adv.argmax(-1), rnd)
+    assert torch.equal(got, ref)
+  assert int(qops.policy_head(adv, u, rnd, 0.0)[5]) == 100
+
+
+def test_fused_policy_equals_dqn_policy(ref_pool):
+  from stackrl_amd import nets, qops
+  from stackrl_amd.dqn import DQN
+  net = nets.DeepQSiamFCN(seed=4).cuda()
+  g = torch.Generator(device='cuda').manual_seed(1)
+  s = (torch.randint(0, 256, (6, 128, 128, 2), generator=g, device='cuda', dtype=torch.uint8),
+       torch.randint(0, 256, (6, 32, 32, 1), generator=g, device='cuda', dtype=torch.uint8))
+  a = DQN(net, exploration=0.4, collect_batch_size=6, replay_memory_size=60, seed=9)
+  b = DQN(net, exploration=0.4, collect_batch_size=6, replay_memory_size=60, seed=9, policy_op=qops.FusedPolicy(chunk=4))
+  for _ in range(3):
+    assert torch.equal(a.policy(s, exploration=True), b.policy(s, exploration=True))
+
+
+def test_end_to_end_dqn_iterations(ref_pool):
+  """T1: collect -> non-blocking env.step -> train, a few iterations, on the HIP env with the reference's agent settings
+  (config.gin:90-112)."""
+  from stackrl_amd import env as envs, nets, qops
+  from stackrl_amd.dqn import DQN, PolynomialDecay
+  from stackrl_amd.training import Trainer
+  B, L = 16, 4
+  env = envs.make('Stack-v0', n_parallel=B, seed=3, pool=ref_pool, episode_length=L)
+  net = nets.DeepQSiamFCN(env.observation_spec, seed=1).cuda()
+  agent = DQN(net, learning_rate=6.25e-5, adam_betas=(0.95, 0.95), minibatch_size=8, replay_memory_size=B * 16,
+              discount_factor=.966667, collect_batch_size=B, exploration=PolynomialDecay(1.0, 400000, .1),
+              prioritization=0.6, priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=7,
+              policy_op=qops.FusedPolicy())
+  tr = Trainer(env, agent)
+  tr.initialize(num_steps=12)
+  assert len(agent._replay_memory) > 8
+  w0 = [p.detach().clone() for p in net.parameters()]
+  losses = tr.run(6)
+  assert losses.shape == (6,) and bool(torch.isfinite(losses).all()) and agent.iterations == 6
+  assert any(not torch.equal(a, b) for a, b in zip(w0, net.parameters()))
+  # stored transitions are the env's own uint8 observations
+  mem = agent._replay_memory
+  assert mem._states[0].dtype == torch.uint8 and mem._states[0].shape[1:] == (128, 128, 2)
+  assert int(mem._actions.max()) < env.n_actions
+  env.close()

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""DQN rollout + update timing (BASELINE configs[2] shape: B envs, L rocks, Q-net rollout + minibatch-32 update).
+Reports iterations/s, env steps/s and the achieved FLOP/s of the Q-net forward against the dtype's gfx950 peak."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from stackrl_amd import assets, env as envs, nets, qops
+from stackrl_amd.dqn import DQN, PolynomialDecay
+from stackrl_amd.training import Trainer
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--envs', type=int, default=1024)
+ap.add_argument('--rocks', type=int, default=16)
+ap.add_argument('--iters', type=int, default=10)
+ap.add_argument('--slots', type=int, default=16)
+args = ap.parse_args()
+B, L = args.envs, args.rocks
+env = envs.make('Stack-v0', n_parallel=B, seed=11, pool=assets.default_pool(), episode_length=L)
+net = nets.DeepQSiamFCN(env.observation_spec, seed=1).cuda()
+agent = DQN(net, learning_rate=6.25e-5, adam_betas=(0.95, 0.95), minibatch_size=32, replay_memory_size=B * args.slots,
+            discount_factor=.966667, collect_batch_size=B, exploration=PolynomialDecay(1.0, 400000, .1), prioritization=0.6,
+            priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=7, policy_op=qops.FusedPolicy())
+tr = Trainer(env, agent)
+tr.initialize(num_steps=4)
+tr.run(2)
+torch.cuda.synchronize()
+# forward-only timing of the rollout policy
+obs = env.reset()()[0]
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3): agent.policy(obs, exploration=True)
+torch.cuda.synchronize(); tf = (time.perf_counter() - t0) / 3
+macs = sum(nets.forward_macs().values())
+t0 = time.perf_counter(); tr.collect_time = tr.train_time = 0.0
+tr.run(args.iters)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(json.dumps({'envs': B, 'rocks': L, 'iters_per_s': args.iters / dt, 'env_steps_per_s': args.iters * B / dt,
+                  'rollout_forward_ms': tf * 1e3, 'rollout_forward_tflops': 2 * macs * B / tf / 1e12,
+                  'fp32_peak_tflops': 157.3, 'frac_of_fp32_peak': 2 * macs * B / tf / 157.3e12,
+                  'collect_s': tr.collect_time, 'train_s': tr.train_time}))
