@@ -44,7 +44,7 @@ class VecStackEnv(object):
   """B independent Stack-v0 envs on one GPU (drop-in for `ParallelEnv`, utils.py:302)."""
 
   def __init__(self, n_parallel=None, block=None, seed=None, pool=None, device=None,
-               env_index_offset=0, **kwargs):
+               env_index_offset=0, side_stream=False, **kwargs):
     """
     Args:
       n_parallel: number of environments B (utils.py:324).
@@ -53,6 +53,9 @@ class VecStackEnv(object):
       pool: `assets.MeshPool` (the urdf list of env.py:92-103); None -> synthetic default pool.
       device: torch device (defaults to the current cuda device).
       env_index_offset: global index of env 0 when the batch is sharded over ranks.
+      side_stream: run the env kernels on their own HIP stream so that a non-blocking `step` overlaps the
+        caller's work on the current stream (the reference overlaps env processes with `agent.train()`,
+        training.py:359-368); the returned callable joins the streams.
       kwargs: StackEnv arguments (env.py:28-51), e.g. episode_length, sim_time_step, rewarder.
     """
     if not torch.cuda.is_available():
@@ -74,6 +77,7 @@ class VecStackEnv(object):
     self._action_spec = TensorSpec((), torch.int64)
     self._B, self._H, self._hh = B, H, h
     self._closed = False
+    self._side = torch.cuda.Stream(device=self._device) if side_stream else None
     self.seed(seed if seed is not None else 0)
 
   # ---- properties (utils.py:270-281, :417-422)
@@ -133,7 +137,16 @@ class VecStackEnv(object):
 
   # ---- stepping
   def _stream(self):
-    return ctypes.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+    st = self._side if self._side is not None else torch.cuda.current_stream(self._device)
+    return ctypes.c_void_p(st.cuda_stream)
+
+  def _fork(self):
+    if self._side is not None:      # env kernels start after everything already queued by the caller (the action)
+      self._side.wait_stream(torch.cuda.current_stream(self._device))
+
+  def _join(self):
+    if self._side is not None:
+      torch.cuda.current_stream(self._device).wait_stream(self._side)
 
   def _new_obs(self):
     return (torch.empty((self._B, self._H, self._H, 2), dtype=torch.uint8, device=self._device),
@@ -142,11 +155,13 @@ class VecStackEnv(object):
   def _finish(self, out):
     def wait():
       _check(self._lib.srl_sync_status(self._h, self._stream()))
+      self._join()
       return out
     return wait
 
   def reset(self, block=None):
     om, oo = self._new_obs()
+    self._fork()
     with torch.cuda.device(self._device):
       _check(self._lib.srl_reset(self._h, om.data_ptr(), oo.data_ptr(), self._stream()))
     out = ((om, oo), torch.zeros(self._B, dtype=torch.float32, device=self._device),
@@ -164,9 +179,13 @@ class VecStackEnv(object):
     om, oo = self._new_obs()
     reward = torch.empty(self._B, dtype=torch.float32, device=self._device)
     done = torch.empty(self._B, dtype=torch.uint8, device=self._device)
+    self._fork()
     with torch.cuda.device(self._device):
       _check(self._lib.srl_step(self._h, action.data_ptr(), om.data_ptr(), oo.data_ptr(), reward.data_ptr(),
                                 done.data_ptr(), self._stream()))
+    if self._side is not None:
+      for t in (om, oo, reward, done, action):
+        t.record_stream(self._side)
     out = ((om, oo), reward, done.view(torch.bool))
     self._keep = action   # keep the action tensor alive until the kernels consumed it
     wait = self._finish(out)
@@ -176,8 +195,10 @@ class VecStackEnv(object):
   def sample(self):
     """utils.py:534-538: a batch of uniform random actions."""
     a = torch.empty(self._B, dtype=torch.int64, device=self._device)
+    self._fork()
     with torch.cuda.device(self._device):
       _check(self._lib.srl_sample(self._h, a.data_ptr(), self._stream()))
+    self._join()
     return a
 
   # ---- telemetry (Simulator.poses / n_steps, Observer.state, Rewarder.goal)

@@ -52,10 +52,12 @@ class ReplayMemory(object):
     self._actions = torch.zeros(max_length, dtype=torch.int64, device=self.device)
     self._logits = torch.full((max_length,), -math.inf, dtype=torch.float32, device=self.device)
     self._insert_index = 0
-    self._max_logit = 0.0
-    self._max_logit_index = 0
-    self._min_logit = 0.0
-    self._min_logit_index = 0
+    # min / max logit trackers (memory.py:118-127) live on the device: no host round trip on the update path
+    self._max_logit = torch.zeros((), dtype=torch.float32, device=self.device)
+    self._max_logit_index = torch.zeros((), dtype=torch.int64, device=self.device)
+    self._min_logit = torch.zeros((), dtype=torch.float32, device=self.device)
+    self._min_logit_index = torch.zeros((), dtype=torch.int64, device=self.device)
+    self.check = False      # True: raise like the reference's tf.debugging asserts (costs a device sync)
 
   def __len__(self):
     return int(torch.isfinite(self._logits).sum())                 # memory.py:129-132
@@ -73,17 +75,17 @@ class ReplayMemory(object):
     return float(self._beta(self._iters_counter())) if callable(self._beta) else self._beta
 
   # ------------------------------------------------------------------ add (memory.py:151-196)
-  def _recompute_max(self):
-    idx = int(torch.argmax(self._logits))
-    self._max_logit_index, self._max_logit = idx, float(self._logits[idx])
+  def _argmax_all(self):
+    idx = torch.argmax(self._logits)
+    return idx, self._logits[idx]
 
-  def _recompute_min(self):
+  def _argmin_finite(self):
     finite = torch.isfinite(self._logits)
-    if not bool(finite.any()):
+    if self.check and not bool(finite.any()):
       raise FloatingPointError('No sampleable transition (failed to compute min logit)')   # memory.py:174-177
     masked = torch.where(finite, self._logits, torch.full_like(self._logits, math.inf))
-    idx = int(torch.argmin(masked))
-    self._min_logit_index, self._min_logit = idx, float(self._logits[idx])
+    idx = torch.argmin(masked)
+    return idx, self._logits[idx]
 
   def add(self, state, reward, terminal, action):
     L = self._max_length
@@ -96,15 +98,21 @@ class ReplayMemory(object):
     self._logits.index_fill_(0, idx, -math.inf)                    # unsampleable until the next state exists
     if self._insert_index > 0:
       slot = self._insert_index % L
-      if self._max_logit_index % L == slot:                        # tf.reduce_any(index == indexes), memory.py:164
-        self._recompute_max()
-      if self._min_logit_index % L == slot:
-        self._recompute_min()
+      # tf.reduce_any(index == indexes) (memory.py:164, :168): the tracked slot was just overwritten -> recompute
+      hit_max = (self._max_logit_index % L) == slot
+      hit_min = (self._min_logit_index % L) == slot
+      i, v = self._argmax_all()
+      self._max_logit_index = torch.where(hit_max, i, self._max_logit_index)
+      self._max_logit = torch.where(hit_max, v, self._max_logit)
+      if self.check and bool(hit_min):
+        self._argmin_finite()
+      i, v = self._argmin_finite()
+      self._min_logit_index = torch.where(hit_min, i, self._min_logit_index)
+      self._min_logit = torch.where(hit_min, v, self._min_logit)
     # the transition n steps back becomes sampleable unless an episode boundary lies in between (memory.py:181-194)
     back = self._offsets[:, None] + ((self._insert_index - self._n_range) % L)[None, :]      # [B, n]
     boundary = self._terminal[back].any(dim=-1)
-    val = torch.where(boundary, torch.full((), -math.inf, device=self.device),
-                      torch.full((), self._max_logit, device=self.device))
+    val = torch.where(boundary, torch.full((), -math.inf, device=self.device), self._max_logit)
     self._logits.index_copy_(0, back[:, -1], val.to(torch.float32))
     self._insert_index += 1
 
@@ -126,7 +134,7 @@ class ReplayMemory(object):
     z = -torch.log(-torch.log(u))                                  # Gumbel-max trick, memory.py:220-222
     keys = torch.where(torch.isinf(self._logits), self._logits, alpha * self._logits) + z
     values, indexes = torch.topk(keys, minibatch_size)
-    if not bool(torch.isfinite(values).all()):
+    if self.check and not bool(torch.isfinite(values).all()):
       raise FloatingPointError('Not enough elements to sample')    # memory.py:227-230
     states = tuple(s[indexes] for s in self._states)
     actions = self._actions[indexes]
@@ -145,15 +153,16 @@ class ReplayMemory(object):
   def update_priorities(self, indexes, deltas):
     logits = torch.log(deltas.to(torch.float32) + self.epsilon)    # memory.py:272
     self._logits.index_copy_(0, indexes, logits)
-    amax = int(torch.argmax(logits)); amin = int(torch.argmin(logits))
-    max_logit, min_logit = float(logits[amax]), float(logits[amin])
-    hit_max = bool((indexes == self._max_logit_index).any())
-    hit_min = bool((indexes == self._min_logit_index).any())
-    if max_logit >= self._max_logit:
-      self._max_logit_index, self._max_logit = int(indexes[amax]), max_logit
-    elif hit_max:
-      self._recompute_max()
-    if min_logit <= self._min_logit:
-      self._min_logit_index, self._min_logit = int(indexes[amin]), min_logit
-    elif hit_min:
-      self._recompute_min()
+    amax = torch.argmax(logits); amin = torch.argmin(logits)
+    max_logit, min_logit = logits[amax], logits[amin]
+    hit_max = (indexes == self._max_logit_index).any()
+    hit_min = (indexes == self._min_logit_index).any()
+    # memory.py:282-292: a larger maximum replaces the tracker; else if the tracked slot was rewritten, recompute
+    ri, rv = self._argmax_all()
+    ge = max_logit >= self._max_logit
+    self._max_logit_index = torch.where(ge, indexes[amax], torch.where(hit_max, ri, self._max_logit_index))
+    self._max_logit = torch.where(ge, max_logit, torch.where(hit_max, rv, self._max_logit))
+    ri, rv = self._argmin_finite()                                 # memory.py:298-316
+    le = min_logit <= self._min_logit
+    self._min_logit_index = torch.where(le, indexes[amin], torch.where(hit_min, ri, self._min_logit_index))
+    self._min_logit = torch.where(le, min_logit, torch.where(hit_min, rv, self._min_logit))

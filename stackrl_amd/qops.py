@@ -63,8 +63,9 @@ class FusedPolicy(object):
   library convs for the two U-Nets and the position convs, HIP cross-correlation, HIP arg-max + epsilon-greedy.
   Draws the same random numbers in the same order as `DQN.policy`, so both paths give identical actions."""
 
-  def __init__(self, chunk=512):
+  def __init__(self, chunk=512, autocast=None):
     self.chunk = int(chunk)      # rollout batches are processed in chunks to bound activation memory
+    self.autocast = autocast     # None = fp32 like the reference; torch.bfloat16 runs the library convs on MFMA
 
   @torch.no_grad()
   def __call__(self, net, inputs, epsilon, gen):
@@ -75,7 +76,11 @@ class FusedPolicy(object):
     out = torch.empty(B, dtype=torch.int64, device=xm.device)
     for s in range(0, B, self.chunk):
       e = min(B, s + self.chunk)
-      x, _, w = net.features((xm[s:e], xo[s:e]))
+      if self.autocast is not None:
+        with torch.autocast('cuda', dtype=self.autocast):
+          x, _, w = net.features((xm[s:e], xo[s:e]))
+      else:
+        x, _, w = net.features((xm[s:e], xo[s:e]))
       adv = net.pos(xcorr_forward(x, w)).flatten(1)
       out[s:e] = policy_head(adv, u[s:e], rnd[s:e], epsilon)
     return out

@@ -78,6 +78,7 @@ def test_replay_memory_against_restatement(P, L, n, literal):
   rng = np.random.RandomState(P * 100 + L)
   spec = (((P, 2, 2, 1), torch.uint8),)
   mem = ReplayMemory(spec, P * L, alpha=0.6, beta=0.5, n_steps=n, seed=0, reference_next_index=literal)
+  mem.check = True
   ref = O.RefMemory(P, P * L, n_steps=n, literal_next_index=literal)
   assert mem.max_length == ref.L
   for t in range(4 * L):
@@ -112,8 +113,8 @@ def test_replay_memory_against_restatement(P, L, n, literal):
       d = rng.uniform(0, 2, size=len(pick)).astype(np.float32)
       mem.update_priorities(torch.from_numpy(pick), torch.from_numpy(d))
       ref.update_priorities([int(i) for i in pick], d)
-      assert mem._max_logit_index == ref.max_idx and mem._min_logit_index == ref.min_idx
-      assert abs(mem._max_logit - ref.max_logit) < 1e-6 and abs(mem._min_logit - ref.min_logit) < 1e-6
+      assert int(mem._max_logit_index) == ref.max_idx and int(mem._min_logit_index) == ref.min_idx
+      assert abs(float(mem._max_logit) - ref.max_logit) < 1e-6 and abs(float(mem._min_logit) - ref.min_logit) < 1e-6
     # index arithmetic (bit-exact) and gathered transition for every sampleable slot
     for i in idx:
       nxt = int(mem.next_indexes(torch.tensor(int(i)), n))
