@@ -174,6 +174,20 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   const float* gb = P.blob + (size_t)e * P.BLOB;
   const bool ext = poses_ext != nullptr;
   const int nb = ext ? nb_ext[e] : h->nb;
+  // header fields and the object map are requested up front: their latency overlaps the ray cast
+  int g0 = 0, g1 = 0, g2 = 0, g3 = 0, pending = -1, mode = 0, hdone = 0;
+  float prev_metric = 0.0f;
+  if (!ext) {
+    g0 = h->goal[0]; g1 = h->goal[1]; g2 = h->goal[2]; g3 = h->goal[3]; pending = h->pending;
+    mode = h->mode; hdone = h->done; prev_metric = h->prev_metric;
+  }
+  const int rr = P.c.object_res * P.c.object_res;
+  float om_pref[2] = {0.0f, 0.0f};
+  if (!ext && pending >= 0) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tid + k * SRL_RENDER_THREADS < rr) om_pref[k] = P.objmap[(size_t)pending * rr + tid + k * SRL_RENDER_THREADS];
+  }
 
   {
     float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -337,8 +351,6 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   const uint32_t zbyte = (uint8_t)((0.0f * 255.0f) / den);
   const float h_empty = elev_overhead(P, depth_encode(SRL_FAR - 0.0f, nearp, SRL_FAR));
   const uint32_t b_empty = (uint8_t)((h_empty * 255.0f) / den);
-  int g0 = 0, g1 = 0, g2 = 0, g3 = 0;
-  if (!ext) { g0 = h->goal[0]; g1 = h->goal[1]; g2 = h->goal[2]; g3 = h->goal[3]; }
   float* Hout = ext ? height_ext + (size_t)e * npx : P.H + (size_t)e * npx;
   uint8_t* om = ext ? nullptr : obs_map + (size_t)e * npx * 2;
   float spi = 0.0f, spu = 0.0f;
@@ -370,34 +382,41 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     if (om) ((uint2*)om)[g] = make_uint2(pk[0] | (pk[1] << 16), pk[2] | (pk[3] << 16));
   }
   if (ext) return;
+  // ---- object observation (O2 from the per-mesh cache, requested at kernel start; empty map when nothing is pending)
+  {
+    uint8_t* oo = obs_obj + (size_t)e * rr;
+    const float empty = elev_object(P, 1.0f);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = tid + k * SRL_RENDER_THREADS;
+      if (idx < rr) oo[idx] = (uint8_t)(((pending >= 0 ? om_pref[k] : empty) * 255.0f) / den);
+    }
+    for (int idx = tid + 2 * SRL_RENDER_THREADS; idx < rr; idx += SRL_RENDER_THREADS)
+      oo[idx] = (uint8_t)(((pending >= 0 ? P.objmap[(size_t)pending * rr + idx] : empty) * 255.0f) / den);
+  }
+  // ---- halving tree over the 512 partials: cross-wave stages through LDS, in-wave stages by shuffles
   L.pi[tid] = spi; L.pu[tid] = spu;
   __syncthreads();
-  for (int s = SRL_RENDER_THREADS / 2; s >= 1; s >>= 1) {
-    if (tid < s) { L.pi[tid] += L.pi[tid + s]; L.pu[tid] += L.pu[tid + s]; }
-    __syncthreads();
-  }
-  // ---- object observation (O2 from the per-mesh cache; empty map when nothing is pending)
-  {
-    const int r = P.c.object_res;
-    const int pending = h->pending;
-    uint8_t* oo = obs_obj + (size_t)e * r * r;
-    const float empty = elev_object(P, 1.0f);
-    for (int k = tid; k < r * r; k += SRL_RENDER_THREADS) {
-      float o = pending >= 0 ? P.objmap[(size_t)pending * r * r + k] : empty;
-      oo[k] = (uint8_t)((o * 255.0f) / den);
-    }
+  if (tid < 256) { L.pi[tid] += L.pi[tid + 256]; L.pu[tid] += L.pu[tid + 256]; }
+  __syncthreads();
+  if (tid < 128) { L.pi[tid] += L.pi[tid + 128]; L.pu[tid] += L.pu[tid + 128]; }
+  __syncthreads();
+  float sum_i = 0.0f, sum_u = 0.0f;
+  if (tid < 64) {
+    sum_i = L.pi[tid] + L.pi[tid + 64]; sum_u = L.pu[tid] + L.pu[tid + 64];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { sum_i = sum_i + __shfl_down(sum_i, s); sum_u = sum_u + __shfl_down(sum_u, s); }   // p[t] += p[t+s], t < s
   }
   // ---- K5: reward = scale * (metric_t - metric_{t-1})  (rewarder.py:176-179)
   if (tid == 0) {
-    int mode = h->mode;
     if (mode == 0) {
       float mv;
-      if (P.c.metric == SRL_METRIC_IOU) mv = L.pi[0] / L.pu[0];
-      else if (P.c.metric == SRL_METRIC_OR) mv = L.pi[0] / ((float)(g2 * g3) * gz);
+      if (P.c.metric == SRL_METRIC_IOU) mv = sum_i / sum_u;
+      else if (P.c.metric == SRL_METRIC_OR) mv = sum_i / ((float)(g2 * g3) * gz);
       else mv = discounted_metric(P, h, gb);
-      reward[e] = (mv - h->prev_metric) * P.scale;
+      reward[e] = (mv - prev_metric) * P.scale;
       h->prev_metric = mv;
-      done[e] = (uint8_t)h->done;
+      done[e] = (uint8_t)hdone;
     } else {   // reset step (env.py:235-236) or rejected action
       reward[e] = 0.0f;
       done[e] = 0;
