@@ -25,7 +25,7 @@
 #include "srl_device.h"
 #include "srl_kernels.h"
 
-#define SRL_GJK_GROUP 16
+#define SRL_GJK_GROUP 32
 
 __constant__ uint8_t c_pair_i[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
 __constant__ uint8_t c_pair_j[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
@@ -113,7 +113,7 @@ __device__ void env_reset(const DevParams& P, EnvHdr* h, int e) {
 // ------------------------------------------------------------------ per-body derived state
 // lane = body: damping then gravity (btRigidBody::applyDamping, then the external-force impulse), rotation
 // matrix and world inverse inertia
-__device__ void body_frame(const Lds& L, int b) {
+__device__ __forceinline__ void body_frame(const Lds& L, int b) {
   const DevParams& P = *L.P;
   const float dt = P.c.sim_time_step;
   v3 v = ld3(L.Vl(b)) * P.lin_damp;
@@ -131,7 +131,7 @@ __device__ void body_frame(const Lds& L, int b) {
 // 16 lanes = body: AABB of the world vertices + ground manifold (up to 8 deepest vertices within the breaking
 // threshold in (dist, index) order; warm-start impulses carried over by vertex id).  Each lane owns the
 // vertices gl, gl + 16, ...; the group repeatedly extracts the minimum (dist, index) with xor shuffles.
-__device__ void body_bounds_ground(const Lds& L, int b, int gl) {
+__device__ __forceinline__ void body_bounds_ground(const Lds& L, int b, int gl) {
   const DevParams& P = *L.P;
   const float* bc = L.BC(b);
   const int nv = __float_as_int(bc[5]);
@@ -208,7 +208,7 @@ __device__ void body_bounds_ground(const Lds& L, int b, int gl) {
 }
 
 // ------------------------------------------------------------------ persistent manifold (lane = slot)
-__device__ void manifold_refresh(float* mp, v3 xa, const m3& Ra, v3 xb, const m3& Rb, float thr) {
+__device__ __forceinline__ void manifold_refresh(float* mp, v3 xa, const m3& Ra, v3 xb, const m3& Rb, float thr) {
   int np = __float_as_int(mp[0]);
   for (int i = np - 1; i >= 0; --i) {
     float* p = mp + 4 + SRL_MP_WORDS * i;
@@ -233,7 +233,7 @@ __device__ void manifold_refresh(float* mp, v3 xa, const m3& Ra, v3 xb, const m3
   mp[0] = __int_as_float(np);
 }
 
-__device__ int manifold_sort_replace(const float* mp, v3 nla, float ndist) {
+__device__ __forceinline__ int manifold_sort_replace(const float* mp, v3 nla, float ndist) {
   int deep = -1; float maxpen = ndist;
   for (int i = 0; i < 4; ++i) {
     float d = mp[4 + SRL_MP_WORDS * i + 9];
@@ -252,7 +252,7 @@ __device__ int manifold_sort_replace(const float* mp, v3 nla, float ndist) {
   return best;
 }
 
-__device__ void manifold_add(float* mp, v3 la, v3 lb, v3 n, float dist, float thr) {
+__device__ __forceinline__ void manifold_add(float* mp, v3 la, v3 lb, v3 n, float dist, float thr) {
   int np = __float_as_int(mp[0]);
   float shortest = thr * thr; int near_i = -1;
   for (int i = 0; i < np; ++i) {
@@ -269,16 +269,19 @@ __device__ void manifold_add(float* mp, v3 la, v3 lb, v3 n, float dist, float th
   if (!keep_impulses) { p[10] = 0.0f; p[11] = 0.0f; p[12] = 0.0f; }
 }
 
-// least-penetration face axis for overlapping hulls
-__device__ void sat_faces(const DevParams& P, int mesh_a, const float* VA, int na, int mesh_b, const float* VB, int nb,
-                          v3& pa, v3& pb, v3& nrm, float& dist) {
-  float best = -1e30f; int btype = 0, bvert = 0; v3 bn = V(0.0f, 0.0f, 1.0f);
+// least-penetration face axis for overlapping hulls; the faces are split over the G lanes of the slot's group
+// (lane gl takes faces gl, gl + G, ... of body A then of body B) and the best axis is combined with xor shuffles:
+// larger separation wins, ties go to the earlier face in (A faces, B faces) order, as in the sequential scan
+template <int G>
+__device__ __forceinline__ void sat_faces(const DevParams& P, int mesh_a, const float* VA, int na, int mesh_b,
+                                          const float* VB, int nb, v3& pa, v3& pb, v3& nrm, float& dist, int gl) {
+  float best = -1e30f; int border = 0x7fffffff, bvert = 0; v3 bn = V(0.0f, 0.0f, 1.0f);
   for (int pass = 0; pass < 2; ++pass) {
     const MeshHdr mh = P.mh[pass ? mesh_b : mesh_a];
     const float* VF = pass ? VB : VA;
     const float* VO = pass ? VA : VB;
     int no = pass ? na : nb;
-    for (int t = 0; t < mh.nt; ++t) {
+    for (int t = gl; t < mh.nt; t += G) {
       uchar4 tr = P.mt[mh.to + t];
       v3 a = ld3(VF + 3 * tr.x), b = ld3(VF + 3 * tr.y), c = ld3(VF + 3 * tr.z);
       v3 n = cross(b - a, c - a);
@@ -290,17 +293,24 @@ __device__ void sat_faces(const DevParams& P, int mesh_a, const float* VA, int n
         float sd = dot(n, ld3(VO + 3 * k) - a);
         if (sd < smin) { smin = sd; kmin = k; }
       }
-      if (smin > best) { best = smin; btype = pass; bvert = kmin; bn = n; }
+      if (smin > best) { best = smin; border = pass * 1024 + t; bvert = kmin; bn = n; }
     }
   }
-  if (btype == 0) { nrm = neg(bn); pb = ld3(VB + 3 * bvert); pa = madd(pb, bn, -best); }
+#pragma unroll
+  for (int m = 1; m < G; m <<= 1) {
+    const float ob = __shfl_xor(best, m, G);
+    const int oo = __shfl_xor(border, m, G), ov = __shfl_xor(bvert, m, G);
+    const float nx = __shfl_xor(bn.x, m, G), ny = __shfl_xor(bn.y, m, G), nz = __shfl_xor(bn.z, m, G);
+    if (ob > best || (ob == best && oo < border)) { best = ob; border = oo; bvert = ov; bn = V(nx, ny, nz); }
+  }
+  if (border < 1024 || border == 0x7fffffff) { nrm = neg(bn); pb = ld3(VB + 3 * bvert); pa = madd(pb, bn, -best); }
   else { nrm = bn; pa = ld3(VA + 3 * bvert); pb = madd(pa, bn, -best); }
   dist = best;
 }
 
 // 16 lanes per slot: GJK runs in lock step on all of them (support scans split), the first lane maintains
 // the manifold
-__device__ void narrowphase_slot(const Lds& L, int sl, int gl) {
+__device__ __forceinline__ void narrowphase_slot(const Lds& L, int sl, int gl) {
   const DevParams& P = *L.P;
   int pid = L.POS()[sl];
   int a = c_pair_i[pid], b = c_pair_j[pid];
@@ -312,20 +322,31 @@ __device__ void narrowphase_slot(const Lds& L, int sl, int gl) {
   float thr = 0.02f * fminf(bca[4], bcb[4]);
   v3 xa = ld3(L.X(a)), xb = ld3(L.X(b));
   m3 Ra = ldm(L.R(a)), Rb = ldm(L.R(b));
+#ifdef SRL_STAMPS
+  long long _n0 = wall_clock64();
+#endif
   if (gl == 0) manifold_refresh(mp, xa, Ra, xb, Rb, thr);
+#ifdef SRL_STAMPS
+  long long _n1 = wall_clock64();
+#endif
   v3 axis = ld3(mp + 1);
   v3 pa, pb, n; float d;
   int cache[3];
   cache[0] = __float_as_int(mp[56]); cache[1] = __float_as_int(mp[57]); cache[2] = __float_as_int(mp[58]);
   int rc = gjk_distance<SRL_GJK_GROUP>(L.WV(a), na, L.WV(b), nb, axis, cache, (mg + mg) + thr, pa, pb, n, d, gl);
-  if (gl != 0) return;
-  mp[56] = __int_as_float(cache[0]); mp[57] = __int_as_float(cache[1]); mp[58] = __int_as_float(cache[2]);
-  if (rc == 2) {
-    sat_faces(P, __float_as_int(bca[7]), L.WV(a), na, __float_as_int(bcb[7]), L.WV(b), nb, pa, pb, n, d);
+#ifdef SRL_STAMPS
+  if (threadIdx.x == 0) { long long _n2 = wall_clock64(); EnvHdr* hh = &L.P->hdr[blockIdx.x]; hh->stamps2[0] += _n1 - _n0; hh->stamps2[1] += _n2 - _n1; hh->stamps2[3] += 1; }
+  long long _n3 = wall_clock64();
+#endif
+  if (rc == 2) {   // every lane of the group got the same rc: the face scan is shared
+    sat_faces<SRL_GJK_GROUP>(P, __float_as_int(bca[7]), L.WV(a), na, __float_as_int(bcb[7]), L.WV(b), nb, pa, pb, n, d, gl);
+    if (gl != 0) return;
     rc = 1;
   } else {
+    if (gl != 0) return;
     st3(mp + 1, axis);
   }
+  mp[56] = __int_as_float(cache[0]); mp[57] = __int_as_float(cache[1]); mp[58] = __int_as_float(cache[2]);
   if (rc == 1) {
     float dist = d - (mg + mg);
     if (dist < thr) {
@@ -334,6 +355,9 @@ __device__ void narrowphase_slot(const Lds& L, int sl, int gl) {
       manifold_add(mp, mtmul(Ra, sa - xa), mtmul(Rb, sb - xb), n, dist, thr);
     }
   }
+#ifdef SRL_STAMPS
+  if (threadIdx.x == 0) { EnvHdr* hh = &L.P->hdr[blockIdx.x]; hh->stamps2[2] += wall_clock64() - _n3; }
+#endif
 }
 
 // ------------------------------------------------------------------ sequential impulses (lane = contact point)
@@ -513,7 +537,7 @@ __device__ __forceinline__ void solver_sweep(const Lds& L, Point& gp, Point (&pp
 #endif
 
 template <int T, int PP>
-__device__ void substep(const Lds& L, int nb, int tid) {
+__device__ __forceinline__ void substep(const Lds& L, int nb, int tid) {
   const DevParams& P = *L.P;
 #ifdef SRL_STAMPS
   long long _t0 = wall_clock64();
@@ -782,32 +806,40 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
   }
   __syncthreads();
 
-  // ---- Simulator.step (simulator.py:190-258)
-  int counter = 0;
+  // ---- Simulator.step (simulator.py:190-258) as one loop around a single sub-step call site:
+  //   PLACE  : the sub-step of _place (simulator.py:320)
+  //   SMOOTH : "zero the newest body's velocity, step" until _drop (simulator.py:212-224)
+  //   SETTLE : step until _stop (simulator.py:239-245)
+  enum { PH_PLACE = 0, PH_SMOOTH = 1, PH_ENTER = 2, PH_SETTLE = 3 };
+  int counter = 0, phase = PH_PLACE, s_a = 0;
   bool diverged = false;
-  substep<T, PP>(L, nb, tid);
-  counter = 1;
-  if (P.c.smooth_placing) {
-    for (;;) {
-      bool drop = newest_contacts(L, nb, tid, T) >= 3;   // _drop, simulator.py:337-341
-      bool stop = sim_stop(L, nb, tid);
-      if (drop || stop) break;
+  for (;;) {
+    if (phase == PH_SMOOTH) {
       if (tid == 0) { st3(L.Vl(nb - 1), V(0, 0, 0)); st3(L.Wl(nb - 1), V(0, 0, 0)); }   // resetBaseVelocity
       __syncthreads();
-      substep<T, PP>(L, nb, tid);
-      counter++;
-      if (counter > P.max_substeps) { diverged = true; break; }
     }
-  }
-  if (tid == 0) {
-    st3(L.PX(nb - 1), ld3(L.X(nb - 1)));
-    for (int k = 0; k < 4; ++k) L.PQ(nb - 1)[k] = L.Q(nb - 1)[k];
-  }
-  const int s_a = counter;
-  while (!diverged && !sim_stop(L, nb, tid)) {
     substep<T, PP>(L, nb, tid);
     counter++;
-    if (counter > P.max_substeps) { diverged = true; break; }
+    if (phase != PH_PLACE && counter > P.max_substeps) diverged = true;
+    if (phase == PH_PLACE) phase = P.c.smooth_placing ? PH_SMOOTH : PH_ENTER;
+    if (phase == PH_SMOOTH) {
+      bool leave = diverged;
+      if (!leave) {
+        const bool drop = newest_contacts(L, nb, tid, T) >= 3;   // _drop, simulator.py:337-341
+        const bool stop = sim_stop(L, nb, tid);
+        leave = drop || stop;
+      }
+      if (leave) phase = PH_ENTER;
+    }
+    if (phase == PH_ENTER) {   // simulator.py:227-230: pose where the rock was left, steps before the drop
+      if (tid == 0) {
+        st3(L.PX(nb - 1), ld3(L.X(nb - 1)));
+        for (int k = 0; k < 4; ++k) L.PQ(nb - 1)[k] = L.Q(nb - 1)[k];
+      }
+      s_a = counter;
+      phase = PH_SETTLE;
+    }
+    if (phase == PH_SETTLE && (diverged || sim_stop(L, nb, tid))) break;
   }
   __syncthreads();
 

@@ -31,6 +31,7 @@ struct EnvHdr {
   int32_t script_goal[4];
 #ifdef SRL_STAMPS
   long long stamps[8];          // diagnostic build only: accumulated wall-clock ticks per sub-step phase
+  long long stamps2[4];         // narrowphase of slot 0: refresh, gjk, insert ticks, calls
 #endif
 };
 

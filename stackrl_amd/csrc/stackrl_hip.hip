@@ -522,7 +522,7 @@ int srl_debug_stamps(srl_env* env, long long* out) {
   HIP_TRY(hipDeviceSynchronize());
   std::vector<EnvHdr> h((size_t)n);
   HIP_TRY(hipMemcpy(h.data(), env->P.hdr, sizeof(EnvHdr) * (size_t)n, hipMemcpyDeviceToHost));
-  for (int i = 0; i < n; ++i) for (int k = 0; k < 8; ++k) out[8 * i + k] = h[i].stamps[k];
+  for (int i = 0; i < n; ++i) { for (int k = 0; k < 8; ++k) out[12 * i + k] = h[i].stamps[k]; for (int k = 0; k < 4; ++k) out[12 * i + 8 + k] = h[i].stamps2[k]; }
   return SRL_OK;
 }
 #endif

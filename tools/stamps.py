@@ -19,12 +19,14 @@ g.reset()
 tot_sub = 0
 for k in range(L):
   g.step(g.sample()); tot_sub += g.state()[2].sum(1)
-out = np.zeros((n, 8), np.int64)
+out = np.zeros((n, 12), np.int64)
 lib.load().srl_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.load().srl_debug_stamps(g._h, out.ctypes.data_as(ctypes.c_void_p))
 names = ['frame', 'verts', 'bounds+ground', 'broadphase+colour', 'narrowphase', 'point setup', 'solver', 'integrate']
-per = out.sum(0) / tot_sub.sum() * 10.0   # 100 MHz ticks -> ns
+per = out[:, :8].sum(0) / tot_sub.sum() * 10.0   # 100 MHz ticks -> ns
+np2 = out[:, 8:].sum(0)
 slow = np.argmax(tot_sub)
 print('mean ns per sub-step by phase (all envs):')
 for nm, v in zip(names, per): print('  %-20s %8.0f ns  %5.1f%%' % (nm, v, 100 * v / per.sum()))
-print('  total %.1f us; slowest env: %d sub-steps, %.2f ms' % (per.sum() / 1e3, tot_sub[slow], out[slow].sum() * 1e-5))
+print('  total %.1f us; slowest env: %d sub-steps, %.2f ms' % (per.sum() / 1e3, tot_sub[slow], out[slow, :8].sum() * 1e-5))
+print('  slot-0 narrowphase per call: refresh %.0f ns, gjk %.0f ns, insert %.0f ns (%d calls, %.2f per sub-step)' % (10 * np2[0] / np2[3], 10 * np2[1] / np2[3], 10 * np2[2] / np2[3], np2[3], np2[3] / tot_sub.sum()))
