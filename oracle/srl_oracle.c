@@ -986,7 +986,8 @@ static inline float row_solve(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float
     k = k + (imb + vdot(vcross(ab, rb), d));
     vrel = vrel - (vdot(d, u->vb) + vdot(cb, u->wb));
   }
-  float dl = (target - vrel) / k;
+  float rk = 1.0f / k;            /* reciprocal effective mass, as the kernel precomputes it per row */
+  float dl = (target - vrel) * rk;
   float na = *acc + dl;
   if (na < lo) na = lo;
   if (na > hi) na = hi;

@@ -70,12 +70,12 @@ __device__ float discounted_metric(const DevParams& P, const EnvHdr* h, const fl
   float omax = 3.14159265358979f;
   float r = 0.0f; int nout = 0;
   for (int b = 0; b < h->nb; ++b) {
-    v3 x = ld3(gb + P.OFF_X + 3 * b);
+    v3 x = ld3(gb + P.OFF_X + 4 * b);
     float fu = floorf(x.x / P.px), fv = floorf(x.y / P.px);   // xy_to_pixel (observer.py:388-390)
     bool in = fu >= (float)h->goal[0] && fv >= (float)h->goal[1] && fu < (float)(h->goal[0] + h->goal[2]) &&
               fv < (float)(h->goal[1] + h->goal[3]);
     if (!in) { nout++; continue; }
-    v3 dp = ld3(gb + P.OFF_PX + 3 * b) - x;
+    v3 dp = ld3(gb + P.OFF_PX + 4 * b) - x;
     float perr = sqrtf(dot(dp, dp));
     const float* a = gb + P.OFF_PQ + 4 * b;
     const float* q = gb + P.OFF_Q + 4 * b;
@@ -201,7 +201,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       x = V(p[0], p[1], p[2]); q.x = p[3]; q.y = p[4]; q.z = p[5]; q.w = p[6];
       m = mesh_ext[(size_t)e * SRL_MAX_BODIES + tid];
     } else {
-      x = ld3(gb + P.OFF_X + 3 * tid);
+      x = ld3(gb + P.OFF_X + 4 * tid);
       const float* qq = gb + P.OFF_Q + 4 * tid;
       q.x = qq[0]; q.y = qq[1]; q.z = qq[2]; q.w = qq[3];
       m = ((const int*)gb)[P.OFF_MESH + tid];

@@ -36,11 +36,11 @@ enum { M_MODE = 0, M_U, M_V, M_NEXT, M_ZMAX, M_FLAGS, M_NCOL, M_CNT, M_NB, M_PEN
 struct Lds {
   float* sm;
   const DevParams* P;
-  __device__ __forceinline__ float* X(int b) const { return sm + P->OFF_X + 3 * b; }
+  __device__ __forceinline__ float* X(int b) const { return sm + P->OFF_X + 4 * b; }
   __device__ __forceinline__ float* Q(int b) const { return sm + P->OFF_Q + 4 * b; }
-  __device__ __forceinline__ float* Vl(int b) const { return sm + P->OFF_V + 3 * b; }
-  __device__ __forceinline__ float* Wl(int b) const { return sm + P->OFF_W + 3 * b; }
-  __device__ __forceinline__ float* PX(int b) const { return sm + P->OFF_PX + 3 * b; }
+  __device__ __forceinline__ float* Vl(int b) const { return sm + P->OFF_V + 4 * b; }
+  __device__ __forceinline__ float* Wl(int b) const { return sm + P->OFF_W + 4 * b; }
+  __device__ __forceinline__ float* PX(int b) const { return sm + P->OFF_PX + 4 * b; }
   __device__ __forceinline__ float* PQ(int b) const { return sm + P->OFF_PQ + 4 * b; }
   __device__ __forceinline__ int* MESH() const { return (int*)(sm + P->OFF_MESH); }
   __device__ __forceinline__ float* GM(int b) const { return sm + P->OFF_GM + SRL_GM_WORDS * b; }
@@ -363,7 +363,7 @@ __device__ __forceinline__ void narrowphase_slot(const Lds& L, int sl, int gl) {
 // ------------------------------------------------------------------ sequential impulses (lane = contact point)
 // One solver row in precomputed form: direction d, ca = ra x d, aa = Ia ca (and cb, ab for body B),
 // k = effective mass denominator.  Same expression trees as the sequential definition.
-struct Row { v3 d, ca, aa, cb, ab; float k; };
+struct Row { v3 d, ca, aa, cb, ab; float rk; };   // rk = 1 / effective mass denominator
 struct Vel4 { v3 va, wa, vb, wb; };
 
 template <bool HAS_B>
@@ -373,12 +373,13 @@ __device__ __forceinline__ Row make_row(v3 d, v3 ra, v3 rb, float ima, const m3&
   r.ca = cross(ra, d);
   r.aa = mmul(Ia, r.ca);
   r.cb = V(0.0f, 0.0f, 0.0f); r.ab = V(0.0f, 0.0f, 0.0f);
-  r.k = ima + dot(cross(r.aa, ra), d);
+  float k = ima + dot(cross(r.aa, ra), d);
   if (HAS_B) {
     r.cb = cross(rb, d);
     r.ab = mmul(Ib, r.cb);
-    r.k = r.k + (imb + dot(cross(r.ab, rb), d));
+    k = k + (imb + dot(cross(r.ab, rb), d));
   }
+  r.rk = 1.0f / k;
   return r;
 }
 
@@ -387,7 +388,7 @@ __device__ __forceinline__ void row_solve(const Row& r, float ima, float imb, Ve
                                           float lo, float hi) {
   float vrel = dot(r.d, u.va) + dot(r.ca, u.wa);
   if (HAS_B) vrel = vrel - (dot(r.d, u.vb) + dot(r.cb, u.wb));
-  float dl = (target - vrel) / r.k;
+  float dl = (target - vrel) * r.rk;
   float na = acc + dl;
   if (na < lo) na = lo;
   if (na > hi) na = hi;
@@ -489,9 +490,14 @@ template <bool WARM, bool HAS_B>
 __device__ __forceinline__ void point_turn(const Lds& L, Point& p) {
   const float ws = L.P->c.warmstart;
   Vel4 u;
-  u.va = ld3(L.Vl(p.a)); u.wa = ld3(L.Wl(p.a));
-  if (HAS_B) { u.vb = ld3(L.Vl(p.b)); u.wb = ld3(L.Wl(p.b)); }
-  else { u.vb = V(0.0f, 0.0f, 0.0f); u.wb = V(0.0f, 0.0f, 0.0f); }
+  {   // 16-byte LDS reads (vectors are stored with a stride of 4 words)
+    const float4 a0 = *(const float4*)L.Vl(p.a), a1 = *(const float4*)L.Wl(p.a);
+    u.va = V(a0.x, a0.y, a0.z); u.wa = V(a1.x, a1.y, a1.z);
+    if (HAS_B) {
+      const float4 b0 = *(const float4*)L.Vl(p.b), b1 = *(const float4*)L.Wl(p.b);
+      u.vb = V(b0.x, b0.y, b0.z); u.wb = V(b1.x, b1.y, b1.z);
+    } else { u.vb = V(0.0f, 0.0f, 0.0f); u.wb = V(0.0f, 0.0f, 0.0f); }
+  }
   if (WARM) {
     p.in = p.in * ws; p.i1 = p.i1 * ws; p.i2 = p.i2 * ws;
     row_apply<HAS_B>(p.n, p.ima, p.imb, u, p.in);
@@ -503,8 +509,10 @@ __device__ __forceinline__ void point_turn(const Lds& L, Point& p) {
     row_solve<HAS_B>(p.t1, p.ima, p.imb, u, 0.0f, p.i1, -lim, lim);
     row_solve<HAS_B>(p.t2, p.ima, p.imb, u, 0.0f, p.i2, -lim, lim);
   }
-  st3(L.Vl(p.a), u.va); st3(L.Wl(p.a), u.wa);
-  if (HAS_B) { st3(L.Vl(p.b), u.vb); st3(L.Wl(p.b), u.wb); }
+  *(float4*)L.Vl(p.a) = make_float4(u.va.x, u.va.y, u.va.z, 0.0f); *(float4*)L.Wl(p.a) = make_float4(u.wa.x, u.wa.y, u.wa.z, 0.0f);
+  if (HAS_B) {
+    *(float4*)L.Vl(p.b) = make_float4(u.vb.x, u.vb.y, u.vb.z, 0.0f); *(float4*)L.Wl(p.b) = make_float4(u.wb.x, u.wb.y, u.wb.z, 0.0f);
+  }
 }
 
 template <bool WARM, int PP>
@@ -702,7 +710,7 @@ template <int T, int PP>
 __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, const int64_t* __restrict__ action,
                                           int force_reset) {
   const DevParams& P = *Pp;
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int e = blockIdx.x, tid = threadIdx.x;
   Lds L; L.sm = sm; L.P = Pp;
   int* misc = L.MISC();

@@ -98,11 +98,12 @@ void layout(DevParams& P) {
   P.NS = nslots(L);
   P.NP = L * (L - 1) / 2 > 0 ? L * (L - 1) / 2 : 1;
   int o = 0;
-  P.OFF_X = o; o += 3 * L;
+  // xyz vectors are stored with a stride of 4 words so that the kernels move them with 16-byte LDS accesses
+  P.OFF_V = o; o += 4 * L;
+  P.OFF_W = o; o += 4 * L;
+  P.OFF_X = o; o += 4 * L;
   P.OFF_Q = o; o += 4 * L;
-  P.OFF_V = o; o += 3 * L;
-  P.OFF_W = o; o += 3 * L;
-  P.OFF_PX = o; o += 3 * L;
+  P.OFF_PX = o; o += 4 * L;
   P.OFF_PQ = o; o += 4 * L;
   P.OFF_MESH = o; o += L;
   P.OFF_GM = o; o += SRL_GM_WORDS * L;
@@ -422,7 +423,7 @@ int srl_get_state(srl_env* env, float* poses, int32_t* n_bodies, int32_t* subste
       const float* gb = blob.data() + (size_t)i * P.BLOB;
       float* p = poses + (size_t)i * SRL_MAX_BODIES * 8;
       for (int b = 0; b < h[i].nb; ++b) {
-        for (int k = 0; k < 3; ++k) p[b * 8 + k] = gb[P.OFF_X + 3 * b + k];
+        for (int k = 0; k < 3; ++k) p[b * 8 + k] = gb[P.OFF_X + 4 * b + k];
         for (int k = 0; k < 4; ++k) p[b * 8 + 3 + k] = gb[P.OFF_Q + 4 * b + k];
         p[b * 8 + 7] = (float)((const int32_t*)gb)[P.OFF_MESH + b];
       }
@@ -448,7 +449,7 @@ int srl_get_velocities(srl_env* env, float* vel) {
     const float* gb = blob.data() + (size_t)i * P.BLOB;
     float* p = vel + (size_t)i * SRL_MAX_BODIES * 8;
     for (int b = 0; b < h[i].nb; ++b)
-      for (int k = 0; k < 3; ++k) { p[b * 8 + k] = gb[P.OFF_V + 3 * b + k]; p[b * 8 + 4 + k] = gb[P.OFF_W + 3 * b + k]; }
+      for (int k = 0; k < 3; ++k) { p[b * 8 + k] = gb[P.OFF_V + 4 * b + k]; p[b * 8 + 4 + k] = gb[P.OFF_W + 4 * b + k]; }
   }
   return SRL_OK;
 }
