@@ -46,7 +46,7 @@ def _cpu_worker(args):
   return n * L * episodes, time.perf_counter() - t0
 
 
-def cpu_baseline(L, seed, budget_envs=32, episodes=1):
+def cpu_baseline(L, seed, budget_envs=64, episodes=3):
   """The oracle on this host's cores: `cores` processes x `budget_envs` envs x `episodes` episodes."""
   import multiprocessing as mp
   cores = min(os.cpu_count() or 1, 16)
@@ -143,7 +143,15 @@ def main():
   last()     # raises if any env diverged / action invalid
   ms, nl = env.kernel_times()
   env.set_profiling(False)
-  poses, nbod, sub, st = env.state()
+  # sub-step statistics of one further (untimed) episode: what the stop criterion asked of the settle kernel
+  subs = []
+  while phase['k'] != 0:
+    do_step()[0]()
+  for _ in range(L):
+    do_step()[0]()
+    subs.append(env.state()[2].sum(1))
+  do_step()[0]()
+  sub = np.stack(subs)
 
   t = torch.tensor([dt], dtype=torch.float64, device='cuda')
   tot = torch.tensor([float(placed)], dtype=torch.float64, device='cuda')
@@ -170,6 +178,11 @@ def main():
     mse = {'value': se / cnt, 'envs': 64, 'steps': L, 'obs_and_done_bit_exact': idx_ok}
     g.close()
 
+  traffic = None
+  pmc = os.path.join(ROOT, 'profiles', 'r01_render_pmc.json')   # separate rocprofv3 --pmc passes of this command
+  if os.path.isfile(pmc) and B == 1024 and L == 8:
+    with open(pmc) as f:
+      traffic = json.load(f).get('traffic_bytes_per_launch')
   if rank == 0:
     render_s = float(ms[1]) / 1e3
     line = {
@@ -187,14 +200,15 @@ def main():
       'roofline': {
         'kernel': 'srl_k_render', 'bound': 'hbm', 'achieved': alg / render_s / 1e9 if render_s > 0 else None,
         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': (alg / render_s / 1e9) / HBM_PEAK_GBS if render_s > 0 else None, 'traffic': None,
+        'frac': (alg / render_s / 1e9) / HBM_PEAK_GBS if render_s > 0 else None, 'traffic': traffic,
         'avg_launch_us': 1e3 * float(ms[1]) / max(int(nl[1]), 1), 'launches': int(nl[1]),
         'alg_bytes_per_launch': alg / max(int(nl[1]), 1),
       },
       'settle': {
         'kernel': 'srl_k_step', 'avg_launch_ms': float(ms[0]) / max(int(nl[0]), 1), 'launches': int(nl[0]),
-        'share_of_wall': float(ms[0]) / 1e3 / dt, 'substeps_last_step_mean': float(sub.sum(1).mean()),
-        'substeps_last_step_max': int(sub.sum(1).max()),
+        'share_of_wall': float(ms[0]) / 1e3 / dt, 'substeps_mean': float(sub.mean()),
+        'substeps_mean_of_per_step_max': float(sub.max(1).mean()), 'substeps_max': int(sub.max()),
+        'note': 'latency-bound: one launch lasts as long as its slowest env (stop criterion simulator.py:322-335)',
       },
       'cpu_baseline': cpu, 'reward_mse_vs_cpu': mse,
     }

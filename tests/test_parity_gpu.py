@@ -135,3 +135,48 @@ def test_nonblocking_step_returns_callable(ref_pool, oracle_mod):
   (om, oo), r, d = nxt()
   assert g.batch_size == 8 and not g.multiprocessing
   assert g.observation_spec[0].shape == (128, 128, 2) and g.action_spec.dtype == torch.int64
+
+
+@pytest.mark.parametrize('L,n,kw', [
+  (32, 4, {}),                                   # BASELINE config 5 episode length: 192 manifold slots, 3 points/thread
+  (12, 6, dict(resolution_factor=4)),            # 64 x 64 height map, 16 x 16 object map, 2,401 actions (config 5)
+])
+def test_large_configs(ref_pool, oracle_mod, L, n, kw):
+  g, o = _mk(ref_pool, oracle_mod, n, L, seed=31, **kw)
+  gout, oout = g.reset(), o.reset()
+  assert np.array_equal(gout[0][0].cpu().numpy(), oout[0][0])
+  for k in range(L + 1):
+    ga, oa = g.sample(), o.sample()
+    assert np.array_equal(ga.cpu().numpy(), oa)
+    _cmp_step(g, o, g.step(ga), o.step(oa), 'step {}'.format(k))
+  assert g.n_actions == (2401 if kw else 9409)
+
+
+def test_full_size_batch_properties(ref_pool):
+  """BASELINE configs[1] size (1,024 envs x 8 rocks): size-independent properties instead of the oracle —
+  every env places exactly L rocks, done on the L-th step, rocks at rest above the ground inside the time cap,
+  height map consistent with the packed observation, rewards telescope to the final IoU."""
+  from stackrl_amd import env as envs
+  B, L = 1024, 8
+  g = envs.VecStackEnv(n_parallel=B, seed=5, pool=ref_pool, block=True, episode_length=L)
+  g.reset()
+  total = torch.zeros(B, device='cuda')
+  for k in range(L):
+    (om, oo), r, d = g.step(g.sample())
+    total += r
+    assert bool(d.all()) == (k == L - 1) and bool(d.any()) == (k == L - 1)
+  poses, nb, sub, st = g.state()
+  assert (nb == L).all() and (st == 0).all() and (sub.sum(1) < 3000).all()
+  v = g.velocities()
+  assert np.linalg.norm(v[..., :3], axis=-1).max() <= 0.01 + 1e-7
+  assert (poses[:, :, 2][:, :L] > 0.004).all()
+  Hm, Om, goal = g.maps()
+  assert np.array_equal(om[..., 0].cpu().numpy(), (Hm * np.float32(255) / np.float32(0.375)).astype(np.uint8))
+  G = np.zeros_like(Hm)
+  for i, (u, v_, h, w) in enumerate(goal):
+    G[i, u:u + h, v_:v_ + w] = 0.25
+  iou = np.minimum(Hm, 0.25)[G > 0].reshape(B, -1).sum(1) / np.maximum(Hm, G).reshape(B, -1).sum(1) if len(set((goal[:, 2] * goal[:, 3]).tolist())) == 1 else \
+      np.array([np.minimum(Hm[i], 0.25)[G[i] > 0].sum() / np.maximum(Hm[i], G[i]).sum() for i in range(B)])
+  np.testing.assert_allclose(total.cpu().numpy(), iou, rtol=2e-4, atol=2e-6)    # sum of reward differences = final metric
+  assert float(oo.max()) == 0                                                     # terminal observation: nothing pending
+  g.close()
