@@ -29,6 +29,20 @@ int srl_xcorr_forward(const float* x_dev, const float* w_dev, float* out_dev, in
 int srl_policy_head(const float* adv_dev, const float* u_dev, const int64_t* rnd_dev, float epsilon,
                     int64_t* actions_dev, int32_t B, int32_t A, void* stream);
 
+/* Heuristic baseline policies (stackrl/baselines.py), the reference's yardstick and optional initial-collect policy
+ * (training.py:256-263).  method: 1 correlate (:141-143), 2 height (:28-43), 3 difference (:45-77), 4 corrcoef
+ * (:79-114).  obs_map uint8 [B][H][H][2], obs_obj uint8 [B][h][h][1] as the env returns them; values float64
+ * [B][(H-h+1)^2]; mask (may be NULL) uint8 [B][(H-h+1)^2] = goal_overlap (:152-156) with `threshold`. */
+int srl_heuristic(int32_t method, const uint8_t* obs_map_dev, const uint8_t* obs_obj_dev, double* values_dev,
+                  uint8_t* mask_dev, int32_t B, int32_t H, int32_t h, int32_t difference_exponent,
+                  int32_t weights_exponent, int32_t localized, double threshold, void* stream);
+
+/* `Baseline.call` (baselines.py:201-217): arg-min of the values over the goal mask (if use_goal), restricted to local
+ * minima of a (1 + 2 minorder)^2 window when any exist; actions int64 [B]; neg_values (may be NULL) float64 [B][A] is
+ * the second return value (-values outside the mask replaced by -(max masked value + 0.001)). */
+int srl_baseline_select(const double* values_dev, const uint8_t* mask_dev, int32_t use_goal, int32_t minorder,
+                        int64_t* actions_dev, double* neg_values_dev, int32_t B, int32_t OH, void* stream);
+
 const char* srl_qnet_last_error(void);
 
 #ifdef __cplusplus
