@@ -67,6 +67,19 @@ def cpu_baseline(L, seed, budget_envs=64, episodes=3):
   }
 
 
+def aggregate(dt, placed, world, device):
+  """Whole-job numbers from per-rank ones: MAX of the elapsed time over ranks, SUM of the placements.  These two tiny
+  all-reduces (and the barriers) are the only collectives of the env path: envs are independent (utils.py:424-448)."""
+  import torch
+  import torch.distributed as dist
+  t = torch.tensor([dt], dtype=torch.float64, device=device)
+  tot = torch.tensor([float(placed)], dtype=torch.float64, device=device)
+  if world > 1:
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+  return float(t.item()), float(tot.item())
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -153,12 +166,7 @@ def main():
   do_step()[0]()
   sub = np.stack(subs)
 
-  t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-  tot = torch.tensor([float(placed)], dtype=torch.float64, device='cuda')
-  if world > 1:
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-  dt_max, placed_all = float(t.item()), float(tot.item())
+  dt_max, placed_all = aggregate(dt, placed, world, 'cuda')
 
   mse = None
   if rank == 0 and args.gpus == 1 and not args.no_cpu:

@@ -287,8 +287,14 @@ def cuboid(extents=(0.10714286, 0.05357143, 0.03571429), density=2400.):
 
 
 def default_pool(n=5000, seed=11, cache_dir=None):
-  """The bench/test pool: generated once and cached next to the package (git-ignored)."""
-  cache_dir = cache_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), '_cache')
+  """The bench/test pool (5,000 synthetic rocks, generator seed 11).  The default pool ships as data
+  (`stackrl_amd/data/pool_5000_11.npz`, written by this very function); other sizes/seeds are generated once and
+  cached next to the package (git-ignored)."""
+  here = os.path.dirname(os.path.abspath(__file__))
+  shipped = os.path.join(here, 'data', 'pool_{}_{}.npz'.format(n, seed))
+  if os.path.isfile(shipped):
+    return MeshPool.load(shipped)
+  cache_dir = cache_dir or os.path.join(here, '_cache')
   path = os.path.join(cache_dir, 'pool_{}_{}.npz'.format(n, seed))
   if os.path.isfile(path):
     try:

@@ -45,3 +45,13 @@ def test_obj_urdf_roundtrip(tmp_path, ref_pool):
   pool = assets.load_directory(str(tmp_path), 'r')
   v2, t2, mc2 = pool.mesh(0)
   assert np.allclose(v2, v, atol=1e-7) and np.array_equal(t2, t) and np.allclose(mc2, mc, rtol=1e-6)
+
+
+def test_shipped_default_pool_is_the_generators_output():
+  """The 5,000-rock pool shipped as data is what `generate_pool(seed=11)` produces (first family re-generated)."""
+  pool = assets.default_pool()
+  assert len(pool) == 5000
+  head = assets.generate_pool(500, seed=11, irregularities=[0.5])
+  n = head.vert_off[20]
+  assert np.array_equal(pool.vert_off[:21], head.vert_off[:21])
+  assert np.array_equal(pool.verts[:n], head.verts[:n])

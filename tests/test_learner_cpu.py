@@ -280,3 +280,23 @@ def test_env_shards_equal_one_batch(oracle_mod, ref_pool):
     (lm, lo_), lr, ld = lo.step(a[:3]); (hm, ho_), hr, hd = hi.step(a[3:])
     assert np.array_equal(fm, np.concatenate([lm, hm])) and np.array_equal(fo, np.concatenate([lo_, ho_]))
     assert np.array_equal(fr, np.concatenate([lr, hr])) and np.array_equal(fd, np.concatenate([ld, hd]))
+
+
+def _bench_rank(rank, world, port, out):
+  import torch.distributed as dist
+  import bench
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  dt, placed = bench.aggregate(1.0 + rank, 100 * (rank + 1), world, 'cpu')
+  if rank == 0:
+    torch.save({'dt': dt, 'placed': placed}, out)
+  dist.destroy_process_group()
+
+
+def test_bench_aggregation_world_size_2_gloo(tmp_path):
+  """bench.py's N > 1 bookkeeping: value = placements of all ranks / max-over-ranks time."""
+  import torch.multiprocessing as mp
+  out = str(tmp_path / 'agg.pt')
+  mp.spawn(_bench_rank, args=(2, 31000 + os.getpid() % 2000, out), nprocs=2, join=True)
+  res = torch.load(out)
+  assert res == {'dt': 2.0, 'placed': 300.0}
