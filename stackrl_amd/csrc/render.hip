@@ -22,6 +22,12 @@
 
 #define SRL_RENDER_THREADS 512
 
+#ifdef SRL_STAMPS
+#define RSTAMP(k) do { if (tid == 0) { long long _t = wall_clock64(); P.hdr[e].rstamps[k] += _t - _t0; _t0 = _t; } } while (0)
+#else
+#define RSTAMP(k)
+#endif
+
 __device__ __forceinline__ float elev_overhead(const DevParams& P, float d) {
   return SRL_FAR - P.elev_num / (SRL_FAR - P.c.max_z * d);
 }
@@ -173,6 +179,9 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   EnvHdr* h = &P.hdr[e];
   const float* gb = P.blob + (size_t)e * P.BLOB;
   const bool ext = poses_ext != nullptr;
+#ifdef SRL_STAMPS
+  long long _t0 = wall_clock64();
+#endif
   const int nb = ext ? nb_ext[e] : h->nb;
   // header fields and the object map are requested up front: their latency overlaps the ray cast
   int g0 = 0, g1 = 0, g2 = 0, g3 = 0, pending = -1, mode = 0, hdone = 0;
@@ -216,6 +225,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     L.bbox[4 * tid + 2] = f2o(1e30f); L.bbox[4 * tid + 3] = f2o(-1e30f);
   }
   __syncthreads();
+  RSTAMP(0);
   // ---- groups of rocks whose planes fit the staging area; the first group's face planes are requested
   //      now so that their latency overlaps the vertex pass
   int bs = 0, be = 0;
@@ -248,6 +258,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     }
   }
   __syncthreads();
+  RSTAMP(1);
   if (tid < nb) {
     int i0 = 0, i1 = -1, j0 = 0, j1 = -1;
     bool okx = pixel_range(o2f(L.bbox[4 * tid + 0]), o2f(L.bbox[4 * tid + 1]), P.inv_px, res, i0, i1);
@@ -294,6 +305,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       if (slot >= 0) L.planes[slot] = myp;
     }
     __syncthreads();
+  RSTAMP(2);
     // (b) lanes over the flattened (rock, 2 x 2 pixel quad) list; when the list is short each quad is
     //     shared by S adjacent lanes that split the planes and combine with shuffles
     {
@@ -336,6 +348,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       }
     }
     __syncthreads();
+  RSTAMP(3);
     bs = be;
     {
       int np_group = 0;
@@ -343,6 +356,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     }
   }
   __syncthreads();
+  RSTAMP(4);
   // ---- epilogue: depth codec, H out, uint8 pack, IoU partial sums (4 pixels per thread per round)
   const float nearp = SRL_FAR - P.c.max_z;
   const float den = fmaxf(P.c.max_z, P.c.object_max_dimension);   // env.py:171-172
@@ -381,6 +395,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     ((float4*)Hout)[g] = make_float4(hv[0], hv[1], hv[2], hv[3]);
     if (om) ((uint2*)om)[g] = make_uint2(pk[0] | (pk[1] << 16), pk[2] | (pk[3] << 16));
   }
+  RSTAMP(5);
   if (ext) return;
   // ---- object observation (O2 from the per-mesh cache, requested at kernel start; empty map when nothing is pending)
   {

@@ -32,6 +32,7 @@ struct EnvHdr {
 #ifdef SRL_STAMPS
   long long stamps[8];          // diagnostic build only: accumulated wall-clock ticks per sub-step phase
   long long stamps2[4];         // narrowphase of slot 0: refresh, gjk, insert ticks, calls
+  long long rstamps[8];         // render kernel phases
 #endif
 };
 
