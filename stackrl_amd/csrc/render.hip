@@ -116,13 +116,14 @@ struct RenderLds {
   uint32_t* bbox;   // [32][4] ordered-uint xmin, xmax, ymin, ymax
   int* prange;      // [32][4] i0|i1<<16, j0|j1<<16, w2 (quads per row), quads
   int* reg;         // [32][4] region base, up cursor, down cursor (exclusive, counts down), -
+  uint32_t* rowmask;   // [8] bit i set: tile row i may hold a rock pixel (union of the rocks' row ranges)
   float* pi;        // [512]  (aliases the plane staging area: used after the ray cast)
   float* pu;        // [512]
 };
 
 __host__ __device__ inline size_t render_lds_bytes(int res) {
   return sizeof(float) * (size_t)res * res + sizeof(float4) * SRL_PLANE_CAP +
-         sizeof(float) * (3 + 9 + 4 + 4 + 4 + 4) * SRL_MAX_BODIES;
+         sizeof(float) * (3 + 9 + 4 + 4 + 4 + 4) * SRL_MAX_BODIES + sizeof(uint32_t) * 8;
 }
 
 // one min / max sweep over planes [0, n) of a region, this lane taking 4-plane batches s, s+S, ...
@@ -174,6 +175,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   L.bbox = (uint32_t*)(L.mhdr + 4 * SRL_MAX_BODIES);
   L.prange = (int*)(L.bbox + 4 * SRL_MAX_BODIES);
   L.reg = L.prange + 4 * SRL_MAX_BODIES;
+  L.rowmask = (uint32_t*)(L.reg + 4 * SRL_MAX_BODIES);
   L.pi = (float*)L.planes;
   L.pu = L.pi + SRL_RENDER_THREADS;
   EnvHdr* h = &P.hdr[e];
@@ -203,6 +205,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     float4* t4 = (float4*)L.tile;
     for (int k = tid; k < npx / 4; k += SRL_RENDER_THREADS) t4[k] = z4;
   }
+  if (tid < 8) L.rowmask[tid] = 0u;
   if (tid < nb) {
     q4 q; v3 x; int m;
     if (ext) {
@@ -266,7 +269,48 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     int w2 = 0, items = 0;
     if (okx && oky) { w2 = (j1 - j0 + 2) >> 1; items = ((i1 - i0 + 2) >> 1) * w2; }   // 2 x 2 pixel quads
     L.prange[4 * tid + 0] = i0 | (i1 << 16); L.prange[4 * tid + 1] = j0 | (j1 << 16); L.prange[4 * tid + 2] = w2; L.prange[4 * tid + 3] = items;
+    if (items > 0)
+      for (int w = i0 >> 5; w <= i1 >> 5; ++w) {
+        const int lo = max(i0 - 32 * w, 0), hi = min(i1 - 32 * w, 31);
+        atomicOr(&L.rowmask[w], (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo));
+      }
   }
+  // epilogue constants (the rows no rock reaches are written out before the ray cast, see below)
+  const float nearp = SRL_FAR - P.c.max_z;
+  const float den = fmaxf(P.c.max_z, P.c.object_max_dimension);   // env.py:171-172
+  const float gz = P.goal_z;
+  const uint32_t gbyte = (uint8_t)((gz * 255.0f) / den);
+  const uint32_t zbyte = (uint8_t)((0.0f * 255.0f) / den);
+  const float h_empty = elev_overhead(P, depth_encode(SRL_FAR - 0.0f, nearp, SRL_FAR));
+  const uint32_t b_empty = (uint8_t)((h_empty * 255.0f) / den);
+  float* Hout = ext ? height_ext + (size_t)e * npx : P.H + (size_t)e * npx;
+  uint8_t* om = ext ? nullptr : obs_map + (size_t)e * npx * 2;
+  __syncthreads();
+  // ---- rows no rock reaches hold the empty-pixel constants: their H / observation bytes leave now, so
+  //      that HBM drains them while the ray cast computes.  cov bit k: this thread's k-th pixel group lies
+  //      in a row some rock may reach (handled by the epilogue).  The IoU sums of all groups are taken in
+  //      the epilogue, in the fixed order.
+  uint32_t cov = 0u;
+  {
+    int k = 0;
+    const float4 he4 = make_float4(h_empty, h_empty, h_empty, h_empty);
+    for (int g = tid; g < npx / 4; g += SRL_RENDER_THREADS, ++k) {
+      const int k0 = g * 4, i = k0 / res, jb = k0 - i * res;
+      if ((L.rowmask[i >> 5] >> (i & 31)) & 1u) { cov |= 1u << k; continue; }
+      ((float4*)Hout)[g] = he4;
+      if (om) {
+        const bool row_in = (i >= g0 && i < g0 + g2);
+        uint32_t pk[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int j = jb + t;
+          pk[t] = b_empty | (((row_in && (j >= g1 && j < g1 + g3)) ? gbyte : zbyte) << 8);
+        }
+        ((uint2*)om)[g] = make_uint2(pk[0] | (pk[1] << 16), pk[2] | (pk[3] << 16));
+      }
+    }
+  }
+  RSTAMP(6);
   while (bs < nb) {
     if (bs > 0) {   // later groups: cursors, then request the planes
       if (tid >= bs && tid < be) {
@@ -358,42 +402,45 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   __syncthreads();
   RSTAMP(4);
   // ---- epilogue: depth codec, H out, uint8 pack, IoU partial sums (4 pixels per thread per round)
-  const float nearp = SRL_FAR - P.c.max_z;
-  const float den = fmaxf(P.c.max_z, P.c.object_max_dimension);   // env.py:171-172
-  const float gz = P.goal_z;
-  const uint32_t gbyte = (uint8_t)((gz * 255.0f) / den);
-  const uint32_t zbyte = (uint8_t)((0.0f * 255.0f) / den);
-  const float h_empty = elev_overhead(P, depth_encode(SRL_FAR - 0.0f, nearp, SRL_FAR));
-  const uint32_t b_empty = (uint8_t)((h_empty * 255.0f) / den);
-  float* Hout = ext ? height_ext + (size_t)e * npx : P.H + (size_t)e * npx;
-  uint8_t* om = ext ? nullptr : obs_map + (size_t)e * npx * 2;
   float spi = 0.0f, spu = 0.0f;
-  for (int g = tid; g < npx / 4; g += SRL_RENDER_THREADS) {
-    const int k0 = g * 4;
-    const float4 z4 = ((const float4*)L.tile)[g];
-    const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-    const bool any = (z4.x > 0.0f) || (z4.y > 0.0f) || (z4.z > 0.0f) || (z4.w > 0.0f);
-    const int i = k0 / res, jb = k0 - i * res;
-    const bool row_in = (i >= g0 && i < g0 + g2);
-    float hv[4];
-    uint32_t pk[4];
+  {
+    int k = 0;
+    for (int g = tid; g < npx / 4; g += SRL_RENDER_THREADS, ++k) {
+      const int k0 = g * 4;
+      const int i = k0 / res, jb = k0 - i * res;
+      const bool row_in = (i >= g0 && i < g0 + g2);
+      if (!((cov >> k) & 1u)) {   // written out above; sums only
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      float hh = h_empty;
-      uint32_t hb = b_empty;
-      if (any && zz[t] > 0.0f) {
-        hh = elev_overhead(P, depth_encode(SRL_FAR - zz[t], nearp, SRL_FAR));
-        hb = (uint8_t)((hh * 255.0f) / den);
+        for (int t = 0; t < 4; ++t) {
+          const int j = jb + t;
+          if (row_in && (j >= g1 && j < g1 + g3)) { spi += fminf(h_empty, gz); spu += fmaxf(h_empty, gz); }
+          else spu += fmaxf(h_empty, 0.0f);
+        }
+        continue;
       }
-      hv[t] = hh;
-      const int j = jb + t;
-      const bool in = row_in && (j >= g1 && j < g1 + g3);
-      if (in) { spi += fminf(hh, gz); spu += fmaxf(hh, gz); }
-      else spu += fmaxf(hh, 0.0f);
-      pk[t] = hb | ((in ? gbyte : zbyte) << 8);
+      const float4 z4 = ((const float4*)L.tile)[g];
+      const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+      const bool any = (z4.x > 0.0f) || (z4.y > 0.0f) || (z4.z > 0.0f) || (z4.w > 0.0f);
+      float hv[4];
+      uint32_t pk[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float hh = h_empty;
+        uint32_t hb = b_empty;
+        if (any && zz[t] > 0.0f) {
+          hh = elev_overhead(P, depth_encode(SRL_FAR - zz[t], nearp, SRL_FAR));
+          hb = (uint8_t)((hh * 255.0f) / den);
+        }
+        hv[t] = hh;
+        const int j = jb + t;
+        const bool in = row_in && (j >= g1 && j < g1 + g3);
+        if (in) { spi += fminf(hh, gz); spu += fmaxf(hh, gz); }
+        else spu += fmaxf(hh, 0.0f);
+        pk[t] = hb | ((in ? gbyte : zbyte) << 8);
+      }
+      ((float4*)Hout)[g] = make_float4(hv[0], hv[1], hv[2], hv[3]);
+      if (om) ((uint2*)om)[g] = make_uint2(pk[0] | (pk[1] << 16), pk[2] | (pk[3] << 16));
     }
-    ((float4*)Hout)[g] = make_float4(hv[0], hv[1], hv[2], hv[3]);
-    if (om) ((uint2*)om)[g] = make_uint2(pk[0] | (pk[1] << 16), pk[2] | (pk[3] << 16));
   }
   RSTAMP(5);
   if (ext) return;
