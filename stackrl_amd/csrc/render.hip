@@ -104,58 +104,91 @@ __device__ float discounted_metric(const DevParams& P, const EnvHdr* h, const fl
   return r / (float)(P.c.episode_length + nout);
 }
 
-#define SRL_PLANE_CAP 512    // planes staged in LDS per group of rocks (8 KB); = SRL_RENDER_THREADS
+#ifndef SRL_PLANE_CAP
+#define SRL_PLANE_CAP 768    // planes staged in LDS per group of rocks (12 KB): 8 rocks of the default pool in one group
+#endif
+#define SRL_PLANE_ROUNDS ((SRL_PLANE_CAP + SRL_RENDER_THREADS - 1) / SRL_RENDER_THREADS)
 
-// LDS carve of srl_k_render
+// LDS carve of srl_k_render (64 KB tile + 12 KB planes + 3 KB per-rock records at 128^2: two workgroups per CU)
 struct RenderLds {
   float* tile;      // [res*res]
   float4* planes;   // [SRL_PLANE_CAP] per rock region: up-facing from the front, down-facing from the back
   float* sx;        // [32][3]
   float* sR;        // [32][9]
   int* mhdr;        // [32][4] vo, nv, to, nt
-  uint32_t* bbox;   // [32][4] ordered-uint xmin, xmax, ymin, ymax
   int* prange;      // [32][4] i0|i1<<16, j0|j1<<16, w2 (quads per row), quads
-  int* reg;         // [32][4] region base, up cursor, down cursor (exclusive, counts down), -
+  int* reg;         // [32][4] region base in its group, end of its up-facing planes, plane count, planes before this rock
   uint32_t* rowmask;   // [8] bit i set: tile row i may hold a rock pixel (union of the rocks' row ranges)
-  float* pi;        // [512]  (aliases the plane staging area: used after the ray cast)
+  int* misc;        // [4] rocks in the first group
+  float* pi;        // [512]  (pi, pu and the codec scratch alias the plane staging area: used after the ray cast)
   float* pu;        // [512]
+  float* cz;        // [8 waves][3][64] epilogue codec scratch
 };
 
 __host__ __device__ inline size_t render_lds_bytes(int res) {
   return sizeof(float) * (size_t)res * res + sizeof(float4) * SRL_PLANE_CAP +
-         sizeof(float) * (3 + 9 + 4 + 4 + 4 + 4) * SRL_MAX_BODIES + sizeof(uint32_t) * 8;
+         sizeof(float) * (3 + 9 + 4 + 4 + 4) * SRL_MAX_BODIES + sizeof(uint32_t) * (8 + 4);
 }
 
 // one min / max sweep over planes [0, n) of a region, this lane taking 4-plane batches s, s+S, ...
+// z = fmaf(a, px, fmaf(b, py, c)) per pixel (the definition), evaluated two pixels at a
+// time with packed fp32 FMAs (v_pk_fma_f32: IEEE fma per half, same bits as the scalar form).  The plane is
+// fetched as one 16-byte LDS read (ds_read_b128: 4 LDS cycles per wave against 8 for a 12-byte read).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool UP>
+__device__ __forceinline__ void plane_eval(const float4 q, const f32x2 py, const f32x2 px0, const f32x2 px1, f32x2& za,
+                                           f32x2& zb) {
+  const f32x2 a = {q.x, q.x}, b = {q.y, q.y}, c = {q.z, q.z};
+  const f32x2 t = __builtin_elementwise_fma(b, py, c);
+  const f32x2 r0 = __builtin_elementwise_fma(a, px0, t), r1 = __builtin_elementwise_fma(a, px1, t);
+  if (UP) { za.x = fminf(za.x, r0.x); za.y = fminf(za.y, r0.y); zb.x = fminf(zb.x, r1.x); zb.y = fminf(zb.y, r1.y); }
+  else { za.x = fmaxf(za.x, r0.x); za.y = fmaxf(za.y, r0.y); zb.x = fmaxf(zb.x, r1.x); zb.y = fmaxf(zb.y, r1.y); }
+}
+
 template <bool UP>
 __device__ __forceinline__ void plane_sweep(const float4* pl, int n, int s, int S, float px0, float px1, float py0,
                                             float py1, float& z00, float& z01, float& z10, float& z11) {
+  const f32x2 py = {py0, py1}, vx0 = {px0, px0}, vx1 = {px1, px1};
+  f32x2 za = {z00, z01}, zb = {z10, z11};
   const int nb4 = n >> 2;
-  for (int kb = s; kb < nb4; kb += S) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float4 q = pl[4 * kb + u];
-      const float t0 = fmaf(q.y, py0, q.z), t1 = fmaf(q.y, py1, q.z);
-      if (UP) {
-        z00 = fminf(z00, fmaf(q.x, px0, t0)); z01 = fminf(z01, fmaf(q.x, px0, t1));
-        z10 = fminf(z10, fmaf(q.x, px1, t0)); z11 = fminf(z11, fmaf(q.x, px1, t1));
-      } else {
-        z00 = fmaxf(z00, fmaf(q.x, px0, t0)); z01 = fmaxf(z01, fmaf(q.x, px0, t1));
-        z10 = fmaxf(z10, fmaf(q.x, px1, t0)); z11 = fmaxf(z11, fmaf(q.x, px1, t1));
-      }
+  if (s < nb4) {   // 4-plane batches, two per trip, the next one in flight while one is evaluated; a trip
+                   // whose second batch would run past the end re-reads its first (min / max are idempotent)
+    float4 q0 = pl[4 * s], q1 = pl[4 * s + 1], q2 = pl[4 * s + 2], q3 = pl[4 * s + 3];
+    for (int kb = s; kb < nb4; kb += 2 * S) {
+      const int k1 = kb + S < nb4 ? kb + S : kb;
+      float4 r0 = pl[4 * k1], r1 = pl[4 * k1 + 1], r2 = pl[4 * k1 + 2], r3 = pl[4 * k1 + 3];
+      asm volatile("" : "+v"(q0.w), "+v"(q1.w), "+v"(q2.w), "+v"(q3.w));   // keeps each fetch one 16-byte read
+      plane_eval<UP>(q0, py, vx0, vx1, za, zb); plane_eval<UP>(q1, py, vx0, vx1, za, zb);
+      plane_eval<UP>(q2, py, vx0, vx1, za, zb); plane_eval<UP>(q3, py, vx0, vx1, za, zb);
+      const int k2 = kb + 2 * S < nb4 ? kb + 2 * S : kb;
+      q0 = pl[4 * k2]; q1 = pl[4 * k2 + 1]; q2 = pl[4 * k2 + 2]; q3 = pl[4 * k2 + 3];
+      asm volatile("" : "+v"(r0.w), "+v"(r1.w), "+v"(r2.w), "+v"(r3.w));
+      plane_eval<UP>(r0, py, vx0, vx1, za, zb); plane_eval<UP>(r1, py, vx0, vx1, za, zb);
+      plane_eval<UP>(r2, py, vx0, vx1, za, zb); plane_eval<UP>(r3, py, vx0, vx1, za, zb);
     }
   }
   for (int t = 4 * nb4 + s; t < n; t += S) {
-    const float4 q = pl[t];
-    const float t0 = fmaf(q.y, py0, q.z), t1 = fmaf(q.y, py1, q.z);
-    if (UP) {
-      z00 = fminf(z00, fmaf(q.x, px0, t0)); z01 = fminf(z01, fmaf(q.x, px0, t1));
-      z10 = fminf(z10, fmaf(q.x, px1, t0)); z11 = fminf(z11, fmaf(q.x, px1, t1));
-    } else {
-      z00 = fmaxf(z00, fmaf(q.x, px0, t0)); z01 = fmaxf(z01, fmaf(q.x, px0, t1));
-      z10 = fmaxf(z10, fmaf(q.x, px1, t0)); z11 = fmaxf(z11, fmaf(q.x, px1, t1));
-    }
+    float4 q = pl[t];
+    asm volatile("" : "+v"(q.w));
+    plane_eval<UP>(q, py, vx0, vx1, za, zb);
   }
+  z00 = za.x; z01 = za.y; z10 = zb.x; z11 = zb.y;
+}
+
+// min / max over the 64 lanes of a wave by DPP row shifts and row broadcasts (no LDS traffic); the result is
+// returned to every lane through an SGPR.  min / max are idempotent, so lanes without a source keep their own value.
+template <bool MIN>
+__device__ __forceinline__ float wave_minmax(float v) {
+#define SRL_DPP_STEP(ctrl, rows)                                                                                      \
+  {                                                                                                                   \
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rows, 0xf, false)); \
+    v = MIN ? fminf(v, o) : fmaxf(v, o);                                                                              \
+  }
+  SRL_DPP_STEP(0x111, 0xf) SRL_DPP_STEP(0x112, 0xf) SRL_DPP_STEP(0x114, 0xf) SRL_DPP_STEP(0x118, 0xf)   // row_shr:1,2,4,8
+  SRL_DPP_STEP(0x142, 0xa) SRL_DPP_STEP(0x143, 0xc)                                                      // row_bcast:15, :31
+#undef SRL_DPP_STEP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // poses_ext != nullptr: test/profiling hook rendering explicit poses (srl_render_heightmap)
@@ -164,7 +197,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
              uint8_t* __restrict__ done, const float* __restrict__ poses_ext, const int32_t* __restrict__ mesh_ext,
              const int32_t* __restrict__ nb_ext, float* __restrict__ height_ext) {
   extern __shared__ float4 lds_raw[];
-  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int res = P.c.overhead_res, npx = res * res;
   RenderLds L;
   L.tile = (float*)lds_raw;
@@ -172,20 +205,41 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   L.sx = (float*)(L.planes + SRL_PLANE_CAP);
   L.sR = L.sx + 3 * SRL_MAX_BODIES;
   L.mhdr = (int*)(L.sR + 9 * SRL_MAX_BODIES);
-  L.bbox = (uint32_t*)(L.mhdr + 4 * SRL_MAX_BODIES);
-  L.prange = (int*)(L.bbox + 4 * SRL_MAX_BODIES);
+  L.prange = L.mhdr + 4 * SRL_MAX_BODIES;
   L.reg = L.prange + 4 * SRL_MAX_BODIES;
   L.rowmask = (uint32_t*)(L.reg + 4 * SRL_MAX_BODIES);
+  L.misc = (int*)(L.rowmask + 8);
   L.pi = (float*)L.planes;
   L.pu = L.pi + SRL_RENDER_THREADS;
+  L.cz = L.pu + SRL_RENDER_THREADS;
   EnvHdr* h = &P.hdr[e];
   const float* gb = P.blob + (size_t)e * P.BLOB;
   const bool ext = poses_ext != nullptr;
 #ifdef SRL_STAMPS
   long long _t0 = wall_clock64();
 #endif
+  // ---- prologue.  Pose, mesh id and mesh header of every body slot are requested before the rock count is
+  //      known (one memory round trip less); the header fields and the object map are requested up front too:
+  //      their latency overlaps the ray cast.
+  q4 q; v3 x = V(0.0f, 0.0f, 0.0f); MeshHdr mh;
+  q.x = q.y = q.z = 0.0f; q.w = 1.0f;
+  mh.vo = mh.nv = mh.to = mh.nt = 0;
+  if (tid < (ext ? SRL_MAX_BODIES : P.c.episode_length)) {
+    int m;
+    if (ext) {
+      const float* p = poses_ext + ((size_t)e * SRL_MAX_BODIES + tid) * 7;
+      x = V(p[0], p[1], p[2]); q.x = p[3]; q.y = p[4]; q.z = p[5]; q.w = p[6];
+      m = mesh_ext[(size_t)e * SRL_MAX_BODIES + tid];
+    } else {
+      x = ld3(gb + P.OFF_X + 4 * tid);
+      const float* qq = gb + P.OFF_Q + 4 * tid;
+      q.x = qq[0]; q.y = qq[1]; q.z = qq[2]; q.w = qq[3];
+      m = ((const int*)gb)[P.OFF_MESH + tid];
+    }
+    m = min(max(m, 0), P.n_mesh - 1);   // slots past the rock count hold stale or no data
+    mh = P.mh[m];
+  }
   const int nb = ext ? nb_ext[e] : h->nb;
-  // header fields and the object map are requested up front: their latency overlaps the ray cast
   int g0 = 0, g1 = 0, g2 = 0, g3 = 0, pending = -1, mode = 0, hdone = 0;
   float prev_metric = 0.0f;
   if (!ext) {
@@ -199,83 +253,31 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     for (int k = 0; k < 2; ++k)
       if (tid + k * SRL_RENDER_THREADS < rr) om_pref[k] = P.objmap[(size_t)pending * rr + tid + k * SRL_RENDER_THREADS];
   }
-
   {
     float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float4* t4 = (float4*)L.tile;
     for (int k = tid; k < npx / 4; k += SRL_RENDER_THREADS) t4[k] = z4;
   }
   if (tid < 8) L.rowmask[tid] = 0u;
-  if (tid < nb) {
-    q4 q; v3 x; int m;
-    if (ext) {
-      const float* p = poses_ext + ((size_t)e * SRL_MAX_BODIES + tid) * 7;
-      x = V(p[0], p[1], p[2]); q.x = p[3]; q.y = p[4]; q.z = p[5]; q.w = p[6];
-      m = mesh_ext[(size_t)e * SRL_MAX_BODIES + tid];
-    } else {
-      x = ld3(gb + P.OFF_X + 4 * tid);
-      const float* qq = gb + P.OFF_Q + 4 * tid;
-      q.x = qq[0]; q.y = qq[1]; q.z = qq[2]; q.w = qq[3];
-      m = ((const int*)gb)[P.OFF_MESH + tid];
-    }
-    m3 R = quat_to_mat(q);
-    st3(L.sx + 3 * tid, x);
+  if (tid < SRL_MAX_BODIES) {
+    const int nt = tid < nb ? mh.nt : 0;
+    int pre = nt;   // inclusive prefix of the plane counts over the rocks (lanes 0..31 of wave 0)
 #pragma unroll
-    for (int i = 0; i < 9; ++i) L.sR[9 * tid + i] = R.m[i];
-    const MeshHdr mh = P.mh[m];
-    L.mhdr[4 * tid + 0] = mh.vo; L.mhdr[4 * tid + 1] = mh.nv; L.mhdr[4 * tid + 2] = mh.to; L.mhdr[4 * tid + 3] = mh.nt;
-    L.bbox[4 * tid + 0] = f2o(1e30f); L.bbox[4 * tid + 1] = f2o(-1e30f);
-    L.bbox[4 * tid + 2] = f2o(1e30f); L.bbox[4 * tid + 3] = f2o(-1e30f);
-  }
-  __syncthreads();
-  RSTAMP(0);
-  // ---- groups of rocks whose planes fit the staging area; the first group's face planes are requested
-  //      now so that their latency overlaps the vertex pass
-  int bs = 0, be = 0;
-  {
-    int np_group = 0;
-    while (be < nb && np_group + L.mhdr[4 * be + 3] <= SRL_PLANE_CAP) { np_group += L.mhdr[4 * be + 3]; ++be; }
-  }
-  float4 myp = make_float4(0.0f, 0.0f, 0.0f, 0.0f); int myb = -1;
-  {
-    int b = bs, ts = 0, ntb = nb > 0 ? L.mhdr[3] : 0;
-    while (b < be && tid >= ts + ntb) { ts += ntb; ++b; ntb = b < be ? L.mhdr[4 * b + 3] : 0; }
-    if (b < be) { myp = P.mp[L.mhdr[4 * b + 2] + (tid - ts)]; myb = b; }
-    if (tid < be) {   // region cursors of group 0
-      int base = 0;
-      for (int k = 0; k < tid; ++k) base += L.mhdr[4 * k + 3];
-      L.reg[4 * tid + 0] = base; L.reg[4 * tid + 1] = base; L.reg[4 * tid + 2] = base + L.mhdr[4 * tid + 3];
+    for (int d = 1; d < SRL_MAX_BODIES; d <<= 1) { const int v = __shfl_up(pre, d); if (lane >= d) pre += v; }
+    const int be0 = __popcll(__ballot(tid < nb && pre <= SRL_PLANE_CAP));   // rocks whose planes fit the first group
+    if (tid == 0) L.misc[0] = be0;
+    if (tid < nb) {
+      m3 R = quat_to_mat(q);
+      st3(L.sx + 3 * tid, x);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) L.sR[9 * tid + i] = R.m[i];
+      L.mhdr[4 * tid + 0] = mh.vo; L.mhdr[4 * tid + 1] = mh.nv; L.mhdr[4 * tid + 2] = mh.to; L.mhdr[4 * tid + 3] = mh.nt;
+      // cursors as for the first group (later groups reset theirs)
+      L.reg[4 * tid + 0] = pre - nt; L.reg[4 * tid + 1] = pre - nt; L.reg[4 * tid + 2] = nt; L.reg[4 * tid + 3] = pre - nt;
+      L.prange[4 * tid + 3] = 0;
     }
   }
-  // ---- xy bounds of every rock: lanes over the flattened (rock, vertex) list
-  {
-    int b = 0, vs = 0, nvb = nb > 0 ? L.mhdr[1] : 0;
-    for (int it = tid;; it += SRL_RENDER_THREADS) {
-      while (b < nb && it >= vs + nvb) { vs += nvb; ++b; nvb = b < nb ? L.mhdr[4 * b + 1] : 0; }
-      if (b >= nb) break;
-      m3 R = ldm(L.sR + 9 * b);
-      float4 lv = P.mv[L.mhdr[4 * b + 0] + (it - vs)];
-      v3 a = mmul_add(R, V(lv.x, lv.y, lv.z), ld3(L.sx + 3 * b));
-      atomicMin(&L.bbox[4 * b + 0], f2o(a.x)); atomicMax(&L.bbox[4 * b + 1], f2o(a.x));
-      atomicMin(&L.bbox[4 * b + 2], f2o(a.y)); atomicMax(&L.bbox[4 * b + 3], f2o(a.y));
-    }
-  }
-  __syncthreads();
-  RSTAMP(1);
-  if (tid < nb) {
-    int i0 = 0, i1 = -1, j0 = 0, j1 = -1;
-    bool okx = pixel_range(o2f(L.bbox[4 * tid + 0]), o2f(L.bbox[4 * tid + 1]), P.inv_px, res, i0, i1);
-    bool oky = pixel_range(o2f(L.bbox[4 * tid + 2]), o2f(L.bbox[4 * tid + 3]), P.inv_px, res, j0, j1);
-    int w2 = 0, items = 0;
-    if (okx && oky) { w2 = (j1 - j0 + 2) >> 1; items = ((i1 - i0 + 2) >> 1) * w2; }   // 2 x 2 pixel quads
-    L.prange[4 * tid + 0] = i0 | (i1 << 16); L.prange[4 * tid + 1] = j0 | (j1 << 16); L.prange[4 * tid + 2] = w2; L.prange[4 * tid + 3] = items;
-    if (items > 0)
-      for (int w = i0 >> 5; w <= i1 >> 5; ++w) {
-        const int lo = max(i0 - 32 * w, 0), hi = min(i1 - 32 * w, 31);
-        atomicOr(&L.rowmask[w], (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo));
-      }
-  }
-  // epilogue constants (the rows no rock reaches are written out before the ray cast, see below)
+  // epilogue constants
   const float nearp = SRL_FAR - P.c.max_z;
   const float den = fmaxf(P.c.max_z, P.c.object_max_dimension);   // env.py:171-172
   const float gz = P.goal_z;
@@ -285,93 +287,149 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   const uint32_t b_empty = (uint8_t)((h_empty * 255.0f) / den);
   float* Hout = ext ? height_ext + (size_t)e * npx : P.H + (size_t)e * npx;
   uint8_t* om = ext ? nullptr : obs_map + (size_t)e * npx * 2;
+  const int ngroups4 = npx / 4, nrounds = (ngroups4 + SRL_RENDER_THREADS - 1) / SRL_RENDER_THREADS;
+  // pixel-group walk of a thread: group g = tid + 512 k holds pixels 4 g .. 4 g + 3 = row i, columns jb .. jb + 3
+  // (res is a multiple of 8); from one round to the next the group advances by di rows and dj columns
+  const int walk_di = (4 * SRL_RENDER_THREADS) / res, walk_dj = 4 * SRL_RENDER_THREADS - walk_di * res;
+  const int walk_i0 = (4 * tid) / res, walk_j0 = 4 * tid - walk_i0 * res;
+  const uint32_t gdiff = (gbyte ^ zbyte) << 8, zpair = (zbyte << 8) | (zbyte << 24);
   __syncthreads();
-  // ---- rows no rock reaches hold the empty-pixel constants: their H / observation bytes leave now, so
-  //      that HBM drains them while the ray cast computes.  cov bit k: this thread's k-th pixel group lies
-  //      in a row some rock may reach (handled by the epilogue).  The IoU sums of all groups are taken in
-  //      the epilogue, in the fixed order.
+  RSTAMP(0);
+  // ---- groups of rocks whose planes fit the staging area
+  int bs = 0, be = L.misc[0];   // (be >= 1 when nb >= 1: a mesh has at most SRL_MAX_TRIS <= SRL_PLANE_CAP faces)
   uint32_t cov = 0u;
-  {
-    int k = 0;
-    const float4 he4 = make_float4(h_empty, h_empty, h_empty, h_empty);
-    for (int g = tid; g < npx / 4; g += SRL_RENDER_THREADS, ++k) {
-      const int k0 = g * 4, i = k0 / res, jb = k0 - i * res;
-      if ((L.rowmask[i >> 5] >> (i & 31)) & 1u) { cov |= 1u << k; continue; }
-      ((float4*)Hout)[g] = he4;
-      if (om) {
-        const bool row_in = (i >= g0 && i < g0 + g2);
-        uint32_t pk[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int j = jb + t;
-          pk[t] = b_empty | (((row_in && (j >= g1 && j < g1 + g3)) ? gbyte : zbyte) << 8);
-        }
-        ((uint2*)om)[g] = make_uint2(pk[0] | (pk[1] << 16), pk[2] | (pk[3] << 16));
-      }
-    }
-  }
-  RSTAMP(6);
-  while (bs < nb) {
-    if (bs > 0) {   // later groups: cursors, then request the planes
-      if (tid >= bs && tid < be) {
-        int base = 0;
-        for (int k = bs; k < tid; ++k) base += L.mhdr[4 * k + 3];
-        L.reg[4 * tid + 0] = base; L.reg[4 * tid + 1] = base; L.reg[4 * tid + 2] = base + L.mhdr[4 * tid + 3];
-      }
-      int b = bs, ts = 0, ntb = L.mhdr[4 * bs + 3];
-      myb = -1;
-      while (b < be && tid >= ts + ntb) { ts += ntb; ++b; ntb = b < be ? L.mhdr[4 * b + 3] : 0; }
-      if (b < be) { myp = P.mp[L.mhdr[4 * b + 2] + (tid - ts)]; myb = b; }
-      __syncthreads();
-    }
-    // (a) world-frame plane; slot by wave-aggregated cursor bumps (up from the front, down from the back;
-    //     the order inside a region is irrelevant: min / max)
+  bool first = true;
+  do {
+    // (a) one wave per rock (rocks wave, wave + 8, ...).  First trip: xy bounds of every rock (vertices over
+    //     the lanes, DPP min / max) -> pixel range, quad count, row mask.  Every trip: the world-frame planes of
+    //     the group's rocks, up-facing ones packed from the front of the rock's region and down-facing ones
+    //     from its back by ballot ranks (the order inside a region is irrelevant: min / max).
     {
-      int key = -1;
-      if (myb >= 0) {
-        myp = make_rplane(myp, ldm(L.sR + 9 * myb), ld3(L.sx + 3 * myb));
-        key = (myb << 1) | __float_as_int(myp.w);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      for (int b = (first ? 0 : bs) + wave; b < (first ? nb : be); b += SRL_RENDER_THREADS / 64) {
+        const m3 R = ldm(L.sR + 9 * b);
+        const v3 xb = ld3(L.sx + 3 * b);
+        const int vo = L.mhdr[4 * b + 0], nv = L.mhdr[4 * b + 1], to = L.mhdr[4 * b + 2], nt = L.mhdr[4 * b + 3];
+        const bool planes = b >= bs && b < be;
+        float4 pl0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pl1 = pl0;
+        if (planes) {   // the first two chunks are requested before the vertex pass
+          if (lane < nt) pl0 = P.mp[to + lane];
+          if (64 + lane < nt) pl1 = P.mp[to + 64 + lane];
+        }
+        if (first) {
+          float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+          for (int v = lane; v < nv; v += 64) {
+            const float4 lv = P.mv[vo + v];
+            const v3 a = mmul_add(R, V(lv.x, lv.y, lv.z), xb);
+            xmin = fminf(xmin, a.x); xmax = fmaxf(xmax, a.x); ymin = fminf(ymin, a.y); ymax = fmaxf(ymax, a.y);
+          }
+          xmin = wave_minmax<true>(xmin); xmax = wave_minmax<false>(xmax);
+          ymin = wave_minmax<true>(ymin); ymax = wave_minmax<false>(ymax);
+          if (lane == 0) {
+            int i0 = 0, i1 = -1, j0 = 0, j1 = -1;
+            const bool okx = pixel_range(xmin, xmax, P.inv_px, res, i0, i1);
+            const bool oky = pixel_range(ymin, ymax, P.inv_px, res, j0, j1);
+            int w2 = 0, items = 0;
+            if (okx && oky) { w2 = (j1 - j0 + 2) >> 1; items = ((i1 - i0 + 2) >> 1) * w2; }   // 2 x 2 pixel quads
+            L.prange[4 * b + 0] = i0 | (i1 << 16); L.prange[4 * b + 1] = j0 | (j1 << 16); L.prange[4 * b + 2] = w2; L.prange[4 * b + 3] = items;
+            if (items > 0)
+              for (int w = i0 >> 5; w <= i1 >> 5; ++w) {
+                const int lo = max(i0 - 32 * w, 0), hi = min(i1 - 32 * w, 31);
+                atomicOr(&L.rowmask[w], (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo));
+              }
+          }
+        }
+        if (planes) {
+          const int base = L.reg[4 * b + 0];
+          int nup = 0, ndn = 0;
+          for (int c = 0; c < nt; c += 64) {
+            const bool act = c + lane < nt;
+            float4 pl = c == 0 ? pl0 : pl1;
+            if (c >= 128 && act) pl = P.mp[to + c + lane];
+            const float4 wp = make_rplane(pl, R, xb);
+            const bool up = act && __float_as_int(wp.w) == 0, dn = act && __float_as_int(wp.w) != 0;
+            const unsigned long long mu = __ballot(up), md = __ballot(dn);
+            if (up) L.planes[base + nup + __popcll(mu & below)] = wp;
+            if (dn) L.planes[base + nt - 1 - (ndn + __popcll(md & below))] = wp;
+            nup += __popcll(mu); ndn += __popcll(md);
+          }
+          if (lane == 0) L.reg[4 * b + 1] = base + nup;   // end of the up-facing planes = start of the down-facing ones
+        }
       }
-      unsigned long long todo = __ballot(key >= 0);
-      int slot = -1;
-      while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int k = __shfl(key, leader);
-        const unsigned long long m = __ballot(key == k);
-        const int cnt = __popcll(m);
-        const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        int basev = 0;
-        if (lane == leader) basev = (k & 1) ? atomicSub(&L.reg[4 * (k >> 1) + 2], cnt) : atomicAdd(&L.reg[4 * (k >> 1) + 1], cnt);
-        basev = __shfl(basev, leader);
-        if (key == k) slot = (k & 1) ? (basev - 1 - rank) : (basev + rank);
-        todo &= ~m;
-      }
-      if (slot >= 0) L.planes[slot] = myp;
     }
     __syncthreads();
-  RSTAMP(2);
-    // (b) lanes over the flattened (rock, 2 x 2 pixel quad) list; when the list is short each quad is
-    //     shared by S adjacent lanes that split the planes and combine with shuffles
-    {
+    RSTAMP(1);
+    // (d) first trip: rows no rock reaches hold the empty-pixel constants; their H / observation bytes leave
+    //     now, so that HBM drains them while the ray cast computes.  cov bit k: this thread's k-th pixel group
+    //     lies in a row some rock may reach (written by the epilogue).
+    if (first) {
+      const float4 he4 = make_float4(h_empty, h_empty, h_empty, h_empty);
+      const uint32_t epair = b_empty | (b_empty << 16);
+      int i = walk_i0, jb = walk_j0;
+      for (int k = 0; k < nrounds; ++k) {
+        const int g = tid + k * SRL_RENDER_THREADS;
+        if (g >= ngroups4) break;
+        if ((L.rowmask[i >> 5] >> (i & 31)) & 1u) cov |= 1u << k;
+        else {
+          ((float4*)Hout)[g] = he4;
+          if (om) {
+            uint32_t lo = epair | zpair, hi = epair | zpair;
+            if (i >= g0 && i < g0 + g2) {
+              if (jb >= g1 && jb < g1 + g3) lo ^= gdiff;
+              if (jb + 1 >= g1 && jb + 1 < g1 + g3) lo ^= gdiff << 16;
+              if (jb + 2 >= g1 && jb + 2 < g1 + g3) hi ^= gdiff;
+              if (jb + 3 >= g1 && jb + 3 < g1 + g3) hi ^= gdiff << 16;
+            }
+            ((uint2*)om)[g] = make_uint2(lo, hi);
+          }
+        }
+        jb += walk_dj; i += walk_di;
+        if (jb >= res) { jb -= res; ++i; }
+      }
+      RSTAMP(2);
+    }
+    // (e) ray cast: lanes over the flattened (rock, 2 x 2 pixel quad) list; when the list is short each quad
+    //     is shared by S adjacent lanes that split the planes and combine with shuffles
+    if (be > bs) {
+      // quad counts of the group's rocks as running sums (registers, one LDS round trip); groups of more
+      // than 8 rocks fall back to walking the list
+      const bool few = be - bs <= 8;
+      int pre[8];
       int total = 0;
-      for (int b = bs; b < be; ++b) total += L.prange[4 * b + 3];
+      if (few) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pre[r] = bs + r < be ? L.prange[4 * (bs + r) + 3] : 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { total += pre[r]; pre[r] = total; }
+      } else {
+        for (int b = bs; b < be; ++b) total += L.prange[4 * b + 3];
+      }
       int lg = 0;
       while (lg < 3 && (total << (lg + 1)) <= SRL_RENDER_THREADS) ++lg;
       const int S = 1 << lg, s = tid & (S - 1);
-      int b = bs, is = 0, nib = L.prange[4 * bs + 3];
-      for (int it = tid >> lg;; it += SRL_RENDER_THREADS >> lg) {
-        while (b < be && it >= is + nib) { is += nib; ++b; nib = b < be ? L.prange[4 * b + 3] : 0; }
-        if (b >= be) break;
-        const int w2 = L.prange[4 * b + 2], jj = L.prange[4 * b + 1], ii = L.prange[4 * b + 0];
+      int wb = bs, wis = 0, wnib = few ? 0 : L.prange[4 * bs + 3];
+      for (int it = tid >> lg; it < total; it += SRL_RENDER_THREADS >> lg) {
+        int b, is;
+        if (few) {
+          b = bs; is = 0;
+#pragma unroll
+          for (int r = 0; r < 7; ++r) if (it >= pre[r]) { b = bs + r + 1; is = pre[r]; }
+        } else {
+          while (it >= wis + wnib) { wis += wnib; ++wb; wnib = L.prange[4 * wb + 3]; }
+          b = wb; is = wis;
+        }
+        const int4 pr = ((const int4*)L.prange)[b], rg = ((const int4*)L.reg)[b];
+        const int w2 = pr.z, jj = pr.y, ii = pr.x;
         const int j0 = jj & 0xffff, j1 = jj >> 16, i1 = ii >> 16;
         const int p = it - is;
-        const int di = p / w2;
+        // p / w2 without the integer-division sequence: (p + 0.5) / w2 stays at least 0.5 / w2 >= 1 / 256 away from
+        // an integer, far more than the error of the reciprocal (p < 2^14, w2 <= 128)
+        const int di = (int)(((float)p + 0.5f) * __builtin_amdgcn_rcpf((float)w2));
         const int i = (ii & 0xffff) + 2 * di, j = j0 + 2 * (p - di * w2);
         const bool row2 = i + 1 <= i1, col2 = j + 1 <= j1;
         const float px0 = ((float)i + 0.5f) * P.px, px1 = ((float)(i + 1) + 0.5f) * P.px;
         const float py0 = ((float)j + 0.5f) * P.px, py1 = ((float)(j + 1) + 0.5f) * P.px;
-        const int base = L.reg[4 * b + 0], nup = L.reg[4 * b + 1] - base;
-        const int dn0 = L.reg[4 * b + 2], ndn = base + L.mhdr[4 * b + 3] - dn0;
+        const int base = rg.x, nup = rg.y - base, dn0 = rg.y, ndn = rg.z - nup;
         float h00 = 1e30f, h01 = 1e30f, h10 = 1e30f, h11 = 1e30f;
         float l00 = -1e30f, l01 = -1e30f, l10 = -1e30f, l11 = -1e30f;
         plane_sweep<true>(L.planes + base, nup, s, S, px0, px1, py0, py1, h00, h01, h10, h11);
@@ -392,54 +450,92 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       }
     }
     __syncthreads();
-  RSTAMP(3);
+    RSTAMP(3);
+    first = false;
     bs = be;
-    {
-      int np_group = 0;
-      while (be < nb && np_group + L.mhdr[4 * be + 3] <= SRL_PLANE_CAP) { np_group += L.mhdr[4 * be + 3]; ++be; }
+    if (bs < nb) {   // next group: its extent, then its region cursors
+      const int p0 = L.reg[4 * bs + 3];
+      while (be < nb && L.reg[4 * be + 3] + L.mhdr[4 * be + 3] - p0 <= SRL_PLANE_CAP) ++be;
+      if (tid >= bs && tid < be) {
+        const int base = L.reg[4 * tid + 3] - p0;
+        L.reg[4 * tid + 0] = base; L.reg[4 * tid + 1] = base;
+      }
+      __syncthreads();
     }
-  }
-  __syncthreads();
+  } while (bs < nb);
   RSTAMP(4);
-  // ---- epilogue: depth codec, H out, uint8 pack, IoU partial sums (4 pixels per thread per round)
+  // ---- epilogue: depth codec, H out, uint8 pack, IoU partial sums (4 pixels per thread per round, fixed order).
+  //      The codec (three divisions per pixel) is only needed where a rock was seen: each wave gathers its
+  //      rock pixels of the round (usually well under 64 of 256) into a wave-private list, runs the codec
+  //      once over the list, one pixel per lane, and hands the results back.
   float spi = 0.0f, spu = 0.0f;
   {
-    int k = 0;
-    for (int g = tid; g < npx / 4; g += SRL_RENDER_THREADS, ++k) {
-      const int k0 = g * 4;
-      const int i = k0 / res, jb = k0 - i * res;
-      const bool row_in = (i >= g0 && i < g0 + g2);
-      if (!((cov >> k) & 1u)) {   // written out above; sums only
+    volatile float* czf = L.cz + wave * 192;
+    volatile uint32_t* czu = (volatile uint32_t*)czf;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int i = walk_i0, jb = walk_j0;
+    for (int k = 0; k < nrounds; ++k) {
+      const int g = tid + k * SRL_RENDER_THREADS;
+      const bool valid = g < ngroups4;
+      const bool covg = valid && ((cov >> k) & 1u);
+      float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (covg) z4 = ((const float4*)L.tile)[g];
+      float hv[4] = {h_empty, h_empty, h_empty, h_empty};
+      uint32_t hb[4] = {b_empty, b_empty, b_empty, b_empty};
+      const bool rock = (z4.x > 0.0f) || (z4.y > 0.0f) || (z4.z > 0.0f) || (z4.w > 0.0f);
+      if (__ballot(rock) != 0ull) {   // wave-uniform: some lane of this round saw a rock
+        const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+        unsigned long long mk[4];
+        int cnt[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { mk[t] = __ballot(zz[t] > 0.0f); cnt[t] = __popcll(mk[t]); }
+        const int total = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        if (total <= 64) {
+          int slot[4], off = 0;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            slot[t] = off + __popcll(mk[t] & below); off += cnt[t];
+            if (zz[t] > 0.0f) czf[slot[t]] = zz[t];
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (lane < total) {
+            const float hh = elev_overhead(P, depth_encode(SRL_FAR - czf[lane], nearp, SRL_FAR));
+            czf[64 + lane] = hh;
+            czu[128 + lane] = (uint8_t)((hh * 255.0f) / den);
+          }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (zz[t] > 0.0f) { hv[t] = czf[64 + slot[t]]; hb[t] = czu[128 + slot[t]]; }
+          __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (zz[t] > 0.0f) {
+              hv[t] = elev_overhead(P, depth_encode(SRL_FAR - zz[t], nearp, SRL_FAR));
+              hb[t] = (uint8_t)((hv[t] * 255.0f) / den);
+            }
+        }
+      }
+      if (valid) {
+        const bool row_in = (i >= g0 && i < g0 + g2);
+        uint32_t lo = hb[0] | (hb[1] << 16) | zpair, hi = hb[2] | (hb[3] << 16) | zpair;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int j = jb + t;
-          if (row_in && (j >= g1 && j < g1 + g3)) { spi += fminf(h_empty, gz); spu += fmaxf(h_empty, gz); }
-          else spu += fmaxf(h_empty, 0.0f);
+          const bool in = row_in && (jb + t >= g1 && jb + t < g1 + g3);
+          // rewarder.py:297-307: goal pixels add min / max(h, goal) to the two sums, the others max(h, 0) to the
+          // union only (x + 0 = x bit for bit here: the partial sums never hold -0)
+          spu += fmaxf(hv[t], in ? gz : 0.0f);
+          spi += in ? fminf(hv[t], gz) : 0.0f;
+          if (in) { if (t < 2) lo ^= gdiff << (16 * t); else hi ^= gdiff << (16 * (t - 2)); }
         }
-        continue;
-      }
-      const float4 z4 = ((const float4*)L.tile)[g];
-      const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-      const bool any = (z4.x > 0.0f) || (z4.y > 0.0f) || (z4.z > 0.0f) || (z4.w > 0.0f);
-      float hv[4];
-      uint32_t pk[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        float hh = h_empty;
-        uint32_t hb = b_empty;
-        if (any && zz[t] > 0.0f) {
-          hh = elev_overhead(P, depth_encode(SRL_FAR - zz[t], nearp, SRL_FAR));
-          hb = (uint8_t)((hh * 255.0f) / den);
+        if (covg) {
+          ((float4*)Hout)[g] = make_float4(hv[0], hv[1], hv[2], hv[3]);
+          if (om) ((uint2*)om)[g] = make_uint2(lo, hi);
         }
-        hv[t] = hh;
-        const int j = jb + t;
-        const bool in = row_in && (j >= g1 && j < g1 + g3);
-        if (in) { spi += fminf(hh, gz); spu += fmaxf(hh, gz); }
-        else spu += fmaxf(hh, 0.0f);
-        pk[t] = hb | ((in ? gbyte : zbyte) << 8);
       }
-      ((float4*)Hout)[g] = make_float4(hv[0], hv[1], hv[2], hv[3]);
-      if (om) ((uint2*)om)[g] = make_uint2(pk[0] | (pk[1] << 16), pk[2] | (pk[3] << 16));
+      jb += walk_dj; i += walk_di;
+      if (jb >= res) { jb -= res; ++i; }
     }
   }
   RSTAMP(5);
@@ -457,6 +553,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       oo[idx] = (uint8_t)(((pending >= 0 ? P.objmap[(size_t)pending * rr + idx] : empty) * 255.0f) / den);
   }
   // ---- halving tree over the 512 partials: cross-wave stages through LDS, in-wave stages by shuffles
+  __syncthreads();   // the codec scratch of slower waves shares the staging area with pi / pu
   L.pi[tid] = spi; L.pu[tid] = spu;
   __syncthreads();
   if (tid < 256) { L.pi[tid] += L.pi[tid + 256]; L.pu[tid] += L.pu[tid + 256]; }

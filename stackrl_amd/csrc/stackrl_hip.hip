@@ -136,12 +136,12 @@ hipEvent_t get_event(srl_env* env) {
 void prof_begin(srl_env* env, hipStream_t st, int which) {
   if (!env->profiling) return;
   EventPair p; p.a = get_event(env); p.b = get_event(env); p.which = which;
-  hipEventRecord(p.a, st);
+  (void)hipEventRecord(p.a, st);
   env->pending.push_back(p);
 }
 void prof_end(srl_env* env, hipStream_t st) {
   if (!env->profiling) return;
-  hipEventRecord(env->pending.back().b, st);
+  (void)hipEventRecord(env->pending.back().b, st);
 }
 
 int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void* obs_obj, float* reward, uint8_t* done,
@@ -233,10 +233,10 @@ int srl_create(const srl_config* cfg, srl_env** out) {
 void srl_destroy(srl_env* env) {
   if (!env) return;
   (void)hipDeviceSynchronize();
-  for (auto& p : env->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-  for (auto& e : env->pool) hipEventDestroy(e);
-  hipFree(env->P.hdr); hipFree(env->P.blob); hipFree(env->P.H); hipFree(env->P.flags); hipFree(env->d_P);
-  hipFree(env->d_mh); hipFree(env->d_mv); hipFree(env->d_mt); hipFree(env->d_mp); hipFree(env->d_objmap);
+  for (auto& p : env->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto& e : env->pool) (void)hipEventDestroy(e);
+  (void)hipFree(env->P.hdr); (void)hipFree(env->P.blob); (void)hipFree(env->P.H); (void)hipFree(env->P.flags); (void)hipFree(env->d_P);
+  (void)hipFree(env->d_mh); (void)hipFree(env->d_mv); (void)hipFree(env->d_mt); (void)hipFree(env->d_mp); (void)hipFree(env->d_objmap);
   delete env;
 }
 
@@ -293,7 +293,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
     M.inv_mass = 1.0f / mass;
     M.iix = 1.0f / Ix; M.iiy = 1.0f / Iy; M.iiz = 1.0f / Iz;
   }
-  hipFree(env->d_mh); hipFree(env->d_mv); hipFree(env->d_mt); hipFree(env->d_mp); hipFree(env->d_objmap);
+  (void)hipFree(env->d_mh); (void)hipFree(env->d_mv); (void)hipFree(env->d_mt); (void)hipFree(env->d_mp); (void)hipFree(env->d_objmap);
   env->d_mh = nullptr; env->d_mv = nullptr; env->d_mt = nullptr; env->d_mp = nullptr; env->d_objmap = nullptr;
   const int r = P.c.object_res;
   HIP_TRY(hipMalloc((void**)&env->d_mh, sizeof(MeshHdr) * mh.size()));
@@ -371,7 +371,7 @@ int srl_reset(srl_env* env, void* obs_map, void* obs_obj, void* stream) {
   static thread_local int scratch_n = 0;
   const int n = env->P.c.n_envs;
   if (scratch_n < n) {
-    hipFree(scratch_r); hipFree(scratch_d);
+    (void)hipFree(scratch_r); (void)hipFree(scratch_d);
     HIP_TRY(hipMalloc((void**)&scratch_r, sizeof(float) * (size_t)n));
     HIP_TRY(hipMalloc((void**)&scratch_d, (size_t)n));
     scratch_n = n;
@@ -464,7 +464,7 @@ int srl_get_contacts(srl_env* env, float* max_penetration, int32_t* n_points) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(max_penetration, d_mp, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(n_points, d_np, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
-  hipFree(d_mp); hipFree(d_np);
+  (void)hipFree(d_mp); (void)hipFree(d_np);
   return SRL_OK;
 }
 

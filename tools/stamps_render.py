@@ -7,7 +7,7 @@ import numpy as np
 from stackrl_amd import build as B
 so = os.path.join(ROOT, 'gpurun_out', 'libstackrl_stamps.so')
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call(['/opt/rocm/bin/hipcc'] + B.FLAGS + ['-DSRL_STAMPS', os.path.join(B.CSRC, 'stackrl_hip.hip'), '-o', so])
+subprocess.check_call(['/opt/rocm/bin/hipcc'] + B.FLAGS + sys.argv[1:] + ['-DSRL_STAMPS', os.path.join(B.CSRC, 'stackrl_hip.hip'), '-o', so])
 B.LIB = so
 import torch
 from stackrl_amd import assets, env as envs, lib
@@ -17,7 +17,7 @@ g = envs.VecStackEnv(n_parallel=n, seed=11, pool=pool, block=True, episode_lengt
 fn = lib.load().srl_debug_rstamps; fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 out = np.zeros((n, 8), np.int64)
 g.reset(); fn(g._h, out.ctypes.data_as(ctypes.c_void_p), 1)
-names = ['prologue (hdr, poses, mesh hdr)', 'bbox vertex pass', 'plane staging', 'pixel pass', '(loop end)', 'epilogue']
+names = ['prologue (hdr, poses, mesh hdr)', 'bounds+staging', 'early-stores', 'pixel pass', '(loop end)', 'epilogue']
 print('mean ns per workgroup by phase; thread-0 wall clock (100 MHz)')
 for k in range(L):
   g.step(g.sample()); fn(g._h, out.ctypes.data_as(ctypes.c_void_p), 1)
