@@ -5,15 +5,15 @@
 // z_hi = min over up-facing planes and z_lo = max over down-facing planes.  The overhead camera
 // (observer.py:252-260) sees z_hi, the object camera from below (observer.py:262-277) sees z_lo.
 //
-// K2: one 512-thread workgroup per env.  The res x res tile lives in LDS (64 KB at 128^2 -> 2
-// workgroups = 16 waves per CU).  Rocks are visited one after the other; for each rock all lanes take
-// pixels of its pixel bounding box (lane = pixel, fully regular, no atomics) and loop over the rock's
-// planes, which are staged in LDS (double buffered, one barrier per rock) and read as wave-uniform
-// broadcasts.  One epilogue pass applies the reference's depth codec (observer.py:259-260), streams out
-// H (16 B per lane, 1 KB contiguous per wave store), the packed uint8 observation (env.py:171-172,
-// :228-231) and accumulates the IoU sums (rewarder.py:297-307) in the fixed order DESIGN.md defines.
-// Empty pixels (the majority) skip the codec arithmetic.  HBM traffic per env step is the algorithmic
-// 6*res^2 + 5*r^2 bytes out plus ~1.4 KB per rock of mesh/pose data in (L2-resident pool).
+// K2: one 512-thread workgroup per env.  The res x res tile lives in LDS (64 KB at 128^2 -> 2 workgroups = 16
+// waves per CU).  Prologue (speculative pose / mesh-header loads, tile zeroing) -> one wave per rock: xy bounds by
+// DPP min / max and world-frame planes staged type-sorted by ballot ranks -> rows no rock reaches are written out
+// at once -> ray cast: lanes over the flattened (rock, 2 x 2 pixel quad) list sweep the rock's planes (LDS
+// broadcasts, packed FMAs, min3 / max3) and merge into the tile with integer atomicMax -> one epilogue pass applies
+// the reference's depth codec (observer.py:259-260) to the pixels that saw a rock (compacted per wave), streams out
+// H (16 B per lane, 1 KB contiguous per wave store), the packed uint8 observation (env.py:171-172, :228-231) and
+// accumulates the IoU sums (rewarder.py:297-307) in the fixed order DESIGN.md defines.  HBM traffic per env step
+// is the algorithmic 6*res^2 + 5*r^2 bytes out plus ~1.4 KB per rock of mesh/pose data in (L2-resident pool).
 //
 // K3: per-mesh underside map rendered once at srl_load_meshes and cached: it depends only on the mesh
 // (spawn orientation is the identity, env.py:120-121).

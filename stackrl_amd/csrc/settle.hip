@@ -1,6 +1,7 @@
 // settle.hip — K1 (place / smooth placing / settle) + K4 (Observer.pose) + the episode machine.
 //
-// One 256-thread workgroup (4 waves) per env.  The env's whole persistent state ("blob": poses,
+// One workgroup per env: 128 threads (2 waves) for L <= 8 bodies, 256 threads with 1 - 3 contact points per
+// thread above that (srl_k_step / _pp1 / _pp2 / _pp3).  The env's whole persistent state ("blob": poses,
 // velocities, ground and body-body manifolds with their warm-start impulses, slot tables) is loaded into
 // LDS once, every sub-step runs out of LDS, and the blob is written back once — HBM traffic per env step
 // is 2 x BLOB words regardless of how many sub-steps the stop criterion takes.
@@ -9,10 +10,12 @@
 // as SIMDs, and a launch lasts as long as its slowest env (stop criterion simulator.py:322-335), so the
 // kernel is organised for the LATENCY of one env's sub-step, not for throughput per lane:
 //   lane = (body, vertex)   world vertices from an LDS copy of the local ones (one pass, no loops)
-//   lane = body             damping + gravity, rotation, inertia, AABB, ground manifold, integration
+//   lane = body             damping + gravity, rotation, inertia, integration
+//   16 lanes = body         AABB + ground manifold (deepest-vertex extraction by xor-shuffle min)
 //   lane = pair             AABB broadphase over all i<j pairs, slot release
-//   16 lanes = slot         GJK closest points: the support scans are split over the 16 lanes and combined
-//                           with xor shuffles; manifold refresh / insert by the group's first lane
+//   16 lanes = slot         GJK closest points and the face-normal SAT fallback: the support / face scans are
+//                           split over the 16 lanes and combined with xor shuffles; manifold refresh /
+//                           insert by the group's first lane
 //   lane = contact point    sequential impulses: each lane keeps the constants of its three rows (normal +
 //                           two friction) in registers for all sweeps; body velocities live in LDS
 // A sweep visits "ground" then the contact-graph colours in order (block barrier between phases); inside a
