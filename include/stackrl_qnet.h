@@ -25,6 +25,14 @@ extern "C" {
 int srl_xcorr_forward(const float* x_dev, const float* w_dev, float* out_dev, int32_t B, int32_t C, int32_t H,
                       int32_t W, int32_t kh, int32_t kw, void* stream);
 
+/* The same op on the matrix cores for the bf16 rollout path (csrc/xcorr_mfma.hip): x bfloat16 [B][C][H][H], w bfloat16
+ * [B][C][kh][kh] with (H, kh) in {(128, 32), (64, 16)}, out float32 (fp32 accumulation), contiguous.  `scratch` is
+ * caller-owned device memory of at least srl_xcorr_bf16_scratch_bytes(B, C, kh) bytes (Toeplitz fragments of w). */
+int64_t srl_xcorr_bf16_scratch_bytes(int32_t B, int32_t C, int32_t kh);
+int srl_xcorr_forward_bf16(const void* x_dev, const void* w_dev, float* out_dev, void* scratch_dev, int64_t scratch_bytes,
+                           int32_t B, int32_t C, int32_t H, int32_t W, int32_t kh, int32_t kw, void* stream);
+const char* srl_xcorr_bf16_last_error(void);
+
 /* adv float32 [B][A]; u float32 [B] uniform(0,1); rnd int64 [B] uniform {0..A-1}; actions int64 [B] */
 int srl_policy_head(const float* adv_dev, const float* u_dev, const int64_t* rnd_dev, float epsilon,
                     int64_t* actions_dev, int32_t B, int32_t A, void* stream);

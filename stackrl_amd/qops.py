@@ -19,6 +19,11 @@ def load():
     VP = ctypes.c_void_p
     L.srl_xcorr_forward.restype = ctypes.c_int
     L.srl_xcorr_forward.argtypes = [VP, VP, VP] + [ctypes.c_int32] * 6 + [VP]
+    L.srl_xcorr_bf16_scratch_bytes.restype = ctypes.c_int64
+    L.srl_xcorr_bf16_scratch_bytes.argtypes = [ctypes.c_int32] * 3
+    L.srl_xcorr_forward_bf16.restype = ctypes.c_int
+    L.srl_xcorr_forward_bf16.argtypes = [VP, VP, VP, VP, ctypes.c_int64] + [ctypes.c_int32] * 6 + [VP]
+    L.srl_xcorr_bf16_last_error.restype = ctypes.c_char_p
     L.srl_policy_head.restype = ctypes.c_int
     L.srl_policy_head.argtypes = [VP, VP, VP, ctypes.c_float, VP, ctypes.c_int32, ctypes.c_int32, VP]
     L.srl_qnet_last_error.restype = ctypes.c_char_p
@@ -30,10 +35,45 @@ def _stream(t):
   return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+_SCRATCH = {}
+MFMA_SHAPES = ((128, 32), (64, 16))   # (H, kh) instantiations of csrc/xcorr_mfma.hip
+
+
+def xcorr_forward_bf16(x, w):
+  """`layers.correlation` forward on the matrix cores: x [B,C,H,H], w [B,C,kh,kh] bfloat16 -> float32 [B,1,OH,OW]
+  (bf16 products, fp32 accumulation)."""
+  if not x.is_cuda:
+    raise RuntimeError('xcorr_forward_bf16 needs a HIP device (no CPU fallback)')
+  x = x.to(torch.bfloat16).contiguous(); w = w.to(torch.bfloat16).contiguous()
+  B, C, H, W = x.shape
+  kh, kw = w.shape[-2:]
+  L = load()
+  need = L.srl_xcorr_bf16_scratch_bytes(B, C, kh)
+  if need < 0:
+    raise RuntimeError('xcorr_forward_bf16: unsupported kernel size %d' % kh)
+  key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+  scratch = _SCRATCH.get(key)
+  if scratch is None or scratch.numel() < need:
+    scratch = torch.empty(need, dtype=torch.uint8, device=x.device)
+    _SCRATCH[key] = scratch
+  out = torch.empty((B, 1, H - kh + 1, W - kw + 1), dtype=torch.float32, device=x.device)
+  with torch.cuda.device(x.device):
+    rc = L.srl_xcorr_forward_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                                  B, C, H, W, kh, kw, _stream(x))
+  if rc:
+    raise RuntimeError(L.srl_xcorr_bf16_last_error().decode())
+  return out
+
+
 def xcorr_forward(x, w):
-  """`layers.correlation` forward (layers.py:21-38): x [B,C,H,W], w [B,C,kh,kw] float32 -> [B,1,OH,OW]."""
+  """`layers.correlation` forward (layers.py:21-38): x [B,C,H,W], w [B,C,kh,kw] -> float32 [B,1,OH,OW].
+  float32 features take the fp32 vector kernel (the reference's precision); bfloat16 features of the shapes in
+  MFMA_SHAPES (the autocast rollout path) take the MFMA kernel."""
   if not x.is_cuda:
     raise RuntimeError('xcorr_forward needs a HIP device (no CPU fallback)')
+  if x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.shape[-1] == x.shape[-2] and \
+     w.shape[-1] == w.shape[-2] and (x.shape[-1], w.shape[-1]) in MFMA_SHAPES:
+    return xcorr_forward_bf16(x, w)
   x = x.contiguous().float(); w = w.contiguous().float()
   B, C, H, W = x.shape
   kh, kw = w.shape[-2:]

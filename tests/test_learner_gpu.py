@@ -24,6 +24,26 @@ def test_xcorr_hip_matches_torch_fp32(B, C, H, h):
   assert float((got - ref32).abs().max()) <= 5e-5 * scale
 
 
+@pytest.mark.parametrize('B,C,H,h', [(3, 16, 128, 32), (5, 16, 64, 16), (2, 7, 128, 32)])
+def test_xcorr_mfma_bf16_matches_torch(B, C, H, h):
+  """MFMA path of the cross-correlation (csrc/xcorr_mfma.hip): bf16 products are exact in fp32, so against an fp64
+  accumulation of the same bf16-rounded operands only the fp32 accumulation order differs."""
+  from stackrl_amd import nets, qops
+  g = torch.Generator(device='cuda').manual_seed(B * 11 + C)
+  x = torch.rand((B, C, H, H), generator=g, device='cuda').to(torch.bfloat16)
+  w = (torch.rand((B, C, h, h), generator=g, device='cuda') - 0.3).to(torch.bfloat16)
+  got = qops.xcorr_forward(x, w)
+  assert got.dtype == torch.float32 and got.shape == (B, 1, H - h + 1, H - h + 1)
+  ref = nets.correlation_reference(x.double(), w.double()).float()
+  scale = float(ref.abs().max())
+  assert float((got - ref).abs().max()) <= 2e-5 * scale          # stated tolerance: fp32 accumulation of <= 16,384 terms
+  # against the fp32 vector kernel on the un-rounded operands the difference is the bf16 input rounding (2^-9 relative
+  # per operand, averaging out over the sum)
+  x32 = torch.rand((B, C, H, H), generator=g, device='cuda'); w32 = torch.rand((B, C, h, h), generator=g, device='cuda') - 0.3
+  a = qops.xcorr_forward(x32.to(torch.bfloat16), w32.to(torch.bfloat16)); b = qops.xcorr_forward(x32, w32)
+  assert float((a - b).abs().max()) <= 4e-3 * float(b.abs().max())
+
+
 def test_policy_head_matches_torch():
   from stackrl_amd import qops
   g = torch.Generator(device='cuda').manual_seed(3)

@@ -25,3 +25,14 @@ run('fp32 channels_last chunk 512', 512, None, True)
 run('bf16 nchw chunk 512', 512, torch.bfloat16, False)
 run('bf16 channels_last chunk 512', 512, torch.bfloat16, True)
 run('fp16 channels_last chunk 512', 512, torch.float16, True)
+
+# the cross-correlation alone: fp32 vector kernel vs the bf16 MFMA kernel
+from stackrl_amd import qops as _q
+xf = torch.rand((B, 16, 128, 128), device='cuda'); wf = torch.rand((B, 16, 32, 32), device='cuda') - 0.3
+for tag, a, b in (('xcorr fp32 VALU', xf, wf), ('xcorr bf16 MFMA', xf.to(torch.bfloat16), wf.to(torch.bfloat16))):
+  for _ in range(2): _q.xcorr_forward(a, b)
+  torch.cuda.synchronize(); t0 = time.perf_counter()
+  for _ in range(5): _q.xcorr_forward(a, b)
+  torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+  useful = 2.0 * 97 * 97 * 32 * 32 * 16 * B
+  print('%-40s %.2f ms  %.1f useful TFLOP/s' % (tag, dt * 1e3, useful / dt / 1e12), flush=True)
