@@ -25,13 +25,20 @@ extern "C" {
 int srl_xcorr_forward(const float* x_dev, const float* w_dev, float* out_dev, int32_t B, int32_t C, int32_t H,
                       int32_t W, int32_t kh, int32_t kw, void* stream);
 
-/* The same op on the matrix cores for the bf16 rollout path (csrc/xcorr_mfma.hip): x bfloat16 [B][C][H][H], w bfloat16
- * [B][C][kh][kh] with (H, kh) in {(128, 32), (64, 16)}, out float32 (fp32 accumulation), contiguous.  `scratch` is
- * caller-owned device memory of at least srl_xcorr_bf16_scratch_bytes(B, C, kh) bytes (Toeplitz fragments of w). */
-int64_t srl_xcorr_bf16_scratch_bytes(int32_t B, int32_t C, int32_t kh);
-int srl_xcorr_forward_bf16(const void* x_dev, const void* w_dev, float* out_dev, void* scratch_dev, int64_t scratch_bytes,
-                           int32_t B, int32_t C, int32_t H, int32_t W, int32_t kh, int32_t kw, void* stream);
-const char* srl_xcorr_bf16_last_error(void);
+/* The same op and its two gradients on the matrix cores (csrc/xcorr_mfma.hip), for the forward shapes (H, kh) in
+ * {(128, 32), (64, 16)}; O = H - kh + 1.  All tensors contiguous; `in` / `kern` are bfloat16 (in_f32 / kern_f32 = 0)
+ * or float32 (= 1); out is float32 (fp32 accumulation).
+ *   mode 0  forward : in x [B][C][H][H],            kern w [B][C][kh][kh]            -> out [B][O][O]
+ *   mode 1  d/dx    : in [B][O+2(kh-1)]^2 = dOut zero-padded by kh-1 on every side, kern = w flipped in both axes
+ *                     [B][C][kh][kh]                                                 -> out [B][C][H][H]
+ *   mode 2  d/dw    : in x [B][C][H][H],            kern dOut [B][O][O]              -> out [B][C][kh][kh]
+ * precision 0: operands rounded to bf16; 1 ("bf16x3", float32 operands only): hi/lo bf16 split, hi*hi + hi*lo + lo*hi.
+ * `scratch` is caller-owned device memory of at least srl_xcorr_mfma_scratch_bytes(...) bytes (Toeplitz fragments). */
+int64_t srl_xcorr_mfma_scratch_bytes(int32_t mode, int32_t precision, int32_t B, int32_t C, int32_t H, int32_t kh);
+int srl_xcorr_mfma(int32_t mode, int32_t precision, const void* in_dev, int32_t in_f32, const void* kern_dev,
+                   int32_t kern_f32, float* out_dev, void* scratch_dev, int64_t scratch_bytes, int32_t B, int32_t C,
+                   int32_t H, int32_t kh, void* stream);
+const char* srl_xcorr_mfma_last_error(void);
 
 /* adv float32 [B][A]; u float32 [B] uniform(0,1); rnd int64 [B] uniform {0..A-1}; actions int64 [B] */
 int srl_policy_head(const float* adv_dev, const float* u_dev, const int64_t* rnd_dev, float epsilon,

@@ -37,11 +37,20 @@ class DQN(object):
                discount_factor=.99, collect_batch_size=None, exploration_mode=None, exploration=None,
                prioritization=None, priority_bias_compensation=None, double=False, n_step=None, seed=None,
                device=None, process_group=None, policy_op=None, reference_next_index=False,
-               adam_betas=(0.9, 0.999)):
+               adam_betas=(0.9, 0.999), xcorr=None):
     if not isinstance(q_net, torch.nn.Module):
       raise TypeError('Invalid type {} for argument q_net. Must be a torch Module.'.format(type(q_net)))   # dqn.py:122-125
     self.device = torch.device(device) if device is not None else next(q_net.parameters()).device
     self._q_net = q_net.to(self.device)
+    # xcorr: how `layers.correlation` (layers.py:21-38) is evaluated and differentiated in the update.  None keeps the
+    # net's own (library grouped convolution, fp32); 'bf16x3' / 'bf16' use the MFMA kernels of csrc/xcorr_mfma.hip
+    # (hi/lo-split fp32-class accuracy / operands rounded to bf16) on a HIP device.
+    if xcorr is not None:
+      if xcorr not in ('bf16x3', 'bf16'):
+        raise ValueError("Invalid value {} for argument xcorr. Must be None, 'bf16x3' or 'bf16'.".format(xcorr))
+      if self.device.type == 'cuda' and hasattr(self._q_net, 'correlation'):
+        from stackrl_amd import qops
+        self._q_net.correlation = qops.correlation(qops.BF16X3 if xcorr == 'bf16x3' else qops.BF16)
     import copy
     self._target_q_net = copy.deepcopy(self._q_net)                 # clone + set_weights, dqn.py:116-117
     for p in self._target_q_net.parameters():

@@ -19,11 +19,12 @@ def load():
     VP = ctypes.c_void_p
     L.srl_xcorr_forward.restype = ctypes.c_int
     L.srl_xcorr_forward.argtypes = [VP, VP, VP] + [ctypes.c_int32] * 6 + [VP]
-    L.srl_xcorr_bf16_scratch_bytes.restype = ctypes.c_int64
-    L.srl_xcorr_bf16_scratch_bytes.argtypes = [ctypes.c_int32] * 3
-    L.srl_xcorr_forward_bf16.restype = ctypes.c_int
-    L.srl_xcorr_forward_bf16.argtypes = [VP, VP, VP, VP, ctypes.c_int64] + [ctypes.c_int32] * 6 + [VP]
-    L.srl_xcorr_bf16_last_error.restype = ctypes.c_char_p
+    L.srl_xcorr_mfma_scratch_bytes.restype = ctypes.c_int64
+    L.srl_xcorr_mfma_scratch_bytes.argtypes = [ctypes.c_int32] * 6
+    L.srl_xcorr_mfma.restype = ctypes.c_int
+    L.srl_xcorr_mfma.argtypes = [ctypes.c_int32, ctypes.c_int32, VP, ctypes.c_int32, VP, ctypes.c_int32, VP, VP,
+                                 ctypes.c_int64] + [ctypes.c_int32] * 4 + [VP]
+    L.srl_xcorr_mfma_last_error.restype = ctypes.c_char_p
     L.srl_policy_head.restype = ctypes.c_int
     L.srl_policy_head.argtypes = [VP, VP, VP, ctypes.c_float, VP, ctypes.c_int32, ctypes.c_int32, VP]
     L.srl_qnet_last_error.restype = ctypes.c_char_p
@@ -36,33 +37,87 @@ def _stream(t):
 
 
 _SCRATCH = {}
-MFMA_SHAPES = ((128, 32), (64, 16))   # (H, kh) instantiations of csrc/xcorr_mfma.hip
+MFMA_SHAPES = ((128, 32), (64, 16))   # forward (H, kh) shapes built in csrc/xcorr_mfma.hip
+BF16, BF16X3 = 0, 1                   # precisions of the MFMA path (include/stackrl_qnet.h)
 
 
-def xcorr_forward_bf16(x, w):
-  """`layers.correlation` forward on the matrix cores: x [B,C,H,H], w [B,C,kh,kh] bfloat16 -> float32 [B,1,OH,OW]
-  (bf16 products, fp32 accumulation)."""
-  if not x.is_cuda:
-    raise RuntimeError('xcorr_forward_bf16 needs a HIP device (no CPU fallback)')
-  x = x.to(torch.bfloat16).contiguous(); w = w.to(torch.bfloat16).contiguous()
-  B, C, H, W = x.shape
-  kh, kw = w.shape[-2:]
+def _xcorr_mfma(mode, precision, a, k, B, C, H, kh):
+  """One launch of srl_xcorr_mfma (see the header for the three modes).  a / k: contiguous bf16 or fp32 tensors."""
+  if not a.is_cuda:
+    raise RuntimeError('the MFMA cross-correlation needs a HIP device (no CPU fallback)')
+  if precision == BF16X3:
+    a = a.float(); k = k.float()
+  a = a.contiguous(); k = k.contiguous()
+  for t in (a, k):
+    if t.dtype not in (torch.float32, torch.bfloat16):
+      raise TypeError('xcorr operands must be float32 or bfloat16')
   L = load()
-  need = L.srl_xcorr_bf16_scratch_bytes(B, C, kh)
+  need = L.srl_xcorr_mfma_scratch_bytes(mode, precision, B, C, H, kh)
   if need < 0:
-    raise RuntimeError('xcorr_forward_bf16: unsupported kernel size %d' % kh)
-  key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+    raise RuntimeError('MFMA cross-correlation: unsupported shape (H=%d, kh=%d)' % (H, kh))
+  key = (a.device.index, torch.cuda.current_stream(a.device).cuda_stream)
   scratch = _SCRATCH.get(key)
   if scratch is None or scratch.numel() < need:
-    scratch = torch.empty(need, dtype=torch.uint8, device=x.device)
+    scratch = torch.empty(need, dtype=torch.uint8, device=a.device)
     _SCRATCH[key] = scratch
-  out = torch.empty((B, 1, H - kh + 1, W - kw + 1), dtype=torch.float32, device=x.device)
-  with torch.cuda.device(x.device):
-    rc = L.srl_xcorr_forward_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), scratch.data_ptr(), scratch.numel(),
-                                  B, C, H, W, kh, kw, _stream(x))
+  O = H - kh + 1
+  shape = {0: (B, 1, O, O), 1: (B, C, H, H), 2: (B, C, kh, kh)}[mode]
+  out = torch.empty(shape, dtype=torch.float32, device=a.device)
+  with torch.cuda.device(a.device):
+    rc = L.srl_xcorr_mfma(mode, precision, a.data_ptr(), int(a.dtype == torch.float32), k.data_ptr(),
+                          int(k.dtype == torch.float32), out.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                          B, C, H, kh, _stream(a))
   if rc:
-    raise RuntimeError(L.srl_xcorr_bf16_last_error().decode())
+    raise RuntimeError(L.srl_xcorr_mfma_last_error().decode())
   return out
+
+
+def _mfma_ok(x, w):
+  return x.dim() == 4 and x.shape[-1] == x.shape[-2] and w.shape[-1] == w.shape[-2] and \
+         (x.shape[-1], w.shape[-1]) in MFMA_SHAPES
+
+
+def xcorr_forward_mfma(x, w, precision=BF16):
+  """`layers.correlation` forward on the matrix cores: x [B,C,H,H], w [B,C,kh,kh] -> float32 [B,1,OH,OW]."""
+  B, C, H, _ = x.shape
+  return _xcorr_mfma(0, precision, x, w, B, C, H, w.shape[-1])
+
+
+class _XCorrMFMA(torch.autograd.Function):
+  """Differentiable `layers.correlation` (layers.py:21-38) on the matrix cores: forward and both gradients are the
+  same Toeplitz-MFMA kernel family (csrc/xcorr_mfma.hip)."""
+
+  @staticmethod
+  def forward(ctx, x, w, precision):
+    ctx.save_for_backward(x, w)
+    ctx.precision = precision
+    return xcorr_forward_mfma(x, w, precision)
+
+  @staticmethod
+  def backward(ctx, g):
+    x, w = ctx.saved_tensors
+    B, C, H, _ = x.shape
+    kh = w.shape[-1]
+    g = g[:, 0].float()
+    dx = dw = None
+    if ctx.needs_input_grad[0]:
+      gp = torch.nn.functional.pad(g, (kh - 1, kh - 1, kh - 1, kh - 1))
+      dx = _xcorr_mfma(1, ctx.precision, gp, w.flip(-1, -2), B, C, H, kh).to(x.dtype)
+    if ctx.needs_input_grad[1]:
+      dw = _xcorr_mfma(2, ctx.precision, x, g, B, C, H, kh).to(w.dtype)
+    return dx, dw, None
+
+
+def correlation(precision=BF16X3):
+  """A drop-in for `nets.correlation_reference` (assign to `net.correlation`): MFMA kernels for the shapes in
+  MFMA_SHAPES on a HIP device, the library formulation otherwise."""
+  from stackrl_amd import nets
+
+  def f(x, w):
+    if x.is_cuda and _mfma_ok(x, w):
+      return _XCorrMFMA.apply(x, w, precision)
+    return nets.correlation_reference(x, w)
+  return f
 
 
 def xcorr_forward(x, w):
@@ -71,9 +126,8 @@ def xcorr_forward(x, w):
   MFMA_SHAPES (the autocast rollout path) take the MFMA kernel."""
   if not x.is_cuda:
     raise RuntimeError('xcorr_forward needs a HIP device (no CPU fallback)')
-  if x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.shape[-1] == x.shape[-2] and \
-     w.shape[-1] == w.shape[-2] and (x.shape[-1], w.shape[-1]) in MFMA_SHAPES:
-    return xcorr_forward_bf16(x, w)
+  if x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and _mfma_ok(x, w):
+    return xcorr_forward_mfma(x, w, BF16)
   x = x.contiguous().float(); w = w.contiguous().float()
   B, C, H, W = x.shape
   kh, kw = w.shape[-2:]

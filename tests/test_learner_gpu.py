@@ -44,6 +44,28 @@ def test_xcorr_mfma_bf16_matches_torch(B, C, H, h):
   assert float((a - b).abs().max()) <= 4e-3 * float(b.abs().max())
 
 
+@pytest.mark.parametrize('B,C,H,h', [(3, 16, 128, 32), (4, 16, 64, 16), (2, 5, 128, 32)])
+@pytest.mark.parametrize('precision,tol', [(0, 6e-3), (1, 2e-5)])
+def test_xcorr_mfma_autograd_matches_torch_fp64(B, C, H, h, precision, tol):
+  """Forward and both gradients of the MFMA cross-correlation against the library formulation in fp64.
+  Stated tolerances relative to each tensor's scale: 6e-3 with operands rounded to bf16, 2e-5 (the fp32 vector
+  kernel's own tolerance) with the bf16x3 split."""
+  from stackrl_amd import nets, qops
+  g = torch.Generator(device='cuda').manual_seed(B * 13 + C + precision)
+  x = torch.rand((B, C, H, H), generator=g, device='cuda').requires_grad_()
+  w = (torch.rand((B, C, h, h), generator=g, device='cuda') - 0.3).requires_grad_()
+  go = torch.randn((B, 1, H - h + 1, H - h + 1), generator=g, device='cuda')
+  out = qops.correlation(precision)(x, w)
+  out.backward(go)
+  xd = x.detach().double().requires_grad_(); wd = w.detach().double().requires_grad_()
+  ref = nets.correlation_reference(xd, wd)
+  ref.backward(go.double())
+  for got, want in ((out, ref), (x.grad, xd.grad), (w.grad, wd.grad)):
+    assert got.shape == want.shape and got.dtype == torch.float32
+    err = float((got.double() - want).abs().max()); scale = float(want.abs().max())
+    assert err <= tol * scale, (err, scale)
+
+
 def test_policy_head_matches_torch():
   from stackrl_amd import qops
   g = torch.Generator(device='cuda').manual_seed(3)

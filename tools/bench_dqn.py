@@ -14,6 +14,7 @@ ap.add_argument('--rocks', type=int, default=16)
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--slots', type=int, default=16)
 ap.add_argument('--side-stream', type=int, default=1)
+ap.add_argument('--xcorr', default='bf16x3', help="update-path cross-correlation: bf16x3 | bf16 | library")
 ap.add_argument('--bf16', type=int, default=0, help='run the rollout forward under bf16 autocast (MFMA); fp32 is the reference dtype')
 args = ap.parse_args()
 B, L = args.envs, args.rocks
@@ -22,7 +23,8 @@ net = nets.DeepQSiamFCN(env.observation_spec, seed=1).cuda()
 agent = DQN(net, learning_rate=6.25e-5, adam_betas=(0.95, 0.95), minibatch_size=32, replay_memory_size=B * args.slots,
             discount_factor=.966667, collect_batch_size=B, exploration=PolynomialDecay(1.0, 400000, .1), prioritization=0.6,
             priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=7,
-            policy_op=qops.FusedPolicy(autocast=torch.bfloat16 if args.bf16 else None))
+            policy_op=qops.FusedPolicy(autocast=torch.bfloat16 if args.bf16 else None),
+            xcorr=None if args.xcorr == 'library' else args.xcorr)
 tr = Trainer(env, agent)
 tr.initialize(num_steps=4)
 tr.run(2)
@@ -39,4 +41,4 @@ torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(json.dumps({'envs': B, 'rocks': L, 'iters_per_s': args.iters / dt, 'env_steps_per_s': args.iters * B / dt,
                   'rollout_forward_ms': tf * 1e3, 'rollout_forward_tflops': 2 * macs * B / tf / 1e12,
                   'rollout_dtype': 'bf16' if args.bf16 else 'f32', 'fp32_peak_tflops': 157.3, 'frac_of_fp32_peak': 2 * macs * B / tf / 157.3e12,
-                  'collect_s': tr.collect_time, 'train_s': tr.train_time}))
+                  'update_xcorr': args.xcorr, 'collect_s': tr.collect_time, 'train_s': tr.train_time}))
