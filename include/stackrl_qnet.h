@@ -40,6 +40,20 @@ int srl_xcorr_mfma(int32_t mode, int32_t precision, const void* in_dev, int32_t 
                    int32_t H, int32_t kh, void* stream);
 const char* srl_xcorr_mfma_last_error(void);
 
+/* Fused element-wise passes of the U-Nets' inference forward (csrc/epilogue.hip), replacing Conv2D bias + ReLU,
+ * MaxPool2D and Concatenate of `layers.unet` (stackrl/nets/layers.py:135-259) around the library convolutions.
+ * Tensors are bfloat16, channels-last ([pixel][channel] in memory), C a multiple of 8.
+ *   srl_bias_act      : y = act(x + bias[c]); x [npix][C]; y goes to out[pix * out_stride + out_offset + c] (a channel
+ *                       slice of a wider channels-last buffer; in place with out = in, out_stride = C, out_offset = 0)
+ *                       or, when nchw_hw > 0, to [npix / nchw_hw][C][nchw_hw] (channel-major, for the cross-correlation)
+ *   srl_bias_act_pool : x [B][H][W][C] -> skip = relu(x + bias) (channel slice as above) and its 2 x 2 max-pool
+ *                       pooled [B][H/2][W/2][C] */
+int srl_bias_act(const void* in_dev, void* out_dev, const float* bias_dev, int64_t npix, int32_t C, int32_t out_stride,
+                 int32_t out_offset, int32_t nchw_hw, int32_t relu, void* stream);
+int srl_bias_act_pool(const void* in_dev, void* skip_dev, void* pooled_dev, const float* bias_dev, int32_t B, int32_t H,
+                      int32_t W, int32_t C, int32_t skip_stride, int32_t skip_offset, void* stream);
+const char* srl_epilogue_last_error(void);
+
 /* adv float32 [B][A]; u float32 [B] uniform(0,1); rnd int64 [B] uniform {0..A-1}; actions int64 [B] */
 int srl_policy_head(const float* adv_dev, const float* u_dev, const int64_t* rnd_dev, float epsilon,
                     int64_t* actions_dev, int32_t B, int32_t A, void* stream);

@@ -1,0 +1,141 @@
+// epilogue.hip — fused element-wise passes of the Q-net rollout forward (inference only), gfx950.
+//
+// The U-Net convolutions are library calls (MIOpen); around every one of them the stock graph runs a bias add, a
+// ReLU, and — per level — a 2 x 2 max-pool, a concatenation copy and finally a layout change for the
+// cross-correlation: 45 % of the rollout's GPU time in separate memory-bound kernels.  These two kernels do that work
+// in one pass over each convolution output (channels-last, `[pixel][channel]` in memory):
+//
+//   k_bias_act       y = relu(x + bias[c])  written in place, or into a channel slice of a wider channels-last
+//                    buffer (the decoder's concatenation buffer: no torch.cat), or transposed to [channel][pixel]
+//                    (the layout the cross-correlation kernel stages from)
+//   k_bias_act_pool  the same, plus the 2 x 2 max-pooled copy for the next encoder level
+//
+// Reference ops replaced: Conv2D bias + activation='relu', MaxPool2D, Concatenate of `layers.unet`
+// (stackrl/nets/layers.py:135-259).  8 channels (16 bytes of bf16) per thread.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/stackrl_qnet.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t e_bf16_rne(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void unpack8(const uint4 q, float* v) {
+  const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+  uint32_t w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = e_bf16_rne(v[2 * k]) | (e_bf16_rne(v[2 * k + 1]) << 16);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// in [npix][C] bf16; out: channels-last slice (pixel stride ostride, channel offset ooff) or, when nchw_hw > 0,
+// [B][C][nchw_hw] with npix = B * nchw_hw
+__global__ void __launch_bounds__(256) k_bias_act(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                  const float* __restrict__ bias, long long npix, int C, int ostride,
+                                                  int ooff, int nchw_hw, int relu) {
+  const int cg = C / 8;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= npix * cg) return;
+  long long pix; int g;
+  if (nchw_hw > 0) { g = (int)(idx / npix); pix = idx - (long long)g * npix; }   // adjacent lanes = adjacent pixels
+  else { pix = idx / cg; g = (int)(idx - pix * cg); }
+  float v[8];
+  unpack8(*(const uint4*)(in + pix * C + g * 8), v);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v[k] += bias[g * 8 + k];
+    if (relu) v[k] = fmaxf(v[k], 0.0f);
+  }
+  if (nchw_hw > 0) {
+    const long long b = pix / nchw_hw, p = pix - b * nchw_hw;
+    uint16_t* o = out + (b * C + g * 8) * nchw_hw + p;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[(long long)k * nchw_hw] = (uint16_t)e_bf16_rne(v[k]);
+  } else {
+    *(uint4*)(out + pix * ostride + ooff + g * 8) = pack8(v);
+  }
+}
+
+// in [B][H][W][C] bf16 (H, W even); skip out: channels-last slice as above; pooled [B][H/2][W/2][C]
+__global__ void __launch_bounds__(256) k_bias_act_pool(const uint16_t* __restrict__ in, uint16_t* __restrict__ skip,
+                                                       uint16_t* __restrict__ pooled, const float* __restrict__ bias,
+                                                       int B, int H, int W, int C, int ostride, int ooff) {
+  const int cg = C / 8, H2 = H / 2, W2 = W / 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)B * H2 * W2 * cg) return;
+  const int g = (int)(idx % cg);
+  long long q = idx / cg;
+  const int x2 = (int)(q % W2); q /= W2;
+  const int y2 = (int)(q % H2);
+  const long long b = q / H2;
+  float bz[8], m[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { bz[k] = bias[g * 8 + k]; m[k] = 0.0f; }   // post-ReLU values are >= 0
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const long long pix = (b * H + 2 * y2 + dy) * W + 2 * x2 + dx;
+      float v[8];
+      unpack8(*(const uint4*)(in + pix * C + g * 8), v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + bz[k], 0.0f);
+      const uint4 pk = pack8(v);
+      *(uint4*)(skip + pix * ostride + ooff + g * 8) = pk;
+      float r[8];
+      unpack8(pk, r);   // pool the rounded values, like MaxPool2D on the stored tensor
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], r[k]);
+    }
+  *(uint4*)(pooled + ((b * H2 + y2) * W2 + x2) * C + g * 8) = pack8(m);
+}
+
+thread_local char e_err[256] = "";
+
+int finish(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(e_err, sizeof e_err, "%s: %s", what, hipGetErrorString(e)); return 2; }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* srl_epilogue_last_error(void) { return e_err; }
+
+int srl_bias_act(const void* in, void* out, const float* bias, int64_t npix, int32_t C, int32_t out_stride,
+                 int32_t out_offset, int32_t nchw_hw, int32_t relu, void* stream) {
+  if (!in || !out || !bias || npix < 1 || C < 8 || C % 8 || out_stride % 8 || out_offset % 8 ||
+      (nchw_hw > 0 && npix % nchw_hw)) {
+    snprintf(e_err, sizeof e_err, "srl_bias_act: bad arguments (channel counts, strides and offsets must be multiples of 8)");
+    return 1;
+  }
+  const long long n = npix * (C / 8);
+  hipLaunchKernelGGL(k_bias_act, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in,
+                     (uint16_t*)out, bias, (long long)npix, C, out_stride, out_offset, nchw_hw, relu);
+  return finish("srl_bias_act");
+}
+
+int srl_bias_act_pool(const void* in, void* skip, void* pooled, const float* bias, int32_t B, int32_t H, int32_t W,
+                      int32_t C, int32_t skip_stride, int32_t skip_offset, void* stream) {
+  if (!in || !skip || !pooled || !bias || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 8 || C % 8 ||
+      skip_stride % 8 || skip_offset % 8) {
+    snprintf(e_err, sizeof e_err, "srl_bias_act_pool: bad arguments");
+    return 1;
+  }
+  const long long n = (long long)B * (H / 2) * (W / 2) * (C / 8);
+  hipLaunchKernelGGL(k_bias_act_pool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)in, (uint16_t*)skip, (uint16_t*)pooled, bias, B, H, W, C, skip_stride, skip_offset);
+  return finish("srl_bias_act_pool");
+}
+
+}  // extern "C"

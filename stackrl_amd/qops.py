@@ -25,6 +25,11 @@ def load():
     L.srl_xcorr_mfma.argtypes = [ctypes.c_int32, ctypes.c_int32, VP, ctypes.c_int32, VP, ctypes.c_int32, VP, VP,
                                  ctypes.c_int64] + [ctypes.c_int32] * 4 + [VP]
     L.srl_xcorr_mfma_last_error.restype = ctypes.c_char_p
+    L.srl_bias_act.restype = ctypes.c_int
+    L.srl_bias_act.argtypes = [VP, VP, VP, ctypes.c_int64] + [ctypes.c_int32] * 5 + [VP]
+    L.srl_bias_act_pool.restype = ctypes.c_int
+    L.srl_bias_act_pool.argtypes = [VP, VP, VP, VP] + [ctypes.c_int32] * 6 + [VP]
+    L.srl_epilogue_last_error.restype = ctypes.c_char_p
     L.srl_policy_head.restype = ctypes.c_int
     L.srl_policy_head.argtypes = [VP, VP, VP, ctypes.c_float, VP, ctypes.c_int32, ctypes.c_int32, VP]
     L.srl_qnet_last_error.restype = ctypes.c_char_p
@@ -120,14 +125,18 @@ def correlation(precision=BF16X3):
   return f
 
 
-def xcorr_forward(x, w):
+def xcorr_forward(x, w, precision=None):
   """`layers.correlation` forward (layers.py:21-38): x [B,C,H,W], w [B,C,kh,kw] -> float32 [B,1,OH,OW].
-  float32 features take the fp32 vector kernel (the reference's precision); bfloat16 features of the shapes in
-  MFMA_SHAPES (the autocast rollout path) take the MFMA kernel."""
+  For the shapes in MFMA_SHAPES the matrix-core kernel runs: bfloat16 features (the autocast rollout path) with
+  operands as they are, float32 features with the hi/lo split (bf16x3: fp32-class accuracy, same stated tolerance as
+  the vector kernel).  Other shapes, or precision='fp32', take the fp32 vector kernel."""
   if not x.is_cuda:
     raise RuntimeError('xcorr_forward needs a HIP device (no CPU fallback)')
-  if x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and _mfma_ok(x, w):
-    return xcorr_forward_mfma(x, w, BF16)
+  if precision != 'fp32' and _mfma_ok(x, w):
+    if x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16:
+      return xcorr_forward_mfma(x, w, BF16)
+    if x.dtype == torch.float32 and w.dtype == torch.float32:
+      return xcorr_forward_mfma(x, w, BF16X3)
   x = x.contiguous().float(); w = w.contiguous().float()
   B, C, H, W = x.shape
   kh, kw = w.shape[-2:]
@@ -152,14 +161,117 @@ def policy_head(adv, u, rnd, epsilon):
   return actions
 
 
+_CL = torch.channels_last
+
+
+def _cl(t):
+  return t if t.is_contiguous(memory_format=_CL) else t.contiguous(memory_format=_CL)
+
+
+def bias_act(y, bias, out=None, out_offset=0, relu=True, nchw=False):
+  """relu(y + bias[c]) in one pass (csrc/epilogue.hip).  y: bf16 [B,C,H,W] channels-last.  out: None = in place; a
+  channels-last bf16 tensor with >= C channels = write into its channel slice [out_offset, out_offset + C); nchw=True
+  returns a new NCHW-contiguous tensor (the layout the cross-correlation kernel reads)."""
+  B, C, H, W = y.shape
+  if nchw:
+    dst = torch.empty((B, C, H, W), dtype=y.dtype, device=y.device)
+    stride, hw = C, H * W
+  else:
+    dst = y if out is None else out
+    stride, hw = dst.shape[1], 0
+  with torch.cuda.device(y.device):
+    rc = load().srl_bias_act(y.data_ptr(), dst.data_ptr(), bias.data_ptr(), B * H * W, C, stride, out_offset, hw,
+                             int(relu), _stream(y))
+  if rc:
+    raise RuntimeError(load().srl_epilogue_last_error().decode())
+  return dst
+
+
+def bias_act_pool(y, bias, skip, skip_offset):
+  """relu(y + bias[c]) into the channel slice [skip_offset, skip_offset + C) of `skip`, plus its 2 x 2 max-pool."""
+  B, C, H, W = y.shape
+  pooled = torch.empty((B, C, H // 2, W // 2), dtype=y.dtype, device=y.device, memory_format=_CL)
+  with torch.cuda.device(y.device):
+    rc = load().srl_bias_act_pool(y.data_ptr(), skip.data_ptr(), pooled.data_ptr(), bias.data_ptr(), B, H, W, C,
+                                  skip.shape[1], skip_offset, _stream(y))
+  if rc:
+    raise RuntimeError(load().srl_epilogue_last_error().decode())
+  return pooled
+
+
+class FastFeatures(object):
+  """Inference-only forward of the two U-Nets (`DeepQSiamFCN.features`, models.py:160-177; `layers.unet`,
+  layers.py:135-259) in bf16 channels-last: library convolutions without bias, and the fused element-wise passes of
+  csrc/epilogue.hip instead of separate bias / ReLU / max-pool / concatenate / layout kernels.  Returns the left and
+  right feature maps NCHW-contiguous, ready for the MFMA cross-correlation."""
+
+  def __init__(self, net):
+    self.net = net
+    self._key = None
+    self._w = {}
+
+  def _refresh(self):
+    key = tuple(p._version for p in self.net.parameters()) + (id(self.net),)
+    if key == self._key:
+      return
+    self._w = {}
+    for m in self.net.modules():
+      if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+        self._w[m] = (m.weight.detach().to(torch.bfloat16).contiguous(memory_format=_CL), m.bias.detach().float().contiguous())
+    self._key = key
+
+  def _conv(self, m, x):
+    w, b = self._w[m]
+    return _cl(torch.nn.functional.conv2d(x, w, None, padding=m.padding)), b
+
+  def _unet(self, U, x):
+    F = torch.nn.functional
+    B = x.shape[0]
+    cats = []
+    for blk in U.down:
+      f = blk[0].out_channels
+      y, b = self._conv(blk[0], x)
+      bias_act(y, b)
+      y, b = self._conv(blk[2], y)
+      cat = torch.empty((B, 2 * f, y.shape[2], y.shape[3]), dtype=y.dtype, device=y.device, memory_format=_CL)
+      x = bias_act_pool(y, b, cat, f)               # skip -> second half of the decoder's concat buffer
+      cats.append(cat)
+    y, b = self._conv(U.bottom[0], x)
+    bias_act(y, b)
+    y, b = self._conv(U.bottom[2], y)
+    x = bias_act(y, b)
+    n = len(U.up)
+    for k, (up, blk) in enumerate(zip(U.up, U.upconv)):
+      cat = cats.pop()
+      w, b = self._w[up]
+      y = _cl(F.conv_transpose2d(x, w, None, stride=up.stride))
+      bias_act(y, b, out=cat, out_offset=0)         # Concatenate([up, skip]) without a copy
+      y, b = self._conv(blk[0], cat)
+      bias_act(y, b)
+      y, b = self._conv(blk[2], y)
+      x = bias_act(y, b, nchw=(k == n - 1))
+    return x
+
+  @torch.no_grad()
+  def __call__(self, inputs):
+    self._refresh()
+    xm, xo = inputs
+    # uint8 NHWC / 255 (models.py:144-147); the NHWC memory is exactly a channels-last NCHW tensor
+    x = (xm.float() / 255.0).to(torch.bfloat16).permute(0, 3, 1, 2)
+    w = (xo.float() / 255.0).to(torch.bfloat16).permute(0, 3, 1, 2)
+    return self._unet(self.net.left, x), self._unet(self.net.right, w)
+
+
 class FusedPolicy(object):
   """Rollout policy (`DQN.collect` -> `policy(exploration=True)`, dqn.py:391-395) with the hand-written head:
   library convs for the two U-Nets and the position convs, HIP cross-correlation, HIP arg-max + epsilon-greedy.
   Draws the same random numbers in the same order as `DQN.policy`, so both paths give identical actions."""
 
-  def __init__(self, chunk=512, autocast=None):
+  def __init__(self, chunk=512, autocast=None, fast=None):
     self.chunk = int(chunk)      # rollout batches are processed in chunks to bound activation memory
     self.autocast = autocast     # None = fp32 like the reference; torch.bfloat16 runs the library convs on MFMA
+    self.fast = (autocast == torch.bfloat16) if fast is None else bool(fast)   # fused epilogues (bf16 only)
+    self._ff = None
 
   @torch.no_grad()
   def __call__(self, net, inputs, epsilon, gen):
@@ -170,7 +282,11 @@ class FusedPolicy(object):
     out = torch.empty(B, dtype=torch.int64, device=xm.device)
     for s in range(0, B, self.chunk):
       e = min(B, s + self.chunk)
-      if self.autocast is not None:
+      if self.fast:
+        if self._ff is None or self._ff.net is not net:
+          self._ff = FastFeatures(net)
+        x, w = self._ff((xm[s:e], xo[s:e]))
+      elif self.autocast is not None:
         with torch.autocast('cuda', dtype=self.autocast):
           x, _, w = net.features((xm[s:e], xo[s:e]))
       else:

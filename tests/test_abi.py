@@ -32,7 +32,8 @@ def test_qnet_library_exports_every_declared_symbol():
   build.build()
   with open(os.path.join(ROOT, 'include', 'stackrl_qnet.h')) as f:
     names = sorted(set(re.findall(r'\b(srl_[a-z_]+)\s*\(', f.read())))
-  assert names == ['srl_baseline_select', 'srl_heuristic', 'srl_policy_head', 'srl_qnet_last_error', 'srl_xcorr_forward',
+  assert names == ['srl_baseline_select', 'srl_bias_act', 'srl_bias_act_pool', 'srl_epilogue_last_error', 'srl_heuristic',
+                   'srl_policy_head', 'srl_qnet_last_error', 'srl_xcorr_forward',
                    'srl_xcorr_mfma', 'srl_xcorr_mfma_last_error', 'srl_xcorr_mfma_scratch_bytes']
   L = ctypes.CDLL(build.QLIB)
   for n in names:

@@ -14,9 +14,11 @@ def test_xcorr_hip_matches_torch_fp32(B, C, H, h):
   g = torch.Generator(device='cuda').manual_seed(B * 7 + C)
   x = torch.rand((B, C, H, H), generator=g, device='cuda')          # post-ReLU features are non-negative
   w = torch.rand((B, C, h, h), generator=g, device='cuda') - 0.3
-  got = qops.xcorr_forward(x, w)
   ref = nets.correlation_reference(x.double(), w.double()).float()  # fp64 accumulate reference
-  assert got.shape == ref.shape == (B, 1, H - h + 1, H - h + 1)
+  for precision in (None, 'fp32'):                                  # default route (MFMA bf16x3 where built) and the vector kernel
+    got = qops.xcorr_forward(x, w, precision)
+    assert got.shape == ref.shape == (B, 1, H - h + 1, H - h + 1)
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
   # fp32 accumulation of C*h*h <= 16,384 products: stated tolerance 2e-5 relative to the result scale
   scale = float(ref.abs().max())
   assert float((got - ref).abs().max()) <= 2e-5 * scale
@@ -64,6 +66,34 @@ def test_xcorr_mfma_autograd_matches_torch_fp64(B, C, H, h, precision, tol):
     assert got.shape == want.shape and got.dtype == torch.float32
     err = float((got.double() - want).abs().max()); scale = float(want.abs().max())
     assert err <= tol * scale, (err, scale)
+
+
+def test_fast_features_match_autocast_features():
+  """Fused-epilogue inference forward of the U-Nets (qops.FastFeatures, csrc/epilogue.hip) against the stock module
+  graph under bf16 autocast: same bf16 convolutions, the bias add / ReLU rounding points differ, so the stated
+  tolerance is bf16-level: 3 % of the feature scale per element, 0.3 % on average."""
+  from stackrl_amd import nets, qops
+  net = nets.DeepQSiamFCN(seed=5).cuda().eval()
+  g = torch.Generator(device='cuda').manual_seed(4)
+  xm = torch.randint(0, 256, (6, 128, 128, 2), generator=g, device='cuda', dtype=torch.uint8)
+  xo = torch.randint(0, 256, (6, 32, 32, 1), generator=g, device='cuda', dtype=torch.uint8)
+  fx, fw = qops.FastFeatures(net)((xm, xo))
+  with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+    rx, _, rw = net.features((xm, xo))
+  with torch.no_grad():
+    ex, _, ew = net.features((xm, xo))            # fp32
+  for got, ref, exact in ((fx, rx, ex), (fw, rw, ew)):
+    assert got.shape == ref.shape and got.dtype == torch.bfloat16 and got.is_contiguous()
+    scale = float(exact.abs().max())
+    d = (got.float() - ref.float()).abs()
+    assert float(d.max()) <= 3e-2 * scale and float(d.mean()) <= 3e-3 * scale
+    # and it is as close to the fp32 forward as the autocast graph is
+    e_fast = float((got.float() - exact).abs().mean()); e_auto = float((ref.float() - exact).abs().mean())
+    assert e_fast <= 1.5 * e_auto + 1e-6 * scale
+  # the rollout policy built on it returns valid actions and mostly the arg-max of the fp32 net at epsilon 0
+  pol = qops.FusedPolicy(autocast=torch.bfloat16)
+  a = pol(net, (xm, xo), 0.0, torch.Generator(device='cuda').manual_seed(1))
+  assert a.shape == (6,) and int(a.min()) >= 0 and int(a.max()) < net.n_actions
 
 
 def test_policy_head_matches_torch():

@@ -40,5 +40,7 @@ tr.run(args.iters)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(json.dumps({'envs': B, 'rocks': L, 'iters_per_s': args.iters / dt, 'env_steps_per_s': args.iters * B / dt,
                   'rollout_forward_ms': tf * 1e3, 'rollout_forward_tflops': 2 * macs * B / tf / 1e12,
-                  'rollout_dtype': 'bf16' if args.bf16 else 'f32', 'fp32_peak_tflops': 157.3, 'frac_of_fp32_peak': 2 * macs * B / tf / 157.3e12,
+                  'rollout_dtype': 'bf16' if args.bf16 else 'f32',
+                  'peak_tflops': 2500.0 if args.bf16 else 157.3, 'peak': 'dense bf16 MFMA' if args.bf16 else 'fp32 vector',
+                  'frac_of_peak': 2 * macs * B / tf / ((2500.0 if args.bf16 else 157.3) * 1e12),
                   'update_xcorr': args.xcorr, 'collect_s': tr.collect_time, 'train_s': tr.train_time}))
