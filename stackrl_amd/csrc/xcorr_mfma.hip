@@ -213,12 +213,14 @@ int launch2(const void* in, const void* kern, float* out, void* scratch, int B, 
   hipLaunchKernelGGL((k_toeplitz<KH, KF32, SPLIT>), dim3((unsigned)nrows, G::KB), dim3(64), 0, st, kern, (uint16_t*)scratch, nrows);
   const size_t lds = sizeof(uint16_t) * G::ROWS * G::RS * (SPLIT ? 2 : 1);
   auto fn = k_xcorr_mfma<HIN, KH, IN_PER_C, K_PER_C, SUM, IF32, SPLIT>;
-  if (lds > 65536) {
+  static bool lds_opted_in = false;   // per instantiation; set once, outside any later stream capture
+  if (lds > 65536 && !lds_opted_in) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       snprintf(x_err, sizeof x_err, "srl_xcorr_mfma: LDS opt-in of %zu bytes failed: %s", lds, hipGetErrorString(e));
       return 2;
     }
+    lds_opted_in = true;
   }
   int cper, csplit;
   channel_split(B, C, &cper, &csplit);

@@ -31,13 +31,48 @@ class PolynomialDecay(object):
 EXPLORATION_MODES = ['epsilon-greedy', 'boltzmann']     # dqn.py:23-28
 
 
+class GraphedEval(object):
+  """`net(inputs)` without grad, replayed from a hipGraph (torch.cuda.CUDAGraph) for a fixed input signature.
+  The target evaluations of the update are ~200 launches of microsecond kernels each; as a graph each is one launch.
+  The net's parameters are read in place, so optimiser steps and target syncs need no re-capture."""
+
+  def __init__(self, net):
+    self.net = net
+    self.graph = None
+    self.sig = None
+
+  def _capture(self, inputs):
+    self.static_in = tuple(torch.empty_like(t) for t in inputs)
+    for s, t in zip(self.static_in, inputs):
+      s.copy_(t)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():       # warm-up: library solver search, lazy initialisations
+      for _ in range(2):
+        self.net(self.static_in)
+    torch.cuda.current_stream().wait_stream(side)
+    self.graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(self.graph), torch.no_grad():
+      self.static_out = self.net(self.static_in)
+
+  def __call__(self, inputs):
+    sig = tuple((tuple(t.shape), t.dtype) for t in inputs)
+    if sig != self.sig:
+      self._capture(inputs)
+      self.sig = sig
+    for s, t in zip(self.static_in, inputs):
+      s.copy_(t)
+    self.graph.replay()
+    return self.static_out
+
+
 class DQN(object):
   def __init__(self, q_net, optimizer=None, learning_rate=None, huber_delta=1., minibatch_size=32,
                replay_memory_size=100000, prefetch=None, target_update_period=10000, reward_scale=None,
                discount_factor=.99, collect_batch_size=None, exploration_mode=None, exploration=None,
                prioritization=None, priority_bias_compensation=None, double=False, n_step=None, seed=None,
                device=None, process_group=None, policy_op=None, reference_next_index=False,
-               adam_betas=(0.9, 0.999), xcorr=None):
+               adam_betas=(0.9, 0.999), xcorr=None, graphs=False):
     if not isinstance(q_net, torch.nn.Module):
       raise TypeError('Invalid type {} for argument q_net. Must be a torch Module.'.format(type(q_net)))   # dqn.py:122-125
     self.device = torch.device(device) if device is not None else next(q_net.parameters()).device
@@ -124,6 +159,10 @@ class DQN(object):
     self._pg = process_group
     self._world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
     self._policy_op = policy_op     # optional fused rollout head (stackrl_amd.qops.FusedPolicy)
+    # graphs: replay the no-grad target evaluations of the update from hipGraphs (HIP device only)
+    self._graphs = bool(graphs) and self.device.type == 'cuda'
+    self._g_target = GraphedEval(self._target_q_net) if self._graphs else None
+    self._g_online = GraphedEval(self._q_net) if self._graphs else None
 
   def __call__(self, state, reward, terminal, action=None):
     return self.collect(state, reward, terminal) if action is None else self.observe(state, reward, terminal, action)
@@ -191,9 +230,9 @@ class DQN(object):
         rewards = rewards * self._reward_scale
       if self._gamma == 0 and not self._n_step:
         return rewards
-      tq = self._target_q_net(next_states)
+      tq = self._g_target(next_states) if self._graphs else self._target_q_net(next_states)
       if self._double:
-        a = torch.argmax(self._q_net(next_states), dim=-1)
+        a = torch.argmax(self._g_online(next_states) if self._graphs else self._q_net(next_states), dim=-1)
         tq = tq.gather(1, a[:, None])[:, 0]
       else:
         tq = tq.amax(dim=-1)

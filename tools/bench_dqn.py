@@ -15,6 +15,7 @@ ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--slots', type=int, default=16)
 ap.add_argument('--side-stream', type=int, default=1)
 ap.add_argument('--xcorr', default='bf16x3', help="update-path cross-correlation: bf16x3 | bf16 | library")
+ap.add_argument('--graphs', type=int, default=0, help='replay the target evaluations of the update from hipGraphs')
 ap.add_argument('--bf16', type=int, default=0, help='run the rollout forward under bf16 autocast (MFMA); fp32 is the reference dtype')
 args = ap.parse_args()
 B, L = args.envs, args.rocks
@@ -24,7 +25,7 @@ agent = DQN(net, learning_rate=6.25e-5, adam_betas=(0.95, 0.95), minibatch_size=
             discount_factor=.966667, collect_batch_size=B, exploration=PolynomialDecay(1.0, 400000, .1), prioritization=0.6,
             priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=7,
             policy_op=qops.FusedPolicy(autocast=torch.bfloat16 if args.bf16 else None),
-            xcorr=None if args.xcorr == 'library' else args.xcorr)
+            xcorr=None if args.xcorr == 'library' else args.xcorr, graphs=bool(args.graphs))
 tr = Trainer(env, agent)
 tr.initialize(num_steps=4)
 tr.run(2)
@@ -43,4 +44,4 @@ print(json.dumps({'envs': B, 'rocks': L, 'iters_per_s': args.iters / dt, 'env_st
                   'rollout_dtype': 'bf16' if args.bf16 else 'f32',
                   'peak_tflops': 2500.0 if args.bf16 else 157.3, 'peak': 'dense bf16 MFMA' if args.bf16 else 'fp32 vector',
                   'frac_of_peak': 2 * macs * B / tf / ((2500.0 if args.bf16 else 157.3) * 1e12),
-                  'update_xcorr': args.xcorr, 'collect_s': tr.collect_time, 'train_s': tr.train_time}))
+                  'update_xcorr': args.xcorr, 'graphs': bool(args.graphs), 'collect_s': tr.collect_time, 'train_s': tr.train_time}))
