@@ -195,7 +195,8 @@ class DQN(object):
   def policy(self, inputs, exploration=False, values=False):
     if self._policy_op is not None and exploration and not values and self._exploration_mode == 'epsilon-greedy':
       return self._policy_op(self._q_net, inputs, self.exploration, self._gen)
-    q = self._q_net(inputs)
+    with torch.no_grad():
+      q = self._q_net(inputs)
     greedy = torch.argmax(q, dim=-1)                 # ties -> lowest index
     if exploration:
       e = self.exploration
@@ -281,3 +282,21 @@ class DQN(object):
 
   def save_weights(self, path):
     torch.save(self._q_net.state_dict(), path)
+
+  def state_dict(self, memory=True):
+    """Everything `tf.train.Checkpoint(agent=...)` tracks in the reference (training.py:199-208): both nets, the
+    optimiser slots, the iteration counter, the RNG stream and (optionally) the replay memory."""
+    d = {'q_net': self._q_net.state_dict(), 'target_q_net': self._target_q_net.state_dict(),
+         'optimizer': self._optimizer.state_dict(), 'iterations': int(self._iterations), 'gen': self._gen.get_state()}
+    if memory:
+      d['replay_memory'] = self._replay_memory.state_dict()
+    return d
+
+  def load_state_dict(self, d):
+    self._q_net.load_state_dict(d['q_net'])
+    self._target_q_net.load_state_dict(d['target_q_net'])
+    self._optimizer.load_state_dict(d['optimizer'])
+    self._iterations = int(d['iterations'])
+    self._gen.set_state(d['gen'].cpu())
+    if 'replay_memory' in d:
+      self._replay_memory.load_state_dict(d['replay_memory'])

@@ -62,6 +62,26 @@ class ReplayMemory(object):
   def __len__(self):
     return int(torch.isfinite(self._logits).sum())                 # memory.py:129-132
 
+  # ------------------------------------------------------------------ checkpointing (the reference tracks these as
+  # tf.Variables of the agent module, training.py:199-208)
+  _STATE = ('_rewards', '_terminal', '_actions', '_logits', '_max_logit', '_max_logit_index', '_min_logit',
+            '_min_logit_index')
+
+  def state_dict(self):
+    d = {k: getattr(self, k).clone() for k in self._STATE}
+    d['states'] = [s.clone() for s in self._states]
+    d['insert_index'] = int(self._insert_index)
+    d['gen'] = self._gen.get_state()
+    return d
+
+  def load_state_dict(self, d):
+    for k in self._STATE:
+      setattr(self, k, d[k].to(self.device).clone())
+    for s, v in zip(self._states, d['states']):
+      s.copy_(v)
+    self._insert_index = int(d['insert_index'])
+    self._gen.set_state(d['gen'].cpu())
+
   @property
   def max_length(self):
     return self._max_length

@@ -1,21 +1,100 @@
-"""The loop that calls the hot path: `Training.initialize` / `Training.run` (stackrl/train/training.py:233-296,
-:338-380) restated as sequencing only — one vectorised env step and one minibatch update per iteration, the env
-step enqueued non-blocking so that it overlaps `agent.train()` (training.py:359-368).  Logging, checkpoints, eval
-and curriculum of the reference class are out of scope."""
+"""The loop that calls the hot path: `Training` (stackrl/train/training.py) restated — `initialize` (:233-296), `run`
+(:298-423: one vectorised env step and one minibatch update per iteration, the env step enqueued non-blocking so that
+it overlaps `agent.train()`, :359-368), `eval` (:398-452), `log_train` (:487-509), `save` (:454-465), `checkpoint`
+(:467-485), with the reference's on-disk formats: `train.csv` (`Iter,Return,Loss,MeanError,CollectTime,TrainTime`),
+`eval.csv` (`Iter,Return,Value,MeanValue,StdValue,MinValue,MaxValue`), `train.log`, `saved_weights/<iter>/weights`,
+`checkpoint/`.  Weights and checkpoints are torch files (the reference writes TF checkpoints; TensorFlow is not part
+of this build).  Curriculum sequencing (:521-575) is not built."""
+import os
+import sys
 import time
+import traceback
+from datetime import datetime
 
 import torch
 
+from stackrl_amd import metrics
+
 
 class Trainer(object):
-  def __init__(self, env, agent):
-    self._env, self._agent = env, agent
-    self.collect_time = self.train_time = 0.0
-    self.returns = torch.zeros(env.batch_size, device=agent.device)
+  def __init__(self, env, agent, eval_env=None, directory=None, log_interval=100, eval_interval=10000,
+               checkpoint_interval=10000, eval_seed=None, train_reward_buffer_length=10, eval_reward_buffer_length=10,
+               save_evaluated_policies=False, log_to_file=True, checkpoint_memory=True):
+    """
+    Args (training.py:40-103):
+      env, agent: the vectorised environment and the DQN agent.
+      eval_env: environment for `eval()`; None disables evaluation.
+      directory: where train.csv / eval.csv / train.log / saved_weights / checkpoint go; None disables all files.
+      log_interval, eval_interval, checkpoint_interval: in agent iterations.
+      eval_seed: seed of the evaluation env, reapplied at every evaluation (:404).
+      train_reward_buffer_length, eval_reward_buffer_length: episodes averaged by the `Return` columns (:176-184).
+      save_evaluated_policies: save the Q-net weights after every evaluation (:190-197, :386-387).
+      checkpoint_memory: include the replay memory in checkpoints (the reference always does).
+    """
+    self._env, self._agent, self._eval_env = env, agent, eval_env
+    self._directory = directory
+    self._log_interval, self._eval_interval = int(log_interval), int(eval_interval)
+    self._checkpoint_interval = int(checkpoint_interval)
+    self._eval_seed = eval_seed
+    self._save_weights = bool(save_evaluated_policies)
+    self._checkpoint_memory = bool(checkpoint_memory)
+    dev = agent.device
+    self._reward = metrics.AverageReward(env.batch_size, length=train_reward_buffer_length, device=dev)
+    self._eval_reward = metrics.AverageReward(eval_env.batch_size if eval_env is not None else 1,
+                                              length=eval_reward_buffer_length, device=dev)
+    self._loss = metrics.AverageMetric(length=self._log_interval, device=dev)
+    self._mean_error = metrics.AverageMetric(length=self._log_interval, device=dev)
+    self._collect_timer, self._train_timer = metrics.Timer(), metrics.Timer()
+    self.collect_time = self.train_time = 0.0          # cumulative, for the benchmarks
+    self._train_file = self._eval_file = self._log_file = self._ckpt_file = None
+    if directory is not None:
+      os.makedirs(directory, exist_ok=True)
+      self._train_file = os.path.join(directory, 'train.csv')
+      self._eval_file = os.path.join(directory, 'eval.csv')
+      self._log_file = os.path.join(directory, 'train.log') if log_to_file else None
+      self._ckpt_file = os.path.join(directory, 'checkpoint', 'ckpt.pt')
+    self._last_checkpoint_iter = self._last_save_iter = None
+    self._initialized = False
+    self._reset_env = False
 
+  # ------------------------------------------------------------------ small helpers
+  @property
+  def iterations(self):
+    return self._agent.iterations
+
+  @property
+  def returns(self):
+    """Average return of the last finished training episodes (`Return` column of train.csv)."""
+    return self._reward.result
+
+  def log(self, line):
+    """training.py:577-588: timestamped line to train.log (or stdout)."""
+    line = '{}: {}\n'.format(datetime.now(), line)
+    if self._log_file is not None:
+      with open(self._log_file, 'a') as f:
+        f.write(line)
+    elif self._directory is not None:
+      sys.stdout.write(line)
+
+  def log_exception(self):
+    error = str(datetime.now()) + ': Exception.\n' + traceback.format_exc()
+    if self._log_file is not None:
+      with open(self._log_file, 'a') as f:
+        f.write(error)
+    else:
+      sys.stderr.write(error)
+
+  # ------------------------------------------------------------------ initialize (training.py:233-296)
   def initialize(self, num_steps=None, policy=None):
-    """training.py:256-289: initial (random) collect; the last stored step is marked terminal."""
+    """Restores the last checkpoint if there is one; otherwise the initial collect (random policy by default,
+    training.py:256-263) whose last stored step is marked terminal (:284-289), then a first evaluation."""
     env, agent = self._env, self._agent
+    if self._ckpt_file is not None and os.path.isfile(self._ckpt_file):
+      self.log('Restoring checkpoint.')
+      self.restore()
+      self._initialized = True
+      return
+    self.log('Collecting initial experience...')
     num_steps = num_steps or agent.replay_memory_size
     policy = policy or (lambda o: env.sample())
     step = env.reset()
@@ -30,26 +109,129 @@ class Trainer(object):
     if a is None:
       a = policy(o)
     agent.observe(o, r, torch.ones(env.batch_size, dtype=torch.bool, device=r.device), a)
+    self.log('Done.')
+    if self._eval_env is not None and self._directory is not None:
+      self.eval()
+    self._initialized = True
 
-  def run(self, max_num_iters):
-    """training.py:335-380."""
+  # ------------------------------------------------------------------ run (training.py:298-396)
+  def run(self, max_num_iters=sys.maxsize):
     env, agent = self._env, self._agent
-    step = env.reset()
-    agent.acknowledge_reset()
+    if not self._initialized:
+      self.initialize()
     losses = []
-    for _ in range(max_num_iters):
-      t0 = time.perf_counter()
+    step = None
+    try:
+      step = env.reset()
+      agent.acknowledge_reset()
+      for _ in range(max_num_iters):
+        t0 = time.perf_counter()
+        with self._collect_timer:
+          if callable(step):
+            step = step()
+          self._reward += step
+          action = agent.collect(*step)
+          step = env.step(action)          # non-blocking: the settle/render kernels overlap the update below
+        t1 = time.perf_counter()
+        with self._train_timer:
+          loss, merr = agent.train()
+          self._loss += loss
+          self._mean_error += merr
+        losses.append(loss)
+        t2 = time.perf_counter()
+        self.collect_time += t1 - t0
+        self.train_time += t2 - t1
+        iters = self.iterations
+        if self._directory is not None:
+          if iters % self._log_interval == 0:
+            self.log_train()
+          if self._eval_env is not None and iters % self._eval_interval == 0:
+            self.eval()
+            if self._save_weights:
+              self.save()
+          if iters % self._checkpoint_interval == 0:
+            self.checkpoint()
+        if self._reset_env:
+          self._reset_env = False
+          if callable(step):
+            step()
+          step = env.reset()
+          agent.acknowledge_reset()
+    except Exception:
+      self.log_exception()
+      raise
+    finally:
+      if callable(step):
+        step()
+      if self._directory is not None:
+        self.checkpoint()
+    return torch.stack(losses) if losses else torch.zeros(0)
+
+  # ------------------------------------------------------------------ eval (training.py:398-452)
+  def eval(self):
+    """Greedy policy on the evaluation env until `eval_reward_buffer_length` episodes finished; one eval.csv row."""
+    env, agent = self._eval_env, self._agent
+    self.log('Running evaluation...')
+    self._eval_reward.reset(full=True)
+    if self._eval_seed is not None:
+      env.seed(self._eval_seed)
+    step = env.reset()
+    if callable(step):
+      step = step()
+    values = []
+    while not self._eval_reward.full:
+      a, value = agent.policy(step[0], values=True)
+      step = env.step(a)
       if callable(step):
         step = step()
-      self.returns += step[1]
-      action = agent.collect(*step)
-      step = env.step(action)            # non-blocking: the settle/render kernels overlap the update below
-      t1 = time.perf_counter()
-      loss, merr = agent.train()
-      losses.append(loss)
-      t2 = time.perf_counter()
-      self.collect_time += t1 - t0
-      self.train_time += t2 - t1
-    if callable(step):
-      step()
-    return torch.stack(losses) if losses else torch.zeros(0)
+      self._eval_reward += step
+      values.append(value)
+    values = torch.stack(values)                                   # [steps, B, A]
+    row = (self.iterations, float(self._eval_reward.result), float(values.amax(dim=-1).mean()), float(values.mean()),
+           float(values.std(unbiased=False)), float(values.min()), float(values.max()))
+    if self._eval_file is not None:
+      header = '' if os.path.isfile(self._eval_file) else 'Iter,Return,Value,MeanValue,StdValue,MinValue,MaxValue\n'
+      with open(self._eval_file, 'a') as f:
+        f.write(header + '{},{},{},{},{},{},{}\n'.format(*row))
+    self.log('Done.')
+    return row
+
+  # ------------------------------------------------------------------ logs, weights, checkpoints
+  def log_train(self):
+    """training.py:487-509: one train.csv row."""
+    iters = self.iterations
+    reward, loss, merr = float(self._reward.result), float(self._loss.result), float(self._mean_error.result)
+    if self._train_file is not None:
+      header = '' if os.path.isfile(self._train_file) else 'Iter,Return,Loss,MeanError,CollectTime,TrainTime\n'
+      with open(self._train_file, 'a') as f:
+        f.write(header + '{},{},{},{},{},{}\n'.format(iters, reward, loss, merr, self._collect_timer(), self._train_timer()))
+    self.log('Iter {:8} Return {:<11.6} Loss {:<11.6}'.format(iters, reward, loss))
+
+  def save(self):
+    """training.py:454-465: the current Q-net weights under saved_weights/<iter>/weights."""
+    iters = self.iterations
+    if iters != self._last_save_iter and self._directory is not None:
+      self.log("Saving Q network's weights...")
+      path = os.path.join(self._directory, 'saved_weights', str(iters), 'weights')
+      os.makedirs(os.path.dirname(path), exist_ok=True)
+      self._agent.save_weights(path)
+      self._last_save_iter = iters
+      self.log('Done.')
+
+  def checkpoint(self):
+    """training.py:467-485: agent (nets, optimiser, counters, replay memory) + the training-return metric."""
+    iters = self.iterations
+    if iters != self._last_checkpoint_iter and self._ckpt_file is not None:
+      self.log('Saving checkpoint...')
+      os.makedirs(os.path.dirname(self._ckpt_file), exist_ok=True)
+      tmp = self._ckpt_file + '.tmp'
+      torch.save({'agent': self._agent.state_dict(memory=self._checkpoint_memory), 'reward': self._reward.state_dict()}, tmp)
+      os.replace(tmp, self._ckpt_file)                             # max_to_keep=1, never a half-written file
+      self._last_checkpoint_iter = iters
+      self.log('Done.')
+
+  def restore(self):
+    d = torch.load(self._ckpt_file, map_location=self._agent.device, weights_only=False)
+    self._agent.load_state_dict(d['agent'])
+    self._reward.load_state_dict(d['reward'])
+    self._last_checkpoint_iter = self.iterations

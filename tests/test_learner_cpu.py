@@ -300,3 +300,121 @@ def test_bench_aggregation_world_size_2_gloo(tmp_path):
   mp.spawn(_bench_rank, args=(2, 31000 + os.getpid() % 2000, out), nprocs=2, join=True)
   res = torch.load(out)
   assert res == {'dt': 2.0, 'placed': 300.0}
+
+
+# ---------------------------------------------------------------------------- training loop, logs, checkpoints
+class _ToyEnv(object):
+  """The env interface `Training` uses (training.py:105, :267-275, :335-368) on CPU tensors: episodes of `L` steps,
+  done on the L-th step, the step after a done is the reset step (reward 0, done False) like env.py:235-236."""
+
+  def __init__(self, B, L, spec, seed=0):
+    self.batch_size, self.L, self.spec = B, L, spec
+    self.n_actions = (spec[0][0] - spec[1][0] + 1) ** 2
+    self.seed(seed)
+
+  def seed(self, seed=None):
+    self._g = torch.Generator().manual_seed(int(seed or 0))
+    self._t = 0
+    return [seed]
+
+  def _obs(self):
+    return tuple(torch.randint(0, 256, (self.batch_size,) + tuple(s), generator=self._g, dtype=torch.uint8) for s in self.spec)
+
+  def reset(self):
+    self._t = 0
+    return self._obs(), torch.zeros(self.batch_size), torch.zeros(self.batch_size, dtype=torch.bool)
+
+  def sample(self):
+    return torch.randint(0, self.n_actions, (self.batch_size,), generator=self._g)
+
+  def step(self, action):
+    assert action.shape == (self.batch_size,) and int(action.max()) < self.n_actions
+    self._t += 1
+    if self._t % (self.L + 1) == 0:      # auto-reset call
+      step = (self._obs(), torch.zeros(self.batch_size), torch.zeros(self.batch_size, dtype=torch.bool))
+    else:
+      done = torch.full((self.batch_size,), self._t % (self.L + 1) == self.L)
+      step = (self._obs(), torch.rand(self.batch_size, generator=self._g), done)
+    return lambda: step                  # non-blocking flavour: a callable, training.py:269-270
+
+
+def _toy_agent(spec, B, seed):
+  net = nets.DeepQSiamFCN(spec, left_filters=4, left_depth=2, pos_filters=4, dueling_units=8, seed=seed)
+  return DQN(net, learning_rate=1e-3, minibatch_size=4, replay_memory_size=B * 8, discount_factor=.9,
+             collect_batch_size=B, exploration=0.5, prioritization=0.6, priority_bias_compensation=0.5, double=True,
+             seed=seed, target_update_period=3)
+
+
+def test_metrics_follow_the_reference_semantics():
+  from stackrl_amd import metrics
+  m = metrics.AverageMetric(length=3)
+  assert math.isnan(float(m.result)) and not m.full
+  for v in (1., 2.):
+    m += v
+  assert float(m.result) == 1.5 and not m.full                     # partial buffer: sum / count (metrics.py:101-104)
+  m += 6.; m += 10.                                                # wraps: [10, 2, 6]
+  assert m.full and float(m.result) == 6.0 and m > 5 and m <= 6
+  r = metrics.AverageReward(batch_size=3, length=2)
+  r += (None, torch.tensor([1., 2., 3.]), torch.tensor([False, False, False]))
+  r += (None, torch.tensor([1., 1., 1.]), torch.tensor([True, False, True]))   # returns 2 and 4 enter in env order
+  assert r.full and float(r.result) == 3.0
+  r += (None, torch.tensor([5., 1., 1.]), torch.tensor([True, True, False]))    # 5 then 4 replace them
+  assert float(r.result) == 4.5
+  r.reset()
+  assert not r.full and float(r._episode_reward[2]) == 1.0                       # ongoing episodes are kept (metrics.py:168-173)
+  r.reset(full=True)
+  assert float(r._episode_reward.abs().sum()) == 0.0
+  t = metrics.Timer()
+  assert t() is None
+  with t:
+    pass
+  with t:
+    pass
+  assert t.n == 2 and t(reset=False) >= 0.0 and t() is not None and t() is None
+
+
+def test_training_loop_writes_the_reference_file_formats_and_resumes(tmp_path):
+  from stackrl_amd.training import Trainer
+  spec = ((16, 16, 2), (4, 4, 1))
+  B, L = 3, 4
+  d = str(tmp_path / 'run')
+
+  def make():
+    agent = _toy_agent(spec, B, seed=3)
+    return agent, Trainer(_ToyEnv(B, L, spec, seed=1), agent, eval_env=_ToyEnv(2, L, spec, seed=2), directory=d,
+                          log_interval=2, eval_interval=4, checkpoint_interval=4, eval_seed=5,
+                          train_reward_buffer_length=2, eval_reward_buffer_length=4, save_evaluated_policies=True)
+
+  agent, tr = make()
+  tr.initialize(num_steps=6)
+  losses = tr.run(8)
+  assert losses.shape == (8,) and agent.iterations == 8
+  rows = open(os.path.join(d, 'train.csv')).read().strip().split('\n')
+  assert rows[0] == 'Iter,Return,Loss,MeanError,CollectTime,TrainTime'          # training.py:495-497
+  assert [int(r.split(',')[0]) for r in rows[1:]] == [2, 4, 6, 8] and all(len(r.split(',')) == 6 for r in rows[1:])
+  rows = open(os.path.join(d, 'eval.csv')).read().strip().split('\n')
+  assert rows[0] == 'Iter,Return,Value,MeanValue,StdValue,MinValue,MaxValue'    # training.py:435-437
+  assert [int(r.split(',')[0]) for r in rows[1:]] == [0, 4, 8]                  # initial evaluation + every 4
+  vals = [float(x) for x in rows[-1].split(',')[1:]]
+  assert vals[4] <= vals[2] <= vals[1] <= vals[5] and vals[3] >= 0                # min <= mean <= mean-of-max <= max
+  assert os.path.isfile(os.path.join(d, 'saved_weights', '4', 'weights')) and os.path.isfile(os.path.join(d, 'saved_weights', '8', 'weights'))
+  assert 'Running evaluation' in open(os.path.join(d, 'train.log')).read()
+  assert os.path.isfile(os.path.join(d, 'checkpoint', 'ckpt.pt'))
+  # same evaluation seed -> the evaluation env replays the same episodes: a second eval now gives the same row
+  again = tr.eval()
+  assert again[1:] == tuple(vals)
+  # a fresh process: initialize() restores agent, memory and the return metric instead of collecting
+  agent2, tr2 = make()
+  assert agent2.iterations == 0
+  tr2.initialize()
+  assert agent2.iterations == 8
+  for p, q in zip(agent._q_net.parameters(), agent2._q_net.parameters()):
+    assert torch.equal(p, q)
+  for p, q in zip(agent._target_q_net.parameters(), agent2._target_q_net.parameters()):
+    assert torch.equal(p, q)
+  assert torch.equal(agent._replay_memory._actions, agent2._replay_memory._actions)
+  assert torch.equal(agent._replay_memory._logits, agent2._replay_memory._logits)
+  assert float(tr2._reward.result) == float(tr._reward.result)
+  # and continues: the next update draws the same minibatch and lands on the same weights in both
+  la, _ = agent.train(); lb, _ = agent2.train()
+  assert float(la) == float(lb)

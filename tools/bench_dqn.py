@@ -14,12 +14,14 @@ ap.add_argument('--rocks', type=int, default=16)
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--slots', type=int, default=16)
 ap.add_argument('--side-stream', type=int, default=1)
+ap.add_argument('--res', type=int, default=128, help='overhead map side (object map = res / 4): 128 = Stack-v0 default, 64 = BASELINE configs[4]')
 ap.add_argument('--xcorr', default='bf16x3', help="update-path cross-correlation: bf16x3 | bf16 | library")
 ap.add_argument('--graphs', type=int, default=0, help='replay the target evaluations of the update from hipGraphs')
 ap.add_argument('--bf16', type=int, default=0, help='run the rollout forward under bf16 autocast (MFMA); fp32 is the reference dtype')
 args = ap.parse_args()
 B, L = args.envs, args.rocks
-env = envs.make('Stack-v0', n_parallel=B, seed=11, pool=assets.default_pool(), episode_length=L, side_stream=bool(args.side_stream))
+env = envs.make('Stack-v0', n_parallel=B, seed=11, pool=assets.default_pool(), episode_length=L, side_stream=bool(args.side_stream),
+                **({} if args.res == 128 else dict(resolution_factor={64: 4, 256: 6}[args.res])))
 net = nets.DeepQSiamFCN(env.observation_spec, seed=1).cuda()
 agent = DQN(net, learning_rate=6.25e-5, adam_betas=(0.95, 0.95), minibatch_size=32, replay_memory_size=B * args.slots,
             discount_factor=.966667, collect_batch_size=B, exploration=PolynomialDecay(1.0, 400000, .1), prioritization=0.6,
@@ -35,7 +37,7 @@ obs = env.reset()()[0]
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(3): agent.policy(obs, exploration=True)
 torch.cuda.synchronize(); tf = (time.perf_counter() - t0) / 3
-macs = sum(nets.forward_macs().values())
+macs = sum(nets.forward_macs(H=args.res, h=args.res // 4).values())
 t0 = time.perf_counter(); tr.collect_time = tr.train_time = 0.0
 tr.run(args.iters)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
