@@ -187,9 +187,12 @@ def main():
     g.close()
 
   traffic = None
-  pmc = os.path.join(ROOT, 'profiles', 'r01_render_pmc.json')   # separate rocprofv3 --pmc passes of this command
-  if os.path.isfile(pmc) and B == 1024 and L == 8:
-    with open(pmc) as f:
+  # HBM bytes per launch from the PMC counters: separate rocprofv3 --pmc passes of this command (they cannot run inside
+  # this process), summarised by tools/pmc_summary.py into profiles/rNN_render_pmc.json; the latest round's file is used
+  import glob
+  pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_render_pmc.json')))
+  if pmcs and B == 1024 and L == 8:
+    with open(pmcs[-1]) as f:
       traffic = json.load(f).get('traffic_bytes_per_launch')
   if rank == 0:
     render_s = float(ms[1]) / 1e3
