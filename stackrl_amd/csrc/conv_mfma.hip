@@ -1,0 +1,182 @@
+// conv_mfma.hip — 3 x 3 convolution (stride 1, SAME) + bias + ReLU of the U-Nets' wide, thin layers on the matrix
+// cores, inference only, gfx950.  Replaces Conv2D(f, 3, padding='same', activation='relu') [+ MaxPool2D / Concatenate]
+// of `layers.unet` (stackrl/nets/layers.py:135-259) for the 16- and 32-channel layers at 128^2 .. 16^2, which carry
+// most of the forward's activation traffic and are bound by HBM, not by MFMA: the library route writes the raw
+// convolution output and re-reads it for bias / ReLU / pooling; here one kernel reads the input once and writes the
+// finished tensor(s) once.
+//
+// Implicit GEMM, D[cout][pixel] += W[cout][k] X[k][pixel], k = (tap, cin), v_mfma_f32_16x16x32_bf16 (K = 32 per
+// instruction: one tap x 32 channels, or two taps x 16 channels).  bf16 channels-last in and out, fp32 accumulation.
+//   workgroup = 4 waves = a 16 x 16 pixel tile of one image; wave = 4 rows of 16 pixels x all output channels
+//   input tile + halo (18 x 18 pixels x CIN) staged once in LDS (zero padding at the image border); a B fragment is
+//   the 8 consecutive channels of one pixel (16 bytes, ds_read_b128)
+//   weights: pre-packed in A-fragment order (host side, once per weight update) and held in registers for the whole
+//   kernel (<= 72 VGPRs for 32 -> 32)
+//   epilogue: bias + ReLU on the 4 consecutive output channels a lane holds, 8-byte stores into a channel slice of a
+//   channels-last buffer (the decoder's concat buffer), optionally the 2 x 2 max-pooled tensor too (rows in registers,
+//   columns by a DPP quad permute), or channel-major output for the cross-correlation.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/stackrl_qnet.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t c_bf16_rne(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <int CIN>
+struct ConvCfg {
+  static constexpr int KS = CIN == 16 ? 5 : 9 * (CIN / 32);   // K = 32 steps: tap pairs (the 10th tap is zero) | taps x 32-channel blocks
+  static constexpr int PS = CIN + 8;                          // LDS pixel stride in elements (16-byte aligned, de-phased banks)
+  static constexpr int TW = 18;                               // tile width / height incl. halo
+};
+
+// tap and first channel of the 8 k-values lane group g (0..3) holds in K-step ks
+template <int CIN>
+__device__ __forceinline__ void k_of(int ks, int g, int& tap, int& ci0) {
+  if (CIN == 16) { tap = 2 * ks + (g >> 1); ci0 = 8 * (g & 1); }
+  else { tap = ks / (CIN / 32); ci0 = 32 * (ks % (CIN / 32)) + 8 * g; }
+}
+
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256)
+k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, const float* __restrict__ bias,
+          uint16_t* __restrict__ out, uint16_t* __restrict__ pooled, int H, int W, int ostride, int ooff, int nchw) {
+  typedef ConvCfg<CIN> G;
+  constexpr int MT = COUT / 16;
+  extern __shared__ uint16_t tile[];   // [18][18][PS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = W / 16;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  const int x0 = 16 * tx, y0 = 16 * ty;
+  // weights -> registers (A fragments: lane l holds row l & 15 = output channel, k = 8 (l >> 4) .. + 7)
+  bf16x8 wf[G::KS][MT];
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wf[ks][mt] = ((const bf16x8*)wfrag)[(ks * MT + mt) * 64 + lane];
+  // input tile + halo -> LDS, 16-byte chunks (8 channels); outside the image: zeros (SAME padding)
+  {
+    constexpr int CPP = CIN / 8;   // chunks per pixel
+    const uint16_t* src = in + (size_t)b * H * W * CIN;
+    for (int k = tid; k < G::TW * G::TW * CPP; k += 256) {
+      const int p = k / CPP, ch = k - p * CPP;
+      const int py = p / G::TW, px = p - py * G::TW;
+      const int y = y0 + py - 1, x = x0 + px - 1;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (y >= 0 && y < H && x >= 0 && x < W) v = *(const uint4*)(src + ((size_t)y * W + x) * CIN + ch * 8);
+      *(uint4*)(tile + p * G::PS + ch * 8) = v;
+    }
+  }
+  __syncthreads();
+  f32x4 acc[4][MT];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks) {
+    int tap, ci0;
+    k_of<CIN>(ks, g, tap, ci0);
+    if (tap > 8) tap = 8;   // the padded tenth tap: its weights are zero, any valid address will do
+    const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bf16x8 xf = *(const bf16x8*)(tile + ((4 * wave + r + dy) * G::TW + n + dx) * G::PS + ci0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][mt], xf, acc[r][mt], 0, 0, 0);
+    }
+  }
+  // epilogue.  D: lane holds column lane & 15 = pixel n, rows 4 g .. 4 g + 3 = output channels of tile mt
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int co = 16 * mt + 4 * g;
+    const float4 bz = *(const float4*)(bias + co);
+    uint32_t lo[4], hi[4];   // packed bf16 pairs per row
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v0 = fmaxf(acc[r][mt][0] + bz.x, 0.0f), v1 = fmaxf(acc[r][mt][1] + bz.y, 0.0f);
+      const float v2 = fmaxf(acc[r][mt][2] + bz.z, 0.0f), v3 = fmaxf(acc[r][mt][3] + bz.w, 0.0f);
+      lo[r] = c_bf16_rne(v0) | (c_bf16_rne(v1) << 16); hi[r] = c_bf16_rne(v2) | (c_bf16_rne(v3) << 16);
+      const int y = y0 + 4 * wave + r, x = x0 + n;
+      if (nchw) {
+        uint16_t* o = out + ((size_t)b * COUT + co) * H * W + (size_t)y * W + x;
+        o[0] = (uint16_t)(lo[r] & 0xffffu); o[(size_t)H * W] = (uint16_t)(lo[r] >> 16);
+        o[(size_t)2 * H * W] = (uint16_t)(hi[r] & 0xffffu); o[(size_t)3 * H * W] = (uint16_t)(hi[r] >> 16);
+      } else {
+        *(uint2*)(out + (((size_t)b * H + y) * W + x) * ostride + ooff + co) = make_uint2(lo[r], hi[r]);
+      }
+    }
+    if (pooled) {   // 2 x 2 max of the rounded values (bf16 bit patterns of non-negative numbers order like integers)
+#pragma unroll
+      for (int rp = 0; rp < 2; ++rp) {
+        uint32_t m[2] = {lo[2 * rp], hi[2 * rp]};
+        const uint32_t o[2] = {lo[2 * rp + 1], hi[2 * rp + 1]};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          uint32_t a0 = m[q] & 0xffffu, a1 = m[q] >> 16, b0 = o[q] & 0xffffu, b1 = o[q] >> 16;
+          a0 = a0 > b0 ? a0 : b0; a1 = a1 > b1 ? a1 : b1;
+          // the neighbouring column: lane n ^ 1 (quad_perm [1, 0, 3, 2])
+          const uint32_t mine = a0 | (a1 << 16);
+          const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp((int)mine, (int)mine, 0xb1, 0xf, 0xf, false);
+          uint32_t c0 = other & 0xffffu, c1 = other >> 16;
+          a0 = a0 > c0 ? a0 : c0; a1 = a1 > c1 ? a1 : c1;
+          m[q] = a0 | (a1 << 16);
+        }
+        if (!(n & 1)) {
+          const int y2 = (y0 + 4 * wave) / 2 + rp, x2 = (x0 + n) / 2;
+          *(uint2*)(pooled + (((size_t)b * (H / 2) + y2) * (W / 2) + x2) * COUT + co) = make_uint2(m[0], m[1]);
+        }
+      }
+    }
+  }
+}
+
+thread_local char c_err[256] = "";
+
+template <int CIN, int COUT>
+int launch(const void* in, const void* wfrag, const float* bias, void* out, void* pooled, int B, int H, int W, int ostride,
+           int ooff, int nchw, hipStream_t st) {
+  const size_t lds = sizeof(uint16_t) * ConvCfg<CIN>::TW * ConvCfg<CIN>::TW * ConvCfg<CIN>::PS;
+  hipLaunchKernelGGL((k_conv3x3<CIN, COUT>), dim3((W / 16) * (H / 16), B), dim3(256), lds, st, (const uint16_t*)in,
+                     (const uint16_t*)wfrag, bias, (uint16_t*)out, (uint16_t*)pooled, H, W, ostride, ooff, nchw);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "srl_conv3x3_bias_relu: %s", hipGetErrorString(e)); return 2; }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* srl_conv_last_error(void) { return c_err; }
+
+int32_t srl_conv3x3_wfrag_elems(int32_t cin, int32_t cout) {
+  if ((cin != 16 && cin != 32) || (cout != 16 && cout != 32)) return -1;
+  return (cin == 16 ? 5 : 9) * (cout / 16) * 64 * 8;
+}
+
+int srl_conv3x3_bias_relu(const void* in, const void* wfrag, const float* bias, void* out, void* pooled, int32_t B,
+                          int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset,
+                          int32_t nchw, void* stream) {
+  if (!in || !wfrag || !bias || !out || B < 1 || H < 16 || W < 16 || H % 16 || W % 16 || out_stride % 4 || out_offset % 4 ||
+      srl_conv3x3_wfrag_elems(cin, cout) < 0 || (pooled && nchw)) {
+    snprintf(c_err, sizeof c_err, "srl_conv3x3_bias_relu: bad arguments (H, W multiples of 16; cin, cout in {16, 32})");
+    return 1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (cin == 16 && cout == 16) return launch<16, 16>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+  if (cin == 16 && cout == 32) return launch<16, 32>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+  if (cin == 32 && cout == 16) return launch<32, 16>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+  return launch<32, 32>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+}
+
+}  // extern "C"

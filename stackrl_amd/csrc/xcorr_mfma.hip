@@ -141,13 +141,22 @@ k_xcorr_mfma(const void* __restrict__ in, const uint16_t* __restrict__ frag, flo
       __syncthreads();
     }
     const bf16x4* tw = (const bf16x4*)frag + ((K_PER_C ? (size_t)b * C + c : (size_t)b) * KH) * G::KB * 64 + lane;
+    // kernel-row loop, software-pipelined: the Toeplitz fragments of row i + 1 are requested (global, L2) before the
+    // MFMAs of row i are issued, so their latency is covered by the 21 MFMAs instead of being waited for
+    bf16x4 tf[G::KB], tl[SPLIT ? G::KB : 1];
+#pragma unroll
+    for (int j = 0; j < G::KB; ++j) {
+      tf[j] = tw[(size_t)j * 64];
+      if (SPLIT) tl[j] = tw[lo_off + (size_t)j * 64];
+    }
 #pragma unroll 2
     for (int i = 0; i < KH; ++i) {
-      bf16x4 tf[G::KB], tl[SPLIT ? G::KB : 1];
+      const int in = i + 1 < KH ? i + 1 : i;
+      bf16x4 nf[G::KB], nl[SPLIT ? G::KB : 1];
 #pragma unroll
       for (int j = 0; j < G::KB; ++j) {
-        tf[j] = tw[((size_t)i * G::KB + j) * 64];
-        if (SPLIT) tl[j] = tw[lo_off + ((size_t)i * G::KB + j) * 64];
+        nf[j] = tw[((size_t)in * G::KB + j) * 64];
+        if (SPLIT) nl[j] = tw[lo_off + ((size_t)in * G::KB + j) * 64];
       }
       bf16x4 af[G::NKB], al[SPLIT ? G::NKB : 1];
       const uint16_t* ar = xs + (arow + i) * G::RS + acol;
@@ -166,6 +175,11 @@ k_xcorr_mfma(const void* __restrict__ in, const uint16_t* __restrict__ frag, flo
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[t + j], tf[j], acc[t], 0, 0, 0);
           }
         }
+#pragma unroll
+      for (int j = 0; j < G::KB; ++j) {
+        tf[j] = nf[j];
+        if (SPLIT) tl[j] = nl[j];
+      }
     }
     if (!SUM || c == c1 - 1) {
       // D fragment: lane l holds column l % 16, rows 4 (l / 16) .. + 3 of the tile

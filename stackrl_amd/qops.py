@@ -30,6 +30,11 @@ def load():
     L.srl_bias_act_pool.restype = ctypes.c_int
     L.srl_bias_act_pool.argtypes = [VP, VP, VP, VP] + [ctypes.c_int32] * 6 + [VP]
     L.srl_epilogue_last_error.restype = ctypes.c_char_p
+    L.srl_conv3x3_wfrag_elems.restype = ctypes.c_int32
+    L.srl_conv3x3_wfrag_elems.argtypes = [ctypes.c_int32] * 2
+    L.srl_conv3x3_bias_relu.restype = ctypes.c_int
+    L.srl_conv3x3_bias_relu.argtypes = [VP] * 5 + [ctypes.c_int32] * 8 + [VP]
+    L.srl_conv_last_error.restype = ctypes.c_char_p
     L.srl_policy_head.restype = ctypes.c_int
     L.srl_policy_head.argtypes = [VP, VP, VP, ctypes.c_float, VP, ctypes.c_int32, ctypes.c_int32, VP]
     L.srl_qnet_last_error.restype = ctypes.c_char_p
@@ -199,26 +204,80 @@ def bias_act_pool(y, bias, skip, skip_offset):
   return pooled
 
 
+def pack_conv3x3_weights(w):
+  """Conv2d weight [cout, cin, 3, 3] -> bf16 A-fragment order of csrc/conv_mfma.hip (see include/stackrl_qnet.h)."""
+  cout, cin = int(w.shape[0]), int(w.shape[1])
+  n = load().srl_conv3x3_wfrag_elems(cin, cout)
+  if n < 0:
+    raise ValueError('conv3x3 MFMA kernel: unsupported channels %d -> %d' % (cin, cout))
+  dev = w.device
+  ks = torch.arange(5 if cin == 16 else 9, device=dev)[:, None, None, None]
+  mt = torch.arange(cout // 16, device=dev)[None, :, None, None]
+  lane = torch.arange(64, device=dev)[None, None, :, None]
+  j = torch.arange(8, device=dev)[None, None, None, :]
+  k = 8 * (lane >> 4) + j
+  if cin == 16:
+    tap, ci = 2 * ks + (k >> 4), k & 15
+  else:
+    tap, ci = ks + 0 * k, k
+  co = 16 * mt + (lane & 15)
+  tapc = tap.clamp(max=8)
+  vals = w.detach().float()[co, ci, tapc // 3, tapc % 3] * (tap < 9)
+  out = vals.to(torch.bfloat16).contiguous().reshape(-1)
+  assert out.numel() == n
+  return out
+
+
+def conv3x3_bias_relu(x, wfrag, bias, cout, out=None, out_offset=0, pool=False, nchw=False):
+  """relu(conv3x3(x) + bias) on the matrix cores (csrc/conv_mfma.hip).  x: bf16 [B,cin,H,W] channels-last.  Returns
+  the output (a new channels-last tensor, or `out` whose channel slice [out_offset, out_offset + cout) was written, or
+  an NCHW-contiguous tensor with nchw=True) and, with pool=True, also the 2 x 2 max-pooled tensor."""
+  B, cin, H, W = x.shape
+  if nchw:
+    dst = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device)
+    stride = cout
+  else:
+    dst = out if out is not None else torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=_CL)
+    stride = dst.shape[1]
+  pooled = torch.empty((B, cout, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=_CL) if pool else None
+  with torch.cuda.device(x.device):
+    rc = load().srl_conv3x3_bias_relu(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), dst.data_ptr(),
+                                      pooled.data_ptr() if pool else None, B, H, W, cin, cout, stride, out_offset,
+                                      int(nchw), _stream(x))
+  if rc:
+    raise RuntimeError(load().srl_conv_last_error().decode())
+  return (dst, pooled) if pool else dst
+
+
 class FastFeatures(object):
   """Inference-only forward of the two U-Nets (`DeepQSiamFCN.features`, models.py:160-177; `layers.unet`,
   layers.py:135-259) in bf16 channels-last: library convolutions without bias, and the fused element-wise passes of
   csrc/epilogue.hip instead of separate bias / ReLU / max-pool / concatenate / layout kernels.  Returns the left and
   right feature maps NCHW-contiguous, ready for the MFMA cross-correlation."""
 
-  def __init__(self, net):
+  def __init__(self, net, mfma_conv=True):
     self.net = net
+    self.mfma_conv = bool(mfma_conv)   # hand-written MFMA kernel for the 16- / 32-channel 3 x 3 layers
     self._key = None
     self._w = {}
+    self._wf = {}
 
   def _refresh(self):
     key = tuple(p._version for p in self.net.parameters()) + (id(self.net),)
     if key == self._key:
       return
     self._w = {}
+    self._wf = {}
     for m in self.net.modules():
       if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
         self._w[m] = (m.weight.detach().to(torch.bfloat16).contiguous(memory_format=_CL), m.bias.detach().float().contiguous())
+        if self.mfma_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
+           m.in_channels in (16, 32) and m.out_channels in (16, 32):
+          self._wf[m] = pack_conv3x3_weights(m.weight)
     self._key = key
+
+  def _mine(self, m, x):
+    return m in self._wf and x.shape[2] % 16 == 0 and x.shape[3] % 16 == 0
 
   def _conv(self, m, x):
     w, b = self._w[m]
@@ -230,11 +289,17 @@ class FastFeatures(object):
     cats = []
     for blk in U.down:
       f = blk[0].out_channels
-      y, b = self._conv(blk[0], x)
-      bias_act(y, b)
-      y, b = self._conv(blk[2], y)
+      if self._mine(blk[0], x):
+        y = conv3x3_bias_relu(x, self._wf[blk[0]], self._w[blk[0]][1], f)
+      else:
+        y, b = self._conv(blk[0], x)
+        bias_act(y, b)
       cat = torch.empty((B, 2 * f, y.shape[2], y.shape[3]), dtype=y.dtype, device=y.device, memory_format=_CL)
-      x = bias_act_pool(y, b, cat, f)               # skip -> second half of the decoder's concat buffer
+      if self._mine(blk[2], y):                     # skip -> second half of the decoder's concat buffer, + pooled
+        _, x = conv3x3_bias_relu(y, self._wf[blk[2]], self._w[blk[2]][1], f, out=cat, out_offset=f, pool=True)
+      else:
+        y, b = self._conv(blk[2], y)
+        x = bias_act_pool(y, b, cat, f)
       cats.append(cat)
     y, b = self._conv(U.bottom[0], x)
     bias_act(y, b)
@@ -243,13 +308,21 @@ class FastFeatures(object):
     n = len(U.up)
     for k, (up, blk) in enumerate(zip(U.up, U.upconv)):
       cat = cats.pop()
+      f = up.out_channels
       w, b = self._w[up]
       y = _cl(F.conv_transpose2d(x, w, None, stride=up.stride))
       bias_act(y, b, out=cat, out_offset=0)         # Concatenate([up, skip]) without a copy
-      y, b = self._conv(blk[0], cat)
-      bias_act(y, b)
-      y, b = self._conv(blk[2], y)
-      x = bias_act(y, b, nchw=(k == n - 1))
+      if self._mine(blk[0], cat):
+        y = conv3x3_bias_relu(cat, self._wf[blk[0]], self._w[blk[0]][1], f)
+      else:
+        y, b = self._conv(blk[0], cat)
+        bias_act(y, b)
+      last = k == n - 1
+      if self._mine(blk[2], y):
+        x = conv3x3_bias_relu(y, self._wf[blk[2]], self._w[blk[2]][1], f, nchw=last)
+      else:
+        y, b = self._conv(blk[2], y)
+        x = bias_act(y, b, nchw=last)
     return x
 
   @torch.no_grad()

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
   with open(os.path.join(ROOT, 'include', 'stackrl_hip.h')) as f:
     txt = f.read()
-  return sorted(set(re.findall(r'\b(srl_[a-z_]+)\s*\(', txt)))
+  return sorted(set(re.findall(r'\b(srl_[a-z0-9_]+)\s*\(', txt)))
 
 
 def test_library_builds_and_exports_every_declared_symbol():
@@ -31,8 +31,9 @@ def test_qnet_library_exports_every_declared_symbol():
   from stackrl_amd import build
   build.build()
   with open(os.path.join(ROOT, 'include', 'stackrl_qnet.h')) as f:
-    names = sorted(set(re.findall(r'\b(srl_[a-z_]+)\s*\(', f.read())))
-  assert names == ['srl_baseline_select', 'srl_bias_act', 'srl_bias_act_pool', 'srl_epilogue_last_error', 'srl_heuristic',
+    names = sorted(set(re.findall(r'\b(srl_[a-z0-9_]+)\s*\(', f.read())))
+  assert names == ['srl_baseline_select', 'srl_bias_act', 'srl_bias_act_pool', 'srl_conv3x3_bias_relu', 'srl_conv3x3_wfrag_elems',
+                   'srl_conv_last_error', 'srl_epilogue_last_error', 'srl_heuristic',
                    'srl_policy_head', 'srl_qnet_last_error', 'srl_xcorr_forward',
                    'srl_xcorr_mfma', 'srl_xcorr_mfma_last_error', 'srl_xcorr_mfma_scratch_bytes']
   L = ctypes.CDLL(build.QLIB)

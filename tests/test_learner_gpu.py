@@ -68,6 +68,32 @@ def test_xcorr_mfma_autograd_matches_torch_fp64(B, C, H, h, precision, tol):
     assert err <= tol * scale, (err, scale)
 
 
+@pytest.mark.parametrize('cin,cout,H', [(16, 16, 32), (16, 32, 16), (32, 16, 48), (32, 32, 16)])
+def test_conv3x3_mfma_matches_torch(cin, cout, H):
+  """csrc/conv_mfma.hip against F.conv2d on the same bf16-rounded operands in fp32 (bf16 products are exact in fp32;
+  only the accumulation order and the final bf16 rounding differ: half a bf16 ulp = 2^-9 relative), for the plain,
+  concat-slice + pooled and channel-major output modes."""
+  from stackrl_amd import qops
+  F = torch.nn.functional
+  g = torch.Generator(device='cuda').manual_seed(cin * 3 + cout + H)
+  B, W = 3, H + 16
+  x = torch.rand((B, cin, H, W), generator=g, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+  w = ((torch.rand((cout, cin, 3, 3), generator=g, device='cuda') - 0.5) * 0.2)
+  b = torch.rand(cout, generator=g, device='cuda') - 0.5
+  wf = qops.pack_conv3x3_weights(w)
+  ref = F.relu(F.conv2d(x.float(), w.to(torch.bfloat16).float(), b, padding=1))
+  tol = lambda t: 2.0 ** -8 * t.abs().clamp(min=1e-2)
+  y = qops.conv3x3_bias_relu(x, wf, b, cout)
+  assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+  assert bool(((y.float() - ref).abs() <= tol(ref)).all())
+  cat = torch.full((B, cout + 16, H, W), 7.0, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+  y2, p = qops.conv3x3_bias_relu(x, wf, b, cout, out=cat, out_offset=16, pool=True)
+  assert torch.equal(cat[:, 16:], y) and bool((cat[:, :16] == 7.0).all())          # only the slice was written
+  assert torch.equal(p, F.max_pool2d(y, 2))
+  z = qops.conv3x3_bias_relu(x, wf, b, cout, nchw=True)
+  assert z.is_contiguous() and torch.equal(z, y.contiguous())
+
+
 def test_fast_features_match_autocast_features():
   """Fused-epilogue inference forward of the U-Nets (qops.FastFeatures, csrc/epilogue.hip) against the stock module
   graph under bf16 autocast: same bf16 convolutions, the bias add / ReLU rounding points differ, so the stated

@@ -27,6 +27,10 @@ run('bf16 channels_last chunk 512', 512, torch.bfloat16, True)
 run('fp16 channels_last chunk 512', 512, torch.float16, True)
 run('bf16 fused epilogues chunk 512', 512, torch.bfloat16, False, True)
 run('bf16 fused epilogues chunk 1024', 1024, torch.bfloat16, False, True)
+_ff = qops.FastFeatures
+qops.FastFeatures = lambda net: _ff(net, mfma_conv=False)
+run('bf16 fused epilogues, library convs only', 1024, torch.bfloat16, False, True)
+qops.FastFeatures = _ff
 
 # the cross-correlation alone: fp32 vector kernel vs the bf16 MFMA kernel
 from stackrl_amd import qops as _q
