@@ -99,7 +99,8 @@ class DQN(object):
       o += p.numel()
     self._params = params
     if optimizer is None:                                            # dqn.py:127-130
-      optimizer = torch.optim.Adam(params, lr=learning_rate or 0.00025, betas=adam_betas, eps=1e-7)
+      optimizer = torch.optim.Adam(params, lr=learning_rate or 0.00025, betas=adam_betas, eps=1e-7,
+                                   capturable=bool(graphs) and self.device.type == 'cuda')
     elif callable(optimizer) and not isinstance(optimizer, torch.optim.Optimizer):
       optimizer = optimizer(params, lr=learning_rate or 0.00025)
     elif not isinstance(optimizer, torch.optim.Optimizer):
@@ -163,6 +164,8 @@ class DQN(object):
     self._graphs = bool(graphs) and self.device.type == 'cuda'
     self._g_target = GraphedEval(self._target_q_net) if self._graphs else None
     self._g_online = GraphedEval(self._q_net) if self._graphs else None
+    self._train_graph = None
+    self._graph_calls = 0
 
   def __call__(self, state, reward, terminal, action=None):
     return self.collect(state, reward, terminal) if action is None else self.observe(state, reward, terminal, action)
@@ -252,7 +255,8 @@ class DQN(object):
       loss = loss * weights
     return loss.mean()
 
-  def train(self):
+  def _update(self):
+    """One minibatch update (dqn.py:397-476) without the host-side bookkeeping; returns (loss, mean TD error)."""
     weights = indexes = None
     if self._prioritized:
       indexes, weights, (states, actions, rewards, next_states, terminal) = \
@@ -273,12 +277,51 @@ class DQN(object):
       dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM, group=self._pg)
       self._flat_grad.div_(self._world)
     self._optimizer.step()
-    self._iterations += 1
     if self._prioritized:
       self._replay_memory.update_priorities(indexes, td_abs.detach())   # dqn.py:475-476
-    if self._iterations % self._target_update_period == 0:           # dqn.py:478-484
-      self._target_q_net.load_state_dict(self._q_net.state_dict())
     return loss.detach(), mtd
+
+  _GRAPH_WARMUP = 3   # eager updates before the capture (library solver search, optimiser state, lazy initialisations)
+
+  def train(self):
+    if self._graphs and self._world == 1:
+      loss, mtd = self._train_graphed()
+    else:
+      loss, mtd = self._update()
+    self._iterations += 1
+    if self._iterations % self._target_update_period == 0:           # dqn.py:478-484
+      self._target_q_net.load_state_dict(self._target_sync_source())
+    return loss, mtd
+
+  def _target_sync_source(self):
+    return self._q_net.state_dict()
+
+  def _train_graphed(self):
+    """The whole update — prioritised sampling, target evaluation, forward, backward, Adam, priority update: ~1,100
+    launches of mostly microsecond kernels — replayed as one hipGraph.  Everything it reads or writes lives at fixed
+    addresses (replay tensors, trackers, flat gradient bucket, capturable Adam state, schedule scalars), the sampling
+    generator is registered with the graph, and the nets' parameters are updated in place, so target syncs and
+    checkpoints need no re-capture."""
+    mem = self._replay_memory
+    mem.refresh_schedules()
+    if self._train_graph is None:
+      self._graph_calls += 1
+      if self._graph_calls <= self._GRAPH_WARMUP:
+        return self._update()
+      mem.tensor_schedules = True
+      g = torch.cuda.CUDAGraph()
+      g.register_generator_state(mem._gen)
+      g_eval = self._graphs
+      self._graphs = False                 # the target evaluations are part of this graph, not graphs of their own
+      try:
+        with torch.cuda.graph(g):
+          self._graph_out = self._update()
+      finally:
+        self._graphs = g_eval
+      self._train_graph = g
+    self._train_graph.replay()
+    loss, mtd = self._graph_out
+    return loss.clone(), mtd.clone()
 
   def save_weights(self, path):
     torch.save(self._q_net.state_dict(), path)

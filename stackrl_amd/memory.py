@@ -58,6 +58,10 @@ class ReplayMemory(object):
     self._min_logit = torch.zeros((), dtype=torch.float32, device=self.device)
     self._min_logit_index = torch.zeros((), dtype=torch.int64, device=self.device)
     self.check = False      # True: raise like the reference's tf.debugging asserts (costs a device sync)
+    # schedule values as device scalars for a hipGraph-replayed update (refreshed by `refresh_schedules`)
+    self._alpha_t = torch.zeros((), dtype=torch.float32, device=self.device)
+    self._beta_t = torch.zeros((), dtype=torch.float32, device=self.device)
+    self.tensor_schedules = False
 
   def __len__(self):
     return int(torch.isfinite(self._logits).sum())                 # memory.py:129-132
@@ -76,7 +80,7 @@ class ReplayMemory(object):
 
   def load_state_dict(self, d):
     for k in self._STATE:
-      setattr(self, k, d[k].to(self.device).clone())
+      getattr(self, k).copy_(d[k])
     for s, v in zip(self._states, d['states']):
       s.copy_(v)
     self._insert_index = int(d['insert_index'])
@@ -96,16 +100,16 @@ class ReplayMemory(object):
 
   # ------------------------------------------------------------------ add (memory.py:151-196)
   def _argmax_all(self):
-    idx = torch.argmax(self._logits)
-    return idx, self._logits[idx]
+    v, idx = torch.max(self._logits, dim=0)         # (value, index) in one op: indexing with a device scalar would sync
+    return idx, v
 
   def _argmin_finite(self):
     finite = torch.isfinite(self._logits)
     if self.check and not bool(finite.any()):
       raise FloatingPointError('No sampleable transition (failed to compute min logit)')   # memory.py:174-177
     masked = torch.where(finite, self._logits, torch.full_like(self._logits, math.inf))
-    idx = torch.argmin(masked)
-    return idx, self._logits[idx]
+    v, idx = torch.min(masked, dim=0)
+    return idx, v
 
   def add(self, state, reward, terminal, action):
     L = self._max_length
@@ -122,13 +126,13 @@ class ReplayMemory(object):
       hit_max = (self._max_logit_index % L) == slot
       hit_min = (self._min_logit_index % L) == slot
       i, v = self._argmax_all()
-      self._max_logit_index = torch.where(hit_max, i, self._max_logit_index)
-      self._max_logit = torch.where(hit_max, v, self._max_logit)
+      self._max_logit_index.copy_(torch.where(hit_max, i, self._max_logit_index))    # in place: the trackers keep
+      self._max_logit.copy_(torch.where(hit_max, v, self._max_logit))                # their addresses (hipGraph replay)
       if self.check and bool(hit_min):
         self._argmin_finite()
       i, v = self._argmin_finite()
-      self._min_logit_index = torch.where(hit_min, i, self._min_logit_index)
-      self._min_logit = torch.where(hit_min, v, self._min_logit)
+      self._min_logit_index.copy_(torch.where(hit_min, i, self._min_logit_index))
+      self._min_logit.copy_(torch.where(hit_min, v, self._min_logit))
     # the transition n steps back becomes sampleable unless an episode boundary lies in between (memory.py:181-194)
     back = self._offsets[:, None] + ((self._insert_index - self._n_range) % L)[None, :]      # [B, n]
     boundary = self._terminal[back].any(dim=-1)
@@ -148,8 +152,13 @@ class ReplayMemory(object):
       return (indexes + steps) % L + indexes // L                  # literal memory.py:239-242
     return (indexes % L + steps) % L + (indexes // L) * L
 
+  def refresh_schedules(self):
+    """Write the current alpha / beta (memory.py:133-149) into their device scalars; with `tensor_schedules` set,
+    `sample` reads those instead of Python floats, so that a captured graph follows the schedules."""
+    self._alpha_t.fill_(self.alpha); self._beta_t.fill_(self.beta)
+
   def sample(self, minibatch_size, get_weights=False):
-    alpha = self.alpha
+    alpha = self._alpha_t if self.tensor_schedules else self.alpha
     u = torch.rand(self._logits.shape, generator=self._gen, device=self.device, dtype=torch.float32)
     z = -torch.log(-torch.log(u))                                  # Gumbel-max trick, memory.py:220-222
     keys = torch.where(torch.isinf(self._logits), self._logits, alpha * self._logits) + z
@@ -165,7 +174,8 @@ class ReplayMemory(object):
       nxt = self.next_indexes(indexes[:, None], self._n_range[None, :])
     rewards = self._rewards[nxt]
     if get_weights:
-      weights = torch.exp(self.beta * alpha * (self._min_logit - self._logits[indexes]))   # memory.py:257-260
+      beta = self._beta_t if self.tensor_schedules else self.beta
+      weights = torch.exp(beta * alpha * (self._min_logit - self._logits[indexes]))   # memory.py:257-260
       return indexes, weights, (states, actions, rewards, next_states, terminal)
     return states, actions, rewards, next_states, terminal
 
@@ -173,16 +183,16 @@ class ReplayMemory(object):
   def update_priorities(self, indexes, deltas):
     logits = torch.log(deltas.to(torch.float32) + self.epsilon)    # memory.py:272
     self._logits.index_copy_(0, indexes, logits)
-    amax = torch.argmax(logits); amin = torch.argmin(logits)
-    max_logit, min_logit = logits[amax], logits[amin]
+    max_logit, amax = torch.max(logits, dim=0); min_logit, amin = torch.min(logits, dim=0)
+    imax = indexes.gather(0, amax.view(1))[0]; imin = indexes.gather(0, amin.view(1))[0]
     hit_max = (indexes == self._max_logit_index).any()
     hit_min = (indexes == self._min_logit_index).any()
     # memory.py:282-292: a larger maximum replaces the tracker; else if the tracked slot was rewritten, recompute
     ri, rv = self._argmax_all()
     ge = max_logit >= self._max_logit
-    self._max_logit_index = torch.where(ge, indexes[amax], torch.where(hit_max, ri, self._max_logit_index))
-    self._max_logit = torch.where(ge, max_logit, torch.where(hit_max, rv, self._max_logit))
+    self._max_logit_index.copy_(torch.where(ge, imax, torch.where(hit_max, ri, self._max_logit_index)))
+    self._max_logit.copy_(torch.where(ge, max_logit, torch.where(hit_max, rv, self._max_logit)))
     ri, rv = self._argmin_finite()                                 # memory.py:298-316
     le = min_logit <= self._min_logit
-    self._min_logit_index = torch.where(le, indexes[amin], torch.where(hit_min, ri, self._min_logit_index))
-    self._min_logit = torch.where(le, min_logit, torch.where(hit_min, rv, self._min_logit))
+    self._min_logit_index.copy_(torch.where(le, imin, torch.where(hit_min, ri, self._min_logit_index)))
+    self._min_logit.copy_(torch.where(le, min_logit, torch.where(hit_min, rv, self._min_logit)))

@@ -51,7 +51,11 @@ class AverageMetric(object):
   def __init__(self, length=100, dtype=torch.float32, device=None):
     self._length = int(length)
     self._index = torch.zeros((), dtype=torch.int64, device=device)
-    self._values = torch.zeros(self._length, dtype=dtype, device=device)
+    self._buf = torch.zeros(self._length + 1, dtype=dtype, device=device)   # + one scratch slot for masked-out writes
+
+  @property
+  def _values(self):
+    return self._buf[:self._length]
 
   @property
   def result(self):
@@ -63,11 +67,12 @@ class AverageMetric(object):
     return bool(self._index >= self._length)
 
   def add(self, value):
-    self._values[self._index % self._length] = torch.as_tensor(value, dtype=self._values.dtype, device=self._values.device)
+    value = torch.as_tensor(value, dtype=self._buf.dtype, device=self._buf.device).detach().reshape(1)
+    self._buf.index_copy_(0, (self._index % self._length).reshape(1), value)   # no host round trip
     self._index += 1
 
   def reset(self):
-    self._values.zero_()
+    self._buf.zero_()
     self._index.zero_()
 
   def __call__(self, *args, **kwargs):
@@ -86,7 +91,7 @@ class AverageMetric(object):
     return {'index': self._index.clone(), 'values': self._values.clone()}
 
   def load_state_dict(self, d):
-    self._index.copy_(d['index']); self._values.copy_(d['values'])
+    self._index.copy_(d['index']); self._values.copy_(d['values'])   # `_values` is a view of the buffer
 
 
 class AverageReward(AverageMetric):
@@ -106,8 +111,9 @@ class AverageReward(AverageMetric):
     rank = torch.cumsum(terminal.to(torch.int64), 0) - 1        # order of the finished episodes in this step
     k = terminal.sum()
     keep = terminal & (rank >= k - self._length)                # more than `length` at once: the last ones survive
-    pos = (self._index + rank) % self._length
-    self._values = self._values.index_put((pos[keep],), self._episode_reward[keep])
+    pos = torch.where(keep, (self._index + rank) % self._length, torch.full_like(rank, self._length))
+    self._buf.index_copy_(0, pos, self._episode_reward)         # masked-out envs land in the scratch slot
+    self._buf[self._length] = 0
     self._index += k
     self._episode_reward = torch.where(terminal, torch.zeros_like(self._episode_reward), self._episode_reward)
 
