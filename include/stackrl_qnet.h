@@ -65,6 +65,17 @@ int32_t srl_conv3x3_wfrag_elems(int32_t cin, int32_t cout);
 int srl_conv3x3_bias_relu(const void* in_dev, const void* wfrag_dev, const float* bias_dev, void* out_dev, void* pooled_dev,
                           int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t out_stride,
                           int32_t out_offset, int32_t nchw, void* stream);
+/* The thin first layers (1 or 2 input channels -> 16) on the vector ALU: in uint8 (in_dtype 0: the env's observation
+ * bytes, scaled by 1/255 as in models.py:144-147) or float32 (in_dtype 1) channels-last [B][H][W][cin]; w float32
+ * [16][cin][3][3], bias float32 [16]; out bfloat16 channels-last [B][Hp][Wp][16] with Hp >= H, Wp >= W (only the H x W
+ * region is written: a zero-initialised margin stays zero). */
+int srl_conv3x3_thin(const void* in_dev, int32_t in_dtype, const float* w_dev, const float* bias_dev, void* out_dev,
+                     int32_t B, int32_t H, int32_t W, int32_t cin, int32_t Hp, int32_t Wp, void* stream);
+/* conv3x3 16 -> 16 + bias + ReLU followed by the 1 x 1 convolution to one channel, in one kernel (the tail of
+ * `pos_layers`, layers.py:439-472): in bfloat16 [B][H][W][16] (H, W multiples of 16), out float32 [B][Hv][Wv]. */
+int srl_conv3x3_relu_project(const void* in_dev, const void* wfrag_dev, const float* bias_dev, const float* proj_w_dev,
+                             float proj_b, float* out_dev, int32_t B, int32_t H, int32_t W, int32_t Hv, int32_t Wv,
+                             void* stream);
 const char* srl_conv_last_error(void);
 
 /* adv float32 [B][A]; u float32 [B] uniform(0,1); rnd int64 [B] uniform {0..A-1}; actions int64 [B] */

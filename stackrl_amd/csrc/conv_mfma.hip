@@ -45,10 +45,13 @@ __device__ __forceinline__ void k_of(int ks, int g, int& tap, int& ci0) {
   else { tap = ks / (CIN / 32); ci0 = 32 * (ks % (CIN / 32)) + 8 * g; }
 }
 
-template <int CIN, int COUT>
+// PROJ: instead of storing the activation, project it onto one output channel in fp32 (the 1 x 1 convolution that ends
+// `pos_layers`, layers.py:439-472): proj_out[b][y][x] = sum_c pw[c] relu(conv[c] + bias[c]) + pb for y < Hv, x < Wv.
+template <int CIN, int COUT, bool PROJ>
 __global__ void __launch_bounds__(256)
 k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, const float* __restrict__ bias,
-          uint16_t* __restrict__ out, uint16_t* __restrict__ pooled, int H, int W, int ostride, int ooff, int nchw) {
+          uint16_t* __restrict__ out, uint16_t* __restrict__ pooled, int H, int W, int ostride, int ooff, int nchw,
+          const float* __restrict__ pw, float pb, float* __restrict__ proj_out, int Hv, int Wv) {
   typedef ConvCfg<CIN> G;
   constexpr int MT = COUT / 16;
   extern __shared__ uint16_t tile[];   // [18][18][PS]
@@ -96,6 +99,26 @@ k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, c
     }
   }
   // epilogue.  D: lane holds column lane & 15 = pixel n, rows 4 g .. 4 g + 3 = output channels of tile mt
+  if (PROJ) {
+    float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co = 16 * mt + 4 * g;
+      const float4 bz = *(const float4*)(bias + co), wz = *(const float4*)(pw + co);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        part[r] += (wz.x * fmaxf(acc[r][mt][0] + bz.x, 0.0f) + wz.y * fmaxf(acc[r][mt][1] + bz.y, 0.0f)) +
+                   (wz.z * fmaxf(acc[r][mt][2] + bz.z, 0.0f) + wz.w * fmaxf(acc[r][mt][3] + bz.w, 0.0f));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // the four lane groups hold the four channel quarters of one pixel
+      part[r] += __shfl_xor(part[r], 16);
+      part[r] += __shfl_xor(part[r], 32);
+      const int y = y0 + 4 * wave + r, x = x0 + n;
+      if (g == 0 && y < Hv && x < Wv) proj_out[((size_t)b * Hv + y) * Wv + x] = part[r] + pb;
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int co = 16 * mt + 4 * g;
@@ -140,14 +163,56 @@ k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, c
   }
 }
 
+// 3 x 3 convolution + bias + ReLU from 1 or 2 input channels to 16 (the first layer of each U-Net and of
+// `pos_layers`): K = 9 or 18 is too thin for the matrix cores, the layer is bound by its 32-byte-per-pixel output.
+// One thread per output pixel, fp32 math, weights in LDS (broadcast reads), bf16 channels-last output into a buffer
+// of Hp x Wp pixels (>= H x W; the margin is left untouched: zero for the padded maps the MFMA kernel reads).
+// TIN = uint8_t: the env's observation bytes, scaled by 1/255 here (models.py:144-147); float: as is.
+template <int CIN, typename TIN>
+__global__ void __launch_bounds__(256)
+k_conv3x3_thin(const TIN* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+               uint16_t* __restrict__ out, int H, int W, int Hp, int Wp) {
+  __shared__ float sw[16 * CIN * 9 + 16];
+  for (int k = threadIdx.x; k < 16 * CIN * 9; k += 256) sw[k] = w[k];
+  if (threadIdx.x < 16) sw[16 * CIN * 9 + threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= H * W) return;
+  const int y = p / W, x = p - y * W;
+  const float scale = sizeof(TIN) == 1 ? 1.0f / 255.0f : 1.0f;
+  float v[9][CIN];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) v[t][c] = ok ? (float)in[(((size_t)b * H + yy) * W + xx) * CIN + c] * scale : 0.0f;
+  }
+  uint32_t pk[8];
+#pragma unroll
+  for (int co = 0; co < 16; ++co) {
+    float a = sw[16 * CIN * 9 + co];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) a = fmaf(sw[(co * CIN + c) * 9 + t], v[t][c], a);
+    const uint32_t h = c_bf16_rne(fmaxf(a, 0.0f));
+    if (co & 1) pk[co >> 1] |= h << 16; else pk[co >> 1] = h;
+  }
+  uint4* o = (uint4*)(out + (((size_t)b * Hp + y) * Wp + x) * 16);
+  o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]); o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+}
+
 thread_local char c_err[256] = "";
 
 template <int CIN, int COUT>
 int launch(const void* in, const void* wfrag, const float* bias, void* out, void* pooled, int B, int H, int W, int ostride,
            int ooff, int nchw, hipStream_t st) {
   const size_t lds = sizeof(uint16_t) * ConvCfg<CIN>::TW * ConvCfg<CIN>::TW * ConvCfg<CIN>::PS;
-  hipLaunchKernelGGL((k_conv3x3<CIN, COUT>), dim3((W / 16) * (H / 16), B), dim3(256), lds, st, (const uint16_t*)in,
-                     (const uint16_t*)wfrag, bias, (uint16_t*)out, (uint16_t*)pooled, H, W, ostride, ooff, nchw);
+  hipLaunchKernelGGL((k_conv3x3<CIN, COUT, false>), dim3((W / 16) * (H / 16), B), dim3(256), lds, st, (const uint16_t*)in,
+                     (const uint16_t*)wfrag, bias, (uint16_t*)out, (uint16_t*)pooled, H, W, ostride, ooff, nchw,
+                     (const float*)nullptr, 0.0f, (float*)nullptr, 0, 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "srl_conv3x3_bias_relu: %s", hipGetErrorString(e)); return 2; }
   return 0;
@@ -177,6 +242,41 @@ int srl_conv3x3_bias_relu(const void* in, const void* wfrag, const float* bias, 
   if (cin == 16 && cout == 32) return launch<16, 32>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
   if (cin == 32 && cout == 16) return launch<32, 16>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
   return launch<32, 32>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+}
+
+int srl_conv3x3_thin(const void* in, int32_t in_dtype, const float* w, const float* bias, void* out, int32_t B, int32_t H,
+                     int32_t W, int32_t cin, int32_t Hp, int32_t Wp, void* stream) {
+  if (!in || !w || !bias || !out || B < 1 || H < 1 || W < 1 || Hp < H || Wp < W || (cin != 1 && cin != 2) ||
+      (in_dtype != 0 && in_dtype != 1)) {
+    snprintf(c_err, sizeof c_err, "srl_conv3x3_thin: bad arguments (cin in {1, 2}; in_dtype 0 = uint8 / 255, 1 = float32)");
+    return 1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((H * W + 255) / 256, B), blk(256);
+  uint16_t* o = (uint16_t*)out;
+  if (cin == 1 && in_dtype == 0) hipLaunchKernelGGL((k_conv3x3_thin<1, uint8_t>), grid, blk, 0, st, (const uint8_t*)in, w, bias, o, H, W, Hp, Wp);
+  else if (cin == 1) hipLaunchKernelGGL((k_conv3x3_thin<1, float>), grid, blk, 0, st, (const float*)in, w, bias, o, H, W, Hp, Wp);
+  else if (in_dtype == 0) hipLaunchKernelGGL((k_conv3x3_thin<2, uint8_t>), grid, blk, 0, st, (const uint8_t*)in, w, bias, o, H, W, Hp, Wp);
+  else hipLaunchKernelGGL((k_conv3x3_thin<2, float>), grid, blk, 0, st, (const float*)in, w, bias, o, H, W, Hp, Wp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "srl_conv3x3_thin: %s", hipGetErrorString(e)); return 2; }
+  return 0;
+}
+
+int srl_conv3x3_relu_project(const void* in, const void* wfrag, const float* bias, const float* proj_w, float proj_b,
+                             float* out, int32_t B, int32_t H, int32_t W, int32_t Hv, int32_t Wv, void* stream) {
+  if (!in || !wfrag || !bias || !proj_w || !out || B < 1 || H < 16 || W < 16 || H % 16 || W % 16 || Hv < 1 || Hv > H ||
+      Wv < 1 || Wv > W) {
+    snprintf(c_err, sizeof c_err, "srl_conv3x3_relu_project: bad arguments");
+    return 1;
+  }
+  const size_t lds = sizeof(uint16_t) * ConvCfg<16>::TW * ConvCfg<16>::TW * ConvCfg<16>::PS;
+  hipLaunchKernelGGL((k_conv3x3<16, 16, true>), dim3((W / 16) * (H / 16), B), dim3(256), lds, (hipStream_t)stream,
+                     (const uint16_t*)in, (const uint16_t*)wfrag, bias, (uint16_t*)nullptr, (uint16_t*)nullptr, H, W, 16, 0, 0,
+                     proj_w, proj_b, out, Hv, Wv);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "srl_conv3x3_relu_project: %s", hipGetErrorString(e)); return 2; }
+  return 0;
 }
 
 }  // extern "C"

@@ -35,6 +35,10 @@ def load():
     L.srl_conv3x3_bias_relu.restype = ctypes.c_int
     L.srl_conv3x3_bias_relu.argtypes = [VP] * 5 + [ctypes.c_int32] * 8 + [VP]
     L.srl_conv_last_error.restype = ctypes.c_char_p
+    L.srl_conv3x3_thin.restype = ctypes.c_int
+    L.srl_conv3x3_thin.argtypes = [VP, ctypes.c_int32, VP, VP, VP] + [ctypes.c_int32] * 6 + [VP]
+    L.srl_conv3x3_relu_project.restype = ctypes.c_int
+    L.srl_conv3x3_relu_project.argtypes = [VP, VP, VP, VP, ctypes.c_float, VP] + [ctypes.c_int32] * 5 + [VP]
     L.srl_policy_head.restype = ctypes.c_int
     L.srl_policy_head.argtypes = [VP, VP, VP, ctypes.c_float, VP, ctypes.c_int32, ctypes.c_int32, VP]
     L.srl_qnet_last_error.restype = ctypes.c_char_p
@@ -249,6 +253,33 @@ def conv3x3_bias_relu(x, wfrag, bias, cout, out=None, out_offset=0, pool=False, 
   return (dst, pooled) if pool else dst
 
 
+def conv3x3_thin(x, w, bias, out=None):
+  """relu(conv3x3(x) + bias) for 1 or 2 input channels -> 16 (csrc/conv_mfma.hip, vector ALU).  x: uint8 (scaled by
+  1/255) or float32, channels-last memory [B,H,W,cin].  Returns bf16 [B,16,Hp,Wp] channels-last; `out` (optional) is a
+  larger zero-margined buffer of that kind whose top-left H x W region is written."""
+  B, H, W, cin = x.shape
+  if out is None:
+    out = torch.empty((B, 16, H, W), dtype=torch.bfloat16, device=x.device, memory_format=_CL)
+  with torch.cuda.device(x.device):
+    rc = load().srl_conv3x3_thin(x.data_ptr(), int(x.dtype != torch.uint8), w.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                 B, H, W, cin, out.shape[2], out.shape[3], _stream(x))
+  if rc:
+    raise RuntimeError(load().srl_conv_last_error().decode())
+  return out
+
+
+def conv3x3_relu_project(x, wfrag, bias, proj_w, proj_b, hv, wv):
+  """sum_c proj_w[c] relu(conv3x3(x)[c] + bias[c]) + proj_b, float32 [B,hv,wv]: the last two layers of `pos_layers`."""
+  B, _, H, W = x.shape
+  out = torch.empty((B, hv, wv), dtype=torch.float32, device=x.device)
+  with torch.cuda.device(x.device):
+    rc = load().srl_conv3x3_relu_project(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), proj_w.data_ptr(), float(proj_b),
+                                         out.data_ptr(), B, H, W, hv, wv, _stream(x))
+  if rc:
+    raise RuntimeError(load().srl_conv_last_error().decode())
+  return out
+
+
 class FastFeatures(object):
   """Inference-only forward of the two U-Nets (`DeepQSiamFCN.features`, models.py:160-177; `layers.unet`,
   layers.py:135-259) in bf16 channels-last: library convolutions without bias, and the fused element-wise passes of
@@ -261,6 +292,9 @@ class FastFeatures(object):
     self._key = None
     self._w = {}
     self._wf = {}
+    self._wt = {}
+    self._pos = None
+    self._posbuf = {}
 
   def _refresh(self):
     key = tuple(p._version for p in self.net.parameters()) + (id(self.net),)
@@ -268,12 +302,21 @@ class FastFeatures(object):
       return
     self._w = {}
     self._wf = {}
+    self._wt = {}
     for m in self.net.modules():
       if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
         self._w[m] = (m.weight.detach().to(torch.bfloat16).contiguous(memory_format=_CL), m.bias.detach().float().contiguous())
         if self.mfma_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.in_channels in (16, 32) and m.out_channels in (16, 32):
           self._wf[m] = pack_conv3x3_weights(m.weight)
+        if self.mfma_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
+           m.in_channels in (1, 2) and m.out_channels == 16:
+          self._wt[m] = m.weight.detach().float().contiguous()
+    pos = getattr(self.net, 'pos', None)
+    self._pos = None
+    if self.mfma_conv and pos is not None and len(pos) == 5 and pos[0] in self._wt and pos[2] in self._wf and \
+       pos[4].kernel_size == (1, 1) and pos[4].in_channels == 16 and pos[4].out_channels == 1:
+      self._pos = (pos[4].weight.detach().float().reshape(16).contiguous(), float(pos[4].bias.detach()))
     self._key = key
 
   def _mine(self, m, x):
@@ -283,13 +326,22 @@ class FastFeatures(object):
     w, b = self._w[m]
     return _cl(torch.nn.functional.conv2d(x, w, None, padding=m.padding)), b
 
-  def _unet(self, U, x):
+  def _unet(self, U, obs):
+    """obs: the env's uint8 observation [B,H,W,c] (channels-last memory)."""
     F = torch.nn.functional
-    B = x.shape[0]
+    B = obs.shape[0]
     cats = []
+    x = None
     for blk in U.down:
       f = blk[0].out_channels
-      if self._mine(blk[0], x):
+      if x is None and blk[0] in self._wt:
+        y = conv3x3_thin(obs, self._wt[blk[0]], self._w[blk[0]][1])      # /255 and the cast happen in the kernel
+      elif x is None:
+        # uint8 NHWC / 255 (models.py:144-147); the NHWC memory is exactly a channels-last NCHW tensor
+        x = (obs.float() / 255.0).to(torch.bfloat16).permute(0, 3, 1, 2)
+        y, b = self._conv(blk[0], x)
+        bias_act(y, b)
+      elif self._mine(blk[0], x):
         y = conv3x3_bias_relu(x, self._wf[blk[0]], self._w[blk[0]][1], f)
       else:
         y, b = self._conv(blk[0], x)
@@ -329,10 +381,27 @@ class FastFeatures(object):
   def __call__(self, inputs):
     self._refresh()
     xm, xo = inputs
-    # uint8 NHWC / 255 (models.py:144-147); the NHWC memory is exactly a channels-last NCHW tensor
-    x = (xm.float() / 255.0).to(torch.bfloat16).permute(0, 3, 1, 2)
-    w = (xo.float() / 255.0).to(torch.bfloat16).permute(0, 3, 1, 2)
-    return self._unet(self.net.left, x), self._unet(self.net.right, w)
+    return self._unet(self.net.left, xm.contiguous()), self._unet(self.net.right, xo.contiguous())
+
+  @torch.no_grad()
+  def pos(self, corr):
+    """`pos_layers` (layers.py:439-472) on the correlation map [B,1,oh,ow] float32 -> advantages [B, oh*ow] float32:
+    the 1 -> 16 layer on the vector ALU into a zero-margined bf16 map padded to a multiple of 16, then the 16 -> 16
+    layer on the matrix cores with the final 1 x 1 projection fused into its epilogue (fp32 from the accumulators)."""
+    self._refresh()
+    if self._pos is None:
+      return self.net.pos(corr).flatten(1)
+    pos = self.net.pos
+    B, _, oh, ow = corr.shape
+    hp, wp = (oh + 15) // 16 * 16, (ow + 15) // 16 * 16
+    key = (B, hp, wp, corr.device.index)
+    buf = self._posbuf.get(key)
+    if buf is None:
+      buf = torch.zeros((B, 16, hp, wp), dtype=torch.bfloat16, device=corr.device).contiguous(memory_format=_CL)
+      self._posbuf = {key: buf}
+    conv3x3_thin(corr.reshape(B, oh, ow, 1).contiguous(), self._wt[pos[0]], self._w[pos[0]][1], out=buf)
+    pw, pb = self._pos
+    return conv3x3_relu_project(buf, self._wf[pos[2]], self._w[pos[2]][1], pw, pb, oh, ow).flatten(1)
 
 
 class FusedPolicy(object):
@@ -364,6 +433,7 @@ class FusedPolicy(object):
           x, _, w = net.features((xm[s:e], xo[s:e]))
       else:
         x, _, w = net.features((xm[s:e], xo[s:e]))
-      adv = net.pos(xcorr_forward(x, w)).flatten(1)
+      corr = xcorr_forward(x, w)
+      adv = self._ff.pos(corr) if self.fast else net.pos(corr).flatten(1)
       out[s:e] = policy_head(adv, u[s:e], rnd[s:e], epsilon)
     return out

@@ -64,7 +64,7 @@ def test_xcorr_mfma_autograd_matches_torch_fp64(B, C, H, h, precision, tol):
   ref.backward(go.double())
   for got, want in ((out, ref), (x.grad, xd.grad), (w.grad, wd.grad)):
     assert got.shape == want.shape and got.dtype == torch.float32
-    err = float((got.double() - want).abs().max()); scale = float(want.abs().max())
+    err = float((got.detach().double() - want.detach()).abs().max()); scale = float(want.detach().abs().max())
     assert err <= tol * scale, (err, scale)
 
 
@@ -92,6 +92,54 @@ def test_conv3x3_mfma_matches_torch(cin, cout, H):
   assert torch.equal(p, F.max_pool2d(y, 2))
   z = qops.conv3x3_bias_relu(x, wf, b, cout, nchw=True)
   assert z.is_contiguous() and torch.equal(z, y.contiguous())
+
+
+def test_thin_conv_and_projection_head_match_torch():
+  """The 1|2 -> 16 channel first layers (vector ALU, uint8 / 255 or float input) and the fused 16 -> 16 -> 1 tail of
+  `pos_layers` (MFMA + fp32 projection) against torch in fp32."""
+  from stackrl_amd import qops
+  F = torch.nn.functional
+  g = torch.Generator(device='cuda').manual_seed(12)
+  for cin, dt in ((2, torch.uint8), (1, torch.uint8), (1, torch.float32)):
+    B, H, W = 3, 40, 56
+    x = torch.randint(0, 256, (B, H, W, cin), generator=g, device='cuda', dtype=torch.uint8) if dt == torch.uint8 else \
+        torch.randn((B, H, W, cin), generator=g, device='cuda') * 30.0
+    w = (torch.rand((16, cin, 3, 3), generator=g, device='cuda') - 0.5) * 0.5
+    b = torch.rand(16, generator=g, device='cuda') - 0.5
+    xf = x.float() / 255.0 if dt == torch.uint8 else x
+    ref = F.relu(F.conv2d(xf.permute(0, 3, 1, 2), w, b, padding=1))
+    y = qops.conv3x3_thin(x, w, b)
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16
+    assert bool(((y.float() - ref).abs() <= 2.0 ** -8 * ref.abs().clamp(min=1e-2)).all())   # fp32 math, one bf16 rounding
+  # padded, zero-margined buffer: only the H x W region is written
+  buf = torch.zeros((B, 16, 48, 64), dtype=torch.bfloat16, device='cuda').contiguous(memory_format=torch.channels_last)
+  qops.conv3x3_thin(x, w, b, out=buf)
+  assert torch.equal(buf[:, :, :H, :W], y) and float(buf[:, :, H:].abs().sum()) == 0 and float(buf[:, :, :, W:].abs().sum()) == 0
+  # projection tail on the padded buffer
+  w2 = (torch.rand((16, 16, 3, 3), generator=g, device='cuda') - 0.5) * 0.2
+  b2 = torch.rand(16, generator=g, device='cuda') - 0.5
+  pw = torch.rand(16, generator=g, device='cuda') - 0.5
+  got = qops.conv3x3_relu_project(buf, qops.pack_conv3x3_weights(w2), b2, pw, 0.25, H, W)
+  act = F.relu(F.conv2d(buf.float()[:, :, :H, :W], w2.to(torch.bfloat16).float(), b2, padding=1))
+  ref = (act * pw[None, :, None, None]).sum(1) + 0.25
+  assert got.shape == (B, H, W) and float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+def test_fast_position_head_tracks_the_module():
+  """`FastFeatures.pos` (bf16 activations, fp32 projection) against `net.pos` in fp32 on a correlation-like map: the
+  stated tolerance is bf16-level (1 % of the advantage range), and the arg-max lands on a near-maximal action."""
+  from stackrl_amd import nets, qops
+  net = nets.DeepQSiamFCN(seed=9).cuda().eval()
+  g = torch.Generator(device='cuda').manual_seed(2)
+  corr = torch.randn((4, 1, 97, 97), generator=g, device='cuda') * 20.0
+  got = qops.FastFeatures(net).pos(corr)
+  with torch.no_grad():
+    ref = net.pos(corr).flatten(1)
+  assert got.shape == ref.shape == (4, 97 * 97) and got.dtype == torch.float32
+  span = float(ref.max() - ref.min())
+  assert float((got - ref).abs().max()) <= 1e-2 * span
+  top = ref.gather(1, got.argmax(1, keepdim=True))[:, 0]
+  assert bool((ref.max(1).values - top <= 2e-2 * span).all())
 
 
 def test_fast_features_match_autocast_features():
