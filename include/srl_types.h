@@ -19,6 +19,7 @@ extern "C" {
 #define SRL_MAX_BODIES 32      /* episode_length <= 32 (BASELINE configs: 8/16/32) */
 #define SRL_MAX_VERTS 128      /* reference pool: 24..70 vertices per rock        */
 #define SRL_MAX_TRIS 252       /* reference pool: 44..136 triangles per rock      */
+#define SRL_MAX_ORIENT 16      /* 2^orientation_freedom <= 16                     */
 
 /* Reward metrics, rewarder.py:7-14. */
 enum { SRL_METRIC_IOU = 0, SRL_METRIC_OR = 1, SRL_METRIC_DIOU = 2, SRL_METRIC_DOR = 3 };
@@ -72,6 +73,9 @@ typedef struct srl_config {
   float angular_damping;     /* pybullet default 0.04                             */
   float warmstart;           /* Bullet m_warmstartingFactor 0.85                  */
   int32_t place_at_com;      /* 1: resetBasePositionAndOrientation moves the COM frame (reference quirk) */
+  /* --- TestStackEnv (Stack-v2), env.py:443-470 --- */
+  int32_t orientation_freedom; /* k: the pending rock is observed in 2^k yaw orientations (observer.py:127-140) and the
+                                  action chooses one: action = orientation * A + pixel; 0 = Stack-v0 (one orientation) */
 } srl_config;
 
 #ifdef __cplusplus

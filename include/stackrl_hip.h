@@ -55,12 +55,15 @@ int srl_seed(srl_env* env, uint32_t seed);
  * (env.py:268-272, rewarder.py:211-259), which are gym-version dependent. */
 int srl_set_script(srl_env* env, const int32_t* mesh_ids, const int32_t* goal_rect);
 
-/* `ParallelEnv.reset` (utils.py:488-503, :545-552): obs_map u8[n][H][W][2], obs_obj u8[n][h][w][1]. */
+/* `ParallelEnv.reset` (utils.py:488-503, :545-552): obs_map u8[n][H][W][2], obs_obj u8[n][h][w][1].
+ * With orientation_freedom = k > 0 (`TestStackEnv`, env.py:443-470) obs_obj is u8[n][2^k][h][w][1]: one object map per
+ * observable orientation (the overhead map is returned once, not 2^k copies as env.py:472-480 stacks them). */
 int srl_reset(srl_env* env, void* obs_map_dev, void* obs_obj_dev, void* stream);
 
 /* `ParallelEnv.step` (utils.py:468-486): action int64[n]; reward float[n]; done uint8[n].
  * Auto-reset semantics of env.py:235-236 are kept: a step on a finished env returns the reset
- * observation, reward 0, done 0. */
+ * observation, reward 0, done 0.  With orientation_freedom > 0 the action is orientation * A + pixel
+ * (the reference's `(index, action)` tuple, env.py:485-494) and the rock is placed in that orientation. */
 int srl_step(srl_env* env, const int64_t* action_dev, void* obs_map_dev, void* obs_obj_dev,
              float* reward_dev, uint8_t* done_dev, void* stream);
 
@@ -76,7 +79,7 @@ int srl_sync_status(srl_env* env, void* stream);
  * `Simulator.poses` (simulator.py:90-93) as float[n][SRL_MAX_BODIES][8] = pos xyz, quat xyzw, mesh id;
  * n_bodies int32[n]; `Simulator.n_steps` (simulator.py:79-83) int32[n][2]; status bits int32[n]. */
 int srl_get_state(srl_env* env, float* poses, int32_t* n_bodies, int32_t* substeps, int32_t* status);
-/* `Observer.state` (observer.py:365-368) float[n][H*W], float[n][h*w]; `Rewarder` goal rect int32[n][4]. */
+/* `Observer.state` (observer.py:365-368) float[n][H*W], float[n][2^orientation_freedom][h*w]; `Rewarder` goal rect int32[n][4]. */
 int srl_get_maps(srl_env* env, float* height, float* object_map, int32_t* goal_rect);
 /* velocities float[n][SRL_MAX_BODIES][8] = lin xyz 0, ang xyz 0 */
 int srl_get_velocities(srl_env* env, float* vel);
@@ -88,7 +91,7 @@ int srl_get_contacts(srl_env* env, float* max_penetration, int32_t* n_points);
  * n_bodies_dev int32[n] -> height_dev float[n][H*W]. */
 int srl_render_heightmap(srl_env* env, const float* poses_dev, const int32_t* mesh_ids_dev,
                          const int32_t* n_bodies_dev, float* height_dev, void* stream);
-/* O2 row: underside map of one mesh (observer.py:262-277), host output float[h*w]. */
+/* O2 row: underside map(s) of one mesh (observer.py:262-277), host output float[2^orientation_freedom][h*w]. */
 int srl_get_object_map(srl_env* env, int32_t mesh_id, float* object_map);
 
 /* Per-kernel HIP-event timing (bench.py's roofline leg).  enable != 0 brackets every kernel launch of

@@ -55,7 +55,8 @@ class OracleEnv(object):
     if rc:
       raise ValueError(self.L.srlo_last_error().decode())
     self.obs_map = np.zeros((self.n, self.H, self.H, 2), np.uint8)
-    self.obs_obj = np.zeros((self.n, self.h_, self.h_, 1), np.uint8)
+    self.no = cfg.n_orientations       # TestStackEnv: one object map per observable orientation
+    self.obs_obj = np.zeros((self.n, self.h_, self.h_, 1) if self.no == 1 else (self.n, self.no, self.h_, self.h_, 1), np.uint8)
     self.reward = np.zeros(self.n, np.float32)
     self.done = np.zeros(self.n, np.uint8)
     if seed is not None:
@@ -115,7 +116,7 @@ class OracleEnv(object):
 
   def maps(self):
     Hm = np.zeros((self.n, self.H, self.H), np.float32)
-    Om = np.zeros((self.n, self.h_, self.h_), np.float32)
+    Om = np.zeros((self.n, self.h_, self.h_) if self.no == 1 else (self.n, self.no, self.h_, self.h_), np.float32)
     g = np.zeros((self.n, 4), np.int32)
     self.L.srlo_get_maps(self.h, _p(Hm), _p(Om), _p(g))
     return Hm, Om, g

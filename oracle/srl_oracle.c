@@ -215,6 +215,9 @@ struct srlo_env {
   float goal_z;
   float scale;
   int AW, A;
+  /* observable orientations of the pending rock (TestStackEnv, observer.py:127-140) */
+  int n_orient;
+  q4 orient_q[SRL_MAX_ORIENT];
 };
 
 /* ------------------------------------------------------------------ create */
@@ -241,6 +244,14 @@ static int derive(struct srlo_env* e) {
   e->scale = c->reward_scale > 0.0f ? c->reward_scale : (float)c->episode_length; /* rewarder.py:97 */
   e->AW = H - h + 1;                                            /* env.py:207-211 */
   e->A = e->AW * e->AW;
+  if (c->orientation_freedom < 0 || (1 << c->orientation_freedom) > SRL_MAX_ORIENT)
+    return fail(SRL_EINVAL, "orientation_freedom must be in 0..4");
+  e->n_orient = 1 << c->orientation_freedom;                    /* observer.py:127 */
+  for (int i = 0; i < e->n_orient; ++i) {   /* inverse of getQuaternionFromEuler([0, 0, i 2 pi / n]), observer.py:129-139 */
+    double half = -0.5 * ((double)i * 2.0 * 3.14159265358979323846 / (double)e->n_orient);
+    e->orient_q[i].x = 0.0f; e->orient_q[i].y = 0.0f;
+    e->orient_q[i].z = i == 0 ? 0.0f : (float)sin(half); e->orient_q[i].w = i == 0 ? 1.0f : (float)cos(half);
+  }
   return SRL_OK;
 }
 
@@ -255,7 +266,7 @@ int srlo_create(const srl_config* cfg, srlo_env** out) {
   for (int i = 0; i < cfg->n_envs; ++i) {
     env_t* s = &e->env[i];
     s->H = (float*)calloc((size_t)cfg->overhead_res * cfg->overhead_res, sizeof(float));
-    s->O = (float*)calloc((size_t)cfg->object_res * cfg->object_res, sizeof(float));
+    s->O = (float*)calloc((size_t)cfg->object_res * cfg->object_res * SRL_MAX_ORIENT, sizeof(float));
     s->done = 1;                                                /* env.py:219-220 */
     s->pending = -1;
     for (int k = 0; k < NPAIR; ++k) s->slot_of_pair[k] = -1;
@@ -485,7 +496,8 @@ static void render_heightmap(const struct srlo_env* e, int nb, const int* mesh, 
 
 /* O2: underside map of a mesh at the spawn pose (link frame at spawn, identity orientation;
  * observer.py:262-277).  O = (z_c + oz/2) - z_underside, 0 where empty. */
-static void render_object(const struct srlo_env* e, int mesh_id, float* O) {
+/* one observable orientation oi of the pending rock: it turns about its link-frame origin at the centre of the map */
+static void render_object_1(const struct srlo_env* e, int mesh_id, int oi, float* O) {
   const srl_config* c = &e->c;
   int r = c->object_res;
   float half = c->object_max_dimension * 0.5f;
@@ -495,6 +507,10 @@ static void render_object(const struct srlo_env* e, int mesh_id, float* O) {
     m3 I; for (int k = 0; k < 9; ++k) I.m[k] = (k % 4 == 0) ? 1.0f : 0.0f;
     /* map coordinates: link frame shifted so that the map starts at 0 */
     v3 xs = V(M->com.x + half, M->com.y + half, M->com.z);
+    if (e->n_orient > 1) {
+      I = quat_to_mat(e->orient_q[oi]);
+      xs = vadd(mmul(&I, M->com), V(half, half, 0.0f));
+    }
     rplane_t pl[MAXT];
     int np = make_rplanes(M, &I, xs, pl);
     for (int i = 0; i < r; ++i) {
@@ -511,6 +527,11 @@ static void render_object(const struct srlo_env* e, int mesh_id, float* O) {
     float d = O[k] > 1e29f ? 1.0f : depth_encode(FAR_PLANE + O[k], nearp, farp);
     O[k] = elev_object(c, d);
   }
+}
+
+static void render_object(const struct srlo_env* e, int mesh_id, float* O) {
+  int rr = e->c.object_res * e->c.object_res;
+  for (int oi = 0; oi < e->n_orient; ++oi) render_object_1(e, mesh_id, oi, O + (size_t)oi * rr);
 }
 
 /* ------------------------------------------------------------------ pose (observer.py:392-421) */
@@ -1136,15 +1157,21 @@ static int sim_drop(const struct srlo_env* e, const env_t* s) {
 }
 
 /* Simulator.step, simulator.py:190-258 */
-static void sim_step(const struct srlo_env* e, env_t* s, v3 pos) {
+static void sim_step(const struct srlo_env* e, env_t* s, v3 pos, int oi) {
   int counter = 0, diverged = 0;
   if (s->pending >= 0) {             /* _place, simulator.py:310-320 */
     int b = s->nb;
     const mesh_t* M = &e->mesh[s->pending];
     s->mesh[b] = s->pending;
     /* resetBasePositionAndOrientation moves the inertial (COM) frame; loadURDF placed the link frame */
-    s->x[b] = e->c.place_at_com ? pos : vadd(pos, M->com);
-    s->q[b].x = 0.0f; s->q[b].y = 0.0f; s->q[b].z = 0.0f; s->q[b].w = 1.0f;
+    if (e->n_orient == 1) {
+      s->x[b] = e->c.place_at_com ? pos : vadd(pos, M->com);
+      s->q[b].x = 0.0f; s->q[b].y = 0.0f; s->q[b].z = 0.0f; s->q[b].w = 1.0f;
+    } else {   /* the chosen orientation (observer.py:416-417 -> simulator.py:313) */
+      m3 Ro = quat_to_mat(e->orient_q[oi]);
+      s->x[b] = e->c.place_at_com ? pos : vadd(pos, mmul(&Ro, M->com));
+      s->q[b] = e->orient_q[oi];
+    }
     s->v[b] = V(0, 0, 0); s->w[b] = V(0, 0, 0);
     s->gm[b].np = 0;
     s->nb = b + 1;
@@ -1225,7 +1252,7 @@ static void pack_obs(const struct srlo_env* e, const env_t* s, uint8_t* om, uint
       om[(i * res + j) * 2 + 0] = (uint8_t)((s->H[i * res + j] * 255.0f) / den);
       om[(i * res + j) * 2 + 1] = (uint8_t)((g * 255.0f) / den);
     }
-  for (int k = 0; k < r * r; ++k) oo[k] = (uint8_t)((s->O[k] * 255.0f) / den);
+  for (int k = 0; k < r * r * e->n_orient; ++k) oo[k] = (uint8_t)((s->O[k] * 255.0f) / den);
 }
 
 static void env_reset(struct srlo_env* e, int i) {
@@ -1269,7 +1296,7 @@ static void env_reset(struct srlo_env* e, int i) {
 int srlo_reset(srlo_env* e, uint8_t* obs_map, uint8_t* obs_obj) {
   if (!e->mesh) return fail(SRL_ENOMESH, "load meshes first");
   const srl_config* c = &e->c;
-  size_t nm = (size_t)c->overhead_res * c->overhead_res * 2, no = (size_t)c->object_res * c->object_res;
+  size_t nm = (size_t)c->overhead_res * c->overhead_res * 2, no = (size_t)c->object_res * c->object_res * e->n_orient;
   for (int i = 0; i < c->n_envs; ++i) {
     env_reset(e, i);
     pack_obs(e, &e->env[i], obs_map + nm * i, obs_obj + no * i);
@@ -1281,7 +1308,7 @@ int srlo_step(srlo_env* e, const int64_t* action, uint8_t* obs_map, uint8_t* obs
               uint8_t* done) {
   if (!e->mesh) return fail(SRL_ENOMESH, "load meshes first");
   const srl_config* c = &e->c;
-  size_t nm = (size_t)c->overhead_res * c->overhead_res * 2, no = (size_t)c->object_res * c->object_res;
+  size_t nm = (size_t)c->overhead_res * c->overhead_res * 2, no = (size_t)c->object_res * c->object_res * e->n_orient;
   int rc = SRL_OK;
   for (int i = 0; i < c->n_envs; ++i) {
     env_t* s = &e->env[i];
@@ -1292,6 +1319,8 @@ int srlo_step(srlo_env* e, const int64_t* action, uint8_t* obs_map, uint8_t* obs
       continue;
     }
     int64_t a = action[i];
+    int oi = 0;                                          /* TestStackEnv: (orientation index, pixel), env.py:485-494 */
+    if (e->n_orient > 1 && a >= 0) { oi = (int)(a / (int64_t)e->A); a = oi < e->n_orient ? a % (int64_t)e->A : -1; }
     if (a < 0 || a >= (int64_t)e->A) {                   /* env.py:238 */
       s->status |= SRL_ST_BAD_ACTION;
       reward[i] = 0.0f; done[i] = 0;
@@ -1305,8 +1334,8 @@ int srlo_step(srlo_env* e, const int64_t* action, uint8_t* obs_map, uint8_t* obs
     if (s->list_pos < c->episode_length) next = s->ids[s->list_pos++];   /* env.py:243-247 */
     else s->done = 1;
     float xyz[3];
-    srlo_pose(c, s->H, s->O, u, v, xyz);
-    sim_step(e, s, V(xyz[0], xyz[1], xyz[2]));
+    srlo_pose(c, s->H, s->O + (size_t)oi * c->object_res * c->object_res, u, v, xyz);
+    sim_step(e, s, V(xyz[0], xyz[1], xyz[2]), oi);
     s->pending = next;                                   /* _load, simulator.py:258 */
     render_heightmap(e, s->nb, s->mesh, s->x, s->q, s->H);
     render_object(e, s->pending, s->O);
@@ -1327,7 +1356,7 @@ int srlo_sample(srlo_env* e, int64_t* action) {
   e->sample_counter += 1;
   for (int i = 0; i < c->n_envs; ++i) {
     uint32_t key = e->seed + (uint32_t)c->env_index_offset + (uint32_t)i;
-    action[i] = (int64_t)rng_below(srlo_rng(key, e->sample_counter, STREAM_ACTION, 0), (uint32_t)e->A);
+    action[i] = (int64_t)rng_below(srlo_rng(key, e->sample_counter, STREAM_ACTION, 0), (uint32_t)(e->A * e->n_orient));
   }
   return SRL_OK;
 }
@@ -1382,7 +1411,7 @@ int srlo_get_contacts(srlo_env* e, float* max_pen, int32_t* n_points) {
 
 int srlo_get_maps(srlo_env* e, float* height, float* object_map, int32_t* goal_rect) {
   const srl_config* c = &e->c;
-  size_t nh = (size_t)c->overhead_res * c->overhead_res, no = (size_t)c->object_res * c->object_res;
+  size_t nh = (size_t)c->overhead_res * c->overhead_res, no = (size_t)c->object_res * c->object_res * e->n_orient;
   for (int i = 0; i < c->n_envs; ++i) {
     env_t* s = &e->env[i];
     if (height) memcpy(height + nh * i, s->H, nh * sizeof(float));

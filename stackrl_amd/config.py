@@ -48,6 +48,7 @@ class CConfig(ctypes.Structure):
     ('angular_damping', ctypes.c_float),
     ('warmstart', ctypes.c_float),
     ('place_at_com', ctypes.c_int32),
+    ('orientation_freedom', ctypes.c_int32),
   ]
 
 
@@ -83,8 +84,11 @@ class StackConfig:
   angular_damping: float = 0.04
   warmstart: float = 0.85
   place_at_com: bool = True
+  orientation_freedom: int = 0        # TestStackEnv (Stack-v2, env.py:443-470): 2**k yaw orientations; 0 = Stack-v0
 
   def __post_init__(self):
+    if not 0 <= int(self.orientation_freedom) <= 4:
+      raise ValueError('orientation_freedom must be in 0..4 (at most 16 orientations)')
     if self.dtype != 'uint8':
       # env.py:169-170 raises ValueError for unknown dtypes; the build implements the Stack-v0 one.
       raise ValueError('Invalid value {} for argument dtype.'.format(self.dtype))
@@ -112,6 +116,10 @@ class StackConfig:
   @property
   def n_actions(self):
     return (self.overhead_res - self.object_res + 1) ** 2   # env.py:207-211
+
+  @property
+  def n_orientations(self):
+    return 2 ** int(self.orientation_freedom)               # observer.py:127
 
   @property
   def metric_id(self):
@@ -158,6 +166,7 @@ class StackConfig:
       friction_ground=self.friction_ground, linear_damping=self.linear_damping,
       angular_damping=self.angular_damping, warmstart=self.warmstart,
       place_at_com=int(bool(self.place_at_com)),
+      orientation_freedom=int(self.orientation_freedom),
     )
 
   @classmethod

@@ -246,7 +246,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     g0 = h->goal[0]; g1 = h->goal[1]; g2 = h->goal[2]; g3 = h->goal[3]; pending = h->pending;
     mode = h->mode; hdone = h->done; prev_metric = h->prev_metric;
   }
-  const int rr = P.c.object_res * P.c.object_res;
+  const int rr = P.c.object_res * P.c.object_res * P.n_orient;   // all observable orientations of the pending rock
   float om_pref[2] = {0.0f, 0.0f};
   if (!ext && pending >= 0) {
 #pragma unroll
@@ -583,18 +583,27 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   }
 }
 
-// K3: underside map of one mesh at the spawn pose.  One workgroup per mesh.
+// K3: underside map of one mesh at the spawn pose, in one observable orientation (blockIdx.y; Stack-v0 has only the
+// identity).  One workgroup per (mesh, orientation).  The rock turns about its link-frame origin, which sits at the
+// centre of the map (observer.py:143-164: the camera looks at the object pose).
 extern "C" __global__ void __launch_bounds__(256) srl_k_objmap(DevParams P, float* __restrict__ out) {
   __shared__ float4 planes[SRL_MAX_TRIS];
-  const int m = blockIdx.x, tid = threadIdx.x;
+  const int m = blockIdx.x, oi = blockIdx.y, tid = threadIdx.x;
   const int r = P.c.object_res;
   const float half = P.c.object_max_dimension * 0.5f;
   const MeshHdr mh = P.mh[m];
-  m3 I;
+  m3 R;
+  v3 xs;   // COM in map coordinates: link frame shifted to start at 0
+  if (P.n_orient == 1) {
 #pragma unroll
-  for (int k = 0; k < 9; ++k) I.m[k] = (k % 4 == 0) ? 1.0f : 0.0f;
-  const v3 xs = V(mh.cx + half, mh.cy + half, mh.cz);   // map coordinates: link frame shifted to start at 0
-  for (int t = tid; t < mh.nt; t += 256) planes[t] = make_rplane(P.mp[mh.to + t], I, xs);
+    for (int k = 0; k < 9; ++k) R.m[k] = (k % 4 == 0) ? 1.0f : 0.0f;
+    xs = V(mh.cx + half, mh.cy + half, mh.cz);
+  } else {
+    q4 q; q.x = P.orient_q[oi][0]; q.y = P.orient_q[oi][1]; q.z = P.orient_q[oi][2]; q.w = P.orient_q[oi][3];
+    R = quat_to_mat(q);
+    xs = mmul(R, V(mh.cx, mh.cy, mh.cz)) + V(half, half, 0.0f);
+  }
+  for (int t = tid; t < mh.nt; t += 256) planes[t] = make_rplane(P.mp[mh.to + t], R, xs);
   __syncthreads();
   const float nearp = SRL_FAR - half, farp = SRL_FAR + half;
   for (int k = tid; k < r * r; k += 256) {
@@ -604,6 +613,6 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_objmap(DevParams P, floa
     float z = 1e30f;
     if (ray_cast(planes, mh.nt, px, py, lo, hi)) z = lo;
     float d = z > 1e29f ? 1.0f : depth_encode(SRL_FAR + z, nearp, farp);
-    out[(size_t)m * r * r + k] = elev_object(P, d);
+    out[((size_t)m * P.n_orient + oi) * r * r + k] = elev_object(P, d);
   }
 }

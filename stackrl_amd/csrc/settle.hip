@@ -34,7 +34,7 @@ __constant__ uint8_t c_pair_i[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
 __constant__ uint8_t c_pair_j[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
 
 // misc words in LDS
-enum { M_MODE = 0, M_U, M_V, M_NEXT, M_ZMAX, M_FLAGS, M_NCOL, M_CNT, M_NB, M_PENDING, M_STATUS, M_DONE, M_WORDS = 16 };
+enum { M_MODE = 0, M_U, M_V, M_NEXT, M_ZMAX, M_FLAGS, M_NCOL, M_CNT, M_NB, M_PENDING, M_STATUS, M_DONE, M_ORIENT, M_WORDS = 16 };
 
 struct Lds {
   float* sm;
@@ -727,6 +727,9 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
       mode = 1;
     } else {
       int64_t a = action[e];
+      int oi = 0;                             // TestStackEnv: action = (orientation index, pixel), env.py:485-494
+      if (P.n_orient > 1 && a >= 0) { oi = (int)(a / (int64_t)P.A); a = oi < P.n_orient ? a % (int64_t)P.A : -1; }
+      misc[M_ORIENT] = oi;
       if (a < 0 || a >= (int64_t)P.A) {       // env.py:238
         h->status |= SRL_ST_BAD_ACTION;
         atomicOr(P.flags, 1);
@@ -770,7 +773,7 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
   {
     const int res = P.c.overhead_res, r = P.c.object_res;
     const float* Hm = P.H + (size_t)e * res * res;
-    const float* Om = P.objmap + (size_t)pending * r * r;
+    const float* Om = P.objmap + ((size_t)pending * P.n_orient + misc[M_ORIENT]) * r * r;
     uint32_t best = f2o(-1e30f);
     for (int k = tid; k < r * r; k += T) {
       int i = k / r, j = k % r;
@@ -791,8 +794,15 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
     int b = nb;
     L.MESH()[b] = pending;
     // resetBasePositionAndOrientation moves the inertial (COM) frame; loadURDF had placed the link frame
-    st3(L.X(b), P.c.place_at_com ? pos : pos + V(mh.cx, mh.cy, mh.cz));
-    L.Q(b)[0] = 0.0f; L.Q(b)[1] = 0.0f; L.Q(b)[2] = 0.0f; L.Q(b)[3] = 1.0f;
+    if (P.n_orient == 1) {
+      st3(L.X(b), P.c.place_at_com ? pos : pos + V(mh.cx, mh.cy, mh.cz));
+      L.Q(b)[0] = 0.0f; L.Q(b)[1] = 0.0f; L.Q(b)[2] = 0.0f; L.Q(b)[3] = 1.0f;
+    } else {   // the chosen orientation (observer.py:416-417 -> simulator.py:313)
+      const float* oq = P.orient_q[misc[M_ORIENT]];
+      q4 q; q.x = oq[0]; q.y = oq[1]; q.z = oq[2]; q.w = oq[3];
+      st3(L.X(b), P.c.place_at_com ? pos : pos + mmul(quat_to_mat(q), V(mh.cx, mh.cy, mh.cz)));
+      L.Q(b)[0] = q.x; L.Q(b)[1] = q.y; L.Q(b)[2] = q.z; L.Q(b)[3] = q.w;
+    }
     st3(L.Vl(b), V(0, 0, 0)); st3(L.Wl(b), V(0, 0, 0));
     L.GM(b)[0] = __int_as_float(0);
   }
@@ -893,7 +903,7 @@ extern "C" __global__ void srl_k_sample(DevParams P, int64_t* __restrict__ actio
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.c.n_envs) return;
   uint32_t key = P.seed + (uint32_t)P.c.env_index_offset + (uint32_t)i;
-  action[i] = (int64_t)srl_rng_below(srl_rng(key, P.sample_counter, SRL_STREAM_ACTION, 0), (uint32_t)P.A);
+  action[i] = (int64_t)srl_rng_below(srl_rng(key, P.sample_counter, SRL_STREAM_ACTION, 0), (uint32_t)(P.A * P.n_orient));
 }
 
 // ------------------------------------------------------------------ telemetry reduction

@@ -57,6 +57,10 @@ struct DevParams {
   const float4* mv;       // mesh vertices, COM frame
   const uchar4* mt;       // triangles
   const float4* mp;       // face planes, COM frame: unit normal xyz, offset d
-  const float* objmap;    // [n_mesh][ores*ores] underside maps (O2)
+  const float* objmap;    // [n_mesh][n_orient][ores*ores] underside maps (O2), one per observable orientation
+  // observable orientations of the pending rock (TestStackEnv, observer.py:127-140): quaternion i = inverse of the yaw
+  // i * 2 pi / n_orient ("orientation of the object relative to the view"); n_orient = 1: identity only (Stack-v0)
+  int32_t n_orient;
+  float orient_q[SRL_MAX_ORIENT][4];
   int32_t* flags;         // [1] accumulated error bits since the last srl_sync_status
 };

@@ -85,6 +85,14 @@ int derive(DevParams& P) {
   P.scale = c.reward_scale > 0.0f ? c.reward_scale : (float)c.episode_length;  // rewarder.py:97
   P.AW = H - h + 1;                                                            // env.py:207-211
   P.A = P.AW * P.AW;
+  if (c.orientation_freedom < 0 || (1 << c.orientation_freedom) > SRL_MAX_ORIENT)
+    return fail(SRL_EINVAL, "orientation_freedom must be in 0..4");
+  P.n_orient = 1 << c.orientation_freedom;                                     // observer.py:127
+  for (int i = 0; i < P.n_orient; ++i) {   // inverse of getQuaternionFromEuler([0, 0, i 2 pi / n]) (observer.py:129-139)
+    const double half = -0.5 * ((double)i * 2.0 * 3.14159265358979323846 / (double)P.n_orient);
+    P.orient_q[i][0] = 0.0f; P.orient_q[i][1] = 0.0f;
+    P.orient_q[i][2] = i == 0 ? 0.0f : (float)sin(half); P.orient_q[i][3] = i == 0 ? 1.0f : (float)cos(half);
+  }
   // observer.py:259-260 / :274-275 constants, rounded to float32 the way numpy rounds python scalars
   double oz = (double)c.object_max_dimension;
   P.elev_num = (float)((double)SRL_FAR * ((double)SRL_FAR - (double)c.max_z));
@@ -190,6 +198,7 @@ int srl_config_default(srl_config* c) {
   c->friction_rock = 0.6f; c->friction_ground = 0.5f;
   c->linear_damping = 0.04f; c->angular_damping = 0.04f; c->warmstart = 0.85f;
   c->place_at_com = 1;
+  c->orientation_freedom = 0;
   return SRL_OK;
 }
 
@@ -300,7 +309,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   HIP_TRY(hipMalloc((void**)&env->d_mv, sizeof(float4) * mv.size()));
   HIP_TRY(hipMalloc((void**)&env->d_mt, sizeof(uchar4) * mt.size()));
   HIP_TRY(hipMalloc((void**)&env->d_mp, sizeof(float4) * mp.size()));
-  HIP_TRY(hipMalloc((void**)&env->d_objmap, sizeof(float) * (size_t)n_mesh * r * r));
+  HIP_TRY(hipMalloc((void**)&env->d_objmap, sizeof(float) * (size_t)n_mesh * env->P.n_orient * r * r));
   HIP_TRY(hipMemcpy(env->d_mh, mh.data(), sizeof(MeshHdr) * mh.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(env->d_mv, mv.data(), sizeof(float4) * mv.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(env->d_mt, mt.data(), sizeof(uchar4) * mt.size(), hipMemcpyHostToDevice));
@@ -326,7 +335,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->render_lds));
   // K3: object maps of the whole pool, once
-  hipLaunchKernelGGL(srl_k_objmap, dim3(n_mesh), dim3(256), env->objmap_lds, 0, P, env->d_objmap);
+  hipLaunchKernelGGL(srl_k_objmap, dim3(n_mesh, P.n_orient), dim3(256), env->objmap_lds, 0, P, env->d_objmap);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   if (n_mesh < P.c.episode_length) { /* sampled with replacement, env.py:104-106 */ }
@@ -480,13 +489,14 @@ int srl_get_maps(srl_env* env, float* height, float* object_map, int32_t* goal_r
     for (int i = 0; i < n; ++i) {
       if (goal_rect) for (int k = 0; k < 4; ++k) goal_rect[4 * i + k] = h[i].goal[k];
       if (object_map) {
-        float* o = object_map + (size_t)i * r * r;
+        const size_t per = (size_t)P.n_orient * r * r;   // every observable orientation of the pending rock
+        float* o = object_map + (size_t)i * per;
         if (h[i].pending >= 0) {
-          HIP_TRY(hipMemcpy(o, env->d_objmap + (size_t)h[i].pending * r * r, sizeof(float) * r * r, hipMemcpyDeviceToHost));
+          HIP_TRY(hipMemcpy(o, env->d_objmap + (size_t)h[i].pending * per, sizeof(float) * per, hipMemcpyDeviceToHost));
         } else {
           // empty map = elev_object(1.0), evaluated like the kernel does
           float e0 = P.obj_c1 - P.obj_c2 / (SRL_FAR + P.c.object_max_dimension * (0.5f - 1.0f));
-          for (int k = 0; k < r * r; ++k) o[k] = e0;
+          for (size_t k = 0; k < per; ++k) o[k] = e0;
         }
       }
     }
@@ -498,8 +508,8 @@ int srl_get_object_map(srl_env* env, int32_t mesh_id, float* object_map) {
   if (!env || !object_map) return fail(SRL_EINVAL, "null argument");
   if (!env->d_objmap) return fail(SRL_ENOMESH, "srl_load_meshes must be called first");
   if (mesh_id < 0 || mesh_id >= env->P.n_mesh) return fail(SRL_EINVAL, "mesh id out of range");
-  const int r = env->P.c.object_res;
-  HIP_TRY(hipMemcpy(object_map, env->d_objmap + (size_t)mesh_id * r * r, sizeof(float) * r * r, hipMemcpyDeviceToHost));
+  const size_t per = (size_t)env->P.n_orient * env->P.c.object_res * env->P.c.object_res;
+  HIP_TRY(hipMemcpy(object_map, env->d_objmap + (size_t)mesh_id * per, sizeof(float) * per, hipMemcpyDeviceToHost));
   return SRL_OK;
 }
 

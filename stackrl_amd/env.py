@@ -73,7 +73,10 @@ class VecStackEnv(object):
       _check(self._lib.srl_load_meshes(self._h, _np_ptr(p.verts), _np_ptr(p.vert_off), _np_ptr(p.tris),
                                        _np_ptr(p.tri_off), _np_ptr(p.mass_com), len(p)))
     B, H, h = self.config.n_envs, self.config.overhead_res, self.config.object_res
-    self._observation_spec = (TensorSpec((H, H, 2), torch.uint8), TensorSpec((h, h, 1), torch.uint8))
+    # TestStackEnv (env.py:443-470): one object map per observable orientation, action = orientation * A + pixel
+    self._no = self.config.n_orientations
+    self._observation_spec = (TensorSpec((H, H, 2), torch.uint8),
+                              TensorSpec((h, h, 1) if self._no == 1 else (self._no, h, h, 1), torch.uint8))
     self._action_spec = TensorSpec((), torch.int64)
     self._B, self._H, self._hh = B, H, h
     self._closed = False
@@ -99,7 +102,7 @@ class VecStackEnv(object):
 
   @property
   def n_actions(self):
-    return self.config.n_actions
+    return self.config.n_actions * self._no
 
   def __call__(self, *args, **kwargs):
     return self.step(*args, **kwargs)
@@ -150,7 +153,7 @@ class VecStackEnv(object):
 
   def _new_obs(self):
     return (torch.empty((self._B, self._H, self._H, 2), dtype=torch.uint8, device=self._device),
-            torch.empty((self._B, self._hh, self._hh, 1), dtype=torch.uint8, device=self._device))
+            torch.empty((self._B,) + tuple(self._observation_spec[1].shape), dtype=torch.uint8, device=self._device))
 
   def _finish(self, out):
     def wait():
@@ -224,13 +227,13 @@ class VecStackEnv(object):
 
   def maps(self):
     Hm = np.zeros((self._B, self._H, self._H), np.float32)
-    Om = np.zeros((self._B, self._hh, self._hh), np.float32)
+    Om = np.zeros((self._B, self._hh, self._hh) if self._no == 1 else (self._B, self._no, self._hh, self._hh), np.float32)
     g = np.zeros((self._B, 4), np.int32)
     _check(self._lib.srl_get_maps(self._h, _np_ptr(Hm), _np_ptr(Om), _np_ptr(g)))
     return Hm, Om, g
 
   def object_map(self, mesh_id):
-    o = np.zeros((self._hh, self._hh), np.float32)
+    o = np.zeros((self._hh, self._hh) if self._no == 1 else (self._no, self._hh, self._hh), np.float32)
     _check(self._lib.srl_get_object_map(self._h, int(mesh_id), _np_ptr(o)))
     return o
 
@@ -254,7 +257,12 @@ class VecStackEnv(object):
 
 
 def make(env='Stack-v0', n_parallel=None, block=None, seed=None, **kwargs):
-  """`stackrl.envs.make` (utils.py:44-141) for the one registered id this build implements."""
-  if env != 'Stack-v0':
-    raise ValueError("Only 'Stack-v0' is implemented (Stack-v1/v2 are out of scope, SURVEY.md section 2).")
+  """`stackrl.envs.make` (utils.py:44-141): 'Stack-v0' (envs/stack/__init__.py:4-8) and 'Stack-v2' (`TestStackEnv`,
+  env.py:443-470, with its default `orientation_freedom=3`; `ordering_freedom` is not built)."""
+  if env == 'Stack-v2':
+    if kwargs.pop('ordering_freedom', False):
+      raise ValueError('ordering_freedom=True (TestSimulator) is not implemented')
+    kwargs.setdefault('orientation_freedom', 3)
+  elif env != 'Stack-v0':
+    raise ValueError("Only 'Stack-v0' and 'Stack-v2' are implemented (Stack-v1 is out of scope, SURVEY.md section 2).")
   return VecStackEnv(n_parallel=n_parallel or 1, block=block, seed=seed, **kwargs)
