@@ -49,6 +49,17 @@ class MeshPool:
   def subset(self, idx):
     return pack([self.mesh(i) for i in idx], [self.names[i] for i in idx])
 
+  def select(self, urdfs):
+    """The sub-pool whose file names match `urdfs`, the glob pattern (or list of patterns / irregularity numbers) of
+    `StackEnv(urdfs=...)` (env.py:92-103: `data.generated(name=...)`), e.g. '[5-9]?' or '5?' or 50."""
+    import fnmatch
+    pats = urdfs if isinstance(urdfs, (list, tuple)) else [urdfs]
+    pats = [str(p) if '_' in str(p) else str(p) + '_*' for p in pats]      # file names are '<irregularity>_<index>'
+    idx = [i for i, n in enumerate(self.names) if any(fnmatch.fnmatch(n, p) for p in pats)]
+    if not idx:
+      raise ValueError('no mesh of the pool matches {}'.format(urdfs))
+    return self.subset(idx)
+
   def save(self, path):
     np.savez_compressed(path, verts=self.verts, vert_off=self.vert_off, tris=self.tris,
                         tri_off=self.tri_off, mass_com=self.mass_com,

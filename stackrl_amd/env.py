@@ -256,13 +256,84 @@ class VecStackEnv(object):
     return ms, n
 
 
+class StartedVecStackEnv(VecStackEnv):
+  """`StartedStackEnv` (Stack-v1, env.py:348-441): an episode uses `n_objects` rocks, the first `n_objects -
+  episode_length` of which are placed by `start_policy` inside `reset`, so the agent sees only the last
+  `episode_length` placements.  The default start policy is the reference's: the lowest placement whose footprint
+  lies fully inside the goal (env.py:391-417), evaluated by the heuristic kernels (csrc/heuristics.hip).
+  The batch runs in lock step (same episode length everywhere), so the auto-reset call of `step` (env.py:235-236)
+  performs the start placements for all envs at once; `min_episode_length` (per-env random lengths) is not built."""
+
+  def __init__(self, n_parallel=None, episode_length=15, n_objects=30, start_policy=None, min_episode_length=None,
+               **kwargs):
+    if n_objects < episode_length:
+      raise ValueError("n_objects can't be less than episode_length. Got {} objects for {} steps long episodes.".format(
+        n_objects, episode_length))                                            # env.py:375-378
+    if min_episode_length and min_episode_length < episode_length:
+      raise ValueError('min_episode_length (random episode lengths) is not implemented')
+    super(StartedVecStackEnv, self).__init__(n_parallel=n_parallel, episode_length=n_objects, **kwargs)
+    self._n_start_steps = int(n_objects) - int(episode_length)
+    if start_policy is None:
+      from stackrl_amd import baselines
+      # lowest position with the object fully inside the goal: `height` values under the goal-overlap mask
+      start_policy = baselines.Baseline('height', goal=True, minorder=0, threshold=1.0)
+    elif not callable(start_policy):
+      raise TypeError('Invalid type {} for argument start_policy. Must be callable.'.format(type(start_policy)))
+    self._start_policy = start_policy
+    self._since_reset = 0
+
+  @property
+  def n_start_steps(self):
+    return self._n_start_steps
+
+  def _start(self, step):
+    for _ in range(self._n_start_steps):
+      step = super(StartedVecStackEnv, self).step(self._start_policy(step[0]), block=True)
+    self._since_reset = 0
+    return (step[0], torch.zeros_like(step[1]), torch.zeros_like(step[2]))
+
+  def reset(self, block=None):
+    out = self._start(super(StartedVecStackEnv, self).reset(block=True))
+    block = self._block if block is None else block
+    return out if block else (lambda: out)
+
+  def step(self, action, block=None):
+    block = self._block if block is None else block
+    if self._since_reset == self.config.episode_length - self._n_start_steps:
+      # every env is done: this call is the auto-reset (env.py:235-236), followed by the start placements
+      out = self._start(super(StartedVecStackEnv, self).step(action, block=True))
+      return out if block else (lambda: out)
+    self._since_reset += 1
+    return super(StartedVecStackEnv, self).step(action, block=block)
+
+
 def make(env='Stack-v0', n_parallel=None, block=None, seed=None, **kwargs):
-  """`stackrl.envs.make` (utils.py:44-141): 'Stack-v0' (envs/stack/__init__.py:4-8) and 'Stack-v2' (`TestStackEnv`,
-  env.py:443-470, with its default `orientation_freedom=3`; `ordering_freedom` is not built)."""
+  """`stackrl.envs.make` (utils.py:44-141): 'Stack-v0' (envs/stack/__init__.py:4-8), 'Stack-v1' (`StartedStackEnv`,
+  env.py:348-441) and 'Stack-v2' (`TestStackEnv`, env.py:443-470, with its default `orientation_freedom=3`;
+  `ordering_freedom` is not built)."""
+  urdfs = kwargs.pop('urdfs', None)                      # env.py:92-103: which irregularity families the episode draws from
+  if urdfs is not None:
+    from stackrl_amd import assets
+    kwargs['pool'] = (kwargs.get('pool') or assets.default_pool()).select(urdfs)
   if env == 'Stack-v2':
     if kwargs.pop('ordering_freedom', False):
       raise ValueError('ordering_freedom=True (TestSimulator) is not implemented')
     kwargs.setdefault('orientation_freedom', 3)
+  elif env == 'Stack-v1':
+    return StartedVecStackEnv(n_parallel=n_parallel or 1, block=block, seed=seed, **kwargs)
   elif env != 'Stack-v0':
-    raise ValueError("Only 'Stack-v0' and 'Stack-v2' are implemented (Stack-v1 is out of scope, SURVEY.md section 2).")
+    raise ValueError("Invalid env {}: 'Stack-v0', 'Stack-v1' and 'Stack-v2' are implemented.".format(env))
   return VecStackEnv(n_parallel=n_parallel or 1, block=block, seed=seed, **kwargs)
+
+
+def make_curriculum(env='Stack-v0', n_parallel=None, block=None, curriculum=None, **kwargs):
+  """`stackrl.envs.make_curriculum` (utils.py:143-182): a generator of `(env, goal)` tuples.  `curriculum` is a dict of
+  equally long lists of `make` keyword arguments (e.g. `urdfs`) plus an optional list `goals` of goal returns."""
+  curriculum = dict(curriculum or {})
+  goals = curriculum.pop('goals', None)
+  stages = [dict(zip(curriculum.keys(), values)) for values in zip(*curriculum.values())]
+  if goals is not None and len(goals) != len(stages):
+    raise ValueError("length of goals doesn't match number of environments")
+  for i, cargs in enumerate(stages):
+    instance = make(env, n_parallel=n_parallel, block=block, **cargs, **kwargs)
+    yield instance, (None if goals is None else goals[i])

@@ -3,12 +3,15 @@
 it overlaps `agent.train()`, :359-368), `eval` (:398-452), `log_train` (:487-509), `save` (:454-465), `checkpoint`
 (:467-485), with the reference's on-disk formats: `train.csv` (`Iter,Return,Loss,MeanError,CollectTime,TrainTime`),
 `eval.csv` (`Iter,Return,Value,MeanValue,StdValue,MinValue,MaxValue`), `train.log`, `saved_weights/<iter>/weights`,
-`checkpoint/`.  Weights and checkpoints are torch files (the reference writes TF checkpoints; TensorFlow is not part
-of this build).  Curriculum sequencing (:521-575) is not built."""
+`checkpoint/`, `curriculum.csv` (`EndIter,Goal`).  Weights and checkpoints are torch files (the reference writes TF
+checkpoints; TensorFlow is not part of this build).  Curriculum (:120-158, :521-575): `env` may be a generator of
+`(env, goal)` tuples (`envs.make_curriculum`); when the training return passes `goal * (1 - epsilon)` the next
+environment takes over."""
 import os
 import sys
 import time
 import traceback
+import types
 from datetime import datetime
 
 import torch
@@ -19,7 +22,7 @@ from stackrl_amd import metrics
 class Trainer(object):
   def __init__(self, env, agent, eval_env=None, directory=None, log_interval=100, eval_interval=10000,
                checkpoint_interval=10000, eval_seed=None, train_reward_buffer_length=10, eval_reward_buffer_length=10,
-               save_evaluated_policies=False, log_to_file=True, checkpoint_memory=True):
+               save_evaluated_policies=False, log_to_file=True, checkpoint_memory=True, goal_check_interval=1000):
     """
     Args (training.py:40-103):
       env, agent: the vectorised environment and the DQN agent.
@@ -30,7 +33,23 @@ class Trainer(object):
       train_reward_buffer_length, eval_reward_buffer_length: episodes averaged by the `Return` columns (:176-184).
       save_evaluated_policies: save the Q-net weights after every evaluation (:190-197, :386-387).
       checkpoint_memory: include the replay memory in checkpoints (the reference always does).
+      goal_check_interval: with a curriculum, how often (iterations) the training return is checked against the goal.
     """
+    # curriculum (training.py:120-158): generators of (env, goal)
+    self._curriculum = self._eval_curriculum = None
+    self._current_goal = None
+    self._complete = False
+    self._stop_when_complete = False
+    self._goal_check_interval = None
+    if isinstance(env, types.GeneratorType):
+      self._curriculum = env
+      env, self._current_goal = next(self._curriculum)
+      if self._current_goal is None:
+        raise ValueError('generator returned by env argument must yield tuples with env instance and goal')
+      self._goal_check_interval = int(goal_check_interval)
+    if isinstance(eval_env, types.GeneratorType):
+      self._eval_curriculum = eval_env
+      eval_env, _ = next(self._eval_curriculum)
     self._env, self._agent, self._eval_env = env, agent, eval_env
     self._directory = directory
     self._log_interval, self._eval_interval = int(log_interval), int(eval_interval)
@@ -53,6 +72,17 @@ class Trainer(object):
       self._eval_file = os.path.join(directory, 'eval.csv')
       self._log_file = os.path.join(directory, 'train.log') if log_to_file else None
       self._ckpt_file = os.path.join(directory, 'checkpoint', 'ckpt.pt')
+    self._curriculum_file = os.path.join(directory, 'curriculum.csv') if directory is not None else None
+    if self._curriculum is not None and self._curriculum_file is not None and os.path.isfile(self._curriculum_file):
+      # skip the environments already solved in this train directory (training.py:131-153)
+      with open(self._curriculum_file) as f:
+        achieved = [float(line.split(',')[1]) for line in f.read().strip().split('\n')[1:] if line]
+      for gdone in achieved:
+        if gdone != self._current_goal:
+          break
+        if not self._advance():
+          self._complete = True
+          break
     self._last_checkpoint_iter = self._last_save_iter = None
     self._initialized = False
     self._reset_env = False
@@ -115,10 +145,14 @@ class Trainer(object):
     self._initialized = True
 
   # ------------------------------------------------------------------ run (training.py:298-396)
-  def run(self, max_num_iters=sys.maxsize):
-    env, agent = self._env, self._agent
+  def run(self, max_num_iters=sys.maxsize, stop_when_complete=False):
+    """stop_when_complete: with a curriculum, stop (StopIteration is swallowed) once the last goal is achieved; otherwise
+    training continues on the last environment (training.py:305-309)."""
+    self._stop_when_complete = bool(stop_when_complete)
+    agent = self._agent
     if not self._initialized:
       self.initialize()
+    env = self._env
     losses = []
     step = None
     try:
@@ -151,12 +185,17 @@ class Trainer(object):
               self.save()
           if iters % self._checkpoint_interval == 0:
             self.checkpoint()
+        if self._goal_check_interval and iters % self._goal_check_interval == 0:
+          self.check_goal()
         if self._reset_env:
           self._reset_env = False
           if callable(step):
             step()
+          env = self._env                 # the curriculum may have moved on
           step = env.reset()
           agent.acknowledge_reset()
+    except StopIteration:
+      self.log('Training goal achieved.')
     except Exception:
       self.log_exception()
       raise
@@ -195,6 +234,41 @@ class Trainer(object):
         f.write(header + '{},{},{},{},{},{},{}\n'.format(*row))
     self.log('Done.')
     return row
+
+  # ------------------------------------------------------------------ curriculum (training.py:526-575)
+  def _advance(self):
+    """Next (env, goal) of the curriculum; False when it is exhausted."""
+    try:
+      new_env, self._current_goal = next(self._curriculum)
+    except StopIteration:
+      return False
+    assert (tuple(new_env.observation_spec[0].shape), tuple(new_env.observation_spec[1].shape)) == \
+           (tuple(self._env.observation_spec[0].shape), tuple(self._env.observation_spec[1].shape)), \
+      'All envs in curriculum must have same observation and action specs.'
+    old, self._env = self._env, new_env
+    getattr(old, 'close', lambda: None)()
+    if self._eval_curriculum is not None:
+      new_eval, _ = next(self._eval_curriculum)
+      old, self._eval_env = self._eval_env, new_eval
+      getattr(old, 'close', lambda: None)()
+    return True
+
+  def check_goal(self):
+    """training.py:526-546: goal reached when the training return exceeds goal * (1 - epsilon)."""
+    if not self._complete and float(self._reward.result) > self._current_goal * (1 - self._agent.exploration):
+      self.log('Goal reward achieved.')
+      if self._curriculum_file is not None:
+        header = '' if os.path.isfile(self._curriculum_file) else 'EndIter,Goal\n'
+        with open(self._curriculum_file, 'a') as f:
+          f.write(header + '{},{}\n'.format(self.iterations, self._current_goal))
+      self.log('Updating environment...')
+      if self._advance():
+        self._reset_env = True            # triggers an environment reset in the training loop (:573-574)
+        self.log('Done.')
+      else:
+        self._complete = True
+    if self._complete and self._stop_when_complete:
+      raise StopIteration('Training goal achieved.')
 
   # ------------------------------------------------------------------ logs, weights, checkpoints
   def log_train(self):

@@ -309,6 +309,9 @@ class _ToyEnv(object):
 
   def __init__(self, B, L, spec, seed=0):
     self.batch_size, self.L, self.spec = B, L, spec
+    import collections
+    TS = collections.namedtuple('TS', 'shape dtype')
+    self.observation_spec = tuple(TS(tuple(s), torch.uint8) for s in spec)
     self.n_actions = (spec[0][0] - spec[1][0] + 1) ** 2
     self.seed(seed)
 
@@ -418,3 +421,37 @@ def test_training_loop_writes_the_reference_file_formats_and_resumes(tmp_path):
   # and continues: the next update draws the same minibatch and lands on the same weights in both
   la, _ = agent.train(); lb, _ = agent2.train()
   assert float(la) == float(lb)
+
+
+def test_curriculum_moves_on_when_the_goal_return_is_reached(tmp_path):
+  """training.py:120-158, :526-575 with toy envs: goal reached -> curriculum.csv row, next env, reset; after the last
+  goal `stop_when_complete` ends the run; a new Trainer on the same directory skips the solved stages."""
+  from stackrl_amd.training import Trainer
+  spec = ((16, 16, 2), (4, 4, 1))
+  B, L = 3, 4
+  d = str(tmp_path / 'cur')
+  made = []
+
+  def stages(goals):
+    for i, g in enumerate(goals):
+      e = _ToyEnv(B, L, spec, seed=10 + i)
+      made.append(e)
+      yield e, g
+
+  agent = _toy_agent(spec, B, seed=3)
+  # toy rewards are U(0,1) per step -> episode returns around 2: goals 0.5 and 1.0 are reached at the first checks
+  tr = Trainer(stages([0.5, 1.0]), agent, directory=d, log_interval=50, eval_interval=10 ** 9, checkpoint_interval=10 ** 9,
+               train_reward_buffer_length=2, goal_check_interval=6)
+  tr.initialize(num_steps=6)
+  tr.run(40, stop_when_complete=True)
+  rows = open(os.path.join(d, 'curriculum.csv')).read().strip().split('\n')
+  assert rows[0] == 'EndIter,Goal' and [float(r.split(',')[1]) for r in rows[1:]] == [0.5, 1.0]   # training.py:531-536
+  assert [int(r.split(',')[0]) for r in rows[1:]] == [6, 12] and agent.iterations == 12              # stopped when complete
+  assert len(made) == 2 and tr._env is made[1] and tr._complete
+  # resume: both goals are on file -> the curriculum is exhausted at construction
+  made.clear()
+  tr2 = Trainer(stages([0.5, 1.0]), _toy_agent(spec, B, seed=3), directory=d, goal_check_interval=6)
+  assert tr2._complete and tr2._env is made[1]
+  # a generator without goals is rejected (training.py:124-125)
+  with pytest.raises(ValueError):
+    Trainer(((e, None) for e in [_ToyEnv(B, L, spec)]), _toy_agent(spec, B, seed=3))

@@ -150,3 +150,43 @@ def test_baseline_policy_drives_stack_v2(ref_pool):
   assert bool(d.all()) and bool(torch.isfinite(total).all())
   # lowest placement height over all orientations is never worse than over the first orientation alone
   g.close()
+
+
+@pytest.mark.gpu
+def test_stack_v1_starts_episodes_with_placed_rocks_and_curriculum_selects_families(ref_pool):
+  """Stack-v1 (`StartedStackEnv`, env.py:348-441): reset returns after `n_objects - episode_length` start placements
+  by the lowest-inside-goal policy; the agent then gets exactly `episode_length` steps; the auto-reset call does the
+  start placements again.  `make_curriculum` (utils.py:143-182) yields one env per irregularity family."""
+  import torch
+  from stackrl_amd import assets, env as envs
+  n = 5
+  g = envs.make('Stack-v1', n_parallel=n, seed=2, pool=ref_pool, block=True, episode_length=3, n_objects=5)
+  assert g.n_start_steps == 2 and g.config.episode_length == 5
+  (m, o), r, d = g.reset()
+  assert list(g.state()[1]) == [2] * n and not bool(d.any()) and float(r.abs().sum()) == 0.0
+  assert int((m[..., 0] > 0).sum()) > 0                          # the start rocks are in the first observation
+  Hm, _, goal = g.maps()
+  poses = g.state()[0]
+  for i in range(n):                                             # start rocks lie inside the goal rectangle
+    u0, v0, gh, gw = goal[i]
+    for b in range(2):
+      x, y = poses[i, b, 0] / g.config.pixel_size, poses[i, b, 1] / g.config.pixel_size
+      assert u0 - 2 <= x <= u0 + gh + 2 and v0 - 2 <= y <= v0 + gw + 2
+  for t in range(3):
+    (m, o), r, d = g.step(g.sample())
+    assert bool(d.all()) == (t == 2)
+  (m, o), r, d = g.step(g.sample())                              # auto-reset + start placements
+  assert list(g.state()[1]) == [2] * n and not bool(d.any()) and float(r.abs().sum()) == 0.0
+  (m, o), r, d = g.step(g.sample())
+  assert list(g.state()[1]) == [3] * n
+  g.close()
+  # curriculum over irregularity families of the synthetic pool
+  pool = assets.default_pool()
+  cur = envs.make_curriculum('Stack-v0', n_parallel=2, block=True, episode_length=2, pool=pool,
+                             curriculum={'urdfs': ['5?', '9?'], 'goals': [0.1, 0.2]})
+  stages = list(cur)
+  assert [gl for _, gl in stages] == [0.1, 0.2]
+  assert all(nm.startswith('5') for nm in stages[0][0].pool.names) and all(nm.startswith('9') for nm in stages[1][0].pool.names)
+  assert len(stages[0][0].pool) == 1000
+  for e, _ in stages:
+    e.reset(); e.step(e.sample()); e.close()
