@@ -35,6 +35,18 @@ __device__ __forceinline__ float elev_object(const DevParams& P, float d) {
   return P.obj_c1 - P.obj_c2 / (SRL_FAR + P.c.object_max_dimension * (0.5f - d));
 }
 
+// the overhead depth codec tabulated over the lattice of t = fl(FAR - z) (see DevParams::codec_h)
+extern "C" __global__ void __launch_bounds__(256) srl_k_codec_table(DevParams P, float* __restrict__ th, uint8_t* __restrict__ tb, int n) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const float nearp = SRL_FAR - P.c.max_z;
+  const float den = fmaxf(P.c.max_z, P.c.object_max_dimension);
+  const float t = nearp + (float)k * (1.0f / 16384.0f);   // exact: a lattice point of [512, 1024)
+  const float hh = elev_overhead(P, depth_encode(t, nearp, SRL_FAR));
+  th[k] = hh;
+  tb[k] = (uint8_t)((hh * 255.0f) / den);
+}
+
 // world-frame render plane of one face: z = a x + b y + c; w = 0 up-facing (z_hi = min), 1 down-facing
 // (z_lo = max).  |n_z| is clamped to >= 1e-6: a vertical face becomes a plane of enormous slope that never
 // limits z on its inner side and empties the interval on its outer side.
@@ -470,9 +482,6 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   //      once over the list, one pixel per lane, and hands the results back.
   float spi = 0.0f, spu = 0.0f;
   {
-    volatile float* czf = L.cz + wave * 192;
-    volatile uint32_t* czu = (volatile uint32_t*)czf;
-    const unsigned long long below = (1ull << lane) - 1ull;
     int i = walk_i0, jb = walk_j0;
     for (int k = 0; k < nrounds; ++k) {
       const int g = tid + k * SRL_RENDER_THREADS;
@@ -482,33 +491,20 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       if (covg) z4 = ((const float4*)L.tile)[g];
       float hv[4] = {h_empty, h_empty, h_empty, h_empty};
       uint32_t hb[4] = {b_empty, b_empty, b_empty, b_empty};
-      const bool rock = (z4.x > 0.0f) || (z4.y > 0.0f) || (z4.z > 0.0f) || (z4.w > 0.0f);
-      if (__ballot(rock) != 0ull) {   // wave-uniform: some lane of this round saw a rock
-        const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-        unsigned long long mk[4];
-        int cnt[4];
+      const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+      if (P.codec_n > 0) {
+        // pixels that saw a rock: the codec by table (bit-identical to the arithmetic, DevParams::codec_h)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { mk[t] = __ballot(zz[t] > 0.0f); cnt[t] = __popcll(mk[t]); }
-        const int total = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-        if (total <= 64) {
-          int slot[4], off = 0;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            slot[t] = off + __popcll(mk[t] & below); off += cnt[t];
-            if (zz[t] > 0.0f) czf[slot[t]] = zz[t];
+        for (int t = 0; t < 4; ++t)
+          if (zz[t] > 0.0f) {
+            float tt = SRL_FAR - zz[t];
+            if (tt < nearp) tt = nearp;
+            const int kk = (int)((tt - nearp) * 16384.0f);
+            hv[t] = P.codec_h[kk]; hb[t] = P.codec_b[kk];
           }
-          __builtin_amdgcn_wave_barrier();
-          if (lane < total) {
-            const float hh = elev_overhead(P, depth_encode(SRL_FAR - czf[lane], nearp, SRL_FAR));
-            czf[64 + lane] = hh;
-            czu[128 + lane] = (uint8_t)((hh * 255.0f) / den);
-          }
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (zz[t] > 0.0f) { hv[t] = czf[64 + slot[t]]; hb[t] = czu[128 + slot[t]]; }
-          __builtin_amdgcn_wave_barrier();
-        } else {
+      } else {
+        const bool rock = (z4.x > 0.0f) || (z4.y > 0.0f) || (z4.z > 0.0f) || (z4.w > 0.0f);
+        if (rock) {
 #pragma unroll
           for (int t = 0; t < 4; ++t)
             if (zz[t] > 0.0f) {
