@@ -309,7 +309,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   RSTAMP(0);
   // ---- groups of rocks whose planes fit the staging area
   int bs = 0, be = L.misc[0];   // (be >= 1 when nb >= 1: a mesh has at most SRL_MAX_TRIS <= SRL_PLANE_CAP faces)
-  uint32_t cov = 0u;
+  uint32_t cov = 0u, goalm = 0u;
   bool first = true;
   do {
     // (a) one wave per rock (rocks wave, wave + 8, ...).  First trip: xy bounds of every rock (vertices over
@@ -381,6 +381,8 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       for (int k = 0; k < nrounds; ++k) {
         const int g = tid + k * SRL_RENDER_THREADS;
         if (g >= ngroups4) break;
+        // groups that touch the goal rectangle: their empty pixels still add the goal height to the union sum
+        if (i >= g0 && i < g0 + g2 && jb + 3 >= g1 && jb < g1 + g3) goalm |= 1u << k;
         if ((L.rowmask[i >> 5] >> (i & 31)) & 1u) cov |= 1u << k;
         else {
           ((float4*)Hout)[g] = he4;
@@ -482,9 +484,19 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   //      once over the list, one pixel per lane, and hands the results back.
   float spi = 0.0f, spu = 0.0f;
   {
+    // An empty pixel outside the goal adds max(h_empty, 0) to the union sum and nothing else; when that is +0 (it is
+    // whenever FAR (FAR - max_z) is a float32, e.g. the default geometry) the addition is the identity, bit for bit
+    // (the partial sums never hold -0), so rounds whose group lies in a row no rock reaches and outside the goal
+    // rectangle are skipped altogether.  todo bit k: round k must be visited.
+    const uint32_t todo = fmaxf(h_empty, 0.0f) == 0.0f ? (cov | goalm) : 0xffffffffu;
     int i = walk_i0, jb = walk_j0;
     for (int k = 0; k < nrounds; ++k) {
       const int g = tid + k * SRL_RENDER_THREADS;
+      if (!((todo >> k) & 1u)) {
+        jb += walk_dj; i += walk_di;
+        if (jb >= res) { jb -= res; ++i; }
+        continue;
+      }
       const bool valid = g < ngroups4;
       const bool covg = valid && ((cov >> k) & 1u);
       float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
