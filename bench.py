@@ -74,7 +74,7 @@ def aggregate(dt, placed, world, device):
   import torch.distributed as dist
   t = torch.tensor([dt], dtype=torch.float64, device=device)
   tot = torch.tensor([float(placed)], dtype=torch.float64, device=device)
-  if world > 1:
+  if world > 1 or (dist.is_available() and dist.is_initialized()):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
   return float(t.item()), float(tot.item())
@@ -111,9 +111,11 @@ def main():
   import torch
   import torch.distributed as dist
   torch.cuda.set_device(local_rank)
-  if world > 1:
+  use_dist = world > 1 or os.environ.get('SRL_BENCH_FORCE_DIST') == '1'   # the latter: rehearse the RCCL calls on one GPU
+  if use_dist:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    os.environ.setdefault('MASTER_PORT', '29511')
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
   from stackrl_amd import env as envs
   env = envs.VecStackEnv(n_parallel=B, seed=args.seed, pool=pool, block=False, episode_length=L,
@@ -121,7 +123,7 @@ def main():
 
   def barrier():
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
       dist.barrier()
     torch.cuda.synchronize()
 
@@ -225,7 +227,7 @@ def main():
     }
     print(json.dumps(line))
   env.close()
-  if world > 1:
+  if use_dist:
     dist.destroy_process_group()
 
 
