@@ -55,10 +55,10 @@ int srl_bias_act_pool(const void* in_dev, void* skip_dev, void* pooled_dev, cons
 const char* srl_epilogue_last_error(void);
 
 /* 3 x 3 convolution (stride 1, SAME) + bias + ReLU on the matrix cores for the thin, wide layers of `layers.unet`
- * (csrc/conv_mfma.hip; inference).  in bfloat16 channels-last [B][H][W][cin], H and W multiples of 16, cin and cout in
+ * (csrc/conv_mfma.hip; inference).  in bfloat16 channels-last [B][H][W][cin], H and W multiples of 16, cin in {16, 32, 64}, cout in
  * {16, 32}; wfrag = the weights packed in MFMA A-fragment order (srl_conv3x3_wfrag_elems(cin, cout) bfloat16 elements:
  * [k-step][cout / 16][lane][8], element = w[16 mt + lane % 16][ci][tap / 3][tap % 3] with, for cin = 16,
- * tap = 2 ks + k / 16, ci = k % 16 (tap 9 = zero) and for cin = 32, tap = ks, ci = k, where k = 8 (lane / 16) + j).
+ * tap = 2 ks + k / 16, ci = k % 16 (tap 9 = zero) and for cin = 32 m, tap = ks / m, ci = 32 (ks % m) + k, where k = 8 (lane / 16) + j).
  * out: channel slice [out_offset, out_offset + cout) of a channels-last buffer with out_stride channels per pixel, or
  * (nchw = 1) a [B][cout][H][W] tensor; pooled (may be NULL): the 2 x 2 max-pooled result [B][H/2][W/2][cout]. */
 int32_t srl_conv3x3_wfrag_elems(int32_t cin, int32_t cout);

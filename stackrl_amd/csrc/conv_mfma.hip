@@ -47,24 +47,31 @@ __device__ __forceinline__ void k_of(int ks, int g, int& tap, int& ci0) {
 
 // PROJ: instead of storing the activation, project it onto one output channel in fp32 (the 1 x 1 convolution that ends
 // `pos_layers`, layers.py:439-472): proj_out[b][y][x] = sum_c pw[c] relu(conv[c] + bias[c]) + pb for y < Hv, x < Wv.
-template <int CIN, int COUT, bool PROJ>
-__global__ void __launch_bounds__(256)
+// MT_W: output-channel tiles (of 16) one wave computes.  The four waves split the 16 x 16 pixel tile as
+// (COUT / 16 / MT_W) channel blocks x the remaining factor of row blocks: MT_W = COUT / 16 gives 4 rows x all channels
+// per wave (each B fragment feeds MT_W MFMAs); MT_W = 1 with COUT = 32 gives 8 rows x 16 channels per wave, which
+// keeps the register-resident weights of a 64-channel input at 72 VGPRs.
+template <int CIN, int COUT, int MT_W, bool PROJ>
+__global__ void __launch_bounds__(256, 2)
 k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, const float* __restrict__ bias,
           uint16_t* __restrict__ out, uint16_t* __restrict__ pooled, int H, int W, int ostride, int ooff, int nchw,
           const float* __restrict__ pw, float pb, float* __restrict__ proj_out, int Hv, int Wv) {
   typedef ConvCfg<CIN> G;
   constexpr int MT = COUT / 16;
+  constexpr int WM = MT / MT_W;        // waves along the output channels
+  constexpr int RW = 16 / (4 / WM);    // rows of the tile per wave
   extern __shared__ uint16_t tile[];   // [18][18][PS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = W / 16;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
   const int x0 = 16 * tx, y0 = 16 * ty;
   // weights -> registers (A fragments: lane l holds row l & 15 = output channel, k = 8 (l >> 4) .. + 7)
-  bf16x8 wf[G::KS][MT];
+  const int mt0 = (wave % WM) * MT_W, row0 = (wave / WM) * RW;
+  bf16x8 wf[G::KS][MT_W];
 #pragma unroll
   for (int ks = 0; ks < G::KS; ++ks)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) wf[ks][mt] = ((const bf16x8*)wfrag)[(ks * MT + mt) * 64 + lane];
+    for (int mt = 0; mt < MT_W; ++mt) wf[ks][mt] = ((const bf16x8*)wfrag)[(ks * MT + mt0 + mt) * 64 + lane];
   // input tile + halo -> LDS, 16-byte chunks (8 channels); outside the image: zeros (SAME padding)
   {
     constexpr int CPP = CIN / 8;   // chunks per pixel
@@ -79,11 +86,11 @@ k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, c
     }
   }
   __syncthreads();
-  f32x4 acc[4][MT];
+  f32x4 acc[RW][MT_W];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < RW; ++r)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[r][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int mt = 0; mt < MT_W; ++mt) acc[r][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   const int n = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int ks = 0; ks < G::KS; ++ks) {
@@ -92,44 +99,47 @@ k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, c
     if (tap > 8) tap = 8;   // the padded tenth tap: its weights are zero, any valid address will do
     const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bf16x8 xf = *(const bf16x8*)(tile + ((4 * wave + r + dy) * G::TW + n + dx) * G::PS + ci0);
+    for (int r = 0; r < RW; ++r) {
+      const bf16x8 xf = *(const bf16x8*)(tile + ((row0 + r + dy) * G::TW + n + dx) * G::PS + ci0);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][mt], xf, acc[r][mt], 0, 0, 0);
+      for (int mt = 0; mt < MT_W; ++mt) acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][mt], xf, acc[r][mt], 0, 0, 0);
     }
   }
   // epilogue.  D: lane holds column lane & 15 = pixel n, rows 4 g .. 4 g + 3 = output channels of tile mt
   if (PROJ) {
-    float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    static_assert(!PROJ || MT_W == MT, "the projection epilogue needs all channels in one wave");
+    float part[RW];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int r = 0; r < RW; ++r) part[r] = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < MT_W; ++mt) {
       const int co = 16 * mt + 4 * g;
       const float4 bz = *(const float4*)(bias + co), wz = *(const float4*)(pw + co);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < RW; ++r)
         part[r] += (wz.x * fmaxf(acc[r][mt][0] + bz.x, 0.0f) + wz.y * fmaxf(acc[r][mt][1] + bz.y, 0.0f)) +
                    (wz.z * fmaxf(acc[r][mt][2] + bz.z, 0.0f) + wz.w * fmaxf(acc[r][mt][3] + bz.w, 0.0f));
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {   // the four lane groups hold the four channel quarters of one pixel
+    for (int r = 0; r < RW; ++r) {   // the four lane groups hold the four channel quarters of one pixel
       part[r] += __shfl_xor(part[r], 16);
       part[r] += __shfl_xor(part[r], 32);
-      const int y = y0 + 4 * wave + r, x = x0 + n;
+      const int y = y0 + row0 + r, x = x0 + n;
       if (g == 0 && y < Hv && x < Wv) proj_out[((size_t)b * Hv + y) * Wv + x] = part[r] + pb;
     }
     return;
   }
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int co = 16 * mt + 4 * g;
+  for (int mt = 0; mt < MT_W; ++mt) {
+    const int co = 16 * (mt0 + mt) + 4 * g;
     const float4 bz = *(const float4*)(bias + co);
-    uint32_t lo[4], hi[4];   // packed bf16 pairs per row
+    uint32_t lo[RW], hi[RW];   // packed bf16 pairs per row
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RW; ++r) {
       const float v0 = fmaxf(acc[r][mt][0] + bz.x, 0.0f), v1 = fmaxf(acc[r][mt][1] + bz.y, 0.0f);
       const float v2 = fmaxf(acc[r][mt][2] + bz.z, 0.0f), v3 = fmaxf(acc[r][mt][3] + bz.w, 0.0f);
       lo[r] = c_bf16_rne(v0) | (c_bf16_rne(v1) << 16); hi[r] = c_bf16_rne(v2) | (c_bf16_rne(v3) << 16);
-      const int y = y0 + 4 * wave + r, x = x0 + n;
+      const int y = y0 + row0 + r, x = x0 + n;
       if (nchw) {
         uint16_t* o = out + ((size_t)b * COUT + co) * H * W + (size_t)y * W + x;
         o[0] = (uint16_t)(lo[r] & 0xffffu); o[(size_t)H * W] = (uint16_t)(lo[r] >> 16);
@@ -140,7 +150,7 @@ k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, c
     }
     if (pooled) {   // 2 x 2 max of the rounded values (bf16 bit patterns of non-negative numbers order like integers)
 #pragma unroll
-      for (int rp = 0; rp < 2; ++rp) {
+      for (int rp = 0; rp < RW / 2; ++rp) {
         uint32_t m[2] = {lo[2 * rp], hi[2 * rp]};
         const uint32_t o[2] = {lo[2 * rp + 1], hi[2 * rp + 1]};
 #pragma unroll
@@ -155,7 +165,7 @@ k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, c
           m[q] = a0 | (a1 << 16);
         }
         if (!(n & 1)) {
-          const int y2 = (y0 + 4 * wave) / 2 + rp, x2 = (x0 + n) / 2;
+          const int y2 = (y0 + row0) / 2 + rp, x2 = (x0 + n) / 2;
           *(uint2*)(pooled + (((size_t)b * (H / 2) + y2) * (W / 2) + x2) * COUT + co) = make_uint2(m[0], m[1]);
         }
       }
@@ -210,7 +220,8 @@ template <int CIN, int COUT>
 int launch(const void* in, const void* wfrag, const float* bias, void* out, void* pooled, int B, int H, int W, int ostride,
            int ooff, int nchw, hipStream_t st) {
   const size_t lds = sizeof(uint16_t) * ConvCfg<CIN>::TW * ConvCfg<CIN>::TW * ConvCfg<CIN>::PS;
-  hipLaunchKernelGGL((k_conv3x3<CIN, COUT, false>), dim3((W / 16) * (H / 16), B), dim3(256), lds, st, (const uint16_t*)in,
+  constexpr int MT_W = CIN >= 64 ? 1 : COUT / 16;
+  hipLaunchKernelGGL((k_conv3x3<CIN, COUT, MT_W, false>), dim3((W / 16) * (H / 16), B), dim3(256), lds, st, (const uint16_t*)in,
                      (const uint16_t*)wfrag, bias, (uint16_t*)out, (uint16_t*)pooled, H, W, ostride, ooff, nchw,
                      (const float*)nullptr, 0.0f, (float*)nullptr, 0, 0);
   hipError_t e = hipGetLastError();
@@ -225,8 +236,8 @@ extern "C" {
 const char* srl_conv_last_error(void) { return c_err; }
 
 int32_t srl_conv3x3_wfrag_elems(int32_t cin, int32_t cout) {
-  if ((cin != 16 && cin != 32) || (cout != 16 && cout != 32)) return -1;
-  return (cin == 16 ? 5 : 9) * (cout / 16) * 64 * 8;
+  if ((cin != 16 && cin != 32 && cin != 64) || (cout != 16 && cout != 32)) return -1;
+  return (cin == 16 ? 5 : 9 * (cin / 32)) * (cout / 16) * 64 * 8;
 }
 
 int srl_conv3x3_bias_relu(const void* in, const void* wfrag, const float* bias, void* out, void* pooled, int32_t B,
@@ -234,14 +245,16 @@ int srl_conv3x3_bias_relu(const void* in, const void* wfrag, const float* bias, 
                           int32_t nchw, void* stream) {
   if (!in || !wfrag || !bias || !out || B < 1 || H < 16 || W < 16 || H % 16 || W % 16 || out_stride % 4 || out_offset % 4 ||
       srl_conv3x3_wfrag_elems(cin, cout) < 0 || (pooled && nchw)) {
-    snprintf(c_err, sizeof c_err, "srl_conv3x3_bias_relu: bad arguments (H, W multiples of 16; cin, cout in {16, 32})");
+    snprintf(c_err, sizeof c_err, "srl_conv3x3_bias_relu: bad arguments (H, W multiples of 16; cin in {16, 32, 64}, cout in {16, 32})");
     return 1;
   }
   hipStream_t st = (hipStream_t)stream;
   if (cin == 16 && cout == 16) return launch<16, 16>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
   if (cin == 16 && cout == 32) return launch<16, 32>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
   if (cin == 32 && cout == 16) return launch<32, 16>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
-  return launch<32, 32>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+  if (cin == 32 && cout == 32) return launch<32, 32>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+  if (cin == 64 && cout == 16) return launch<64, 16>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+  return launch<64, 32>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
 }
 
 int srl_conv3x3_thin(const void* in, int32_t in_dtype, const float* w, const float* bias, void* out, int32_t B, int32_t H,
@@ -271,7 +284,7 @@ int srl_conv3x3_relu_project(const void* in, const void* wfrag, const float* bia
     return 1;
   }
   const size_t lds = sizeof(uint16_t) * ConvCfg<16>::TW * ConvCfg<16>::TW * ConvCfg<16>::PS;
-  hipLaunchKernelGGL((k_conv3x3<16, 16, true>), dim3((W / 16) * (H / 16), B), dim3(256), lds, (hipStream_t)stream,
+  hipLaunchKernelGGL((k_conv3x3<16, 16, 1, true>), dim3((W / 16) * (H / 16), B), dim3(256), lds, (hipStream_t)stream,
                      (const uint16_t*)in, (const uint16_t*)wfrag, bias, (uint16_t*)nullptr, (uint16_t*)nullptr, H, W, 16, 0, 0,
                      proj_w, proj_b, out, Hv, Wv);
   hipError_t e = hipGetLastError();

@@ -215,7 +215,7 @@ def pack_conv3x3_weights(w):
   if n < 0:
     raise ValueError('conv3x3 MFMA kernel: unsupported channels %d -> %d' % (cin, cout))
   dev = w.device
-  ks = torch.arange(5 if cin == 16 else 9, device=dev)[:, None, None, None]
+  ks = torch.arange(5 if cin == 16 else 9 * (cin // 32), device=dev)[:, None, None, None]
   mt = torch.arange(cout // 16, device=dev)[None, :, None, None]
   lane = torch.arange(64, device=dev)[None, None, :, None]
   j = torch.arange(8, device=dev)[None, None, None, :]
@@ -223,7 +223,8 @@ def pack_conv3x3_weights(w):
   if cin == 16:
     tap, ci = 2 * ks + (k >> 4), k & 15
   else:
-    tap, ci = ks + 0 * k, k
+    m = cin // 32
+    tap, ci = ks // m + 0 * k, 32 * (ks % m) + k
   co = 16 * mt + (lane & 15)
   tapc = tap.clamp(max=8)
   vals = w.detach().float()[co, ci, tapc // 3, tapc % 3] * (tap < 9)
@@ -307,7 +308,7 @@ class FastFeatures(object):
       if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
         self._w[m] = (m.weight.detach().to(torch.bfloat16).contiguous(memory_format=_CL), m.bias.detach().float().contiguous())
         if self.mfma_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
-           m.in_channels in (16, 32) and m.out_channels in (16, 32):
+           m.in_channels in (16, 32, 64) and m.out_channels in (16, 32):
           self._wf[m] = pack_conv3x3_weights(m.weight)
         if self.mfma_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.in_channels in (1, 2) and m.out_channels == 16:

@@ -68,7 +68,7 @@ def test_xcorr_mfma_autograd_matches_torch_fp64(B, C, H, h, precision, tol):
     assert err <= tol * scale, (err, scale)
 
 
-@pytest.mark.parametrize('cin,cout,H', [(16, 16, 32), (16, 32, 16), (32, 16, 48), (32, 32, 16)])
+@pytest.mark.parametrize('cin,cout,H', [(16, 16, 32), (16, 32, 16), (32, 16, 48), (32, 32, 16), (64, 32, 32), (64, 16, 16)])
 def test_conv3x3_mfma_matches_torch(cin, cout, H):
   """csrc/conv_mfma.hip against F.conv2d on the same bf16-rounded operands in fp32 (bf16 products are exact in fp32;
   only the accumulation order and the final bf16 rounding differ: half a bf16 ulp = 2^-9 relative), for the plain,
