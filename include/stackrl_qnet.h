@@ -76,6 +76,16 @@ int srl_conv3x3_thin(const void* in_dev, int32_t in_dtype, const float* w_dev, c
 int srl_conv3x3_relu_project(const void* in_dev, const void* wfrag_dev, const float* bias_dev, const float* proj_w_dev,
                              float proj_b, float* out_dev, int32_t B, int32_t H, int32_t W, int32_t Hv, int32_t Wv,
                              void* stream);
+/* Transposed convolution 2 x 2, stride 2 + bias + ReLU on the matrix cores (`up{i}` of layers.unet, layers.py:222-229),
+ * (cin, cout) in {(32, 16), (64, 32)}: in bfloat16 [B][H][W][cin] (W a multiple of 16) -> the channel slice
+ * [out_offset, out_offset + cout) of a channels-last buffer [B][2H][2W][out_stride].  wfrag: the ConvTranspose2d weight
+ * w[ci][co][dy][dx] in A-fragment order, srl_convt2x2_wfrag_elems(cin, cout) bfloat16 elements:
+ * [k-step][m-tile][lane][8], element = w[32 ks + 8 (lane / 16) + j][co][dy][dx] for GEMM row 16 mt + lane % 16 =
+ * (2 dy + dx) cout + co. */
+int32_t srl_convt2x2_wfrag_elems(int32_t cin, int32_t cout);
+int srl_convt2x2_bias_relu(const void* in_dev, const void* wfrag_dev, const float* bias_dev, void* out_dev, int32_t B,
+                           int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset,
+                           void* stream);
 const char* srl_conv_last_error(void);
 
 /* adv float32 [B][A]; u float32 [B] uniform(0,1); rnd int64 [B] uniform {0..A-1}; actions int64 [B] */

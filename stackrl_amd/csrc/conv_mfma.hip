@@ -214,6 +214,50 @@ k_conv3x3_thin(const TIN* __restrict__ in, const float* __restrict__ w, const fl
   o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]); o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
 }
 
+// Transposed convolution 2 x 2, stride 2 (`up{i}` of layers.unet, layers.py:222-229) + bias + ReLU: every input pixel
+// produces a 2 x 2 block of output pixels, out[2y+dy][2x+dx][co] = sum_ci in[y][x][ci] w[ci][co][dy][dx] — a plain
+// GEMM per pixel with M = 4 COUT rows (dy, dx, co), no halo, so the B fragments (8 channels of one input pixel,
+// 16 bytes) come straight from global memory.  Wave = 16 consecutive input pixels of a row x all M tiles; weights
+// packed in A-fragment order and register-resident; output written into a channel slice of the channels-last
+// concat buffer (8 bytes per lane: 4 consecutive channels of one output pixel).
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256, 2)
+k_convt2x2(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, const float* __restrict__ bias,
+           uint16_t* __restrict__ out, int H, int W, int ostride, int ooff, long long ntiles) {
+  constexpr int MT = 4 * COUT / 16, KS = CIN / 32;
+  const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+  bf16x8 wf[KS][MT];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wf[ks][mt] = ((const bf16x8*)wfrag)[(ks * MT + mt) * 64 + lane];
+  const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // 16 consecutive input pixels (W % 16 == 0)
+  if (tile >= ntiles) return;
+  const long long pix0 = tile * 16;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const bf16x8 xf = *(const bf16x8*)(in + (pix0 + n) * CIN + 32 * ks + 8 * g);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][mt], xf, acc[mt], 0, 0, 0);
+  }
+  const long long p = pix0 + n;
+  const int x = (int)(p % W);
+  const long long by = p / W;          // b * H + y
+  const long long b = by / H; const int y = (int)(by - b * H);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = 16 * mt + 4 * g;     // row of the GEMM = (dy, dx, co)
+    const int q = m / COUT, co = m - q * COUT, dy = q >> 1, dx = q & 1;
+    const float4 bz = *(const float4*)(bias + co);
+    const uint32_t lo = c_bf16_rne(fmaxf(acc[mt][0] + bz.x, 0.0f)) | (c_bf16_rne(fmaxf(acc[mt][1] + bz.y, 0.0f)) << 16);
+    const uint32_t hi = c_bf16_rne(fmaxf(acc[mt][2] + bz.z, 0.0f)) | (c_bf16_rne(fmaxf(acc[mt][3] + bz.w, 0.0f)) << 16);
+    *(uint2*)(out + (((b * 2 * H + 2 * y + dy) * 2 * W) + 2 * x + dx) * ostride + ooff + co) = make_uint2(lo, hi);
+  }
+}
+
 thread_local char c_err[256] = "";
 
 template <int CIN, int COUT>
@@ -273,6 +317,28 @@ int srl_conv3x3_thin(const void* in, int32_t in_dtype, const float* w, const flo
   else hipLaunchKernelGGL((k_conv3x3_thin<2, float>), grid, blk, 0, st, (const float*)in, w, bias, o, H, W, Hp, Wp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "srl_conv3x3_thin: %s", hipGetErrorString(e)); return 2; }
+  return 0;
+}
+
+int32_t srl_convt2x2_wfrag_elems(int32_t cin, int32_t cout) {
+  if (!((cin == 32 && cout == 16) || (cin == 64 && cout == 32))) return -1;
+  return (cin / 32) * (4 * cout / 16) * 64 * 8;
+}
+
+int srl_convt2x2_bias_relu(const void* in, const void* wfrag, const float* bias, void* out, int32_t B, int32_t H, int32_t W,
+                           int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset, void* stream) {
+  if (!in || !wfrag || !bias || !out || B < 1 || H < 1 || W < 16 || W % 16 || out_stride % 4 || out_offset % 4 ||
+      srl_convt2x2_wfrag_elems(cin, cout) < 0) {
+    snprintf(c_err, sizeof c_err, "srl_convt2x2_bias_relu: bad arguments (W a multiple of 16; 32 -> 16 or 64 -> 32 channels)");
+    return 1;
+  }
+  const long long ntiles = (long long)B * H * W / 16;
+  const dim3 grid((unsigned)((ntiles + 3) / 4)), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (cin == 32) hipLaunchKernelGGL((k_convt2x2<32, 16>), grid, blk, 0, st, (const uint16_t*)in, (const uint16_t*)wfrag, bias, (uint16_t*)out, H, W, out_stride, out_offset, ntiles);
+  else hipLaunchKernelGGL((k_convt2x2<64, 32>), grid, blk, 0, st, (const uint16_t*)in, (const uint16_t*)wfrag, bias, (uint16_t*)out, H, W, out_stride, out_offset, ntiles);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "srl_convt2x2_bias_relu: %s", hipGetErrorString(e)); return 2; }
   return 0;
 }
 

@@ -35,6 +35,10 @@ def load():
     L.srl_conv3x3_bias_relu.restype = ctypes.c_int
     L.srl_conv3x3_bias_relu.argtypes = [VP] * 5 + [ctypes.c_int32] * 8 + [VP]
     L.srl_conv_last_error.restype = ctypes.c_char_p
+    L.srl_convt2x2_wfrag_elems.restype = ctypes.c_int32
+    L.srl_convt2x2_wfrag_elems.argtypes = [ctypes.c_int32] * 2
+    L.srl_convt2x2_bias_relu.restype = ctypes.c_int
+    L.srl_convt2x2_bias_relu.argtypes = [VP] * 4 + [ctypes.c_int32] * 7 + [VP]
     L.srl_conv3x3_thin.restype = ctypes.c_int
     L.srl_conv3x3_thin.argtypes = [VP, ctypes.c_int32, VP, VP, VP] + [ctypes.c_int32] * 6 + [VP]
     L.srl_conv3x3_relu_project.restype = ctypes.c_int
@@ -254,6 +258,37 @@ def conv3x3_bias_relu(x, wfrag, bias, cout, out=None, out_offset=0, pool=False, 
   return (dst, pooled) if pool else dst
 
 
+def pack_convt2x2_weights(w):
+  """ConvTranspose2d weight [cin, cout, 2, 2] -> bf16 A-fragment order of k_convt2x2 (include/stackrl_qnet.h)."""
+  cin, cout = int(w.shape[0]), int(w.shape[1])
+  n = load().srl_convt2x2_wfrag_elems(cin, cout)
+  if n < 0:
+    raise ValueError('convT 2x2 MFMA kernel: unsupported channels %d -> %d' % (cin, cout))
+  dev = w.device
+  ks = torch.arange(cin // 32, device=dev)[:, None, None, None]
+  mt = torch.arange(4 * cout // 16, device=dev)[None, :, None, None]
+  lane = torch.arange(64, device=dev)[None, None, :, None]
+  j = torch.arange(8, device=dev)[None, None, None, :]
+  ci = 32 * ks + 8 * (lane >> 4) + j
+  m = 16 * mt + (lane & 15)
+  q, co = m // cout, m % cout
+  out = w.detach().float()[ci, co, q >> 1, q & 1].to(torch.bfloat16).contiguous().reshape(-1)
+  assert out.numel() == n
+  return out
+
+
+def convt2x2_bias_relu(x, wfrag, bias, cout, out, out_offset=0):
+  """relu(conv_transpose2d(x, k=2, s=2) + bias) into the channel slice [out_offset, out_offset + cout) of `out`
+  (bf16 channels-last, twice the spatial size of x), csrc/conv_mfma.hip."""
+  B, cin, H, W = x.shape
+  with torch.cuda.device(x.device):
+    rc = load().srl_convt2x2_bias_relu(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, cin, cout,
+                                       out.shape[1], out_offset, _stream(x))
+  if rc:
+    raise RuntimeError(load().srl_conv_last_error().decode())
+  return out
+
+
 def conv3x3_thin(x, w, bias, out=None):
   """relu(conv3x3(x) + bias) for 1 or 2 input channels -> 16 (csrc/conv_mfma.hip, vector ALU).  x: uint8 (scaled by
   1/255) or float32, channels-last memory [B,H,W,cin].  Returns bf16 [B,16,Hp,Wp] channels-last; `out` (optional) is a
@@ -310,6 +345,9 @@ class FastFeatures(object):
         if self.mfma_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.in_channels in (16, 32, 64) and m.out_channels in (16, 32):
           self._wf[m] = pack_conv3x3_weights(m.weight)
+        if self.mfma_conv and isinstance(m, torch.nn.ConvTranspose2d) and m.kernel_size == (2, 2) and \
+           (m.in_channels, m.out_channels) in ((32, 16), (64, 32)):
+          self._wf[m] = pack_convt2x2_weights(m.weight)
         if self.mfma_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.in_channels in (1, 2) and m.out_channels == 16:
           self._wt[m] = m.weight.detach().float().contiguous()
@@ -363,8 +401,11 @@ class FastFeatures(object):
       cat = cats.pop()
       f = up.out_channels
       w, b = self._w[up]
-      y = _cl(F.conv_transpose2d(x, w, None, stride=up.stride))
-      bias_act(y, b, out=cat, out_offset=0)         # Concatenate([up, skip]) without a copy
+      if up in self._wf and x.shape[3] % 16 == 0 and x.is_contiguous(memory_format=_CL):
+        convt2x2_bias_relu(x, self._wf[up], b, f, cat, 0)
+      else:
+        y = _cl(F.conv_transpose2d(x, w, None, stride=up.stride))
+        bias_act(y, b, out=cat, out_offset=0)       # Concatenate([up, skip]) without a copy
       if self._mine(blk[0], cat):
         y = conv3x3_bias_relu(cat, self._wf[blk[0]], self._w[blk[0]][1], f)
       else:

@@ -94,6 +94,22 @@ def test_conv3x3_mfma_matches_torch(cin, cout, H):
   assert z.is_contiguous() and torch.equal(z, y.contiguous())
 
 
+@pytest.mark.parametrize('cin,cout,H,W', [(32, 16, 12, 32), (64, 32, 8, 16)])
+def test_convt2x2_mfma_matches_torch(cin, cout, H, W):
+  from stackrl_amd import qops
+  F = torch.nn.functional
+  g = torch.Generator(device='cuda').manual_seed(cin + H)
+  B = 3
+  x = torch.rand((B, cin, H, W), generator=g, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+  w = (torch.rand((cin, cout, 2, 2), generator=g, device='cuda') - 0.5) * 0.3
+  b = torch.rand(cout, generator=g, device='cuda') - 0.5
+  ref = F.relu(F.conv_transpose2d(x.float(), w.to(torch.bfloat16).float(), b, stride=2))
+  cat = torch.full((B, 2 * cout, 2 * H, 2 * W), 3.0, device='cuda', dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+  qops.convt2x2_bias_relu(x, qops.pack_convt2x2_weights(w), b, cout, cat, 0)
+  assert bool(((cat[:, :cout].float() - ref).abs() <= 2.0 ** -8 * ref.abs().clamp(min=1e-2)).all())
+  assert bool((cat[:, cout:] == 3.0).all())
+
+
 def test_thin_conv_and_projection_head_match_torch():
   """The 1|2 -> 16 channel first layers (vector ALU, uint8 / 255 or float input) and the fused 16 -> 16 -> 1 tail of
   `pos_layers` (MFMA + fp32 projection) against torch in fp32."""
