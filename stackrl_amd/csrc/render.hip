@@ -132,9 +132,8 @@ struct RenderLds {
   int* reg;         // [32][4] region base in its group, end of its up-facing planes, plane count, planes before this rock
   uint32_t* rowmask;   // [8] bit i set: tile row i may hold a rock pixel (union of the rocks' row ranges)
   int* misc;        // [4] rocks in the first group
-  float* pi;        // [512]  (pi, pu and the codec scratch alias the plane staging area: used after the ray cast)
+  float* pi;        // [512]  (pi and pu alias the plane staging area: used after the ray cast)
   float* pu;        // [512]
-  float* cz;        // [8 waves][3][64] epilogue codec scratch
 };
 
 __host__ __device__ inline size_t render_lds_bytes(int res) {
@@ -223,7 +222,6 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   L.misc = (int*)(L.rowmask + 8);
   L.pi = (float*)L.planes;
   L.pu = L.pi + SRL_RENDER_THREADS;
-  L.cz = L.pu + SRL_RENDER_THREADS;
   EnvHdr* h = &P.hdr[e];
   const float* gb = P.blob + (size_t)e * P.BLOB;
   const bool ext = poses_ext != nullptr;
@@ -561,7 +559,6 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       oo[idx] = (uint8_t)(((pending >= 0 ? P.objmap[(size_t)pending * rr + idx] : empty) * 255.0f) / den);
   }
   // ---- halving tree over the 512 partials: cross-wave stages through LDS, in-wave stages by shuffles
-  __syncthreads();   // the codec scratch of slower waves shares the staging area with pi / pu
   L.pi[tid] = spi; L.pu[tid] = spu;
   __syncthreads();
   if (tid < 256) { L.pi[tid] += L.pi[tid + 256]; L.pu[tid] += L.pu[tid + 256]; }
