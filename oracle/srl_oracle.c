@@ -139,7 +139,9 @@ typedef struct {
   int nv, nt;
   v3 v[MAXV];           /* vertices, COM frame (link vertex - com) */
   uint8_t tri[MAXT][3];
-  float pl[MAXT][4];    /* face planes, COM frame: unit normal xyz, offset d (n.p <= d inside) */
+ float pl[MAXT][4];    /* face planes, COM frame: unit normal xyz, offset d (n.p <= d inside) */
+  int ne;
+  uint8_t edge[3 * MAXT / 2][4];   /* closed triangulated surface: edge = (vertex a < vertex b, the two faces sharing it) */
   v3 com;               /* URDF inertial origin (link frame) */
   float inv_mass;
   v3 inv_inertia;       /* body-frame diagonal: box inertia of the AABB (Bullet's default for
@@ -322,6 +324,26 @@ int srlo_load_meshes(srlo_env* e, const float* verts, const int32_t* vert_off,
       n = vscale(n, 1.0f / len);
       M->pl[k][0] = n.x; M->pl[k][1] = n.y; M->pl[k][2] = n.z; M->pl[k][3] = vdot(n, a);
     }
+    {   /* edge list (the overhead renderer's silhouette test): every edge of the closed surface has exactly two faces */
+      static int first[MAXV * MAXV];
+      for (int q = 0; q < M->nv * M->nv; ++q) first[q] = -1;
+      M->ne = 0;
+      for (int k = 0; k < M->nt; ++k)
+        for (int j = 0; j < 3; ++j) {
+          int a = M->tri[k][j], b = M->tri[k][(j + 1) % 3];
+          if (a > b) { int tmp = a; a = b; b = tmp; }
+          if (a == b) return fail(SRL_EINVAL, "degenerate triangle");
+          int* slot = &first[a * M->nv + b];
+          if (*slot == -1) *slot = k;
+          else if (*slot >= 0) {
+            uint8_t* e4 = M->edge[M->ne++];
+            e4[0] = (uint8_t)a; e4[1] = (uint8_t)b; e4[2] = (uint8_t)*slot; e4[3] = (uint8_t)k;
+            *slot = -2;
+          } else return fail(SRL_EINVAL, "mesh is not a closed two-manifold (an edge has more than two faces)");
+        }
+      for (int q = 0; q < M->nv * M->nv; ++q)
+        if (first[q] >= 0) return fail(SRL_EINVAL, "mesh is not a closed surface (an edge has only one face)");
+    }
     /* Bullet btCompoundShape/btPolyhedralConvexShape::calculateLocalInertia restated:
      * inertia of the solid box spanned by the shape's AABB (pybullet ignores the URDF
      * inertia unless URDF_USE_INERTIA_FROM_FILE is passed; simulator.py:300 passes no flags). */
@@ -418,8 +440,13 @@ void srlo_depth_to_elevation(const srl_config* c, int which, const float* depth,
 /* A rock is the intersection of its face half-spaces.  Along the vertical line through a pixel centre
  * the hull spans [z_lo, z_hi]: z_hi = min over up-facing planes (n_z >= 0), z_lo = max over down-facing
  * planes (n_z < 0).  |n_z| is clamped to >= 1e-6, so a vertical face acts as an up/down plane of enormous
- * slope: it never limits z on its inner side and empties the interval on its outer side.  The overhead
- * camera sees z_hi, the object camera (from below) sees z_lo; a pixel is hit iff z_lo <= z_hi. */
+ * slope: it never limits z on its inner side and empties the interval on its outer side.
+ * The object camera (from below) sees z_lo where z_lo <= z_hi.
+ * The overhead camera sees z_hi where the pixel centre lies inside the rock's silhouette: the convex polygon whose
+ * sides are the projections of the edges shared by an up-facing and a down-facing face.  Side through the projected
+ * end points A, B (A the lower vertex index): E(p) = fma(ea, p.x, fma(eb, p.y, ec)), ea = A.y - B.y, eb = B.x - A.x,
+ * ec = -fma(ea, A.x, eb * A.y), all three negated if E(centre of mass) < 0; inside iff E(p) >= 0 for every side.
+ * (Same set as z_lo <= z_hi up to pixel centres on the outline; a third of the per-pixel work.) */
 typedef struct { float a, b, c; int type; } rplane_t;   /* z = a x + b y + c; type 0 up, 1 down */
 
 static int make_rplanes(const mesh_t* M, const m3* R, v3 x, rplane_t* out) {
@@ -478,12 +505,27 @@ static void render_heightmap(const struct srlo_env* e, int nb, const int* mesh, 
     if (!pixel_range(ymin, ymax, e->inv_px, res, &j0, &j1)) continue;
     rplane_t pl[MAXT];
     int np = make_rplanes(M, &R, x[b], pl);
+    float ea[3 * MAXT / 2], eb[3 * MAXT / 2], ec[3 * MAXT / 2];
+    int ns = 0;
+    for (int k = 0; k < M->ne; ++k) {
+      const uint8_t* e4 = M->edge[k];
+      if (pl[e4[2]].type == pl[e4[3]].type) continue;       /* not on the outline */
+      v3 A = mmul_add(&R, M->v[e4[0]], x[b]), B = mmul_add(&R, M->v[e4[1]], x[b]);
+      float a = A.y - B.y, bb = B.x - A.x;
+      float cc = -fmaf(a, A.x, bb * A.y);
+      float s = fmaf(a, x[b].x, fmaf(bb, x[b].y, cc));      /* the centre of mass is inside */
+      if (s < 0.0f) { a = -a; bb = -bb; cc = -cc; }
+      ea[ns] = a; eb[ns] = bb; ec[ns] = cc; ++ns;
+    }
     for (int i = i0; i <= i1; ++i) {
       float px = ((float)i + 0.5f) * e->px;
       for (int j = j0; j <= j1; ++j) {
         float py = ((float)j + 0.5f) * e->px;
-        float lo, hi;
-        if (ray_cast(pl, np, px, py, &lo, &hi) && hi > H[i * res + j]) H[i * res + j] = hi;
+        float hi = 1e30f, lo = 1e30f;
+        for (int t = 0; t < np; ++t)
+          if (pl[t].type == 0) hi = fminf(hi, fmaf(pl[t].a, px, fmaf(pl[t].b, py, pl[t].c)));
+        for (int t = 0; t < ns; ++t) lo = fminf(lo, fmaf(ea[t], px, fmaf(eb[t], py, ec[t])));
+        if (lo >= 0.0f && hi > H[i * res + j]) H[i * res + j] = hi;
       }
     }
   }

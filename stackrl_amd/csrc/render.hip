@@ -129,7 +129,8 @@ struct RenderLds {
   float* sR;        // [32][9]
   int* mhdr;        // [32][4] vo, nv, to, nt
   int* prange;      // [32][4] i0|i1<<16, j0|j1<<16, w2 (quads per row), quads
-  int* reg;         // [32][4] region base in its group, end of its up-facing planes, plane count, planes before this rock
+  int* reg;         // [32][4] region base in its group, end of its up-facing planes, start of its outline sides, slots before this rock
+  int* ehdr;        // [32][2] edge offset, edge count of the rock's mesh
   uint32_t* rowmask;   // [8] bit i set: tile row i may hold a rock pixel (union of the rocks' row ranges)
   int* misc;        // [4] rocks in the first group
   float* pi;        // [512]  (pi and pu alias the plane staging area: used after the ray cast)
@@ -138,7 +139,7 @@ struct RenderLds {
 
 __host__ __device__ inline size_t render_lds_bytes(int res) {
   return sizeof(float) * (size_t)res * res + sizeof(float4) * SRL_PLANE_CAP +
-         sizeof(float) * (3 + 9 + 4 + 4 + 4) * SRL_MAX_BODIES + sizeof(uint32_t) * (8 + 4);
+         sizeof(float) * (3 + 9 + 4 + 4 + 4 + 2) * SRL_MAX_BODIES + sizeof(uint32_t) * (8 + 4);
 }
 
 // one min / max sweep over planes [0, n) of a region, this lane taking 4-plane batches s, s+S, ...
@@ -218,7 +219,8 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   L.mhdr = (int*)(L.sR + 9 * SRL_MAX_BODIES);
   L.prange = L.mhdr + 4 * SRL_MAX_BODIES;
   L.reg = L.prange + 4 * SRL_MAX_BODIES;
-  L.rowmask = (uint32_t*)(L.reg + 4 * SRL_MAX_BODIES);
+  L.ehdr = L.reg + 4 * SRL_MAX_BODIES;
+  L.rowmask = (uint32_t*)(L.ehdr + 2 * SRL_MAX_BODIES);
   L.misc = (int*)(L.rowmask + 8);
   L.pi = (float*)L.planes;
   L.pu = L.pi + SRL_RENDER_THREADS;
@@ -233,7 +235,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   //      their latency overlaps the ray cast.
   q4 q; v3 x = V(0.0f, 0.0f, 0.0f); MeshHdr mh;
   q.x = q.y = q.z = 0.0f; q.w = 1.0f;
-  mh.vo = mh.nv = mh.to = mh.nt = 0;
+  mh.vo = mh.nv = mh.to = mh.nt = 0; mh.eo = mh.ne = 0;
   if (tid < (ext ? SRL_MAX_BODIES : P.c.episode_length)) {
     int m;
     if (ext) {
@@ -270,8 +272,10 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   }
   if (tid < 8) L.rowmask[tid] = 0u;
   if (tid < SRL_MAX_BODIES) {
-    const int nt = tid < nb ? mh.nt : 0;
-    int pre = nt;   // inclusive prefix of the plane counts over the rocks (lanes 0..31 of wave 0)
+    // a rock's region holds its up-facing planes and the sides of its outline: at most nt + 2 slots (the down-facing
+    // cap of a closed triangulated surface whose rim has s edges has at least s - 2 triangles)
+    const int nt = tid < nb ? mh.nt + 2 : 0;
+    int pre = nt;   // inclusive prefix of the region sizes over the rocks (lanes 0..31 of wave 0)
 #pragma unroll
     for (int d = 1; d < SRL_MAX_BODIES; d <<= 1) { const int v = __shfl_up(pre, d); if (lane >= d) pre += v; }
     const int be0 = __popcll(__ballot(tid < nb && pre <= SRL_PLANE_CAP));   // rocks whose planes fit the first group
@@ -283,7 +287,8 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       for (int i = 0; i < 9; ++i) L.sR[9 * tid + i] = R.m[i];
       L.mhdr[4 * tid + 0] = mh.vo; L.mhdr[4 * tid + 1] = mh.nv; L.mhdr[4 * tid + 2] = mh.to; L.mhdr[4 * tid + 3] = mh.nt;
       // cursors as for the first group (later groups reset theirs)
-      L.reg[4 * tid + 0] = pre - nt; L.reg[4 * tid + 1] = pre - nt; L.reg[4 * tid + 2] = nt; L.reg[4 * tid + 3] = pre - nt;
+      L.reg[4 * tid + 0] = pre - nt; L.reg[4 * tid + 1] = pre - nt; L.reg[4 * tid + 2] = pre; L.reg[4 * tid + 3] = pre - nt;
+      L.ehdr[2 * tid + 0] = mh.eo; L.ehdr[2 * tid + 1] = mh.ne;
       L.prange[4 * tid + 3] = 0;
     }
   }
@@ -310,60 +315,106 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   uint32_t cov = 0u, goalm = 0u;
   bool first = true;
   do {
-    // (a) one wave per rock (rocks wave, wave + 8, ...).  First trip: xy bounds of every rock (vertices over
-    //     the lanes, DPP min / max) -> pixel range, quad count, row mask.  Every trip: the world-frame planes of
-    //     the group's rocks, up-facing ones packed from the front of the rock's region and down-facing ones
-    //     from its back by ballot ranks (the order inside a region is irrelevant: min / max).
+    // (a) staging.  Two independent tasks per rock, handed to the 8 waves round robin (with few rocks they run side by
+    //     side, with 8 rocks every wave does both for its rock):
+    //     F(b)  first trip: xy bounds of the rock (vertices over the lanes, DPP min / max) -> pixel range, quad count,
+    //           row mask; every trip (rocks of the group): its up-facing world-frame planes, packed from the front of the
+    //           rock's region by ballot ranks
+    //     E(b)  (rocks of the group) its outline: the edges shared by an up-facing and a down-facing face, projected; side
+    //           through A, B (A the lower vertex index): E(p) = fma(ea, p.x, fma(eb, p.y, ec)) >= 0 inside (oriented by
+    //           the centre of mass = the body position), packed from the back of the region.  The facing of the two faces
+    //           is recomputed here from their normals (the very expression make_rplane classifies by), so E does not wait
+    //           for F.
     {
       const unsigned long long below = (1ull << lane) - 1ull;
-      for (int b = (first ? 0 : bs) + wave; b < (first ? nb : be); b += SRL_RENDER_THREADS / 64) {
+      const int f0 = first ? 0 : bs, nf = (first ? nb : be) - f0, ne_tasks = be - bs;
+      for (int task = wave; task < nf + ne_tasks; task += SRL_RENDER_THREADS / 64) {
+        const bool outline = task >= nf;
+        const int b = outline ? bs + (task - nf) : f0 + task;
         const m3 R = ldm(L.sR + 9 * b);
         const v3 xb = ld3(L.sx + 3 * b);
         const int vo = L.mhdr[4 * b + 0], nv = L.mhdr[4 * b + 1], to = L.mhdr[4 * b + 2], nt = L.mhdr[4 * b + 3];
-        const bool planes = b >= bs && b < be;
-        float4 pl0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pl1 = pl0;
-        if (planes) {   // the first two chunks are requested before the vertex pass
-          if (lane < nt) pl0 = P.mp[to + lane];
-          if (64 + lane < nt) pl1 = P.mp[to + 64 + lane];
-        }
-        if (first) {
-          float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+        const int base = L.reg[4 * b + 0];
+        if (!outline) {
+          const bool planes = b >= bs && b < be;
+          float4 pl0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pl1 = pl0;
+          if (planes) {   // the first two chunks are requested before the vertex pass
+            if (lane < nt) pl0 = P.mp[to + lane];
+            if (64 + lane < nt) pl1 = P.mp[to + 64 + lane];
+          }
+          if (first) {
+            float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+            for (int v = lane; v < nv; v += 64) {
+              const float4 lv = P.mv[vo + v];
+              const v3 a = mmul_add(R, V(lv.x, lv.y, lv.z), xb);
+              xmin = fminf(xmin, a.x); xmax = fmaxf(xmax, a.x); ymin = fminf(ymin, a.y); ymax = fmaxf(ymax, a.y);
+            }
+            xmin = wave_minmax<true>(xmin); xmax = wave_minmax<false>(xmax);
+            ymin = wave_minmax<true>(ymin); ymax = wave_minmax<false>(ymax);
+            if (lane == 0) {
+              int i0 = 0, i1 = -1, j0 = 0, j1 = -1;
+              const bool okx = pixel_range(xmin, xmax, P.inv_px, res, i0, i1);
+              const bool oky = pixel_range(ymin, ymax, P.inv_px, res, j0, j1);
+              int w2 = 0, items = 0;
+              if (okx && oky) { w2 = (j1 - j0 + 2) >> 1; items = ((i1 - i0 + 2) >> 1) * w2; }   // 2 x 2 pixel quads
+              L.prange[4 * b + 0] = i0 | (i1 << 16); L.prange[4 * b + 1] = j0 | (j1 << 16); L.prange[4 * b + 2] = w2; L.prange[4 * b + 3] = items;
+              if (items > 0)
+                for (int w = i0 >> 5; w <= i1 >> 5; ++w) {
+                  const int lo = max(i0 - 32 * w, 0), hi = min(i1 - 32 * w, 31);
+                  atomicOr(&L.rowmask[w], (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo));
+                }
+            }
+          }
+          if (planes) {
+            int nup = 0;
+            for (int c = 0; c < nt; c += 64) {
+              const bool act = c + lane < nt;
+              float4 pl = c == 0 ? pl0 : pl1;
+              if (c >= 128 && act) pl = P.mp[to + c + lane];
+              const float4 wp = make_rplane(pl, R, xb);
+              const bool up = act && __float_as_int(wp.w) == 0;
+              const unsigned long long mu = __ballot(up);
+              if (up) L.planes[base + nup + __popcll(mu & below)] = wp;
+              nup += __popcll(mu);
+            }
+            if (lane == 0) L.reg[4 * b + 1] = base + nup;   // end of the up-facing planes
+          }
+        } else {
+          const int eo = L.ehdr[2 * b + 0], ne = L.ehdr[2 * b + 1];
+          const int cap = nt + 2;
+          // world xy of the vertices, one (two) per lane; end points are then cross-lane reads
+          float wx0 = 0.0f, wy0 = 0.0f, wx1 = 0.0f, wy1 = 0.0f;
           for (int v = lane; v < nv; v += 64) {
             const float4 lv = P.mv[vo + v];
             const v3 a = mmul_add(R, V(lv.x, lv.y, lv.z), xb);
-            xmin = fminf(xmin, a.x); xmax = fmaxf(xmax, a.x); ymin = fminf(ymin, a.y); ymax = fmaxf(ymax, a.y);
+            if (v < 64) { wx0 = a.x; wy0 = a.y; } else { wx1 = a.x; wy1 = a.y; }
           }
-          xmin = wave_minmax<true>(xmin); xmax = wave_minmax<false>(xmax);
-          ymin = wave_minmax<true>(ymin); ymax = wave_minmax<false>(ymax);
-          if (lane == 0) {
-            int i0 = 0, i1 = -1, j0 = 0, j1 = -1;
-            const bool okx = pixel_range(xmin, xmax, P.inv_px, res, i0, i1);
-            const bool oky = pixel_range(ymin, ymax, P.inv_px, res, j0, j1);
-            int w2 = 0, items = 0;
-            if (okx && oky) { w2 = (j1 - j0 + 2) >> 1; items = ((i1 - i0 + 2) >> 1) * w2; }   // 2 x 2 pixel quads
-            L.prange[4 * b + 0] = i0 | (i1 << 16); L.prange[4 * b + 1] = j0 | (j1 << 16); L.prange[4 * b + 2] = w2; L.prange[4 * b + 3] = items;
-            if (items > 0)
-              for (int w = i0 >> 5; w <= i1 >> 5; ++w) {
-                const int lo = max(i0 - 32 * w, 0), hi = min(i1 - 32 * w, 31);
-                atomicOr(&L.rowmask[w], (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo));
-              }
+          int nsil = 0;
+          for (int c = 0; c < ne; c += 64) {
+            const bool act = c + lane < ne;
+            uchar4 ed = make_uchar4(0, 0, 0, 0);
+            if (act) ed = P.me[eo + c + lane];
+            const float4 na = P.mp[to + ed.z], nb_ = P.mp[to + ed.w];
+            const bool da = !(mmul(R, V(na.x, na.y, na.z)).z >= 0.0f), db = !(mmul(R, V(nb_.x, nb_.y, nb_.z)).z >= 0.0f);
+            const bool sil = act && (da != db);
+            const unsigned long long ms = __ballot(sil);
+            float Ax = __shfl(wx0, ed.x & 63), Ay = __shfl(wy0, ed.x & 63), Bx = __shfl(wx0, ed.y & 63), By = __shfl(wy0, ed.y & 63);
+            if (nv > 64) {
+              const float ax1 = __shfl(wx1, ed.x & 63), ay1 = __shfl(wy1, ed.x & 63), bx1 = __shfl(wx1, ed.y & 63), by1 = __shfl(wy1, ed.y & 63);
+              if (ed.x >= 64) { Ax = ax1; Ay = ay1; }
+              if (ed.y >= 64) { Bx = bx1; By = by1; }
+            }
+            if (sil) {
+              float ea = Ay - By, eb = Bx - Ax;
+              float ec = -fmaf(ea, Ax, eb * Ay);
+              if (fmaf(ea, xb.x, fmaf(eb, xb.y, ec)) < 0.0f) { ea = -ea; eb = -eb; ec = -ec; }
+              const int r = nsil + __popcll(ms & below);
+              if (r < cap) L.planes[base + cap - 1 - r] = make_float4(ea, eb, ec, 0.0f);
+            }
+            nsil += __popcll(ms);
           }
-        }
-        if (planes) {
-          const int base = L.reg[4 * b + 0];
-          int nup = 0, ndn = 0;
-          for (int c = 0; c < nt; c += 64) {
-            const bool act = c + lane < nt;
-            float4 pl = c == 0 ? pl0 : pl1;
-            if (c >= 128 && act) pl = P.mp[to + c + lane];
-            const float4 wp = make_rplane(pl, R, xb);
-            const bool up = act && __float_as_int(wp.w) == 0, dn = act && __float_as_int(wp.w) != 0;
-            const unsigned long long mu = __ballot(up), md = __ballot(dn);
-            if (up) L.planes[base + nup + __popcll(mu & below)] = wp;
-            if (dn) L.planes[base + nt - 1 - (ndn + __popcll(md & below))] = wp;
-            nup += __popcll(mu); ndn += __popcll(md);
-          }
-          if (lane == 0) L.reg[4 * b + 1] = base + nup;   // end of the up-facing planes = start of the down-facing ones
+          if (nsil > cap) nsil = cap;   // (a closed convex mesh has nup + nsil <= nt + 2, see the prologue)
+          if (lane == 0) L.reg[4 * b + 2] = base + cap - nsil;   // start of the outline sides
         }
       }
     }
@@ -441,23 +492,24 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
         const bool row2 = i + 1 <= i1, col2 = j + 1 <= j1;
         const float px0 = ((float)i + 0.5f) * P.px, px1 = ((float)(i + 1) + 0.5f) * P.px;
         const float py0 = ((float)j + 0.5f) * P.px, py1 = ((float)(j + 1) + 0.5f) * P.px;
-        const int base = rg.x, nup = rg.y - base, dn0 = rg.y, ndn = rg.z - nup;
+        // z_hi = min over the up-facing planes; inside the outline iff the smallest side function is >= 0
+        const int base = rg.x, nup = rg.y - base, e0 = rg.z, nsil = base + L.mhdr[4 * b + 3] + 2 - e0;
         float h00 = 1e30f, h01 = 1e30f, h10 = 1e30f, h11 = 1e30f;
-        float l00 = -1e30f, l01 = -1e30f, l10 = -1e30f, l11 = -1e30f;
+        float l00 = 1e30f, l01 = 1e30f, l10 = 1e30f, l11 = 1e30f;
         plane_sweep<true>(L.planes + base, nup, s, S, px0, px1, py0, py1, h00, h01, h10, h11);
-        plane_sweep<false>(L.planes + dn0, ndn, s, S, px0, px1, py0, py1, l00, l01, l10, l11);
+        plane_sweep<true>(L.planes + e0, nsil, s, S, px0, px1, py0, py1, l00, l01, l10, l11);
         for (int m = 1; m < S; m <<= 1) {
           h00 = fminf(h00, __shfl_xor(h00, m)); h01 = fminf(h01, __shfl_xor(h01, m));
           h10 = fminf(h10, __shfl_xor(h10, m)); h11 = fminf(h11, __shfl_xor(h11, m));
-          l00 = fmaxf(l00, __shfl_xor(l00, m)); l01 = fmaxf(l01, __shfl_xor(l01, m));
-          l10 = fmaxf(l10, __shfl_xor(l10, m)); l11 = fmaxf(l11, __shfl_xor(l11, m));
+          l00 = fminf(l00, __shfl_xor(l00, m)); l01 = fminf(l01, __shfl_xor(l01, m));
+          l10 = fminf(l10, __shfl_xor(l10, m)); l11 = fminf(l11, __shfl_xor(l11, m));
         }
         if (s == 0) {
           int* t0p = (int*)&L.tile[i * res + j];   // positive floats order as ints
-          if (l00 <= h00 && h00 > 0.0f) atomicMax(t0p, __float_as_int(h00));
-          if (col2 && l01 <= h01 && h01 > 0.0f) atomicMax(t0p + 1, __float_as_int(h01));
-          if (row2 && l10 <= h10 && h10 > 0.0f) atomicMax(t0p + res, __float_as_int(h10));
-          if (row2 && col2 && l11 <= h11 && h11 > 0.0f) atomicMax(t0p + res + 1, __float_as_int(h11));
+          if (l00 >= 0.0f && h00 > 0.0f) atomicMax(t0p, __float_as_int(h00));
+          if (col2 && l01 >= 0.0f && h01 > 0.0f) atomicMax(t0p + 1, __float_as_int(h01));
+          if (row2 && l10 >= 0.0f && h10 > 0.0f) atomicMax(t0p + res, __float_as_int(h10));
+          if (row2 && col2 && l11 >= 0.0f && h11 > 0.0f) atomicMax(t0p + res + 1, __float_as_int(h11));
         }
       }
     }
@@ -467,7 +519,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     bs = be;
     if (bs < nb) {   // next group: its extent, then its region cursors
       const int p0 = L.reg[4 * bs + 3];
-      while (be < nb && L.reg[4 * be + 3] + L.mhdr[4 * be + 3] - p0 <= SRL_PLANE_CAP) ++be;
+      while (be < nb && L.reg[4 * be + 3] + L.mhdr[4 * be + 3] + 2 - p0 <= SRL_PLANE_CAP) ++be;
       if (tid >= bs && tid < be) {
         const int base = L.reg[4 * tid + 3] - p0;
         L.reg[4 * tid + 0] = base; L.reg[4 * tid + 1] = base;

@@ -10,6 +10,7 @@ struct MeshHdr {
   float iix, iiy, iiz;          // inverse inertia diagonal (body frame): box inertia of the AABB
   float radius;                 // bounding radius about the centre of mass
   float cx, cy, cz;             // centre of mass in the URDF link frame
+  int32_t eo, ne;               // offset/count into mesh_edges (uchar4: vertex a < vertex b, the two faces sharing it)
 };
 
 // Per-env scalar state (global memory).
@@ -56,6 +57,7 @@ struct DevParams {
   const MeshHdr* mh;
   const float4* mv;       // mesh vertices, COM frame
   const uchar4* mt;       // triangles
+  const uchar4* me;       // edges: (va, vb, fa, fb), closed triangulated surface: every edge has exactly two faces
   const float4* mp;       // face planes, COM frame: unit normal xyz, offset d
   const float* objmap;    // [n_mesh][n_orient][ores*ores] underside maps (O2), one per observable orientation
   // observable orientations of the pending rock (TestStackEnv, observer.py:127-140): quaternion i = inverse of the yaw

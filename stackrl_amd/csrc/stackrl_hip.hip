@@ -44,6 +44,7 @@ struct srl_env {
   DevParams* d_P = nullptr;   // device copy of P for the settle kernel (re-uploaded whenever P changes)
   bool P_dirty = true;
   float* d_objmap = nullptr;
+  uchar4* d_me = nullptr;
   float* d_codec_h = nullptr;     // overhead depth codec tabulated over the lattice of fl(FAR - z) (DevParams::codec_h)
   uint8_t* d_codec_b = nullptr;
   int step_threads = 256;
@@ -260,7 +261,7 @@ void srl_destroy(srl_env* env) {
   for (auto& e : env->pool) (void)hipEventDestroy(e);
   (void)hipFree(env->P.hdr); (void)hipFree(env->P.blob); (void)hipFree(env->P.H); (void)hipFree(env->P.flags); (void)hipFree(env->d_P);
   (void)hipFree(env->d_mh); (void)hipFree(env->d_mv); (void)hipFree(env->d_mt); (void)hipFree(env->d_mp); (void)hipFree(env->d_objmap);
-  (void)hipFree(env->d_codec_h); (void)hipFree(env->d_codec_b);
+  (void)hipFree(env->d_codec_h); (void)hipFree(env->d_codec_b); (void)hipFree(env->d_me);
   delete env;
 }
 
@@ -273,6 +274,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   std::vector<float4> mv((size_t)vert_off[n_mesh]);
   std::vector<uchar4> mt((size_t)tri_off[n_mesh]);
   std::vector<float4> mp((size_t)tri_off[n_mesh]);
+  std::vector<uchar4> me;
   int vs = 4;
   for (int m = 0; m < n_mesh; ++m) {
     MeshHdr& M = mh[m];
@@ -309,6 +311,27 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
       nx = nx * il; ny = ny * il; nz = nz * il;
       mp[(size_t)M.to + k] = make_float4(nx, ny, nz, fmaf(nx, a.x, fmaf(ny, a.y, nz * a.z)));
     }
+    {   // edge list of the closed triangulated surface (the renderer's silhouette test): edge (a < b) -> its two faces
+      std::vector<int> first((size_t)M.nv * M.nv, -1);
+      M.eo = (int32_t)me.size();
+      for (int k = 0; k < M.nt; ++k) {
+        const int32_t* t = tris + 3 * (size_t)(M.to + k);
+        for (int j = 0; j < 3; ++j) {
+          int a = t[j], b = t[(j + 1) % 3];
+          if (a > b) { int tmp = a; a = b; b = tmp; }
+          if (a == b) return fail(SRL_EINVAL, "degenerate triangle");
+          int& slot = first[(size_t)a * M.nv + b];
+          if (slot == -1) slot = k;
+          else if (slot >= 0) {
+            me.push_back(make_uchar4((unsigned char)a, (unsigned char)b, (unsigned char)slot, (unsigned char)k));
+            slot = -2;
+          } else return fail(SRL_EINVAL, "mesh is not a closed two-manifold (an edge has more than two faces)");
+        }
+      }
+      for (size_t q = 0; q < first.size(); ++q)
+        if (first[q] >= 0) return fail(SRL_EINVAL, "mesh is not a closed surface (an edge has only one face)");
+      M.ne = (int32_t)me.size() - M.eo;
+    }
     // Bullet's default for hull shapes when the URDF inertia is not requested (simulator.py:300 passes no
     // flags): inertia of the solid box spanned by the AABB (btCompoundShape::calculateLocalInertia restated)
     float lx = hix - lox, ly = hiy - loy, lz = hiz - loz;
@@ -318,7 +341,8 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
     M.iix = 1.0f / Ix; M.iiy = 1.0f / Iy; M.iiz = 1.0f / Iz;
   }
   (void)hipFree(env->d_mh); (void)hipFree(env->d_mv); (void)hipFree(env->d_mt); (void)hipFree(env->d_mp); (void)hipFree(env->d_objmap);
-  env->d_mh = nullptr; env->d_mv = nullptr; env->d_mt = nullptr; env->d_mp = nullptr; env->d_objmap = nullptr;
+  (void)hipFree(env->d_me);
+  env->d_mh = nullptr; env->d_mv = nullptr; env->d_mt = nullptr; env->d_mp = nullptr; env->d_objmap = nullptr; env->d_me = nullptr;
   const int r = P.c.object_res;
   HIP_TRY(hipMalloc((void**)&env->d_mh, sizeof(MeshHdr) * mh.size()));
   HIP_TRY(hipMalloc((void**)&env->d_mv, sizeof(float4) * mv.size()));
@@ -329,6 +353,9 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   HIP_TRY(hipMemcpy(env->d_mv, mv.data(), sizeof(float4) * mv.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(env->d_mt, mt.data(), sizeof(uchar4) * mt.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(env->d_mp, mp.data(), sizeof(float4) * mp.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&env->d_me, sizeof(uchar4) * me.size()));
+  HIP_TRY(hipMemcpy(env->d_me, me.data(), sizeof(uchar4) * me.size(), hipMemcpyHostToDevice));
+  P.me = env->d_me;
   P.mh = env->d_mh; P.mv = env->d_mv; P.mt = env->d_mt; P.mp = env->d_mp; P.objmap = env->d_objmap;
   P.n_mesh = n_mesh;
   P.VS = vs;
