@@ -3,11 +3,13 @@
 // Renderer definition: convex ray cast.  A rock is the intersection of its face
 // half-spaces; along the vertical line through a pixel centre the hull spans [z_lo, z_hi] with
 // z_hi = min over up-facing planes and z_lo = max over down-facing planes.  The overhead camera
-// (observer.py:252-260) sees z_hi, the object camera from below (observer.py:262-277) sees z_lo.
+// (observer.py:252-260) sees z_hi inside the rock's outline (the projected mesh edges between an up- and a
+// down-facing face; same set as z_lo <= z_hi), the object camera from below (observer.py:262-277) sees z_lo.
 //
 // K2: one 512-thread workgroup per env.  The res x res tile lives in LDS (64 KB at 128^2 -> 2 workgroups = 16
-// waves per CU).  Prologue (speculative pose / mesh-header loads, tile zeroing) -> one wave per rock: xy bounds by
-// DPP min / max and world-frame planes staged type-sorted by ballot ranks -> rows no rock reaches are written out
+// waves per CU).  Prologue (speculative pose / mesh-header loads, tile zeroing) -> two wave tasks per rock: xy
+// bounds by DPP min / max + the up-facing planes packed from the front of the rock's LDS region, and the outline
+// sides packed from its back (ballot ranks, no atomics) -> rows no rock reaches are written out
 // at once -> ray cast: lanes over the flattened (rock, 2 x 2 pixel quad) list sweep the rock's planes (LDS
 // broadcasts, packed FMAs, min3 / max3) and merge into the tile with integer atomicMax -> one epilogue pass applies
 // the reference's depth codec (observer.py:259-260) to the pixels that saw a rock (compacted per wave), streams out
@@ -22,6 +24,9 @@
 
 #define SRL_RENDER_THREADS 512
 
+// Diagnostic builds only (tools/stamps_render.py, tools/ab_render.py; the outputs of the ablations are wrong by design):
+//   SRL_STAMPS        per-phase wall-clock stamps of thread 0
+//   SRL_ABL_NOSTORE   no H / observation stores     SRL_ABL_NOCAST  no ray cast     SRL_ABL_NOSTAGE  no staging, no ray cast
 #ifdef SRL_STAMPS
 #define RSTAMP(k) do { if (tid == 0) { long long _t = wall_clock64(); P.hdr[e].rstamps[k] += _t - _t0; _t0 = _t; } } while (0)
 #else
@@ -328,7 +333,11 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     {
       const unsigned long long below = (1ull << lane) - 1ull;
       const int f0 = first ? 0 : bs, nf = (first ? nb : be) - f0, ne_tasks = be - bs;
+#ifdef SRL_ABL_NOSTAGE
+      for (int task = wave; task < (P.px == 12345.0f ? nf + ne_tasks : 0); task += SRL_RENDER_THREADS / 64) {
+#else
       for (int task = wave; task < nf + ne_tasks; task += SRL_RENDER_THREADS / 64) {
+#endif
         const bool outline = task >= nf;
         const int b = outline ? bs + (task - nf) : f0 + task;
         const m3 R = ldm(L.sR + 9 * b);
@@ -434,7 +443,9 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
         if (i >= g0 && i < g0 + g2 && jb + 3 >= g1 && jb < g1 + g3) goalm |= 1u << k;
         if ((L.rowmask[i >> 5] >> (i & 31)) & 1u) cov |= 1u << k;
         else {
+#ifndef SRL_ABL_NOSTORE
           ((float4*)Hout)[g] = he4;
+#endif
           if (om) {
             uint32_t lo = epair | zpair, hi = epair | zpair;
             if (i >= g0 && i < g0 + g2) {
@@ -443,7 +454,9 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
               if (jb + 2 >= g1 && jb + 2 < g1 + g3) hi ^= gdiff;
               if (jb + 3 >= g1 && jb + 3 < g1 + g3) hi ^= gdiff << 16;
             }
+#ifndef SRL_ABL_NOSTORE
             ((uint2*)om)[g] = make_uint2(lo, hi);
+#endif
           }
         }
         jb += walk_dj; i += walk_di;
@@ -453,7 +466,11 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     }
     // (e) ray cast: lanes over the flattened (rock, 2 x 2 pixel quad) list; when the list is short each quad
     //     is shared by S adjacent lanes that split the planes and combine with shuffles
+#ifdef SRL_ABL_NOCAST
+    if (be > bs && P.px == 12345.0f) {
+#else
     if (be > bs) {
+#endif
       // quad counts of the group's rocks as running sums (registers, one LDS round trip); groups of more
       // than 8 rocks fall back to walking the list
       const bool few = be - bs <= 8;
@@ -587,10 +604,14 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
           spi += in ? fminf(hv[t], gz) : 0.0f;
           if (in) { if (t < 2) lo ^= gdiff << (16 * t); else hi ^= gdiff << (16 * (t - 2)); }
         }
+#ifndef SRL_ABL_NOSTORE
         if (covg) {
           ((float4*)Hout)[g] = make_float4(hv[0], hv[1], hv[2], hv[3]);
           if (om) ((uint2*)om)[g] = make_uint2(lo, hi);
         }
+#else
+        if (covg && hv[0] == 12345.0f && lo == 77u) ((float4*)Hout)[g] = make_float4(hv[0], hv[1], hv[2], hv[3]);
+#endif
       }
       jb += walk_dj; i += walk_di;
       if (jb >= res) { jb -= res; ++i; }
