@@ -76,6 +76,11 @@ typedef struct srl_config {
   /* --- TestStackEnv (Stack-v2), env.py:443-470 --- */
   int32_t orientation_freedom; /* k: the pending rock is observed in 2^k yaw orientations (observer.py:127-140) and the
                                   action chooses one: action = orientation * A + pixel; 0 = Stack-v0 (one orientation) */
+  int32_t ordering_freedom;    /* 1: all rocks of the episode are shown from the start and the action also chooses which
+                                  one to place (env.py:443-470, :496-506; simulator.py:343-378): the observation holds
+                                  episode_length * 2^k object maps, the maps of the n rocks still unplaced first (rock-major,
+                                  orientation-minor, observer.py:310-327), empty maps after them;
+                                  action = (rock * 2^k + orientation) * A + pixel with rock < n; 0 = Stack-v0 */
 } srl_config;
 
 #ifdef __cplusplus

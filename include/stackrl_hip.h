@@ -57,17 +57,24 @@ int srl_set_script(srl_env* env, const int32_t* mesh_ids, const int32_t* goal_re
 
 /* `ParallelEnv.reset` (utils.py:488-503, :545-552): obs_map u8[n][H][W][2], obs_obj u8[n][h][w][1].
  * With orientation_freedom = k > 0 (`TestStackEnv`, env.py:443-470) obs_obj is u8[n][2^k][h][w][1]: one object map per
- * observable orientation (the overhead map is returned once, not 2^k copies as env.py:472-480 stacks them). */
+ * observable orientation (the overhead map is returned once, not 2^k copies as env.py:472-480 stacks them).
+ * With ordering_freedom = 1 (`TestSimulator`, simulator.py:343-378) obs_obj is u8[n][L * 2^k][h][w][1]: the maps of the
+ * rocks still unplaced first (rock-major, orientation-minor, observer.py:310-327), empty maps after them — the fixed-size
+ * form of the reference's shrinking list (env.py:596-608). */
 int srl_reset(srl_env* env, void* obs_map_dev, void* obs_obj_dev, void* stream);
 
 /* `ParallelEnv.step` (utils.py:468-486): action int64[n]; reward float[n]; done uint8[n].
  * Auto-reset semantics of env.py:235-236 are kept: a step on a finished env returns the reset
  * observation, reward 0, done 0.  With orientation_freedom > 0 the action is orientation * A + pixel
- * (the reference's `(index, action)` tuple, env.py:485-494) and the rock is placed in that orientation. */
+ * (the reference's `(index, action)` tuple, env.py:485-494) and the rock is placed in that orientation.  With
+ * ordering_freedom the index also names the rock: action = (rock * 2^k + orientation) * A + pixel, rock counted among
+ * those still unplaced (it is popped from the list, simulator.py:372-378); an index past the maps on show is an invalid
+ * action (env.py:484); the episode ends when no rock is left (env.py:513-514). */
 int srl_step(srl_env* env, const int64_t* action_dev, void* obs_map_dev, void* obs_obj_dev,
              float* reward_dev, uint8_t* done_dev, void* stream);
 
-/* `ParallelEnv.sample` (utils.py:534-538): uniform actions in [0, A), int64[n] on the device. */
+/* `ParallelEnv.sample` (utils.py:534-538): uniform actions in [0, A), int64[n] on the device ([0, maps on show * A) for
+ * `TestStackEnv`). */
 int srl_sample(srl_env* env, int64_t* action_dev, void* stream);
 
 /* Blocks until `stream` is idle and reports what the reference would have raised during the steps

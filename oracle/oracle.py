@@ -55,7 +55,7 @@ class OracleEnv(object):
     if rc:
       raise ValueError(self.L.srlo_last_error().decode())
     self.obs_map = np.zeros((self.n, self.H, self.H, 2), np.uint8)
-    self.no = cfg.n_orientations       # TestStackEnv: one object map per observable orientation
+    self.no = cfg.n_object_maps        # TestStackEnv: one object map per observable orientation (and unplaced rock)
     self.obs_obj = np.zeros((self.n, self.h_, self.h_, 1) if self.no == 1 else (self.n, self.no, self.h_, self.h_, 1), np.uint8)
     self.reward = np.zeros(self.n, np.float32)
     self.done = np.zeros(self.n, np.uint8)
@@ -131,7 +131,8 @@ class OracleEnv(object):
     return out
 
   def render_object(self, mesh_id):
-    out = np.zeros((self.h_, self.h_), np.float32)
+    k = self.cfg.n_orientations
+    out = np.zeros((self.h_, self.h_) if k == 1 else (k, self.h_, self.h_), np.float32)
     rc = self.L.srlo_render_object(self.h, ctypes.c_int32(mesh_id), _p(out))
     if rc:
       raise ValueError(self.L.srlo_last_error().decode())

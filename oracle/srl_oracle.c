@@ -219,6 +219,7 @@ struct srlo_env {
   int AW, A;
   /* observable orientations of the pending rock (TestStackEnv, observer.py:127-140) */
   int n_orient;
+  int n_slots;                      /* object maps per observation: n_orient, or episode_length * n_orient with ordering freedom */
   q4 orient_q[SRL_MAX_ORIENT];
 };
 
@@ -249,6 +250,8 @@ static int derive(struct srlo_env* e) {
   if (c->orientation_freedom < 0 || (1 << c->orientation_freedom) > SRL_MAX_ORIENT)
     return fail(SRL_EINVAL, "orientation_freedom must be in 0..4");
   e->n_orient = 1 << c->orientation_freedom;                    /* observer.py:127 */
+  if (c->ordering_freedom != 0 && c->ordering_freedom != 1) return fail(SRL_EINVAL, "ordering_freedom must be 0 or 1");
+  e->n_slots = c->ordering_freedom ? c->episode_length * e->n_orient : e->n_orient;
   for (int i = 0; i < e->n_orient; ++i) {   /* inverse of getQuaternionFromEuler([0, 0, i 2 pi / n]), observer.py:129-139 */
     double half = -0.5 * ((double)i * 2.0 * 3.14159265358979323846 / (double)e->n_orient);
     e->orient_q[i].x = 0.0f; e->orient_q[i].y = 0.0f;
@@ -268,7 +271,7 @@ int srlo_create(const srl_config* cfg, srlo_env** out) {
   for (int i = 0; i < cfg->n_envs; ++i) {
     env_t* s = &e->env[i];
     s->H = (float*)calloc((size_t)cfg->overhead_res * cfg->overhead_res, sizeof(float));
-    s->O = (float*)calloc((size_t)cfg->object_res * cfg->object_res * SRL_MAX_ORIENT, sizeof(float));
+    s->O = (float*)calloc((size_t)cfg->object_res * cfg->object_res * SRL_MAX_ORIENT * (cfg->ordering_freedom ? SRL_MAX_BODIES : 1), sizeof(float));
     s->done = 1;                                                /* env.py:219-220 */
     s->pending = -1;
     for (int k = 0; k < NPAIR; ++k) s->slot_of_pair[k] = -1;
@@ -1294,7 +1297,15 @@ static void pack_obs(const struct srlo_env* e, const env_t* s, uint8_t* om, uint
       om[(i * res + j) * 2 + 0] = (uint8_t)((s->H[i * res + j] * 255.0f) / den);
       om[(i * res + j) * 2 + 1] = (uint8_t)((g * 255.0f) / den);
     }
-  for (int k = 0; k < r * r * e->n_orient; ++k) oo[k] = (uint8_t)((s->O[k] * 255.0f) / den);
+  for (int k = 0; k < r * r * e->n_slots; ++k) oo[k] = (uint8_t)((s->O[k] * 255.0f) / den);
+}
+
+/* Observer.__call__ object branch for the env's state: the pending rock (observer.py:262-277), or with ordering freedom
+ * every rock still unplaced, in list order (observer.py:310-327), then empty maps up to the fixed slot count */
+static void observe_objects(const struct srlo_env* e, env_t* s) {
+  if (!e->c.ordering_freedom) { render_object(e, s->pending, s->O); return; }
+  size_t rr = (size_t)e->c.object_res * e->c.object_res * e->n_orient;
+  for (int k = 0; k < e->c.episode_length; ++k) render_object(e, k < s->list_pos ? s->ids[k] : -1, s->O + rr * k);
 }
 
 static void env_reset(struct srlo_env* e, int i) {
@@ -1326,19 +1337,19 @@ static void env_reset(struct srlo_env* e, int i) {
   for (int k = 0; k < MAXSLOT; ++k) s->pair_of_slot[k] = -1;
   s->ncolour = -1;
   s->pending = s->ids[0];
-  s->list_pos = 1;
+  s->list_pos = c->ordering_freedom ? L : 1;   /* with ordering freedom: the number of rocks still unplaced, ids[0 .. list_pos) */
   s->prev_metric = 0.0f;                                                  /* rewarder.py:191-194 */
   s->substeps[0] = 0; s->substeps[1] = 0;
   s->status = 0;
   render_heightmap(e, 0, s->mesh, s->x, s->q, s->H);
-  render_object(e, s->pending, s->O);
+  observe_objects(e, s);
   s->done = 0;
 }
 
 int srlo_reset(srlo_env* e, uint8_t* obs_map, uint8_t* obs_obj) {
   if (!e->mesh) return fail(SRL_ENOMESH, "load meshes first");
   const srl_config* c = &e->c;
-  size_t nm = (size_t)c->overhead_res * c->overhead_res * 2, no = (size_t)c->object_res * c->object_res * e->n_orient;
+  size_t nm = (size_t)c->overhead_res * c->overhead_res * 2, no = (size_t)c->object_res * c->object_res * e->n_slots;
   for (int i = 0; i < c->n_envs; ++i) {
     env_reset(e, i);
     pack_obs(e, &e->env[i], obs_map + nm * i, obs_obj + no * i);
@@ -1350,7 +1361,7 @@ int srlo_step(srlo_env* e, const int64_t* action, uint8_t* obs_map, uint8_t* obs
               uint8_t* done) {
   if (!e->mesh) return fail(SRL_ENOMESH, "load meshes first");
   const srl_config* c = &e->c;
-  size_t nm = (size_t)c->overhead_res * c->overhead_res * 2, no = (size_t)c->object_res * c->object_res * e->n_orient;
+  size_t nm = (size_t)c->overhead_res * c->overhead_res * 2, no = (size_t)c->object_res * c->object_res * e->n_slots;
   int rc = SRL_OK;
   for (int i = 0; i < c->n_envs; ++i) {
     env_t* s = &e->env[i];
@@ -1361,8 +1372,14 @@ int srlo_step(srlo_env* e, const int64_t* action, uint8_t* obs_map, uint8_t* obs
       continue;
     }
     int64_t a = action[i];
-    int oi = 0;                                          /* TestStackEnv: (orientation index, pixel), env.py:485-494 */
-    if (e->n_orient > 1 && a >= 0) { oi = (int)(a / (int64_t)e->A); a = oi < e->n_orient ? a % (int64_t)e->A : -1; }
+    int oi = 0, slot = 0;                                /* TestStackEnv: (observation index, pixel), env.py:485-494 */
+    if (e->n_slots > 1 && a >= 0) {
+      /* the index addresses the object maps on show: n_orient of the pending rock, or n_orient of every unplaced rock */
+      int nvalid = c->ordering_freedom ? s->list_pos * e->n_orient : e->n_orient;
+      slot = (int)(a / (int64_t)e->A);
+      a = slot < nvalid ? a % (int64_t)e->A : -1;
+      oi = slot % e->n_orient;
+    }
     if (a < 0 || a >= (int64_t)e->A) {                   /* env.py:238 */
       s->status |= SRL_ST_BAD_ACTION;
       reward[i] = 0.0f; done[i] = 0;
@@ -1373,14 +1390,21 @@ int srlo_step(srlo_env* e, const int64_t* action, uint8_t* obs_map, uint8_t* obs
     s->status &= ~SRL_ST_BAD_ACTION;
     int u = (int)(a / e->AW), v = (int)(a % e->AW);      /* env.py:240-241 */
     int next = -1;
-    if (s->list_pos < c->episode_length) next = s->ids[s->list_pos++];   /* env.py:243-247 */
-    else s->done = 1;
     float xyz[3];
-    srlo_pose(c, s->H, s->O + (size_t)oi * c->object_res * c->object_res, u, v, xyz);
+    srlo_pose(c, s->H, s->O + (size_t)slot * c->object_res * c->object_res, u, v, xyz);   /* observer.py:400-403 */
+    if (c->ordering_freedom) {               /* TestSimulator.step: pop the chosen rock (simulator.py:372-378) */
+      int rk = slot / e->n_orient;
+      s->pending = s->ids[rk];
+      for (int k = rk; k + 1 < s->list_pos; ++k) s->ids[k] = s->ids[k + 1];
+      s->list_pos -= 1;
+      if (s->list_pos == 0) s->done = 1;     /* env.py:513-514: no objects left */
+      else next = s->ids[0];
+    } else if (s->list_pos < c->episode_length) next = s->ids[s->list_pos++];   /* env.py:243-247 */
+    else s->done = 1;
     sim_step(e, s, V(xyz[0], xyz[1], xyz[2]), oi);
     s->pending = next;                                   /* _load, simulator.py:258 */
     render_heightmap(e, s->nb, s->mesh, s->x, s->q, s->H);
-    render_object(e, s->pending, s->O);
+    observe_objects(e, s);
     float mv = metric_value(e, s);
     reward[i] = (mv - s->prev_metric) * e->scale;        /* rewarder.py:176-179 */
     s->prev_metric = mv;
@@ -1398,7 +1422,8 @@ int srlo_sample(srlo_env* e, int64_t* action) {
   e->sample_counter += 1;
   for (int i = 0; i < c->n_envs; ++i) {
     uint32_t key = e->seed + (uint32_t)c->env_index_offset + (uint32_t)i;
-    action[i] = (int64_t)rng_below(srlo_rng(key, e->sample_counter, STREAM_ACTION, 0), (uint32_t)(e->A * e->n_orient));
+    int nvalid = c->ordering_freedom ? (e->env[i].list_pos > 0 ? e->env[i].list_pos : 1) * e->n_orient : e->n_orient;
+    action[i] = (int64_t)rng_below(srlo_rng(key, e->sample_counter, STREAM_ACTION, 0), (uint32_t)(e->A * nvalid));
   }
   return SRL_OK;
 }
@@ -1453,7 +1478,7 @@ int srlo_get_contacts(srlo_env* e, float* max_pen, int32_t* n_points) {
 
 int srlo_get_maps(srlo_env* e, float* height, float* object_map, int32_t* goal_rect) {
   const srl_config* c = &e->c;
-  size_t nh = (size_t)c->overhead_res * c->overhead_res, no = (size_t)c->object_res * c->object_res * e->n_orient;
+  size_t nh = (size_t)c->overhead_res * c->overhead_res, no = (size_t)c->object_res * c->object_res * e->n_slots;
   for (int i = 0; i < c->n_envs; ++i) {
     env_t* s = &e->env[i];
     if (height) memcpy(height + nh * i, s->H, nh * sizeof(float));

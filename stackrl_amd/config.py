@@ -49,6 +49,7 @@ class CConfig(ctypes.Structure):
     ('warmstart', ctypes.c_float),
     ('place_at_com', ctypes.c_int32),
     ('orientation_freedom', ctypes.c_int32),
+    ('ordering_freedom', ctypes.c_int32),
   ]
 
 
@@ -85,6 +86,7 @@ class StackConfig:
   warmstart: float = 0.85
   place_at_com: bool = True
   orientation_freedom: int = 0        # TestStackEnv (Stack-v2, env.py:443-470): 2**k yaw orientations; 0 = Stack-v0
+  ordering_freedom: bool = False      # TestStackEnv: all rocks on show from the start, the action picks the next one
 
   def __post_init__(self):
     if not 0 <= int(self.orientation_freedom) <= 4:
@@ -120,6 +122,12 @@ class StackConfig:
   @property
   def n_orientations(self):
     return 2 ** int(self.orientation_freedom)               # observer.py:127
+
+  @property
+  def n_object_maps(self):
+    """Object maps per observation: the orientations of the pending rock, or with ordering freedom those of every rock
+    of the episode (env.py:472-480; the maps of placed rocks are empty and sit at the end)."""
+    return self.n_orientations * (self.episode_length if self.ordering_freedom else 1)
 
   @property
   def metric_id(self):
@@ -167,6 +175,7 @@ class StackConfig:
       angular_damping=self.angular_damping, warmstart=self.warmstart,
       place_at_com=int(bool(self.place_at_com)),
       orientation_freedom=int(self.orientation_freedom),
+      ordering_freedom=int(bool(self.ordering_freedom)),
     )
 
   @classmethod

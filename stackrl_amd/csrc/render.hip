@@ -265,7 +265,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   }
   const int rr = P.c.object_res * P.c.object_res * P.n_orient;   // all observable orientations of the pending rock
   float om_pref[2] = {0.0f, 0.0f};
-  if (!ext && pending >= 0) {
+  if (!ext && pending >= 0 && !P.c.ordering_freedom) {
 #pragma unroll
     for (int k = 0; k < 2; ++k)
       if (tid + k * SRL_RENDER_THREADS < rr) om_pref[k] = P.objmap[(size_t)pending * rr + tid + k * SRL_RENDER_THREADS];
@@ -620,7 +620,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   RSTAMP(5);
   if (ext) return;
   // ---- object observation (O2 from the per-mesh cache, requested at kernel start; empty map when nothing is pending)
-  {
+  if (!P.c.ordering_freedom) {
     uint8_t* oo = obs_obj + (size_t)e * rr;
     const float empty = elev_object(P, 1.0f);
 #pragma unroll
@@ -630,6 +630,26 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     }
     for (int idx = tid + 2 * SRL_RENDER_THREADS; idx < rr; idx += SRL_RENDER_THREADS)
       oo[idx] = (uint8_t)(((pending >= 0 ? P.objmap[(size_t)pending * rr + idx] : empty) * 255.0f) / den);
+  } else {
+    // ordering freedom (observer.py:310-327): the maps of the rocks still unplaced, in list order, then empty maps;
+    // four pixels per lane (the map size is a multiple of 4)
+    const int shown = P.c.episode_length, left = h->list_pos;
+    uint32_t* oo = (uint32_t*)(obs_obj + (size_t)e * rr * shown);
+    const float empty = elev_object(P, 1.0f);
+    const uint32_t eb = (uint8_t)((empty * 255.0f) / den), eb4 = eb * 0x01010101u;
+    for (int k = 0; k < shown; ++k) {
+      const int m = k < left ? h->ids[k] : -1;
+      const float4* src = (const float4*)(P.objmap + (size_t)(m < 0 ? 0 : m) * rr);
+      for (int idx = tid; idx < rr / 4; idx += SRL_RENDER_THREADS) {
+        uint32_t w = eb4;
+        if (m >= 0) {
+          const float4 v = src[idx];
+          w = (uint32_t)(uint8_t)((v.x * 255.0f) / den) | ((uint32_t)(uint8_t)((v.y * 255.0f) / den) << 8) |
+              ((uint32_t)(uint8_t)((v.z * 255.0f) / den) << 16) | ((uint32_t)(uint8_t)((v.w * 255.0f) / den) << 24);
+        }
+        oo[(size_t)k * (rr / 4) + idx] = w;
+      }
+    }
   }
   // ---- halving tree over the 512 partials: cross-wave stages through LDS, in-wave stages by shuffles
   L.pi[tid] = spi; L.pu[tid] = spu;

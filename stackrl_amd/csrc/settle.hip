@@ -106,7 +106,7 @@ __device__ void env_reset(const DevParams& P, EnvHdr* h, int e) {
   h->nb = 0;
   h->ncolour = -1;
   h->pending = h->ids[0];
-  h->list_pos = 1;
+  h->list_pos = P.c.ordering_freedom ? L : 1;   // ordering freedom: the rocks still unplaced are ids[0 .. list_pos)
   h->prev_metric = 0.0f;   // rewarder.py:191-194
   h->substeps[0] = 0; h->substeps[1] = 0;
   h->status = 0;
@@ -727,8 +727,14 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
       mode = 1;
     } else {
       int64_t a = action[e];
-      int oi = 0;                             // TestStackEnv: action = (orientation index, pixel), env.py:485-494
-      if (P.n_orient > 1 && a >= 0) { oi = (int)(a / (int64_t)P.A); a = oi < P.n_orient ? a % (int64_t)P.A : -1; }
+      int oi = 0, slot = 0;                   // TestStackEnv: action = (observation index, pixel), env.py:485-494
+      if (P.n_slots > 1 && a >= 0) {
+        // the index addresses the object maps on show: n_orient of the pending rock, or n_orient of every unplaced rock
+        const int nvalid = P.c.ordering_freedom ? h->list_pos * P.n_orient : P.n_orient;
+        slot = (int)(a / (int64_t)P.A);
+        a = slot < nvalid ? a % (int64_t)P.A : -1;
+        oi = slot % P.n_orient;
+      }
       misc[M_ORIENT] = oi;
       if (a < 0 || a >= (int64_t)P.A) {       // env.py:238
         h->status |= SRL_ST_BAD_ACTION;
@@ -739,12 +745,19 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
         mode = 0;
         misc[M_U] = (int)(a / P.AW);          // env.py:240-241
         misc[M_V] = (int)(a % P.AW);
-        int next = -1;
-        if (h->list_pos < P.c.episode_length) next = h->ids[h->list_pos++];   // env.py:243-247
+        int next = -1, placed = h->pending;
+        if (P.c.ordering_freedom) {           // TestSimulator.step: pop the chosen rock (simulator.py:372-378)
+          const int rk = slot / P.n_orient;
+          placed = h->ids[rk];
+          for (int k = rk; k + 1 < h->list_pos; ++k) h->ids[k] = h->ids[k + 1];
+          h->list_pos -= 1;
+          if (h->list_pos == 0) h->done = 1;  // env.py:513-514: no objects left
+          else next = h->ids[0];
+        } else if (h->list_pos < P.c.episode_length) next = h->ids[h->list_pos++];   // env.py:243-247
         else h->done = 1;
         misc[M_NEXT] = next;
         misc[M_NB] = h->nb;
-        misc[M_PENDING] = h->pending;
+        misc[M_PENDING] = placed;
         misc[M_NCOL] = h->ncolour;
         misc[M_STATUS] = h->status;
         misc[M_ZMAX] = (int)f2o(-1e30f);
@@ -903,7 +916,9 @@ extern "C" __global__ void srl_k_sample(DevParams P, int64_t* __restrict__ actio
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.c.n_envs) return;
   uint32_t key = P.seed + (uint32_t)P.c.env_index_offset + (uint32_t)i;
-  action[i] = (int64_t)srl_rng_below(srl_rng(key, P.sample_counter, SRL_STREAM_ACTION, 0), (uint32_t)(P.A * P.n_orient));
+  int nvalid = P.n_orient;   // object maps on show: with ordering freedom those of the rocks still unplaced
+  if (P.c.ordering_freedom) { const int left = P.hdr[i].list_pos; nvalid *= left > 0 ? left : 1; }
+  action[i] = (int64_t)srl_rng_below(srl_rng(key, P.sample_counter, SRL_STREAM_ACTION, 0), (uint32_t)(P.A * nvalid));
 }
 
 // ------------------------------------------------------------------ telemetry reduction

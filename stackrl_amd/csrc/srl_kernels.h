@@ -18,7 +18,8 @@ struct EnvHdr {
   int32_t nb;                   // placed bodies
   int32_t done;                 // StackEnv._done (env.py:219-220)
   uint32_t episode;             // episode counter (RNG key part)
-  int32_t list_pos;             // next index into ids (episode_list.pop, env.py:243-247)
+  int32_t list_pos;             // next index into ids (episode_list.pop, env.py:243-247); with ordering freedom the
+                                // number of rocks still unplaced: ids[0 .. list_pos) (simulator.py:343-378)
   int32_t pending;              // mesh id waiting at the spawn pose, -1 = none (Simulator._new)
   int32_t mode;                 // what the last step did: 0 placement, 1 reset, 2 rejected action
   int32_t goal[4];              // u, v, h, w (rewarder.py:255-257)
@@ -63,6 +64,7 @@ struct DevParams {
   // observable orientations of the pending rock (TestStackEnv, observer.py:127-140): quaternion i = inverse of the yaw
   // i * 2 pi / n_orient ("orientation of the object relative to the view"); n_orient = 1: identity only (Stack-v0)
   int32_t n_orient;
+  int32_t n_slots;        // object maps per observation: n_orient, or episode_length * n_orient with ordering freedom
   float orient_q[SRL_MAX_ORIENT][4];
   // depth codec of the overhead camera as a table (srl_k_codec_table): the ray-cast height z enters the codec only as
   // t = fl(FAR - z), a float32 in [512, 1024) and therefore on a lattice of 2^-14 — codec_h[k] / codec_b[k] hold the

@@ -91,6 +91,8 @@ int derive(DevParams& P) {
   if (c.orientation_freedom < 0 || (1 << c.orientation_freedom) > SRL_MAX_ORIENT)
     return fail(SRL_EINVAL, "orientation_freedom must be in 0..4");
   P.n_orient = 1 << c.orientation_freedom;                                     // observer.py:127
+  if (c.ordering_freedom != 0 && c.ordering_freedom != 1) return fail(SRL_EINVAL, "ordering_freedom must be 0 or 1");
+  P.n_slots = c.ordering_freedom ? c.episode_length * P.n_orient : P.n_orient;  // env.py:472-480
   for (int i = 0; i < P.n_orient; ++i) {   // inverse of getQuaternionFromEuler([0, 0, i 2 pi / n]) (observer.py:129-139)
     const double half = -0.5 * ((double)i * 2.0 * 3.14159265358979323846 / (double)P.n_orient);
     P.orient_q[i][0] = 0.0f; P.orient_q[i][1] = 0.0f;
@@ -202,6 +204,7 @@ int srl_config_default(srl_config* c) {
   c->linear_damping = 0.04f; c->angular_damping = 0.04f; c->warmstart = 0.85f;
   c->place_at_com = 1;
   c->orientation_freedom = 0;
+  c->ordering_freedom = 0;
   return SRL_OK;
 }
 
@@ -531,14 +534,19 @@ int srl_get_maps(srl_env* env, float* height, float* object_map, int32_t* goal_r
     for (int i = 0; i < n; ++i) {
       if (goal_rect) for (int k = 0; k < 4; ++k) goal_rect[4 * i + k] = h[i].goal[k];
       if (object_map) {
-        const size_t per = (size_t)P.n_orient * r * r;   // every observable orientation of the pending rock
-        float* o = object_map + (size_t)i * per;
-        if (h[i].pending >= 0) {
-          HIP_TRY(hipMemcpy(o, env->d_objmap + (size_t)h[i].pending * per, sizeof(float) * per, hipMemcpyDeviceToHost));
-        } else {
-          // empty map = elev_object(1.0), evaluated like the kernel does
-          float e0 = P.obj_c1 - P.obj_c2 / (SRL_FAR + P.c.object_max_dimension * (0.5f - 1.0f));
-          for (size_t k = 0; k < per; ++k) o[k] = e0;
+        const size_t per = (size_t)P.n_orient * r * r;   // every observable orientation of one rock
+        // the pending rock, or with ordering freedom every rock still unplaced, then empty maps (observer.py:310-327)
+        const int shown = P.c.ordering_freedom ? P.c.episode_length : 1;
+        for (int k = 0; k < shown; ++k) {
+          float* o = object_map + ((size_t)i * shown + k) * per;
+          const int m = P.c.ordering_freedom ? (k < h[i].list_pos ? h[i].ids[k] : -1) : h[i].pending;
+          if (m >= 0) {
+            HIP_TRY(hipMemcpy(o, env->d_objmap + (size_t)m * per, sizeof(float) * per, hipMemcpyDeviceToHost));
+          } else {
+            // empty map = elev_object(1.0), evaluated like the kernel does
+            float e0 = P.obj_c1 - P.obj_c2 / (SRL_FAR + P.c.object_max_dimension * (0.5f - 1.0f));
+            for (size_t kk = 0; kk < per; ++kk) o[kk] = e0;
+          }
         }
       }
     }

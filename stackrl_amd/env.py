@@ -74,12 +74,13 @@ class VecStackEnv(object):
                                        _np_ptr(p.tri_off), _np_ptr(p.mass_com), len(p)))
     B, H, h = self.config.n_envs, self.config.overhead_res, self.config.object_res
     # TestStackEnv (env.py:443-470): one object map per observable orientation, action = orientation * A + pixel
-    self._no = self.config.n_orientations
+    self._no = self.config.n_object_maps   # with ordering freedom: the maps of every rock of the episode (empty once placed)
     self._observation_spec = (TensorSpec((H, H, 2), torch.uint8),
                               TensorSpec((h, h, 1) if self._no == 1 else (self._no, h, h, 1), torch.uint8))
     self._action_spec = TensorSpec((), torch.int64)
     self._B, self._H, self._hh = B, H, h
     self._closed = False
+    self._left = 0          # rocks of the running episode not yet placed (host mirror of the lock-step episode machine)
     self._side = torch.cuda.Stream(device=self._device) if side_stream else None
     self.seed(seed if seed is not None else 0)
 
@@ -103,6 +104,15 @@ class VecStackEnv(object):
   @property
   def n_actions(self):
     return self.config.n_actions * self._no
+
+  @property
+  def num_maps_on_show(self):
+    """Object maps that hold a rock in the latest observation (`Observer.num_objects`, observer.py:370-376, as
+    env.py:596-608 uses it to size the spaces): an action's index must be below this.  Every env of the batch is at
+    the same point of its episode, so this is one number (valid once the latest step has been waited for)."""
+    if self.config.ordering_freedom:
+      return self._left * self.config.n_orientations
+    return self.config.n_orientations if self._left > 0 else 0
 
   def __call__(self, *args, **kwargs):
     return self.step(*args, **kwargs)
@@ -167,6 +177,7 @@ class VecStackEnv(object):
     self._fork()
     with torch.cuda.device(self._device):
       _check(self._lib.srl_reset(self._h, om.data_ptr(), oo.data_ptr(), self._stream()))
+    self._left = self.config.episode_length
     out = ((om, oo), torch.zeros(self._B, dtype=torch.float32, device=self._device),
            torch.zeros(self._B, dtype=torch.bool, device=self._device))     # utils.py:545-552
     wait = self._finish(out)
@@ -186,6 +197,7 @@ class VecStackEnv(object):
     with torch.cuda.device(self._device):
       _check(self._lib.srl_step(self._h, action.data_ptr(), om.data_ptr(), oo.data_ptr(), reward.data_ptr(),
                                 done.data_ptr(), self._stream()))
+    self._left = self.config.episode_length if self._left == 0 else self._left - 1   # env.py:235-236: auto-reset
     if self._side is not None:
       for t in (om, oo, reward, done, action):
         t.record_stream(self._side)
@@ -233,7 +245,8 @@ class VecStackEnv(object):
     return Hm, Om, g
 
   def object_map(self, mesh_id):
-    o = np.zeros((self._hh, self._hh) if self._no == 1 else (self._no, self._hh, self._hh), np.float32)
+    k = self.config.n_orientations
+    o = np.zeros((self._hh, self._hh) if k == 1 else (k, self._hh, self._hh), np.float32)
     _check(self._lib.srl_get_object_map(self._h, int(mesh_id), _np_ptr(o)))
     return o
 
@@ -310,14 +323,12 @@ class StartedVecStackEnv(VecStackEnv):
 def make(env='Stack-v0', n_parallel=None, block=None, seed=None, **kwargs):
   """`stackrl.envs.make` (utils.py:44-141): 'Stack-v0' (envs/stack/__init__.py:4-8), 'Stack-v1' (`StartedStackEnv`,
   env.py:348-441) and 'Stack-v2' (`TestStackEnv`, env.py:443-470, with its default `orientation_freedom=3`;
-  `ordering_freedom` is not built)."""
+  `ordering_freedom=True` shows every rock of the episode and lets the action choose the next one)."""
   urdfs = kwargs.pop('urdfs', None)                      # env.py:92-103: which irregularity families the episode draws from
   if urdfs is not None:
     from stackrl_amd import assets
     kwargs['pool'] = (kwargs.get('pool') or assets.default_pool()).select(urdfs)
   if env == 'Stack-v2':
-    if kwargs.pop('ordering_freedom', False):
-      raise ValueError('ordering_freedom=True (TestSimulator) is not implemented')
     kwargs.setdefault('orientation_freedom', 3)
   elif env == 'Stack-v1':
     return StartedVecStackEnv(n_parallel=n_parallel or 1, block=block, seed=seed, **kwargs)

@@ -45,8 +45,14 @@ class OrientationGreedy(object):
     self.model, self.value, self.minimize = model, value, minimize
 
   @torch.no_grad()
-  def __call__(self, inputs):
+  def __call__(self, inputs, n_valid=None):
+    """`n_valid` (ordering freedom): only the first `n_valid` object maps hold a rock (`env.num_maps_on_show`); the
+    reference's observation simply has no more rows than that (env.py:596-608)."""
     B, n = inputs[1].shape[0], inputs[1].shape[1]
-    values = self.model(expand_orientations(inputs)).reshape(B, -1)         # [B, n * A]
+    values = self.model(expand_orientations(inputs)).reshape(B, n, -1)      # [B, n, A]
+    if n_valid is not None and n_valid < n:
+      values = values.clone()
+      values[:, n_valid:] = float('inf') if self.minimize else -float('inf')
+    values = values.reshape(B, -1)                                          # [B, n * A]
     actions = torch.argmin(values, dim=-1) if self.minimize else torch.argmax(values, dim=-1)
     return (actions, values) if self.value else actions

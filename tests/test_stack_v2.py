@@ -190,3 +190,131 @@ def test_stack_v1_starts_episodes_with_placed_rocks_and_curriculum_selects_famil
   assert len(stages[0][0].pool) == 1000
   for e, _ in stages:
     e.reset(); e.step(e.sample()); e.close()
+
+
+# ---- ordering freedom (TestStackEnv(ordering_freedom=True), env.py:443-470; TestSimulator, simulator.py:343-378)
+def _ordering_cfg(n, L, k, **kw):
+  return StackConfig(n_envs=n, episode_length=L, orientation_freedom=k, ordering_freedom=True, **kw)
+
+
+@pytest.mark.parametrize('k', [0, 2])
+def test_ordering_freedom_equals_the_plain_episode_with_the_chosen_order(oracle_mod, ref_pool, k):
+  """Choosing rocks c_1 .. c_L from the list on show gives, step for step, the episode whose list is already in that
+  order: same height maps, rewards, poses and done flags; the object maps on show are those of the unplaced rocks in
+  list order followed by empty maps (observer.py:310-352)."""
+  n, L, M = 3, 5, 2 ** k
+  rng = np.random.RandomState(7)
+  ids = np.stack([rng.choice(len(ref_pool), L, replace=False) for _ in range(n)]).astype(np.int32)
+  goal = np.tile(np.array([[30, 40, 64, 64]], np.int32), (n, 1))
+  A = StackConfig().n_actions
+  free = oracle_mod.OracleEnv(_ordering_cfg(n, L, k), ref_pool, seed=3)
+  free.set_script(ids, goal)
+  (fm, fo), _, _ = free.reset()
+  assert fo.shape == (n, L * M, 32, 32, 1)
+  # the choices: a random rock of those left, a random orientation, a random pixel
+  left = [list(r) for r in ids]
+  order = np.zeros((n, L), np.int32)
+  steps = []
+  for t in range(L):
+    rock = np.array([rng.randint(len(left[i])) for i in range(n)])
+    ori = rng.randint(M, size=n)
+    pix = rng.randint(A, size=n)
+    for i in range(n):
+      order[i, t] = left[i].pop(rock[i])
+    steps.append((rock, ori, pix))
+  plain = oracle_mod.OracleEnv(StackConfig(n_envs=n, episode_length=L, orientation_freedom=k), ref_pool, seed=3)
+  plain.set_script(order, goal)
+  (pm, po), _, _ = plain.reset()
+  assert np.array_equal(fm, pm)
+  left = [list(r) for r in ids]
+  for t, (rock, ori, pix) in enumerate(steps):
+    # what is on show: the maps of the rocks left, rock-major; the plain env shows the maps of the rock chosen now
+    po = po.reshape(n, M, 32, 32, 1)
+    for i in range(n):
+      assert np.array_equal(fo[i, rock[i] * M:(rock[i] + 1) * M], po[i])
+      assert not fo[i, len(left[i]) * M:].any()
+      left[i].pop(rock[i])
+    (fm, fo), fr, fd = free.step((rock * M + ori).astype(np.int64) * A + pix)
+    (pm, po), pr, pd = plain.step(ori.astype(np.int64) * A + pix)
+    assert free.rc == 0 and plain.rc == 0
+    assert np.array_equal(fm, pm) and np.array_equal(fr, pr) and np.array_equal(fd, pd)
+    assert np.array_equal(free.state()[0], plain.state()[0])
+    assert list(fd) == [t == L - 1] * n
+  assert not fo.any()                                            # nothing left to show (env.py:513-514)
+  (fm, fo), fr, fd = free.step(np.zeros(n, np.int64))            # auto-reset call (env.py:482-483)
+  assert not fd.any() and not fr.any() and fo[:, :L * M].any()
+
+
+def test_ordering_freedom_rejects_indices_of_placed_rocks(oracle_mod, ref_pool):
+  n, L, k = 2, 3, 1
+  o = oracle_mod.OracleEnv(_ordering_cfg(n, L, k), ref_pool, seed=3)
+  o.reset()
+  A = o.cfg.n_actions
+  o.step(np.array([0, (L * 2 - 1) * A + 5], np.int64))            # both valid: 3 rocks x 2 orientations on show
+  assert o.rc == 0
+  o.step(np.array([(2 * 2) * A, (2 * 2 - 1) * A], np.int64))      # env 0: index 4 of 4 on show -> env.py:484 assert
+  assert o.rc == 2
+  _, nb, _, st = o.state()
+  assert list(nb) == [1, 2] and (st[0] & 4) and not (st[1] & 4)
+  for _ in range(20):                                            # sample() stays inside what is on show
+    a = o.sample()
+    assert (a // A < (L - nb) * 2).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k,L', [(1, 4), (0, 8), (3, 3)])
+def test_ordering_freedom_gpu_matches_oracle_bit_for_bit(oracle_mod, ref_pool, k, L):
+  import torch
+  from stackrl_amd import env as envs
+  n, M = 24, 2 ** k
+  g = envs.make('Stack-v2', n_parallel=n, seed=21, pool=ref_pool, block=True, episode_length=L, orientation_freedom=k,
+                ordering_freedom=True)
+  o = oracle_mod.OracleEnv(_ordering_cfg(n, L, k), ref_pool, seed=21)
+  assert g.observation_spec[1].shape == (L * M, 32, 32, 1) and g.n_actions == L * M * 9409
+  (gm, go), _, _ = g.reset()
+  (om, oo), _, _ = o.reset()
+  assert np.array_equal(gm.cpu().numpy(), om) and np.array_equal(go.cpu().numpy(), oo)
+  assert np.array_equal(g.maps()[1], o.maps()[1])               # float maps of everything on show
+  assert g.num_maps_on_show == L * M
+  picked = set()
+  for t in range(2 * (L + 1)):
+    a = g.sample()
+    assert np.array_equal(a.cpu().numpy(), o.sample())
+    picked.update((a.cpu().numpy() // 9409 // M).tolist())
+    (gm, go), gr, gd = g.step(a)
+    (om, oo), orr, od = o.step(a.cpu().numpy())
+    assert np.array_equal(gm.cpu().numpy(), om) and np.array_equal(go.cpu().numpy(), oo)
+    assert np.array_equal(gd.cpu().numpy().astype(bool), od) and np.array_equal(gr.cpu().numpy(), orr)
+    gp, gn, gs, gst = g.state()
+    op, on, os_, ost = o.state()
+    assert np.array_equal(gn, on) and np.array_equal(gs, os_) and np.array_equal(gp, op)
+    assert np.array_equal(g.maps()[1], o.maps()[1])
+    left = L - int(gn[0]) if not od[0] else 0
+    assert g.num_maps_on_show == (L * M if t % (L + 1) == L else left * M)
+  assert len(picked) > 1                                        # rocks other than the first on show were chosen
+  # an index past the maps on show is an invalid action (env.py:484)
+  g.reset(); g.step(g.sample())
+  bad = torch.full((n,), (L - 1) * M * 9409, dtype=torch.int64)
+  with pytest.raises(AssertionError):
+    g.step(bad)
+  g.close()
+
+
+@pytest.mark.gpu
+def test_greedy_policy_masks_maps_without_a_rock(ref_pool):
+  import torch
+  from stackrl_amd import env as envs, policies
+  n, L, k = 4, 3, 1
+  g = envs.make('Stack-v2', n_parallel=n, seed=2, pool=ref_pool, block=True, episode_length=L, orientation_freedom=k,
+                ordering_freedom=True)
+  A = 9409
+  model = lambda inp: inp[1].float().flatten(1).sum(1, keepdim=True).expand(-1, A) * 0 + \
+      torch.arange(inp[1].shape[0], device=inp[1].device, dtype=torch.float32)[:, None] % (L * 2 ** k)   # prefers the last map
+  pol = policies.OrientationGreedy(model)
+  obs, _, _ = g.reset()
+  for t in range(L):
+    a = pol(obs, n_valid=g.num_maps_on_show)
+    assert (a // A == g.num_maps_on_show - 1).all()               # the last map that still holds a rock
+    obs, _, d = g.step(a)
+  assert d.all()
+  g.close()
