@@ -19,6 +19,9 @@ extern "C" {
 #define SRL_MAX_BODIES 32      /* episode_length <= 32 (BASELINE configs: 8/16/32) */
 #define SRL_MAX_VERTS 128      /* reference pool: 24..70 vertices per rock        */
 #define SRL_MAX_TRIS 252       /* reference pool: 44..136 triangles per rock      */
+#define SRL_ACTION_HOLD (-2)  /* action value: the env sits this call out (no placement, no auto-reset; observation
+                                 unchanged, reward 0, done 0) — lets the host run the start placements of the envs that
+                                 were just reset (`StartedStackEnv.reset`, env.py:436-440) while the others wait */
 #define SRL_MAX_ORIENT 16      /* 2^orientation_freedom <= 16                     */
 
 /* Reward metrics, rewarder.py:7-14. */

@@ -1365,6 +1365,11 @@ int srlo_step(srlo_env* e, const int64_t* action, uint8_t* obs_map, uint8_t* obs
   int rc = SRL_OK;
   for (int i = 0; i < c->n_envs; ++i) {
     env_t* s = &e->env[i];
+    if (action[i] == (int64_t)SRL_ACTION_HOLD) {         /* the env sits this call out (srl_types.h) */
+      reward[i] = 0.0f; done[i] = 0;
+      pack_obs(e, s, obs_map + nm * i, obs_obj + no * i);
+      continue;
+    }
     if (s->done) {                                       /* env.py:235-236 */
       env_reset(e, i);
       reward[i] = 0.0f; done[i] = 0;

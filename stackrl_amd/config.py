@@ -8,6 +8,7 @@ the values of `config.gin` that BASELINE config 1 needs are exposed by `StackCon
 import ctypes
 import dataclasses
 
+ACTION_HOLD = -2      # SRL_ACTION_HOLD (include/srl_types.h)
 MAX_BODIES = 32
 MAX_VERTS = 128
 MAX_TRIS = 252

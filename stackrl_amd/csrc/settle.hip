@@ -722,7 +722,9 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
 
   if (tid == 0) {
     int mode;
-    if (force_reset || h->done) {            // env.py:235-236 auto-reset
+    if (!force_reset && action[e] == (int64_t)SRL_ACTION_HOLD) {
+      mode = 3;                               // this env sits the call out (srl_types.h)
+    } else if (force_reset || h->done) {     // env.py:235-236 auto-reset
       env_reset(P, h, e);
       mode = 1;
     } else {
@@ -774,7 +776,7 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
     for (int k = tid; k < P.NS; k += T) gi[P.OFF_POS + k] = -1;
     return;
   }
-  if (mode == 2) return;
+  if (mode == 2 || mode == 3) return;
 
   // ---- load the persistent blob into LDS
   for (int k = tid; k < P.BLOB; k += T) sm[k] = gblob[k];

@@ -11,6 +11,7 @@ All arithmetic happens in libstackrl_hip.so; torch only owns device memory and s
 """
 import collections
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -275,17 +276,21 @@ class StartedVecStackEnv(VecStackEnv):
   `episode_length` placements.  The default start policy is the reference's: the lowest placement whose footprint
   lies fully inside the goal (env.py:391-417), evaluated by the heuristic kernels (csrc/heuristics.hip).
   The batch runs in lock step (same episode length everywhere), so the auto-reset call of `step` (env.py:235-236)
-  performs the start placements for all envs at once; `min_episode_length` (per-env random lengths) is not built."""
+  performs the start placements for all envs at once.  With `min_episode_length` every episode draws its own number
+  of start placements (env.py:384-387), so the envs finish at different calls: the start placements of the envs a
+  call has just reset run inside that call while the others are held (`SRL_ACTION_HOLD`); this mode waits for every
+  step (it needs the done flags on the host)."""
 
   def __init__(self, n_parallel=None, episode_length=15, n_objects=30, start_policy=None, min_episode_length=None,
                **kwargs):
     if n_objects < episode_length:
       raise ValueError("n_objects can't be less than episode_length. Got {} objects for {} steps long episodes.".format(
         n_objects, episode_length))                                            # env.py:375-378
-    if min_episode_length and min_episode_length < episode_length:
-      raise ValueError('min_episode_length (random episode lengths) is not implemented')
+    self._random_lengths = bool(min_episode_length and min_episode_length < episode_length)
+    self._lower, self._upper = int(n_objects) - int(episode_length), int(n_objects) - int(min_episode_length or 0)
     super(StartedVecStackEnv, self).__init__(n_parallel=n_parallel, episode_length=n_objects, **kwargs)
     self._n_start_steps = int(n_objects) - int(episode_length)
+    self._done_prev = None
     if start_policy is None:
       from stackrl_amd import baselines
       # lowest position with the object fully inside the goal: `height` values under the goal-overlap mask
@@ -299,6 +304,24 @@ class StartedVecStackEnv(VecStackEnv):
   def n_start_steps(self):
     return self._n_start_steps
 
+  def seed(self, seed):
+    self._len_rng = np.random.RandomState(int(seed) % 2**32)   # the episode-length draws (env.py:387)
+    return super(StartedVecStackEnv, self).seed(seed)
+
+  def _start_random(self, step, fresh):
+    """Start placements of the envs `fresh` (bool [B]) marks as just reset, each with its own count drawn from
+    [n_objects - episode_length, n_objects - min_episode_length] (env.py:384-387); the others are held."""
+    (om, oo), r, d = step
+    counts = torch.from_numpy(self._len_rng.randint(self._lower, self._upper + 1, size=self._B)).to(self._device)
+    todo = torch.where(fresh, counts, torch.zeros_like(counts))
+    hold = torch.full((self._B,), _config.ACTION_HOLD, dtype=torch.int64, device=self._device)
+    for j in range(int(todo.max())):
+      a = torch.where(todo > j, self._start_policy((om, oo)).to(torch.int64), hold)
+      (om, oo), _, _ = super(StartedVecStackEnv, self).step(a, block=True)   # a held env's observation does not change
+    self.last_start_steps = todo
+    keep = ~fresh
+    return (om, oo), r * keep, d & keep
+
   def _start(self, step):
     for _ in range(self._n_start_steps):
       step = super(StartedVecStackEnv, self).step(self._start_policy(step[0]), block=True)
@@ -306,12 +329,23 @@ class StartedVecStackEnv(VecStackEnv):
     return (step[0], torch.zeros_like(step[1]), torch.zeros_like(step[2]))
 
   def reset(self, block=None):
-    out = self._start(super(StartedVecStackEnv, self).reset(block=True))
+    out = super(StartedVecStackEnv, self).reset(block=True)
+    if self._random_lengths:
+      out = self._start_random(out, torch.ones(self._B, dtype=torch.bool, device=self._device))
+      self._done_prev = out[2]
+    else:
+      out = self._start(out)
     block = self._block if block is None else block
     return out if block else (lambda: out)
 
   def step(self, action, block=None):
     block = self._block if block is None else block
+    if self._random_lengths:
+      out = super(StartedVecStackEnv, self).step(action, block=True)
+      fresh, self._done_prev = self._done_prev, out[2]
+      if bool(fresh.any()):       # this call was the auto-reset of those envs (env.py:235-236)
+        out = self._start_random(out, fresh)
+      return out if block else (lambda: out)
     if self._since_reset == self.config.episode_length - self._n_start_steps:
       # every env is done: this call is the auto-reset (env.py:235-236), followed by the start placements
       out = self._start(super(StartedVecStackEnv, self).step(action, block=True))
@@ -320,10 +354,50 @@ class StartedVecStackEnv(VecStackEnv):
     return super(StartedVecStackEnv, self).step(action, block=block)
 
 
-def make(env='Stack-v0', n_parallel=None, block=None, seed=None, **kwargs):
+# constructor arguments of the reference's entry points, in signature order, with the registry's kwargs applied
+# (env.py:28-51, :349-357, :444-449; envs/stack/__init__.py:4-27) — what `make(as_path=True)` names a directory after
+_REF_ARGS = (('episode_length', 30), ('urdfs', '[5-9]?'), ('object_max_dimension', 0.125), ('use_gui', False),
+             ('simulator', None), ('sim_time_step', 1 / 100.), ('gravity', 9.8), ('num_sim_steps', None),
+             ('velocity_threshold', 0.01), ('smooth_placing', True), ('observer', None), ('observable_size_ratio', 4),
+             ('resolution_factor', 5), ('max_z', 0.375), ('rewarder', None), ('goal_size_ratio', .25),
+             ('reward_scale', 1.), ('reward_params', 2), ('flat_action', True), ('dtype', 'uint8'), ('seed', None))
+_REF_ENTRY = {
+  'Stack-v0': ('StackEnv', _REF_ARGS),
+  # StartedStackEnv / TestStackEnv take their own arguments and pass the rest on as **kwargs, so only those appear
+  # in the signature the reference inspects (utils.py:104-108)
+  'Stack-v1': ('StartedStackEnv', (('episode_length', 15), ('min_episode_length', None), ('n_objects', 30),
+                                   ('start_policy', None), ('flat_action', True), ('kwargs', None),
+                                   ('urdfs', '[5-9]?'), ('reward_params', 2), ('dtype', 'uint8'))),
+  'Stack-v2': ('TestStackEnv', (('ordering_freedom', False), ('orientation_freedom', 3), ('kwargs', None),
+                                ('urdfs', '[5-9]?'), ('reward_params', 2), ('dtype', 'uint8'))),
+}
+
+
+def env_path(env='Stack-v0', **kwargs):
+  """`make(as_path=True)` (utils.py:89-127): the directory name that identifies an env configuration — the entry
+  point's class name, then one `<short name><value>` item per argument (all but `seed`): a name of several words is
+  shortened to the first letter of the first and three letters of the last, a single word to four letters."""
+  if env not in _REF_ENTRY:
+    raise ValueError('Invalid env {}'.format(env))
+  name, args = _REF_ENTRY[env]
+  args = dict(args)
+  args.update(kwargs)
+  items = []
+  for k, v in args.items():
+    if k == 'seed':
+      continue
+    k = k.split('_')
+    k = k[0][:1] + k[-1][:3] if len(k) > 1 else k[0][:4]
+    items.append(k + str(v))
+  return os.path.join(name, ','.join(items).replace(' ', '').replace("'", '').replace('"', ''))
+
+
+def make(env='Stack-v0', n_parallel=None, block=None, seed=None, as_path=False, **kwargs):
   """`stackrl.envs.make` (utils.py:44-141): 'Stack-v0' (envs/stack/__init__.py:4-8), 'Stack-v1' (`StartedStackEnv`,
   env.py:348-441) and 'Stack-v2' (`TestStackEnv`, env.py:443-470, with its default `orientation_freedom=3`;
   `ordering_freedom=True` shows every rock of the episode and lets the action choose the next one)."""
+  if as_path:
+    return env_path(env, **kwargs)
   urdfs = kwargs.pop('urdfs', None)                      # env.py:92-103: which irregularity families the episode draws from
   if urdfs is not None:
     from stackrl_amd import assets

@@ -455,3 +455,79 @@ def test_curriculum_moves_on_when_the_goal_return_is_reached(tmp_path):
   # a generator without goals is rejected (training.py:124-125)
   with pytest.raises(ValueError):
     Trainer(((e, None) for e in [_ToyEnv(B, L, spec)]), _toy_agent(spec, B, seed=3))
+
+
+def test_env_path_names_follow_the_reference_rule():
+  """`make(as_path=True)` (utils.py:89-127): first letter + three letters of the last word, or four letters."""
+  from stackrl_amd import env as envs
+  p = envs.make(as_path=True)
+  assert p.startswith('StackEnv/elen30,urdf[5-9]?,odim0.125,uguiFalse') and p.endswith('factTrue,dtypuint8') and 'seed' not in p
+  assert envs.make('Stack-v0', as_path=True, episode_length=8, seed=3).split('/')[1].startswith('elen8,')
+  assert envs.make('Stack-v2', as_path=True) == 'TestStackEnv/ofreFalse,ofre3,kwarNone,urdf[5-9]?,rpar2,dtypuint8'
+
+
+def _keras_conv2d_same(x, k, b):
+  """Keras Conv2D(padding='same', activation='relu') on NHWC input with an HWIO kernel, written out."""
+  B, H, W, C = x.shape
+  kh, kw, _, O = k.shape
+  xp = np.pad(x, ((0, 0), (kh // 2, kh // 2), (kw // 2, kw // 2), (0, 0)))
+  out = np.zeros((B, H, W, O), np.float64)
+  for di in range(kh):
+    for dj in range(kw):
+      out += np.einsum('bhwc,co->bhwo', xp[:, di:di + H, dj:dj + W].astype(np.float64), k[di, dj].astype(np.float64))
+  return np.maximum(out + b, 0)
+
+
+def _keras_conv2d_transpose_2x2(x, k, b):
+  """Keras Conv2DTranspose(kernel 2, strides 2, relu) on NHWC input, kernel (kh, kw, out, in)."""
+  B, H, W, C = x.shape
+  O = k.shape[2]
+  out = np.zeros((B, 2 * H, 2 * W, O), np.float64)
+  for di in range(2):
+    for dj in range(2):
+      out[:, di::2, dj::2] = np.einsum('bhwc,oc->bhwo', x.astype(np.float64), k[di, dj].astype(np.float64))
+  return np.maximum(out + b, 0)
+
+
+def test_keras_weight_import_layouts_and_names():
+  import torch
+  from stackrl_amd import nets, keras_weights as kw
+  src = nets.DeepQSiamFCN(seed=1)
+  w = kw.export_keras_weights(src)
+  assert w['Left/convdw00/kernel:0'].shape == (3, 3, 2, 16) and w['Left/up3/kernel:0'].shape == (2, 2, 128, 256)
+  assert w['Right/conv20/kernel:0'].shape == (3, 3, 32, 64) and w['dense/kernel:0'].shape == (256, 256)
+  assert w['dense_1/kernel:0'].shape == (256, 1) and w['conv2d_2/kernel:0'].shape == (1, 1, 16, 1)
+  assert len(w) == 2 * (22 + 12 + 2 + 3)      # Left 22 layers, Right 12, dueling 2, after the correlation 3
+  # automatic names of a later model in the same process (dense_4, dense_5, conv2d_7 ...) resolve by order
+  shifted = {}
+  for k_, v in w.items():
+    k_ = k_.replace('dense_1/', 'dense_5/').replace('dense/', 'dense_4/')
+    for a, b_ in (('conv2d_2/', 'conv2d_9/'), ('conv2d_1/', 'conv2d_8/'), ('conv2d/', 'conv2d_7/')):
+      if k_.startswith(a):
+        k_ = k_.replace(a, b_); break
+    shifted[k_] = v
+  dst = nets.DeepQSiamFCN(seed=2)
+  kw.load_keras_weights(dst, shifted)
+  x = (torch.randint(0, 255, (2, 128, 128, 2), dtype=torch.uint8), torch.randint(0, 255, (2, 32, 32, 1), dtype=torch.uint8))
+  with torch.no_grad():
+    assert torch.equal(src(x), dst(x))
+  # the layouts, against the Keras definitions written out in numpy
+  rng = np.random.RandomState(0)
+  xin = rng.rand(1, 8, 8, 2).astype(np.float32)
+  ref = _keras_conv2d_same(xin, w['Left/convdw00/kernel:0'], w['Left/convdw00/bias:0'])
+  got = torch.relu(dst.left.down[0][0](torch.from_numpy(xin).permute(0, 3, 1, 2))).permute(0, 2, 3, 1).detach().numpy()
+  assert np.allclose(got, ref, atol=1e-5)
+  xin = rng.rand(1, 4, 4, 256).astype(np.float32)
+  ref = _keras_conv2d_transpose_2x2(xin, w['Left/up3/kernel:0'], w['Left/up3/bias:0'])
+  got = torch.relu(dst.left.up[0](torch.from_numpy(xin).permute(0, 3, 1, 2))).permute(0, 2, 3, 1).detach().numpy()
+  assert np.allclose(got, ref, atol=1e-4)
+  xin = rng.rand(3, 256).astype(np.float32)
+  ref = np.maximum(xin.astype(np.float64) @ w['dense/kernel:0'] + w['dense/bias:0'], 0)
+  assert np.allclose(torch.relu(dst.value[0](torch.from_numpy(xin))).detach().numpy(), ref, atol=1e-4)
+  # a checkpoint that does not fit is refused
+  bad = dict(w); bad.pop('Right/up0/bias:0')
+  with pytest.raises(KeyError):
+    kw.load_keras_weights(nets.DeepQSiamFCN(seed=3), bad)
+  bad = dict(w); bad['extra/kernel:0'] = np.zeros(3)
+  with pytest.raises(ValueError):
+    kw.load_keras_weights(nets.DeepQSiamFCN(seed=3), bad)

@@ -318,3 +318,74 @@ def test_greedy_policy_masks_maps_without_a_rock(ref_pool):
     obs, _, d = g.step(a)
   assert d.all()
   g.close()
+
+
+# ---- SRL_ACTION_HOLD and the random episode lengths of StartedStackEnv (env.py:352, :384-387)
+def test_hold_action_leaves_the_env_untouched(oracle_mod, ref_pool):
+  from stackrl_amd.config import ACTION_HOLD
+  n, L = 3, 3
+  o = oracle_mod.OracleEnv(StackConfig(n_envs=n, episode_length=L), ref_pool, seed=4)
+  obs0, _, _ = o.reset()
+  a = o.sample()
+  a[1] = ACTION_HOLD
+  (m1, o1), r1, d1 = o.step(a)
+  assert o.rc == 0 and list(o.state()[1]) == [1, 0, 1]
+  assert np.array_equal(m1[1], obs0[0][1]) and np.array_equal(o1[1], obs0[1][1]) and r1[1] == 0 and not d1[1]
+  for _ in range(L - 1):
+    a = o.sample(); a[1] = ACTION_HOLD
+    _, _, d = o.step(a)
+  assert list(d) == [True, False, True]
+  hold = np.full(n, ACTION_HOLD, np.int64)
+  _, _, d = o.step(hold)                                         # held envs do not auto-reset either
+  assert list(o.state()[1]) == [L, 0, L] and not d.any()
+
+
+@pytest.mark.gpu
+def test_hold_action_gpu_matches_oracle(oracle_mod, ref_pool):
+  import torch
+  from stackrl_amd import env as envs
+  from stackrl_amd.config import ACTION_HOLD
+  n, L = 16, 4
+  g = envs.VecStackEnv(n_parallel=n, seed=9, pool=ref_pool, block=True, episode_length=L)
+  o = oracle_mod.OracleEnv(StackConfig(n_envs=n, episode_length=L), ref_pool, seed=9)
+  g.reset(); o.reset()
+  rng = np.random.RandomState(1)
+  for t in range(4 * L):
+    a = g.sample().cpu().numpy()
+    assert np.array_equal(a, o.sample())
+    a[rng.rand(n) < 0.4] = ACTION_HOLD
+    (gm, go), gr, gd = g.step(torch.from_numpy(a))
+    (om, oo), orr, od = o.step(a)
+    assert np.array_equal(gm.cpu().numpy(), om) and np.array_equal(go.cpu().numpy(), oo)
+    assert np.array_equal(gd.cpu().numpy().astype(bool), od) and np.array_equal(gr.cpu().numpy(), orr)
+    assert np.array_equal(g.state()[0], o.state()[0]) and np.array_equal(g.state()[1], o.state()[1])
+  assert len(set(g.state()[1].tolist())) > 1                     # the envs drifted apart
+  g.close()
+
+
+@pytest.mark.gpu
+def test_stack_v1_random_episode_lengths(ref_pool):
+  import torch
+  from stackrl_amd import env as envs
+  n, N, L, Lmin = 12, 6, 4, 2
+  g = envs.make('Stack-v1', n_parallel=n, seed=5, pool=ref_pool, block=True, n_objects=N, episode_length=L,
+                min_episode_length=Lmin)
+  _, r, d = g.reset()
+  assert not d.any() and not r.any()
+  placed = g.state()[1]
+  assert ((placed >= N - L) & (placed <= N - Lmin)).all() and len(set(placed.tolist())) > 1
+  lengths, run = [], np.zeros(n, int)
+  for t in range(40):
+    nb_before = g.state()[1].copy()
+    _, r, d = g.step(g.sample())
+    d = d.cpu().numpy()
+    nb = g.state()[1]
+    fresh = (nb_before == N)                                      # these were done: the call reset and started them
+    assert ((nb[fresh] >= N - L) & (nb[fresh] <= N - Lmin)).all() and not d[fresh].any() and not r.cpu().numpy()[fresh].any()
+    assert (nb[~fresh] == nb_before[~fresh] + 1).all()            # everyone else placed exactly one rock
+    assert np.array_equal(d, nb == N)
+    run[~fresh] += 1
+    for i in np.nonzero(d)[0]:
+      lengths.append(run[i]); run[i] = 0
+  assert lengths and min(lengths) >= Lmin and max(lengths) <= L and len(set(lengths)) > 1
+  g.close()
