@@ -27,6 +27,7 @@
 // Diagnostic builds only (tools/stamps_render.py, tools/ab_render.py; the outputs of the ablations are wrong by design):
 //   SRL_STAMPS        per-phase wall-clock stamps of thread 0
 //   SRL_ABL_NOSTORE   no H / observation stores     SRL_ABL_NOCAST  no ray cast     SRL_ABL_NOSTAGE  no staging, no ray cast
+//   SRL_ABL_EMPTY     the kernel returns at once (launch + event floor)
 #ifdef SRL_STAMPS
 #define RSTAMP(k) do { if (tid == 0) { long long _t = wall_clock64(); P.hdr[e].rstamps[k] += _t - _t0; _t0 = _t; } } while (0)
 #else
@@ -40,16 +41,16 @@ __device__ __forceinline__ float elev_object(const DevParams& P, float d) {
   return P.obj_c1 - P.obj_c2 / (SRL_FAR + P.c.object_max_dimension * (0.5f - d));
 }
 
-// the overhead depth codec tabulated over the lattice of t = fl(FAR - z) (see DevParams::codec_h)
-extern "C" __global__ void __launch_bounds__(256) srl_k_codec_table(DevParams P, float* __restrict__ th, uint8_t* __restrict__ tb, int n) {
+// the overhead depth codec tabulated over the lattice of t = fl(FAR - z) (see DevParams::codec): entry k < n holds the
+// elevation bits and the observation byte for t = near + k 2^-14; entry n those of a pixel that saw no rock
+extern "C" __global__ void __launch_bounds__(256) srl_k_codec_table(DevParams P, uint2* __restrict__ tab, int n) {
   const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= n) return;
+  if (k > n) return;
   const float nearp = SRL_FAR - P.c.max_z;
   const float den = fmaxf(P.c.max_z, P.c.object_max_dimension);
-  const float t = nearp + (float)k * (1.0f / 16384.0f);   // exact: a lattice point of [512, 1024)
+  const float t = k < n ? nearp + (float)k * (1.0f / 16384.0f) : SRL_FAR - 0.0f;   // exact: a lattice point of [512, 1024]
   const float hh = elev_overhead(P, depth_encode(t, nearp, SRL_FAR));
-  th[k] = hh;
-  tb[k] = (uint8_t)((hh * 255.0f) / den);
+  tab[k] = make_uint2(__float_as_uint(hh), (uint32_t)(uint8_t)((hh * 255.0f) / den));
 }
 
 // world-frame render plane of one face: z = a x + b y + c; w = 0 up-facing (z_hi = min), 1 down-facing
@@ -119,6 +120,19 @@ __device__ float discounted_metric(const DevParams& P, const EnvHdr* h, const fl
   }
   if (P.c.metric == SRL_METRIC_DOR) return r / (float)P.c.episode_length;
   return r / (float)(P.c.episode_length + nout);
+}
+
+// which of the four pixels (row i, columns jb .. jb + 3) lie in the goal rectangle rows [g0, g0 + g2) x columns
+// [g1, g1 + g3): bit t = pixel jb + t.  Branch-free: the epilogue is bound by VALU issue, not by memory.
+__device__ __forceinline__ uint32_t goal_mask4(int i, int jb, int g0, int g2, int g1, int g3) {
+  const int lo = max(g1 - jb, 0), hi = min(g1 + g3 - jb, 4);
+  const bool any = (unsigned)(i - g0) < (unsigned)g2 && hi > lo;
+  return any ? (1u << hi) - (1u << lo) : 0u;
+}
+// the goal-channel bits of two packed pixels (bytes 1 and 3 of the word) selected by bits 0 and 1 of m
+__device__ __forceinline__ uint32_t goal_pair(uint32_t m, uint32_t gdiff) {
+  const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)m, 0, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)m, 1, 1);
+  return (gdiff & m0) | ((gdiff << 16) & m1);
 }
 
 #ifndef SRL_PLANE_CAP
@@ -214,6 +228,9 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
              uint8_t* __restrict__ done, const float* __restrict__ poses_ext, const int32_t* __restrict__ mesh_ext,
              const int32_t* __restrict__ nb_ext, float* __restrict__ height_ext) {
   extern __shared__ float4 lds_raw[];
+#ifdef SRL_ABL_EMPTY
+  if (P.px != 12345.0f) return;
+#endif
   const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int res = P.c.overhead_res, npx = res * res;
   RenderLds L;
@@ -265,7 +282,11 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   }
   const int rr = P.c.object_res * P.c.object_res * P.n_orient;   // all observable orientations of the pending rock
   float om_pref[2] = {0.0f, 0.0f};
+#ifdef SRL_ABL_NOOBJ
+  if (!ext && pending >= 0 && P.px == 12345.0f) {
+#else
   if (!ext && pending >= 0 && !P.c.ordering_freedom) {
+#endif
 #pragma unroll
     for (int k = 0; k < 2; ++k)
       if (tid + k * SRL_RENDER_THREADS < rr) om_pref[k] = P.objmap[(size_t)pending * rr + tid + k * SRL_RENDER_THREADS];
@@ -440,24 +461,18 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
         const int g = tid + k * SRL_RENDER_THREADS;
         if (g >= ngroups4) break;
         // groups that touch the goal rectangle: their empty pixels still add the goal height to the union sum
-        if (i >= g0 && i < g0 + g2 && jb + 3 >= g1 && jb < g1 + g3) goalm |= 1u << k;
+#ifndef SRL_ABL_NOGOAL
+        const uint32_t inm = goal_mask4(i, jb, g0, g2, g1, g3);
+#else
+        const uint32_t inm = 0u;
+#endif
+        if (inm) goalm |= 1u << k;
         if ((L.rowmask[i >> 5] >> (i & 31)) & 1u) cov |= 1u << k;
         else {
 #ifndef SRL_ABL_NOSTORE
           ((float4*)Hout)[g] = he4;
+          if (om) ((uint2*)om)[g] = make_uint2((epair | zpair) ^ goal_pair(inm, gdiff), (epair | zpair) ^ goal_pair(inm >> 2, gdiff));
 #endif
-          if (om) {
-            uint32_t lo = epair | zpair, hi = epair | zpair;
-            if (i >= g0 && i < g0 + g2) {
-              if (jb >= g1 && jb < g1 + g3) lo ^= gdiff;
-              if (jb + 1 >= g1 && jb + 1 < g1 + g3) lo ^= gdiff << 16;
-              if (jb + 2 >= g1 && jb + 2 < g1 + g3) hi ^= gdiff;
-              if (jb + 3 >= g1 && jb + 3 < g1 + g3) hi ^= gdiff << 16;
-            }
-#ifndef SRL_ABL_NOSTORE
-            ((uint2*)om)[g] = make_uint2(lo, hi);
-#endif
-          }
         }
         jb += walk_dj; i += walk_di;
         if (jb >= res) { jb -= res; ++i; }
@@ -546,9 +561,9 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   } while (bs < nb);
   RSTAMP(4);
   // ---- epilogue: depth codec, H out, uint8 pack, IoU partial sums (4 pixels per thread per round, fixed order).
-  //      The codec (three divisions per pixel) is only needed where a rock was seen: each wave gathers its
-  //      rock pixels of the round (usually well under 64 of 256) into a wave-private list, runs the codec
-  //      once over the list, one pixel per lane, and hands the results back.
+  //      The kernel is bound by VALU issue, so the pass is branch-free per pixel: the codec is one 8-byte look-up
+  //      (DevParams::codec; a pixel without a rock reads the table's last entry, the empty-pixel constants), the goal
+  //      terms are selected with bit masks.
   float spi = 0.0f, spu = 0.0f;
   {
     // An empty pixel outside the goal adds max(h_empty, 0) to the union sum and nothing else; when that is +0 (it is
@@ -556,61 +571,41 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     // (the partial sums never hold -0), so rounds whose group lies in a row no rock reaches and outside the goal
     // rectangle are skipped altogether.  todo bit k: round k must be visited.
     const uint32_t todo = fmaxf(h_empty, 0.0f) == 0.0f ? (cov | goalm) : 0xffffffffu;
+    const uint2* __restrict__ ctab = P.codec;
+    const int kempty = P.codec_n;
     int i = walk_i0, jb = walk_j0;
     for (int k = 0; k < nrounds; ++k) {
       const int g = tid + k * SRL_RENDER_THREADS;
-      if (!((todo >> k) & 1u)) {
-        jb += walk_dj; i += walk_di;
-        if (jb >= res) { jb -= res; ++i; }
-        continue;
-      }
-      const bool valid = g < ngroups4;
-      const bool covg = valid && ((cov >> k) & 1u);
-      float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (covg) z4 = ((const float4*)L.tile)[g];
-      float hv[4] = {h_empty, h_empty, h_empty, h_empty};
-      uint32_t hb[4] = {b_empty, b_empty, b_empty, b_empty};
-      const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-      if (P.codec_n > 0) {
-        // pixels that saw a rock: the codec by table (bit-identical to the arithmetic, DevParams::codec_h)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (zz[t] > 0.0f) {
-            float tt = SRL_FAR - zz[t];
-            if (tt < nearp) tt = nearp;
-            const int kk = (int)((tt - nearp) * 16384.0f);
-            hv[t] = P.codec_h[kk]; hb[t] = P.codec_b[kk];
-          }
-      } else {
-        const bool rock = (z4.x > 0.0f) || (z4.y > 0.0f) || (z4.z > 0.0f) || (z4.w > 0.0f);
-        if (rock) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (zz[t] > 0.0f) {
-              hv[t] = elev_overhead(P, depth_encode(SRL_FAR - zz[t], nearp, SRL_FAR));
-              hb[t] = (uint8_t)((hv[t] * 255.0f) / den);
-            }
-        }
-      }
-      if (valid) {
-        const bool row_in = (i >= g0 && i < g0 + g2);
-        uint32_t lo = hb[0] | (hb[1] << 16) | zpair, hi = hb[2] | (hb[3] << 16) | zpair;
+      if (((todo >> k) & 1u) && g < ngroups4) {
+        const bool covg = (cov >> k) & 1u;
+        float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (covg) z4 = ((const float4*)L.tile)[g];
+        const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+        float hv[4]; uint32_t hb[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const bool in = row_in && (jb + t >= g1 && jb + t < g1 + g3);
-          // rewarder.py:297-307: goal pixels add min / max(h, goal) to the two sums, the others max(h, 0) to the
-          // union only (x + 0 = x bit for bit here: the partial sums never hold -0)
-          spu += fmaxf(hv[t], in ? gz : 0.0f);
-          spi += in ? fminf(hv[t], gz) : 0.0f;
-          if (in) { if (t < 2) lo ^= gdiff << (16 * t); else hi ^= gdiff << (16 * (t - 2)); }
+          const float tt = fmaxf(SRL_FAR - zz[t], nearp);
+          const int kx = zz[t] > 0.0f ? (int)((tt - nearp) * 16384.0f) : kempty;   // a pixel that saw no rock: last entry
+          const uint2 en = ctab[kx];
+          hv[t] = __uint_as_float(en.x); hb[t] = en.y;
+        }
+        // rewarder.py:297-307: goal pixels add min / max(h, goal) to the two sums, the others max(h, 0) to the union
+        // only (x + 0 = x bit for bit here: the partial sums never hold -0); m = all ones on a goal pixel
+        const uint32_t inm = goal_mask4(i, jb, g0, g2, g1, g3);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int m = __builtin_amdgcn_sbfe((int)inm, t, 1);
+          spu += fmaxf(hv[t], __int_as_float(__float_as_int(gz) & m));
+          spi += __int_as_float(__float_as_int(fminf(hv[t], gz)) & m);
         }
 #ifndef SRL_ABL_NOSTORE
         if (covg) {
           ((float4*)Hout)[g] = make_float4(hv[0], hv[1], hv[2], hv[3]);
-          if (om) ((uint2*)om)[g] = make_uint2(lo, hi);
+          if (om) ((uint2*)om)[g] = make_uint2((hb[0] | (hb[1] << 16) | zpair) ^ goal_pair(inm, gdiff),
+                                                (hb[2] | (hb[3] << 16) | zpair) ^ goal_pair(inm >> 2, gdiff));
         }
 #else
-        if (covg && hv[0] == 12345.0f && lo == 77u) ((float4*)Hout)[g] = make_float4(hv[0], hv[1], hv[2], hv[3]);
+        if (covg && hv[0] == 12345.0f && hb[0] == 77u) ((float4*)Hout)[g] = make_float4(hv[0], hv[1], hv[2], hv[3]);
 #endif
       }
       jb += walk_dj; i += walk_di;
@@ -620,6 +615,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   RSTAMP(5);
   if (ext) return;
   // ---- object observation (O2 from the per-mesh cache, requested at kernel start; empty map when nothing is pending)
+#ifndef SRL_ABL_NOOBJ
   if (!P.c.ordering_freedom) {
     uint8_t* oo = obs_obj + (size_t)e * rr;
     const float empty = elev_object(P, 1.0f);
@@ -651,7 +647,11 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       }
     }
   }
+#endif
   // ---- halving tree over the 512 partials: cross-wave stages through LDS, in-wave stages by shuffles
+#ifdef SRL_ABL_NOTAIL
+  if (P.px != 12345.0f) return;
+#endif
   L.pi[tid] = spi; L.pu[tid] = spu;
   __syncthreads();
   if (tid < 256) { L.pi[tid] += L.pi[tid + 256]; L.pu[tid] += L.pu[tid + 256]; }
@@ -679,6 +679,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       done[e] = 0;
     }
   }
+  RSTAMP(6);
 }
 
 // K3: underside map of one mesh at the spawn pose, in one observable orientation (blockIdx.y; Stack-v0 has only the

@@ -45,8 +45,7 @@ struct srl_env {
   bool P_dirty = true;
   float* d_objmap = nullptr;
   uchar4* d_me = nullptr;
-  float* d_codec_h = nullptr;     // overhead depth codec tabulated over the lattice of fl(FAR - z) (DevParams::codec_h)
-  uint8_t* d_codec_b = nullptr;
+  uint2* d_codec = nullptr;       // overhead depth codec tabulated over the lattice of fl(FAR - z) (DevParams::codec)
   int step_threads = 256;
   int step_pp = 1;
   size_t step_lds = 0, render_lds = 0, objmap_lds = 0;
@@ -241,17 +240,18 @@ int srl_create(const srl_config* cfg, srl_env** out) {
     for (int i = 0; i < n; ++i) { h[i].done = 1; h[i].pending = -1; h[i].ncolour = -1; }   // env.py:219-220
     HIP_TRY(hipMemcpy(P.hdr, h.data(), sizeof(EnvHdr) * (size_t)n, hipMemcpyHostToDevice));
   }
-  {   // codec table: one entry per float32 between FAR - max_z and FAR (6,145 at max_z = 0.375)
+  {   // codec table: one entry per float32 between FAR - max_z and FAR (6,145 at max_z = 0.375) + the empty-pixel entry
     const float nearp = SRL_FAR - P.c.max_z;
     const double span = ((double)SRL_FAR - (double)nearp) * 16384.0;
-    if (nearp >= 512.0f && span <= 65536.0) {
-      const int nt = (int)span + 1;
-      HIP_TRY(hipMalloc((void**)&env->d_codec_h, sizeof(float) * (size_t)nt));
-      HIP_TRY(hipMalloc((void**)&env->d_codec_b, (size_t)nt));
-      hipLaunchKernelGGL(srl_k_codec_table, dim3((nt + 255) / 256), dim3(256), 0, 0, P, env->d_codec_h, env->d_codec_b, nt);
-      HIP_TRY(hipDeviceSynchronize());
-      P.codec_h = env->d_codec_h; P.codec_b = env->d_codec_b; P.codec_n = nt;
+    if (!(nearp >= 512.0f && span <= 65536.0)) {
+      srl_destroy(env);
+      return fail(SRL_EINVAL, "max_z must be at most 4 (the depth codec is tabulated over the float32 lattice of 1000 - z)");
     }
+    const int nt = (int)span + 1;
+    HIP_TRY(hipMalloc((void**)&env->d_codec, sizeof(uint2) * (size_t)(nt + 1)));
+    hipLaunchKernelGGL(srl_k_codec_table, dim3((nt + 256) / 256), dim3(256), 0, 0, P, env->d_codec, nt);
+    HIP_TRY(hipDeviceSynchronize());
+    P.codec = env->d_codec; P.codec_n = nt;
   }
   *out = env;
   return SRL_OK;
@@ -264,7 +264,7 @@ void srl_destroy(srl_env* env) {
   for (auto& e : env->pool) (void)hipEventDestroy(e);
   (void)hipFree(env->P.hdr); (void)hipFree(env->P.blob); (void)hipFree(env->P.H); (void)hipFree(env->P.flags); (void)hipFree(env->d_P);
   (void)hipFree(env->d_mh); (void)hipFree(env->d_mv); (void)hipFree(env->d_mt); (void)hipFree(env->d_mp); (void)hipFree(env->d_objmap);
-  (void)hipFree(env->d_codec_h); (void)hipFree(env->d_codec_b); (void)hipFree(env->d_me);
+  (void)hipFree(env->d_codec); (void)hipFree(env->d_me);
   delete env;
 }
 

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """A/B timing of render-kernel build variants on one box: each variant (a set of extra -D flags) is compiled into
 gpurun_out/, then the variants are timed in turn, twice (ABAB), on the explicit-pose micro-benchmark.
-usage: ab_render.py "" "-DSRL_X=1" "-DSRL_X=2 -DSRL_Y" ..."""
+usage: ab_render.py "" "-DSRL_X=1" "-DSRL_X=2 -DSRL_Y" ...      (compile on the box, then time)
+       ab_render.py --libs DIR                                  (time every lib*.so of DIR, e.g. cross-compiled variants
+                                                                 of different source revisions; DIR must travel: not gpurun_out/)"""
 import sys, os, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -48,7 +50,11 @@ if __name__ == '__main__':
     run(sys.argv[2]); sys.exit(0)
   variants = sys.argv[1:]
   sos = []
-  for k, v in enumerate(variants):
+  if variants and variants[0] == '--libs':
+    import glob
+    sos = sorted(glob.glob(os.path.join(os.path.abspath(variants[1]), 'lib*.so')))
+    variants = [os.path.basename(x) for x in sos]
+  for k, v in enumerate([] if sos else variants):
     so = os.path.join(ROOT, 'gpurun_out', 'libstackrl_ab%d.so' % k)
     os.makedirs(os.path.dirname(so), exist_ok=True)
     subprocess.check_call(['/opt/rocm/bin/hipcc'] + B.FLAGS + v.split() + [os.path.join(B.CSRC, 'stackrl_hip.hip'), '-o', so])
