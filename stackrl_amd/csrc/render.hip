@@ -333,7 +333,15 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   // (res is a multiple of 8); from one round to the next the group advances by di rows and dj columns
   const int walk_di = (4 * SRL_RENDER_THREADS) / res, walk_dj = 4 * SRL_RENDER_THREADS - walk_di * res;
   const int walk_i0 = (4 * tid) / res, walk_j0 = 4 * tid - walk_i0 * res;
+  // res divides 4 * 512 (64, 128, 256 ...): the walk never changes columns, so the column part of the goal test is
+  // a per-thread constant: bit t of colmask = column walk_j0 + t lies in the goal rectangle's column range
+  const bool aligned = walk_dj == 0;
+  uint32_t colmask = 0u;
   const uint32_t gdiff = (gbyte ^ zbyte) << 8, zpair = (zbyte << 8) | (zbyte << 24);
+  {
+    const int lo = max(g1 - walk_j0, 0), hi = min(g1 + g3 - walk_j0, 4);
+    colmask = hi > lo ? (1u << hi) - (1u << lo) : 0u;
+  }
   __syncthreads();
   RSTAMP(0);
   // ---- groups of rocks whose planes fit the staging area
@@ -456,6 +464,25 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     if (first) {
       const float4 he4 = make_float4(h_empty, h_empty, h_empty, h_empty);
       const uint32_t epair = b_empty | (b_empty << 16);
+      if (aligned) {
+        // every round keeps the thread's four columns and moves walk_di rows down: the column part of the goal test
+        // and the two possible observation words are fixed, a round costs a row test and a row-mask bit
+        const uint32_t w_out = epair | zpair, w_in_lo = w_out ^ goal_pair(colmask, gdiff), w_in_hi = w_out ^ goal_pair(colmask >> 2, gdiff);
+        for (int k = 0; k < nrounds; ++k) {
+          const int g = tid + k * SRL_RENDER_THREADS, i = walk_i0 + k * walk_di;
+          const bool rowin = (unsigned)(i - g0) < (unsigned)g2;
+#ifndef SRL_ABL_NOGOAL
+          if (rowin && colmask) goalm |= 1u << k;
+#endif
+          if ((L.rowmask[i >> 5] >> (i & 31)) & 1u) cov |= 1u << k;
+          else {
+#ifndef SRL_ABL_NOSTORE
+            ((float4*)Hout)[g] = he4;
+            if (om) ((uint2*)om)[g] = make_uint2(rowin ? w_in_lo : w_out, rowin ? w_in_hi : w_out);
+#endif
+          }
+        }
+      } else {
       int i = walk_i0, jb = walk_j0;
       for (int k = 0; k < nrounds; ++k) {
         const int g = tid + k * SRL_RENDER_THREADS;
@@ -476,6 +503,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
         }
         jb += walk_dj; i += walk_di;
         if (jb >= res) { jb -= res; ++i; }
+      }
       }
       RSTAMP(2);
     }
@@ -591,7 +619,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
         }
         // rewarder.py:297-307: goal pixels add min / max(h, goal) to the two sums, the others max(h, 0) to the union
         // only (x + 0 = x bit for bit here: the partial sums never hold -0); m = all ones on a goal pixel
-        const uint32_t inm = goal_mask4(i, jb, g0, g2, g1, g3);
+        const uint32_t inm = aligned ? ((unsigned)(i - g0) < (unsigned)g2 ? colmask : 0u) : goal_mask4(i, jb, g0, g2, g1, g3);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int m = __builtin_amdgcn_sbfe((int)inm, t, 1);
