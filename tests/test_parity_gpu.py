@@ -140,6 +140,7 @@ def test_nonblocking_step_returns_callable(ref_pool, oracle_mod):
 @pytest.mark.parametrize('L,n,kw', [
   (32, 4, {}),                                   # BASELINE config 5 episode length: 192 manifold slots, 3 points/thread
   (12, 6, dict(resolution_factor=4)),            # 64 x 64 height map, 16 x 16 object map, 2,401 actions (config 5)
+  (6, 5, dict(observable_size_ratio=3)),         # 96 x 96 height map: 4.5 epilogue rounds whose groups change columns
 ])
 def test_large_configs(ref_pool, oracle_mod, L, n, kw):
   g, o = _mk(ref_pool, oracle_mod, n, L, seed=31, **kw)
@@ -149,7 +150,7 @@ def test_large_configs(ref_pool, oracle_mod, L, n, kw):
     ga, oa = g.sample(), o.sample()
     assert np.array_equal(ga.cpu().numpy(), oa)
     _cmp_step(g, o, g.step(ga), o.step(oa), 'step {}'.format(k))
-  assert g.n_actions == (2401 if kw else 9409)
+  assert g.n_actions == {4: 2401, 3: 4225}.get(kw.get('resolution_factor', kw.get('observable_size_ratio')), 9409)
 
 
 def test_full_size_batch_properties(ref_pool):
