@@ -601,6 +601,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     const uint32_t todo = fmaxf(h_empty, 0.0f) == 0.0f ? (cov | goalm) : 0xffffffffu;
     const uint2* __restrict__ ctab = P.codec;
     const int kempty = P.codec_n;
+    const uint32_t gp_lo = goal_pair(colmask, gdiff), gp_hi = goal_pair(colmask >> 2, gdiff);
     int i = walk_i0, jb = walk_j0;
     for (int k = 0; k < nrounds; ++k) {
       const int g = tid + k * SRL_RENDER_THREADS;
@@ -614,23 +615,32 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
         for (int t = 0; t < 4; ++t) {
           const float tt = fmaxf(SRL_FAR - zz[t], nearp);
           const int kx = zz[t] > 0.0f ? (int)((tt - nearp) * 16384.0f) : kempty;   // a pixel that saw no rock: last entry
-          const uint2 en = ctab[kx];
+          const uint2 en = *(const uint2*)((const char*)ctab + ((uint32_t)kx << 3));   // 32-bit offset from a uniform base
           hv[t] = __uint_as_float(en.x); hb[t] = en.y;
         }
         // rewarder.py:297-307: goal pixels add min / max(h, goal) to the two sums, the others max(h, 0) to the union
         // only (x + 0 = x bit for bit here: the partial sums never hold -0); m = all ones on a goal pixel
-        const uint32_t inm = aligned ? ((unsigned)(i - g0) < (unsigned)g2 ? colmask : 0u) : goal_mask4(i, jb, g0, g2, g1, g3);
+        uint32_t glo = 0u, ghi = 0u;   // goal-channel bits of the two observation words
+        const bool rowin = (unsigned)(i - g0) < (unsigned)g2;
+        if (aligned && __builtin_amdgcn_ballot_w64(rowin && colmask != 0u) == 0ull) {
+          // none of the wave's groups of this round touches the goal (a wave covers whole rows): union sum only
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int m = __builtin_amdgcn_sbfe((int)inm, t, 1);
-          spu += fmaxf(hv[t], __int_as_float(__float_as_int(gz) & m));
-          spi += __int_as_float(__float_as_int(fminf(hv[t], gz)) & m);
+          for (int t = 0; t < 4; ++t) spu += fmaxf(hv[t], 0.0f);
+        } else {
+          const uint32_t inm = aligned ? (rowin ? colmask : 0u) : goal_mask4(i, jb, g0, g2, g1, g3);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int m = __builtin_amdgcn_sbfe((int)inm, t, 1);
+            spu += fmaxf(hv[t], __int_as_float(__float_as_int(gz) & m));
+            spi += __int_as_float(__float_as_int(fminf(hv[t], gz)) & m);
+          }
+          if (aligned) { glo = rowin ? gp_lo : 0u; ghi = rowin ? gp_hi : 0u; }
+          else { glo = goal_pair(inm, gdiff); ghi = goal_pair(inm >> 2, gdiff); }
         }
 #ifndef SRL_ABL_NOSTORE
         if (covg) {
           ((float4*)Hout)[g] = make_float4(hv[0], hv[1], hv[2], hv[3]);
-          if (om) ((uint2*)om)[g] = make_uint2((hb[0] | (hb[1] << 16) | zpair) ^ goal_pair(inm, gdiff),
-                                                (hb[2] | (hb[3] << 16) | zpair) ^ goal_pair(inm >> 2, gdiff));
+          if (om) ((uint2*)om)[g] = make_uint2((hb[0] | (hb[1] << 16) | zpair) ^ glo, (hb[2] | (hb[3] << 16) | zpair) ^ ghi);
         }
 #else
         if (covg && hv[0] == 12345.0f && hb[0] == 77u) ((float4*)Hout)[g] = make_float4(hv[0], hv[1], hv[2], hv[3]);
