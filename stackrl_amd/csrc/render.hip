@@ -41,16 +41,16 @@ __device__ __forceinline__ float elev_object(const DevParams& P, float d) {
   return P.obj_c1 - P.obj_c2 / (SRL_FAR + P.c.object_max_dimension * (0.5f - d));
 }
 
-// the overhead depth codec tabulated over the lattice of t = fl(FAR - z) (see DevParams::codec): entry k < n holds the
-// elevation bits and the observation byte for t = near + k 2^-14; entry n those of a pixel that saw no rock
+// the overhead depth codec tabulated over the lattice of t = fl(FAR - z) (see DevParams::codec): row 0 holds the
+// elevation bits and the observation byte of a pixel that saw no rock, row v in 1 .. n those for t = near + (n - v) 2^-14
 extern "C" __global__ void __launch_bounds__(256) srl_k_codec_table(DevParams P, uint2* __restrict__ tab, int n) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k > n) return;
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v > n) return;
   const float nearp = SRL_FAR - P.c.max_z;
   const float den = fmaxf(P.c.max_z, P.c.object_max_dimension);
-  const float t = k < n ? nearp + (float)k * (1.0f / 16384.0f) : SRL_FAR - 0.0f;   // exact: a lattice point of [512, 1024]
+  const float t = v > 0 ? nearp + (float)(n - v) * (1.0f / 16384.0f) : SRL_FAR - 0.0f;   // exact: a lattice point of [512, 1024]
   const float hh = elev_overhead(P, depth_encode(t, nearp, SRL_FAR));
-  tab[k] = make_uint2(__float_as_uint(hh), (uint32_t)(uint8_t)((hh * 255.0f) / den));
+  tab[v] = make_uint2(__float_as_uint(hh), (uint32_t)(uint8_t)((hh * 255.0f) / den));
 }
 
 // world-frame render plane of one face: z = a x + b y + c; w = 0 up-facing (z_hi = min), 1 down-facing
@@ -120,6 +120,13 @@ __device__ float discounted_metric(const DevParams& P, const EnvHdr* h, const fl
   }
   if (P.c.metric == SRL_METRIC_DOR) return r / (float)P.c.episode_length;
   return r / (float)(P.c.episode_length + nout);
+}
+
+// row of the codec table (DevParams::codec) for a ray-cast height z > 0: n - k with k the index of t = fl(FAR - z) on the
+// float32 lattice above near (clamped to near: a rock above the window), so that higher z = higher row
+__device__ __forceinline__ int codec_row(float z, float nearp, int n) {
+  const float tt = fmaxf(SRL_FAR - z, nearp);
+  return n - (int)((tt - nearp) * 16384.0f);
 }
 
 // which of the four pixels (row i, columns jb .. jb + 3) lie in the goal rectangle rows [g0, g0 + g2) x columns
@@ -565,11 +572,13 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
           l10 = fminf(l10, __shfl_xor(l10, m)); l11 = fminf(l11, __shfl_xor(l11, m));
         }
         if (s == 0) {
-          int* t0p = (int*)&L.tile[i * res + j];   // positive floats order as ints
-          if (l00 >= 0.0f && h00 > 0.0f) atomicMax(t0p, __float_as_int(h00));
-          if (col2 && l01 >= 0.0f && h01 > 0.0f) atomicMax(t0p + 1, __float_as_int(h01));
-          if (row2 && l10 >= 0.0f && h10 > 0.0f) atomicMax(t0p + res, __float_as_int(h10));
-          if (row2 && col2 && l11 >= 0.0f && h11 > 0.0f) atomicMax(t0p + res + 1, __float_as_int(h11));
+          // the tile holds codec-table rows, not heights: row(z) = codec_n - index of t = fl(FAR - z) is monotone in z,
+          // so the max over rocks commutes with the look-up and the epilogue needs no arithmetic per pixel (0 = no rock)
+          int* t0p = (int*)&L.tile[i * res + j];
+          if (l00 >= 0.0f && h00 > 0.0f) atomicMax(t0p, codec_row(h00, nearp, P.codec_n));
+          if (col2 && l01 >= 0.0f && h01 > 0.0f) atomicMax(t0p + 1, codec_row(h01, nearp, P.codec_n));
+          if (row2 && l10 >= 0.0f && h10 > 0.0f) atomicMax(t0p + res, codec_row(h10, nearp, P.codec_n));
+          if (row2 && col2 && l11 >= 0.0f && h11 > 0.0f) atomicMax(t0p + res + 1, codec_row(h11, nearp, P.codec_n));
         }
       }
     }
@@ -600,22 +609,19 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     // rectangle are skipped altogether.  todo bit k: round k must be visited.
     const uint32_t todo = fmaxf(h_empty, 0.0f) == 0.0f ? (cov | goalm) : 0xffffffffu;
     const uint2* __restrict__ ctab = P.codec;
-    const int kempty = P.codec_n;
     const uint32_t gp_lo = goal_pair(colmask, gdiff), gp_hi = goal_pair(colmask >> 2, gdiff);
     int i = walk_i0, jb = walk_j0;
     for (int k = 0; k < nrounds; ++k) {
       const int g = tid + k * SRL_RENDER_THREADS;
       if (((todo >> k) & 1u) && g < ngroups4) {
         const bool covg = (cov >> k) & 1u;
-        float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (covg) z4 = ((const float4*)L.tile)[g];
-        const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+        uint4 r4 = make_uint4(0u, 0u, 0u, 0u);   // codec-table rows of the four pixels (0: no rock)
+        if (covg) r4 = ((const uint4*)L.tile)[g];
+        const uint32_t rw[4] = {r4.x, r4.y, r4.z, r4.w};
         float hv[4]; uint32_t hb[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const float tt = fmaxf(SRL_FAR - zz[t], nearp);
-          const int kx = zz[t] > 0.0f ? (int)((tt - nearp) * 16384.0f) : kempty;   // a pixel that saw no rock: last entry
-          const uint2 en = *(const uint2*)((const char*)ctab + ((uint32_t)kx << 3));   // 32-bit offset from a uniform base
+          const uint2 en = *(const uint2*)((const char*)ctab + (rw[t] << 3));   // 32-bit offset from a uniform base
           hv[t] = __uint_as_float(en.x); hb[t] = en.y;
         }
         // rewarder.py:297-307: goal pixels add min / max(h, goal) to the two sums, the others max(h, 0) to the union

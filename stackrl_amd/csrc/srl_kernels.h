@@ -67,10 +67,11 @@ struct DevParams {
   int32_t n_slots;        // object maps per observation: n_orient, or episode_length * n_orient with ordering freedom
   float orient_q[SRL_MAX_ORIENT][4];
   // depth codec of the overhead camera as a table (srl_k_codec_table): the ray-cast height z enters the codec only as
-  // t = fl(FAR - z), a float32 in [512, 1024) and therefore on a lattice of 2^-14 — codec[k] = (elevation bits,
-  // observation byte) for t = near + k 2^-14, k < codec_n, computed on the device by the codec's own expressions
-  // (observer.py:259-260, env.py:171-172), so a lookup returns the bits the arithmetic would; codec[codec_n] holds the
-  // constants of a pixel that saw no rock.  srl_create requires FAR - max_z >= 512 and max_z <= 4 (65,536 entries).
+  // t = fl(FAR - z), a float32 in [512, 1024) and therefore on a lattice of 2^-14 — codec[v], v = 1 .. codec_n, =
+  // (elevation bits, observation byte) for t = near + (codec_n - v) 2^-14, computed on the device by the codec's own
+  // expressions (observer.py:259-260, env.py:171-172), so a lookup returns the bits the arithmetic would; codec[0]
+  // holds the constants of a pixel that saw no rock.  Rows grow with z, so the render tile keeps the max row per pixel.
+  // srl_create requires FAR - max_z >= 512 and max_z <= 4 (65,536 rows).
   const uint2* codec;
   int32_t codec_n;
   int32_t* flags;         // [1] accumulated error bits since the last srl_sync_status
