@@ -45,9 +45,17 @@ __device__ __forceinline__ float elev_object(const DevParams& P, float d) {
 // elevation bits and the observation byte of a pixel that saw no rock, row v in 1 .. n those for t = near + (n - v) 2^-14
 extern "C" __global__ void __launch_bounds__(256) srl_k_codec_table(DevParams P, uint2* __restrict__ tab, int n) {
   const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v > n) return;
   const float nearp = SRL_FAR - P.c.max_z;
   const float den = fmaxf(P.c.max_z, P.c.object_max_dimension);
+  if (v == n + 1) {   // goal-channel bytes (env.py:171-172 applied to the goal height and to 0)
+    tab[v] = make_uint2((uint32_t)(uint8_t)((P.goal_z * 255.0f) / den), (uint32_t)(uint8_t)((0.0f * 255.0f) / den));
+    return;
+  }
+  if (v == n + 2) {   // byte of an empty object-map pixel
+    tab[v] = make_uint2((uint32_t)(uint8_t)((elev_object(P, 1.0f) * 255.0f) / den), 0u);
+    return;
+  }
+  if (v > n) return;
   const float t = v > 0 ? nearp + (float)(n - v) * (1.0f / 16384.0f) : SRL_FAR - 0.0f;   // exact: a lattice point of [512, 1024]
   const float hh = elev_overhead(P, depth_encode(t, nearp, SRL_FAR));
   tab[v] = make_uint2(__float_as_uint(hh), (uint32_t)(uint8_t)((hh * 255.0f) / den));
@@ -288,16 +296,6 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     mode = h->mode; hdone = h->done; prev_metric = h->prev_metric;
   }
   const int rr = P.c.object_res * P.c.object_res * P.n_orient;   // all observable orientations of the pending rock
-  float om_pref[2] = {0.0f, 0.0f};
-#ifdef SRL_ABL_NOOBJ
-  if (!ext && pending >= 0 && P.px == 12345.0f) {
-#else
-  if (!ext && pending >= 0 && !P.c.ordering_freedom) {
-#endif
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-      if (tid + k * SRL_RENDER_THREADS < rr) om_pref[k] = P.objmap[(size_t)pending * rr + tid + k * SRL_RENDER_THREADS];
-  }
   {
     float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float4* t4 = (float4*)L.tile;
@@ -327,19 +325,16 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   }
   // epilogue constants
   const float nearp = SRL_FAR - P.c.max_z;
-  const float den = fmaxf(P.c.max_z, P.c.object_max_dimension);   // env.py:171-172
   const float gz = P.goal_z;
-  const uint32_t gbyte = (uint8_t)((gz * 255.0f) / den);
-  const uint32_t zbyte = (uint8_t)((0.0f * 255.0f) / den);
-  const float h_empty = elev_overhead(P, depth_encode(SRL_FAR - 0.0f, nearp, SRL_FAR));
-  const uint32_t b_empty = (uint8_t)((h_empty * 255.0f) / den);
+  const uint32_t gbyte = P.gbyte, zbyte = P.zbyte, b_empty = P.b_empty;   // (DevParams: evaluated once on the device)
+  const float h_empty = P.h_empty;
   float* Hout = ext ? height_ext + (size_t)e * npx : P.H + (size_t)e * npx;
   uint8_t* om = ext ? nullptr : obs_map + (size_t)e * npx * 2;
   const int ngroups4 = npx / 4, nrounds = (ngroups4 + SRL_RENDER_THREADS - 1) / SRL_RENDER_THREADS;
   // pixel-group walk of a thread: group g = tid + 512 k holds pixels 4 g .. 4 g + 3 = row i, columns jb .. jb + 3
   // (res is a multiple of 8); from one round to the next the group advances by di rows and dj columns
-  const int walk_di = (4 * SRL_RENDER_THREADS) / res, walk_dj = 4 * SRL_RENDER_THREADS - walk_di * res;
-  const int walk_i0 = (4 * tid) / res, walk_j0 = 4 * tid - walk_i0 * res;
+  const int walk_di = P.walk_di, walk_dj = P.walk_dj;
+  const int walk_i0 = (int)__umulhi((uint32_t)(4 * tid), P.res_magic), walk_j0 = 4 * tid - walk_i0 * res;
   // res divides 4 * 512 (64, 128, 256 ...): the walk never changes columns, so the column part of the goal test is
   // a per-thread constant: bit t of colmask = column walk_j0 + t lies in the goal rectangle's column range
   const bool aligned = walk_dj == 0;
@@ -660,35 +655,16 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   if (ext) return;
   // ---- object observation (O2 from the per-mesh cache, requested at kernel start; empty map when nothing is pending)
 #ifndef SRL_ABL_NOOBJ
-  if (!P.c.ordering_freedom) {
-    uint8_t* oo = obs_obj + (size_t)e * rr;
-    const float empty = elev_object(P, 1.0f);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int idx = tid + k * SRL_RENDER_THREADS;
-      if (idx < rr) oo[idx] = (uint8_t)(((pending >= 0 ? om_pref[k] : empty) * 255.0f) / den);
-    }
-    for (int idx = tid + 2 * SRL_RENDER_THREADS; idx < rr; idx += SRL_RENDER_THREADS)
-      oo[idx] = (uint8_t)(((pending >= 0 ? P.objmap[(size_t)pending * rr + idx] : empty) * 255.0f) / den);
-  } else {
-    // ordering freedom (observer.py:310-327): the maps of the rocks still unplaced, in list order, then empty maps;
-    // four pixels per lane (the map size is a multiple of 4)
-    const int shown = P.c.episode_length, left = h->list_pos;
+  {
+    // the pending rock's maps, or with ordering freedom (observer.py:310-327) those of the rocks still unplaced, in list
+    // order, then empty maps; bytes from the per-mesh cache, four pixels per lane (the map size is a multiple of 4)
+    const int shown = P.c.ordering_freedom ? P.c.episode_length : 1, left = h->list_pos;
     uint32_t* oo = (uint32_t*)(obs_obj + (size_t)e * rr * shown);
-    const float empty = elev_object(P, 1.0f);
-    const uint32_t eb = (uint8_t)((empty * 255.0f) / den), eb4 = eb * 0x01010101u;
+    const uint32_t eb4 = P.obj_empty_byte * 0x01010101u;
     for (int k = 0; k < shown; ++k) {
-      const int m = k < left ? h->ids[k] : -1;
-      const float4* src = (const float4*)(P.objmap + (size_t)(m < 0 ? 0 : m) * rr);
-      for (int idx = tid; idx < rr / 4; idx += SRL_RENDER_THREADS) {
-        uint32_t w = eb4;
-        if (m >= 0) {
-          const float4 v = src[idx];
-          w = (uint32_t)(uint8_t)((v.x * 255.0f) / den) | ((uint32_t)(uint8_t)((v.y * 255.0f) / den) << 8) |
-              ((uint32_t)(uint8_t)((v.z * 255.0f) / den) << 16) | ((uint32_t)(uint8_t)((v.w * 255.0f) / den) << 24);
-        }
-        oo[(size_t)k * (rr / 4) + idx] = w;
-      }
+      const int m = P.c.ordering_freedom ? (k < left ? h->ids[k] : -1) : pending;
+      const uint32_t* src = (const uint32_t*)(P.objmap_u8 + (size_t)(m < 0 ? 0 : m) * rr);
+      for (int idx = tid; idx < rr / 4; idx += SRL_RENDER_THREADS) oo[(size_t)k * (rr / 4) + idx] = m >= 0 ? src[idx] : eb4;
     }
   }
 #endif
@@ -729,7 +705,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
 // K3: underside map of one mesh at the spawn pose, in one observable orientation (blockIdx.y; Stack-v0 has only the
 // identity).  One workgroup per (mesh, orientation).  The rock turns about its link-frame origin, which sits at the
 // centre of the map (observer.py:143-164: the camera looks at the object pose).
-extern "C" __global__ void __launch_bounds__(256) srl_k_objmap(DevParams P, float* __restrict__ out) {
+extern "C" __global__ void __launch_bounds__(256) srl_k_objmap(DevParams P, float* __restrict__ out, uint8_t* __restrict__ out_u8) {
   __shared__ float4 planes[SRL_MAX_TRIS];
   const int m = blockIdx.x, oi = blockIdx.y, tid = threadIdx.x;
   const int r = P.c.object_res;
@@ -756,6 +732,8 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_objmap(DevParams P, floa
     float z = 1e30f;
     if (ray_cast(planes, mh.nt, px, py, lo, hi)) z = lo;
     float d = z > 1e29f ? 1.0f : depth_encode(SRL_FAR + z, nearp, farp);
-    out[((size_t)m * P.n_orient + oi) * r * r + k] = elev_object(P, d);
+    const float ev = elev_object(P, d);
+    out[((size_t)m * P.n_orient + oi) * r * r + k] = ev;
+    out_u8[((size_t)m * P.n_orient + oi) * r * r + k] = (uint8_t)((ev * 255.0f) / fmaxf(P.c.max_z, P.c.object_max_dimension));   // env.py:171-172
   }
 }

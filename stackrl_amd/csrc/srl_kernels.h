@@ -74,5 +74,15 @@ struct DevParams {
   // srl_create requires FAR - max_z >= 512 and max_z <= 4 (65,536 rows).
   const uint2* codec;
   int32_t codec_n;
+  // constants of the render epilogue, evaluated once on the device by the expressions the oracle uses (rows 0, n + 1 and
+  // n + 2 of the codec table) and read back by srl_create: elevation / observation byte of a pixel that saw no rock,
+  // goal and zero bytes of the goal channel (env.py:171-172), byte of an empty object-map pixel
+  float h_empty;
+  uint32_t b_empty, gbyte, zbyte, obj_empty_byte;
+  // walk of a thread over its pixel groups (group g = tid + 512 k = row i, columns jb .. jb + 3): per round +walk_di
+  // rows and +walk_dj columns; res_magic = floor(2^32 / res) + 1 (exact quotients of x < 2^32 / res by a multiply-high)
+  int32_t walk_di, walk_dj;
+  uint32_t res_magic;
+  const uint8_t* objmap_u8;   // [n_mesh][n_orient][ores*ores] the same maps as observation bytes (env.py:171-172)
   int32_t* flags;         // [1] accumulated error bits since the last srl_sync_status
 };

@@ -44,6 +44,7 @@ struct srl_env {
   DevParams* d_P = nullptr;   // device copy of P for the settle kernel (re-uploaded whenever P changes)
   bool P_dirty = true;
   float* d_objmap = nullptr;
+  uint8_t* d_objmap_u8 = nullptr;
   uchar4* d_me = nullptr;
   uint2* d_codec = nullptr;       // overhead depth codec tabulated over the lattice of fl(FAR - z) (DevParams::codec)
   int step_threads = 256;
@@ -248,10 +249,18 @@ int srl_create(const srl_config* cfg, srl_env** out) {
       return fail(SRL_EINVAL, "max_z must be at most 4 (the depth codec is tabulated over the float32 lattice of 1000 - z)");
     }
     const int nt = (int)span + 1;
-    HIP_TRY(hipMalloc((void**)&env->d_codec, sizeof(uint2) * (size_t)(nt + 1)));
-    hipLaunchKernelGGL(srl_k_codec_table, dim3((nt + 256) / 256), dim3(256), 0, 0, P, env->d_codec, nt);
+    HIP_TRY(hipMalloc((void**)&env->d_codec, sizeof(uint2) * (size_t)(nt + 3)));
+    hipLaunchKernelGGL(srl_k_codec_table, dim3((nt + 3 + 255) / 256), dim3(256), 0, 0, P, env->d_codec, nt);
     HIP_TRY(hipDeviceSynchronize());
     P.codec = env->d_codec; P.codec_n = nt;
+    uint2 row0, rowg, rowo;   // constants evaluated by the device (DevParams::h_empty ...)
+    HIP_TRY(hipMemcpy(&row0, env->d_codec, sizeof(uint2), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&rowg, env->d_codec + nt + 1, sizeof(uint2), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&rowo, env->d_codec + nt + 2, sizeof(uint2), hipMemcpyDeviceToHost));
+    memcpy(&P.h_empty, &row0.x, sizeof(float));
+    P.b_empty = row0.y; P.gbyte = rowg.x; P.zbyte = rowg.y; P.obj_empty_byte = rowo.x;
+    P.walk_di = (4 * SRL_RENDER_THREADS) / res; P.walk_dj = 4 * SRL_RENDER_THREADS - P.walk_di * res;
+    P.res_magic = (uint32_t)(0x100000000ull / (unsigned long long)res) + 1u;
   }
   *out = env;
   return SRL_OK;
@@ -263,7 +272,7 @@ void srl_destroy(srl_env* env) {
   for (auto& p : env->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& e : env->pool) (void)hipEventDestroy(e);
   (void)hipFree(env->P.hdr); (void)hipFree(env->P.blob); (void)hipFree(env->P.H); (void)hipFree(env->P.flags); (void)hipFree(env->d_P);
-  (void)hipFree(env->d_mh); (void)hipFree(env->d_mv); (void)hipFree(env->d_mt); (void)hipFree(env->d_mp); (void)hipFree(env->d_objmap);
+  (void)hipFree(env->d_mh); (void)hipFree(env->d_mv); (void)hipFree(env->d_mt); (void)hipFree(env->d_mp); (void)hipFree(env->d_objmap); (void)hipFree(env->d_objmap_u8);
   (void)hipFree(env->d_codec); (void)hipFree(env->d_me);
   delete env;
 }
@@ -343,15 +352,16 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
     M.inv_mass = 1.0f / mass;
     M.iix = 1.0f / Ix; M.iiy = 1.0f / Iy; M.iiz = 1.0f / Iz;
   }
-  (void)hipFree(env->d_mh); (void)hipFree(env->d_mv); (void)hipFree(env->d_mt); (void)hipFree(env->d_mp); (void)hipFree(env->d_objmap);
+  (void)hipFree(env->d_mh); (void)hipFree(env->d_mv); (void)hipFree(env->d_mt); (void)hipFree(env->d_mp); (void)hipFree(env->d_objmap); (void)hipFree(env->d_objmap_u8);
   (void)hipFree(env->d_me);
-  env->d_mh = nullptr; env->d_mv = nullptr; env->d_mt = nullptr; env->d_mp = nullptr; env->d_objmap = nullptr; env->d_me = nullptr;
+  env->d_mh = nullptr; env->d_mv = nullptr; env->d_mt = nullptr; env->d_mp = nullptr; env->d_objmap = nullptr; env->d_objmap_u8 = nullptr; env->d_me = nullptr;
   const int r = P.c.object_res;
   HIP_TRY(hipMalloc((void**)&env->d_mh, sizeof(MeshHdr) * mh.size()));
   HIP_TRY(hipMalloc((void**)&env->d_mv, sizeof(float4) * mv.size()));
   HIP_TRY(hipMalloc((void**)&env->d_mt, sizeof(uchar4) * mt.size()));
   HIP_TRY(hipMalloc((void**)&env->d_mp, sizeof(float4) * mp.size()));
   HIP_TRY(hipMalloc((void**)&env->d_objmap, sizeof(float) * (size_t)n_mesh * env->P.n_orient * r * r));
+  HIP_TRY(hipMalloc((void**)&env->d_objmap_u8, (size_t)n_mesh * env->P.n_orient * r * r));
   HIP_TRY(hipMemcpy(env->d_mh, mh.data(), sizeof(MeshHdr) * mh.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(env->d_mv, mv.data(), sizeof(float4) * mv.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(env->d_mt, mt.data(), sizeof(uchar4) * mt.size(), hipMemcpyHostToDevice));
@@ -359,7 +369,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   HIP_TRY(hipMalloc((void**)&env->d_me, sizeof(uchar4) * me.size()));
   HIP_TRY(hipMemcpy(env->d_me, me.data(), sizeof(uchar4) * me.size(), hipMemcpyHostToDevice));
   P.me = env->d_me;
-  P.mh = env->d_mh; P.mv = env->d_mv; P.mt = env->d_mt; P.mp = env->d_mp; P.objmap = env->d_objmap;
+  P.mh = env->d_mh; P.mv = env->d_mv; P.mt = env->d_mt; P.mp = env->d_mp; P.objmap = env->d_objmap; P.objmap_u8 = env->d_objmap_u8;
   P.n_mesh = n_mesh;
   P.VS = vs;
   env->P_dirty = true;
@@ -380,7 +390,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->render_lds));
   // K3: object maps of the whole pool, once
-  hipLaunchKernelGGL(srl_k_objmap, dim3(n_mesh, P.n_orient), dim3(256), env->objmap_lds, 0, P, env->d_objmap);
+  hipLaunchKernelGGL(srl_k_objmap, dim3(n_mesh, P.n_orient), dim3(256), env->objmap_lds, 0, P, env->d_objmap, env->d_objmap_u8);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   if (n_mesh < P.c.episode_length) { /* sampled with replacement, env.py:104-106 */ }
