@@ -181,3 +181,18 @@ def test_full_size_batch_properties(ref_pool):
   np.testing.assert_allclose(total.cpu().numpy(), iou, rtol=2e-4, atol=2e-6)    # sum of reward differences = final metric
   assert float(oo.max()) == 0                                                     # terminal observation: nothing pending
   g.close()
+
+
+def test_input_constraints_are_reported(ref_pool):
+  """`max_z` above 4 m has no codec table; a mesh that is not a closed two-manifold has no outline."""
+  import copy
+  from stackrl_amd import env as envs
+  with pytest.raises(ValueError, match='max_z'):
+    envs.VecStackEnv(n_parallel=2, seed=0, pool=ref_pool, episode_length=2, max_z=4.5)
+  g = envs.VecStackEnv(n_parallel=2, seed=0, pool=ref_pool, episode_length=2, max_z=1.0)   # a taller window is fine
+  g.reset(); g.step(g.sample()); g.close()
+  bad = copy.copy(ref_pool)
+  bad.tris = ref_pool.tris.copy()
+  bad.tris[int(ref_pool.tri_off[0])] = bad.tris[int(ref_pool.tri_off[0]) + 1]      # a face listed twice: an edge with 3 faces
+  with pytest.raises(ValueError):
+    envs.VecStackEnv(n_parallel=2, seed=0, pool=bad, episode_length=2)
