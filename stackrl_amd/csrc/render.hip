@@ -197,27 +197,29 @@ __device__ __forceinline__ void plane_sweep(const float4* pl, int n, int s, int 
                                             float py1, float& z00, float& z01, float& z10, float& z11) {
   const f32x2 py = {py0, py1}, vx0 = {px0, px0}, vx1 = {px1, px1};
   f32x2 za = {z00, z01}, zb = {z10, z11};
-  const int nb4 = n >> 2;
-  if (s < nb4) {   // 4-plane batches, two per trip, the next one in flight while one is evaluated; a trip
-                   // whose second batch would run past the end re-reads its first (min / max are idempotent)
-    float4 q0 = pl[4 * s], q1 = pl[4 * s + 1], q2 = pl[4 * s + 2], q3 = pl[4 * s + 3];
-    for (int kb = s; kb < nb4; kb += 2 * S) {
-      const int k1 = kb + S < nb4 ? kb + S : kb;
-      float4 r0 = pl[4 * k1], r1 = pl[4 * k1 + 1], r2 = pl[4 * k1 + 2], r3 = pl[4 * k1 + 3];
+  if (n >= 4) {
+    // ceil(n / 4) batches of four planes; batch k starts at plane min(4 k, n - 4), so the last one overlaps its
+    // predecessor instead of leaving a remainder, and a trip takes two batches, the second clamped to the last batch
+    // of the list (min / max are idempotent: a plane met twice changes nothing).  No selects, no remainder loop: the
+    // ray cast is bound by VALU issue.
+    const int nbt = (n + 3) >> 2, last = n - 4;
+    for (int t = s; t < nbt; t += 2 * S) {
+      const int oa = min(4 * t, last), ob = min(4 * (t + S), last);
+      float4 q0 = pl[oa], q1 = pl[oa + 1], q2 = pl[oa + 2], q3 = pl[oa + 3];
+      float4 r0 = pl[ob], r1 = pl[ob + 1], r2 = pl[ob + 2], r3 = pl[ob + 3];
       asm volatile("" : "+v"(q0.w), "+v"(q1.w), "+v"(q2.w), "+v"(q3.w));   // keeps each fetch one 16-byte read
+      asm volatile("" : "+v"(r0.w), "+v"(r1.w), "+v"(r2.w), "+v"(r3.w));
       plane_eval<UP>(q0, py, vx0, vx1, za, zb); plane_eval<UP>(q1, py, vx0, vx1, za, zb);
       plane_eval<UP>(q2, py, vx0, vx1, za, zb); plane_eval<UP>(q3, py, vx0, vx1, za, zb);
-      const int k2 = kb + 2 * S < nb4 ? kb + 2 * S : kb;
-      q0 = pl[4 * k2]; q1 = pl[4 * k2 + 1]; q2 = pl[4 * k2 + 2]; q3 = pl[4 * k2 + 3];
-      asm volatile("" : "+v"(r0.w), "+v"(r1.w), "+v"(r2.w), "+v"(r3.w));
       plane_eval<UP>(r0, py, vx0, vx1, za, zb); plane_eval<UP>(r1, py, vx0, vx1, za, zb);
       plane_eval<UP>(r2, py, vx0, vx1, za, zb); plane_eval<UP>(r3, py, vx0, vx1, za, zb);
     }
-  }
-  for (int t = 4 * nb4 + s; t < n; t += S) {
-    float4 q = pl[t];
-    asm volatile("" : "+v"(q.w));
-    plane_eval<UP>(q, py, vx0, vx1, za, zb);
+  } else {
+    for (int t = s; t < n; t += S) {
+      float4 q = pl[t];
+      asm volatile("" : "+v"(q.w));
+      plane_eval<UP>(q, py, vx0, vx1, za, zb);
+    }
   }
   z00 = za.x; z01 = za.y; z10 = zb.x; z11 = zb.y;
 }
