@@ -176,52 +176,69 @@ __host__ __device__ inline size_t render_lds_bytes(int res) {
          sizeof(float) * (3 + 9 + 4 + 4 + 4 + 2) * SRL_MAX_BODIES + sizeof(uint32_t) * (8 + 4);
 }
 
-// one min / max sweep over planes [0, n) of a region, this lane taking 4-plane batches s, s+S, ...
+// one min / max sweep over planes [0, n) of a region for a lane's item of SRL_ITEM_ROWS x 2 pixels, this lane taking
+// 4-plane batches s, s+S, ...
 // z = fmaf(a, px, fmaf(b, py, c)) per pixel (the definition), evaluated two pixels at a
 // time with packed fp32 FMAs (v_pk_fma_f32: IEEE fma per half, same bits as the scalar form).  The plane is
 // fetched as one 16-byte LDS read (ds_read_b128: 4 LDS cycles per wave against 8 for a 12-byte read).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef SRL_ITEM_ROWS
+#define SRL_ITEM_ROWS 4   // a lane's item: SRL_ITEM_ROWS rows x 2 columns of pixels (one plane fetch serves them all)
+#endif
+
+// acc[r] = (row r, column 0 | column 1); t = fma(b, y, c) is shared by the rows
 template <bool UP>
-__device__ __forceinline__ void plane_eval(const float4 q, const f32x2 py, const f32x2 px0, const f32x2 px1, f32x2& za,
-                                           f32x2& zb) {
+__device__ __forceinline__ void plane_eval(const float4 q, const f32x2 py, const f32x2 (&vx)[SRL_ITEM_ROWS],
+                                           f32x2 (&acc)[SRL_ITEM_ROWS]) {
   const f32x2 a = {q.x, q.x}, b = {q.y, q.y}, c = {q.z, q.z};
   const f32x2 t = __builtin_elementwise_fma(b, py, c);
-  const f32x2 r0 = __builtin_elementwise_fma(a, px0, t), r1 = __builtin_elementwise_fma(a, px1, t);
-  if (UP) { za.x = fminf(za.x, r0.x); za.y = fminf(za.y, r0.y); zb.x = fminf(zb.x, r1.x); zb.y = fminf(zb.y, r1.y); }
-  else { za.x = fmaxf(za.x, r0.x); za.y = fmaxf(za.y, r0.y); zb.x = fmaxf(zb.x, r1.x); zb.y = fmaxf(zb.y, r1.y); }
+#pragma unroll
+  for (int r = 0; r < SRL_ITEM_ROWS; ++r) {
+    const f32x2 z = __builtin_elementwise_fma(a, vx[r], t);
+    if (UP) { acc[r].x = fminf(acc[r].x, z.x); acc[r].y = fminf(acc[r].y, z.y); }
+    else { acc[r].x = fmaxf(acc[r].x, z.x); acc[r].y = fmaxf(acc[r].y, z.y); }
+  }
 }
 
 template <bool UP>
-__device__ __forceinline__ void plane_sweep(const float4* pl, int n, int s, int S, float px0, float px1, float py0,
-                                            float py1, float& z00, float& z01, float& z10, float& z11) {
-  const f32x2 py = {py0, py1}, vx0 = {px0, px0}, vx1 = {px1, px1};
-  f32x2 za = {z00, z01}, zb = {z10, z11};
+__device__ __forceinline__ void plane_sweep(const float4* pl, int n, int s, int S, const f32x2 py,
+                                            const f32x2 (&vx)[SRL_ITEM_ROWS], f32x2 (&acc)[SRL_ITEM_ROWS]) {
   if (n >= 4) {
     // ceil(n / 4) batches of four planes; batch k starts at plane min(4 k, n - 4), so the last one overlaps its
     // predecessor instead of leaving a remainder, and a trip takes two batches, the second clamped to the last batch
-    // of the list (min / max are idempotent: a plane met twice changes nothing).  No selects, no remainder loop: the
-    // ray cast is bound by VALU issue.
+    // of the list (min / max are idempotent: a plane met twice changes nothing).  No selects, no remainder loop.
     const int nbt = (n + 3) >> 2, last = n - 4;
     for (int t = s; t < nbt; t += 2 * S) {
+#ifdef SRL_ABL_NOPLANEREAD
+      const int oa = 0, ob = 4;   // (diagnostic: the same eight planes every trip, fetched once)
+#else
       const int oa = min(4 * t, last), ob = min(4 * (t + S), last);
+#endif
       float4 q0 = pl[oa], q1 = pl[oa + 1], q2 = pl[oa + 2], q3 = pl[oa + 3];
       float4 r0 = pl[ob], r1 = pl[ob + 1], r2 = pl[ob + 2], r3 = pl[ob + 3];
+#ifndef SRL_ABL_NOPLANEREAD
       asm volatile("" : "+v"(q0.w), "+v"(q1.w), "+v"(q2.w), "+v"(q3.w));   // keeps each fetch one 16-byte read
       asm volatile("" : "+v"(r0.w), "+v"(r1.w), "+v"(r2.w), "+v"(r3.w));
-      plane_eval<UP>(q0, py, vx0, vx1, za, zb); plane_eval<UP>(q1, py, vx0, vx1, za, zb);
-      plane_eval<UP>(q2, py, vx0, vx1, za, zb); plane_eval<UP>(q3, py, vx0, vx1, za, zb);
-      plane_eval<UP>(r0, py, vx0, vx1, za, zb); plane_eval<UP>(r1, py, vx0, vx1, za, zb);
-      plane_eval<UP>(r2, py, vx0, vx1, za, zb); plane_eval<UP>(r3, py, vx0, vx1, za, zb);
+#endif
+      plane_eval<UP>(q0, py, vx, acc); plane_eval<UP>(q1, py, vx, acc);
+      plane_eval<UP>(q2, py, vx, acc); plane_eval<UP>(q3, py, vx, acc);
+      plane_eval<UP>(r0, py, vx, acc); plane_eval<UP>(r1, py, vx, acc);
+      plane_eval<UP>(r2, py, vx, acc); plane_eval<UP>(r3, py, vx, acc);
     }
   } else {
     for (int t = s; t < n; t += S) {
       float4 q = pl[t];
       asm volatile("" : "+v"(q.w));
-      plane_eval<UP>(q, py, vx0, vx1, za, zb);
+      plane_eval<UP>(q, py, vx, acc);
     }
   }
-  z00 = za.x; z01 = za.y; z10 = zb.x; z11 = zb.y;
+}
+
+// min with the lane a DPP control selects (0xB1: lane ^ 1, 0x4E: lane ^ 2 within quads; 0x141: mirror within half rows)
+template <int CTRL>
+__device__ __forceinline__ float dpp_min(float v) {
+  return fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)));
 }
 
 // min / max over the 64 lanes of a wave by DPP row shifts and row broadcasts (no LDS traffic); the result is
@@ -398,7 +415,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
               const bool okx = pixel_range(xmin, xmax, P.inv_px, res, i0, i1);
               const bool oky = pixel_range(ymin, ymax, P.inv_px, res, j0, j1);
               int w2 = 0, items = 0;
-              if (okx && oky) { w2 = (j1 - j0 + 2) >> 1; items = ((i1 - i0 + 2) >> 1) * w2; }   // 2 x 2 pixel quads
+              if (okx && oky) { w2 = (j1 - j0 + 2) >> 1; items = ((i1 - i0 + SRL_ITEM_ROWS) / SRL_ITEM_ROWS) * w2; }   // items of SRL_ITEM_ROWS x 2 pixels
               L.prange[4 * b + 0] = i0 | (i1 << 16); L.prange[4 * b + 1] = j0 | (j1 << 16); L.prange[4 * b + 2] = w2; L.prange[4 * b + 3] = items;
               if (items > 0)
                 for (int w = i0 >> 5; w <= i1 >> 5; ++w) {
@@ -552,30 +569,52 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
         // p / w2 without the integer-division sequence: (p + 0.5) / w2 stays at least 0.5 / w2 >= 1 / 256 away from
         // an integer, far more than the error of the reciprocal (p < 2^14, w2 <= 128)
         const int di = (int)(((float)p + 0.5f) * __builtin_amdgcn_rcpf((float)w2));
-        const int i = (ii & 0xffff) + 2 * di, j = j0 + 2 * (p - di * w2);
-        const bool row2 = i + 1 <= i1, col2 = j + 1 <= j1;
-        const float px0 = ((float)i + 0.5f) * P.px, px1 = ((float)(i + 1) + 0.5f) * P.px;
-        const float py0 = ((float)j + 0.5f) * P.px, py1 = ((float)(j + 1) + 0.5f) * P.px;
+        const int i = (ii & 0xffff) + SRL_ITEM_ROWS * di, j = j0 + 2 * (p - di * w2);
+        const bool col2 = j + 1 <= j1;
+        const f32x2 py = {((float)j + 0.5f) * P.px, ((float)(j + 1) + 0.5f) * P.px};
+        f32x2 vx[SRL_ITEM_ROWS], hh[SRL_ITEM_ROWS], ll[SRL_ITEM_ROWS];
+#pragma unroll
+        for (int r = 0; r < SRL_ITEM_ROWS; ++r) {
+          const float x = ((float)(i + r) + 0.5f) * P.px;
+          vx[r].x = x; vx[r].y = x; hh[r].x = 1e30f; hh[r].y = 1e30f; ll[r].x = 1e30f; ll[r].y = 1e30f;
+        }
         // z_hi = min over the up-facing planes; inside the outline iff the smallest side function is >= 0
         const int base = rg.x, nup = rg.y - base, e0 = rg.z, nsil = base + L.mhdr[4 * b + 3] + 2 - e0;
-        float h00 = 1e30f, h01 = 1e30f, h10 = 1e30f, h11 = 1e30f;
-        float l00 = 1e30f, l01 = 1e30f, l10 = 1e30f, l11 = 1e30f;
-        plane_sweep<true>(L.planes + base, nup, s, S, px0, px1, py0, py1, h00, h01, h10, h11);
-        plane_sweep<true>(L.planes + e0, nsil, s, S, px0, px1, py0, py1, l00, l01, l10, l11);
-        for (int m = 1; m < S; m <<= 1) {
-          h00 = fminf(h00, __shfl_xor(h00, m)); h01 = fminf(h01, __shfl_xor(h01, m));
-          h10 = fminf(h10, __shfl_xor(h10, m)); h11 = fminf(h11, __shfl_xor(h11, m));
-          l00 = fminf(l00, __shfl_xor(l00, m)); l01 = fminf(l01, __shfl_xor(l01, m));
-          l10 = fminf(l10, __shfl_xor(l10, m)); l11 = fminf(l11, __shfl_xor(l11, m));
+        plane_sweep<true>(L.planes + base, nup, s, S, py, vx, hh);
+        plane_sweep<true>(L.planes + e0, nsil, s, S, py, vx, ll);
+        // the S lanes of an item (adjacent, aligned) combine their partial minima with DPP moves folded into the min:
+        // within quads (lanes ^ 1, ^ 2), then across the two quads of a half row (mirror) — no LDS traffic
+        if (S >= 2) {
+#pragma unroll
+          for (int r = 0; r < SRL_ITEM_ROWS; ++r) {
+            hh[r].x = dpp_min<0xB1>(hh[r].x); hh[r].y = dpp_min<0xB1>(hh[r].y);
+            ll[r].x = dpp_min<0xB1>(ll[r].x); ll[r].y = dpp_min<0xB1>(ll[r].y);
+          }
+        }
+        if (S >= 4) {
+#pragma unroll
+          for (int r = 0; r < SRL_ITEM_ROWS; ++r) {
+            hh[r].x = dpp_min<0x4E>(hh[r].x); hh[r].y = dpp_min<0x4E>(hh[r].y);
+            ll[r].x = dpp_min<0x4E>(ll[r].x); ll[r].y = dpp_min<0x4E>(ll[r].y);
+          }
+        }
+        if (S >= 8) {
+#pragma unroll
+          for (int r = 0; r < SRL_ITEM_ROWS; ++r) {
+            hh[r].x = dpp_min<0x141>(hh[r].x); hh[r].y = dpp_min<0x141>(hh[r].y);
+            ll[r].x = dpp_min<0x141>(ll[r].x); ll[r].y = dpp_min<0x141>(ll[r].y);
+          }
         }
         if (s == 0) {
           // the tile holds codec-table rows, not heights: row(z) = codec_n - index of t = fl(FAR - z) is monotone in z,
           // so the max over rocks commutes with the look-up and the epilogue needs no arithmetic per pixel (0 = no rock)
           int* t0p = (int*)&L.tile[i * res + j];
-          if (l00 >= 0.0f && h00 > 0.0f) atomicMax(t0p, codec_row(h00, nearp, P.codec_n));
-          if (col2 && l01 >= 0.0f && h01 > 0.0f) atomicMax(t0p + 1, codec_row(h01, nearp, P.codec_n));
-          if (row2 && l10 >= 0.0f && h10 > 0.0f) atomicMax(t0p + res, codec_row(h10, nearp, P.codec_n));
-          if (row2 && col2 && l11 >= 0.0f && h11 > 0.0f) atomicMax(t0p + res + 1, codec_row(h11, nearp, P.codec_n));
+#pragma unroll
+          for (int r = 0; r < SRL_ITEM_ROWS; ++r) {
+            const bool rowok = i + r <= i1;
+            if (rowok && ll[r].x >= 0.0f && hh[r].x > 0.0f) atomicMax(t0p + r * res, codec_row(hh[r].x, nearp, P.codec_n));
+            if (rowok && col2 && ll[r].y >= 0.0f && hh[r].y > 0.0f) atomicMax(t0p + r * res + 1, codec_row(hh[r].y, nearp, P.codec_n));
+          }
         }
       }
     }
