@@ -10,7 +10,7 @@
 // waves per CU).  Prologue (speculative pose / mesh-header loads, tile zeroing) -> two wave tasks per rock: xy
 // bounds by DPP min / max + the up-facing planes packed from the front of the rock's LDS region, and the outline
 // sides packed from its back (ballot ranks, no atomics) -> rows no rock reaches are written out
-// at once -> ray cast: lanes over the flattened (rock, 2 x 2 pixel quad) list sweep the rock's planes (LDS
+// at once -> ray cast: lanes over the flattened (rock, item of 4 x 2 pixels) list sweep the rock's planes (LDS
 // broadcasts, packed FMAs, min3 / max3) and merge into the tile with integer atomicMax -> one epilogue pass applies
 // the reference's depth codec (observer.py:259-260) to the pixels that saw a rock (compacted per wave), streams out
 // H (16 B per lane, 1 KB contiguous per wave store), the packed uint8 observation (env.py:171-172, :228-231) and
@@ -162,7 +162,7 @@ struct RenderLds {
   float* sx;        // [32][3]
   float* sR;        // [32][9]
   int* mhdr;        // [32][4] vo, nv, to, nt
-  int* prange;      // [32][4] i0|i1<<16, j0|j1<<16, w2 (quads per row), quads
+  int* prange;      // [32][4] i0|i1<<16, j0|j1<<16, w2 (items per row of items), items (SRL_ITEM_ROWS x 2 pixels each)
   int* reg;         // [32][4] region base in its group, end of its up-facing planes, start of its outline sides, slots before this rock
   int* ehdr;        // [32][2] edge offset, edge count of the rock's mesh
   uint32_t* rowmask;   // [8] bit i set: tile row i may hold a rock pixel (union of the rocks' row ranges)
@@ -372,7 +372,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   do {
     // (a) staging.  Two independent tasks per rock, handed to the 8 waves round robin (with few rocks they run side by
     //     side, with 8 rocks every wave does both for its rock):
-    //     F(b)  first trip: xy bounds of the rock (vertices over the lanes, DPP min / max) -> pixel range, quad count,
+    //     F(b)  first trip: xy bounds of the rock (vertices over the lanes, DPP min / max) -> pixel range, item count,
     //           row mask; every trip (rocks of the group): its up-facing world-frame planes, packed from the front of the
     //           rock's region by ballot ranks
     //     E(b)  (rocks of the group) its outline: the edges shared by an up-facing and a down-facing face, projected; side
@@ -528,14 +528,14 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       }
       RSTAMP(2);
     }
-    // (e) ray cast: lanes over the flattened (rock, 2 x 2 pixel quad) list; when the list is short each quad
+    // (e) ray cast: lanes over the flattened (rock, item of SRL_ITEM_ROWS x 2 pixels) list; when the list is short each item
     //     is shared by S adjacent lanes that split the planes and combine with shuffles
 #ifdef SRL_ABL_NOCAST
     if (be > bs && P.px == 12345.0f) {
 #else
     if (be > bs) {
 #endif
-      // quad counts of the group's rocks as running sums (registers, one LDS round trip); groups of more
+      // item counts of the group's rocks as running sums (registers, one LDS round trip); groups of more
       // than 8 rocks fall back to walking the list
       const bool few = be - bs <= 8;
       int pre[8];
