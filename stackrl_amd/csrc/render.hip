@@ -11,8 +11,9 @@
 // bounds by DPP min / max + the up-facing planes packed from the front of the rock's LDS region, and the outline
 // sides packed from its back (ballot ranks, no atomics) -> rows no rock reaches are written out
 // at once -> ray cast: lanes over the flattened (rock, item of 4 x 2 pixels) list sweep the rock's planes (LDS
-// broadcasts, packed FMAs, min3 / max3) and merge into the tile with integer atomicMax -> one epilogue pass applies
-// the reference's depth codec (observer.py:259-260) to the pixels that saw a rock (compacted per wave), streams out
+// broadcasts, packed FMAs, min3) and merge into the tile — as rows of the depth-codec table, which are monotone in the
+// height — with integer atomicMax -> one branch-free epilogue pass looks the reference's depth codec up
+// (observer.py:259-260, tabulated over the float32 lattice of 1000 - z: DevParams::codec), streams out
 // H (16 B per lane, 1 KB contiguous per wave store), the packed uint8 observation (env.py:171-172, :228-231) and
 // accumulates the IoU sums (rewarder.py:297-307) in the fixed order DESIGN.md defines.  HBM traffic per env step
 // is the algorithmic 6*res^2 + 5*r^2 bytes out plus ~1.4 KB per rock of mesh/pose data in (L2-resident pool).
