@@ -39,26 +39,45 @@ enum { M_MODE = 0, M_U, M_V, M_NEXT, M_ZMAX, M_FLAGS, M_NCOL, M_CNT, M_NB, M_PEN
 struct Lds {
   float* sm;
   const DevParams* P;
-  __device__ __forceinline__ float* X(int b) const { return sm + P->OFF_X + 4 * b; }
-  __device__ __forceinline__ float* Q(int b) const { return sm + P->OFF_Q + 4 * b; }
-  __device__ __forceinline__ float* Vl(int b) const { return sm + P->OFF_V + 4 * b; }
-  __device__ __forceinline__ float* Wl(int b) const { return sm + P->OFF_W + 4 * b; }
-  __device__ __forceinline__ float* PX(int b) const { return sm + P->OFF_PX + 4 * b; }
-  __device__ __forceinline__ float* PQ(int b) const { return sm + P->OFF_PQ + 4 * b; }
-  __device__ __forceinline__ int* MESH() const { return (int*)(sm + P->OFF_MESH); }
-  __device__ __forceinline__ float* GM(int b) const { return sm + P->OFF_GM + SRL_GM_WORDS * b; }
-  __device__ __forceinline__ float* MAN(int s) const { return sm + P->OFF_MAN + SRL_MAN_WORDS * s; }
-  __device__ __forceinline__ int* SOP() const { return (int*)(sm + P->OFF_SOP); }
-  __device__ __forceinline__ int* POS() const { return (int*)(sm + P->OFF_POS); }
-  __device__ __forceinline__ int* COL() const { return (int*)(sm + P->OFF_COL); }
-  __device__ __forceinline__ float* R(int b) const { return sm + P->BLOB + P->S_R + 9 * b; }
-  __device__ __forceinline__ float* IW(int b) const { return sm + P->BLOB + P->S_IW + 9 * b; }
-  __device__ __forceinline__ float* AMIN(int b) const { return sm + P->BLOB + P->S_AMIN + 3 * b; }
-  __device__ __forceinline__ float* AMAX(int b) const { return sm + P->BLOB + P->S_AMAX + 3 * b; }
-  __device__ __forceinline__ float* BC(int b) const { return sm + P->BLOB + P->S_BC + 8 * b; }  // inv_mass, ii xyz, radius, nv, vo, mesh
-  __device__ __forceinline__ float* WV(int b) const { return sm + P->BLOB + P->S_WV + 3 * P->VS * b; }
-  __device__ __forceinline__ float* LV(int b) const { return sm + P->BLOB + P->S_LV + 3 * P->VS * b; }
-  __device__ __forceinline__ int* MISC() const { return (int*)(sm + P->BLOB + P->S_MISC); }
+  // the blob / scratch layout of DevParams, read once per kernel and kept in scalar registers (laundered through an
+  // empty asm so that the compiler cannot re-load them from memory wherever they are used: a scalar load next to LDS
+  // traffic shares its wait counter, and with one wave per SIMD nothing hides its latency)
+  int oX, oQ, oV, oW, oPX, oPQ, oMESH, oGM, oMAN, oSOP, oPOS, oCOL, oR, oIW, oAMIN, oAMAX, oBC, oWV, oLV, oMISC, vs3;
+  __device__ __forceinline__ void init(float* sm_, const DevParams* P_) {
+    sm = sm_; P = P_;
+    oX = P->OFF_X; oQ = P->OFF_Q; oV = P->OFF_V; oW = P->OFF_W; oPX = P->OFF_PX; oPQ = P->OFF_PQ; oMESH = P->OFF_MESH;
+    oGM = P->OFF_GM; oMAN = P->OFF_MAN; oSOP = P->OFF_SOP; oPOS = P->OFF_POS; oCOL = P->OFF_COL;
+    const int blob = P->BLOB;
+    oR = blob + P->S_R; oIW = blob + P->S_IW; oAMIN = blob + P->S_AMIN; oAMAX = blob + P->S_AMAX; oBC = blob + P->S_BC;
+    oWV = blob + P->S_WV; oLV = blob + P->S_LV; oMISC = blob + P->S_MISC; vs3 = 3 * P->VS;
+#ifndef SRL_NO_LAUNDER
+#define SRL_KEEP(x) asm volatile("" : "+s"(x))
+    SRL_KEEP(oX); SRL_KEEP(oQ); SRL_KEEP(oV); SRL_KEEP(oW); SRL_KEEP(oPX); SRL_KEEP(oPQ); SRL_KEEP(oMESH); SRL_KEEP(oGM);
+    SRL_KEEP(oMAN); SRL_KEEP(oSOP); SRL_KEEP(oPOS); SRL_KEEP(oCOL); SRL_KEEP(oR); SRL_KEEP(oIW); SRL_KEEP(oAMIN);
+    SRL_KEEP(oAMAX); SRL_KEEP(oBC); SRL_KEEP(oWV); SRL_KEEP(oLV); SRL_KEEP(oMISC); SRL_KEEP(vs3);
+#undef SRL_KEEP
+#endif
+  }
+  __device__ __forceinline__ float* X(int b) const { return sm + oX + 4 * b; }
+  __device__ __forceinline__ float* Q(int b) const { return sm + oQ + 4 * b; }
+  __device__ __forceinline__ float* Vl(int b) const { return sm + oV + 4 * b; }
+  __device__ __forceinline__ float* Wl(int b) const { return sm + oW + 4 * b; }
+  __device__ __forceinline__ float* PX(int b) const { return sm + oPX + 4 * b; }
+  __device__ __forceinline__ float* PQ(int b) const { return sm + oPQ + 4 * b; }
+  __device__ __forceinline__ int* MESH() const { return (int*)(sm + oMESH); }
+  __device__ __forceinline__ float* GM(int b) const { return sm + oGM + SRL_GM_WORDS * b; }
+  __device__ __forceinline__ float* MAN(int s) const { return sm + oMAN + SRL_MAN_WORDS * s; }
+  __device__ __forceinline__ int* SOP() const { return (int*)(sm + oSOP); }
+  __device__ __forceinline__ int* POS() const { return (int*)(sm + oPOS); }
+  __device__ __forceinline__ int* COL() const { return (int*)(sm + oCOL); }
+  __device__ __forceinline__ float* R(int b) const { return sm + oR + 9 * b; }
+  __device__ __forceinline__ float* IW(int b) const { return sm + oIW + 9 * b; }
+  __device__ __forceinline__ float* AMIN(int b) const { return sm + oAMIN + 3 * b; }
+  __device__ __forceinline__ float* AMAX(int b) const { return sm + oAMAX + 3 * b; }
+  __device__ __forceinline__ float* BC(int b) const { return sm + oBC + 8 * b; }  // inv_mass, ii xyz, radius, nv, vo, mesh
+  __device__ __forceinline__ float* WV(int b) const { return sm + oWV + vs3 * b; }
+  __device__ __forceinline__ float* LV(int b) const { return sm + oLV + vs3 * b; }
+  __device__ __forceinline__ int* MISC() const { return (int*)(sm + oMISC); }
 };
 
 // ------------------------------------------------------------------ episode reset (env.py:266-293)
@@ -306,8 +325,13 @@ __device__ __forceinline__ void sat_faces(const DevParams& P, int mesh_a, const 
     const float nx = __shfl_xor(bn.x, m, G), ny = __shfl_xor(bn.y, m, G), nz = __shfl_xor(bn.z, m, G);
     if (ob > best || (ob == best && oo < border)) { best = ob; border = oo; bvert = ov; bn = V(nx, ny, nz); }
   }
-  if (border < 1024 || border == 0x7fffffff) { nrm = neg(bn); pb = ld3(VB + 3 * bvert); pa = madd(pb, bn, -best); }
-  else { nrm = bn; pa = ld3(VA + 3 * bvert); pb = madd(pa, bn, -best); }
+  // (value selects, not two branches writing through pa / pb: the compiler merged those into stores at a computed
+  //  scratch offset)
+  const bool face_of_a = border < 1024 || border == 0x7fffffff;
+  const v3 pv = ld3((face_of_a ? VB : VA) + 3 * bvert), po = madd(pv, bn, -best);
+  nrm = face_of_a ? neg(bn) : bn;
+  pa = face_of_a ? po : pv;
+  pb = face_of_a ? pv : po;
   dist = best;
 }
 
@@ -715,7 +739,7 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
   const DevParams& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int e = blockIdx.x, tid = threadIdx.x;
-  Lds L; L.sm = sm; L.P = Pp;
+  Lds L; L.init(sm, Pp);
   int* misc = L.MISC();
   EnvHdr* h = &P.hdr[e];
   float* gblob = P.blob + (size_t)e * P.BLOB;
