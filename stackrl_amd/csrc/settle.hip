@@ -42,19 +42,19 @@ struct Lds {
   // the blob / scratch layout of DevParams, read once per kernel and kept in scalar registers (laundered through an
   // empty asm so that the compiler cannot re-load them from memory wherever they are used: a scalar load next to LDS
   // traffic shares its wait counter, and with one wave per SIMD nothing hides its latency)
-  int oX, oQ, oV, oW, oPX, oPQ, oMESH, oGM, oMAN, oSOP, oPOS, oCOL, oR, oIW, oAMIN, oAMAX, oBC, oWV, oLV, oMISC, vs3;
+  int oX, oQ, oV, oW, oPX, oPQ, oMESH, oGM, oMAN, oSOP, oPOS, oCOL, oR, oIW, oAMIN, oAMAX, oBC, oWV, oLV, oMISC, oPAIR, vs3;
   __device__ __forceinline__ void init(float* sm_, const DevParams* P_) {
     sm = sm_; P = P_;
     oX = P->OFF_X; oQ = P->OFF_Q; oV = P->OFF_V; oW = P->OFF_W; oPX = P->OFF_PX; oPQ = P->OFF_PQ; oMESH = P->OFF_MESH;
     oGM = P->OFF_GM; oMAN = P->OFF_MAN; oSOP = P->OFF_SOP; oPOS = P->OFF_POS; oCOL = P->OFF_COL;
     const int blob = P->BLOB;
     oR = blob + P->S_R; oIW = blob + P->S_IW; oAMIN = blob + P->S_AMIN; oAMAX = blob + P->S_AMAX; oBC = blob + P->S_BC;
-    oWV = blob + P->S_WV; oLV = blob + P->S_LV; oMISC = blob + P->S_MISC; vs3 = 3 * P->VS;
+    oWV = blob + P->S_WV; oLV = blob + P->S_LV; oMISC = blob + P->S_MISC; oPAIR = blob + P->S_PAIR; vs3 = 3 * P->VS;
 #ifndef SRL_NO_LAUNDER
 #define SRL_KEEP(x) asm volatile("" : "+s"(x))
     SRL_KEEP(oX); SRL_KEEP(oQ); SRL_KEEP(oV); SRL_KEEP(oW); SRL_KEEP(oPX); SRL_KEEP(oPQ); SRL_KEEP(oMESH); SRL_KEEP(oGM);
     SRL_KEEP(oMAN); SRL_KEEP(oSOP); SRL_KEEP(oPOS); SRL_KEEP(oCOL); SRL_KEEP(oR); SRL_KEEP(oIW); SRL_KEEP(oAMIN);
-    SRL_KEEP(oAMAX); SRL_KEEP(oBC); SRL_KEEP(oWV); SRL_KEEP(oLV); SRL_KEEP(oMISC); SRL_KEEP(vs3);
+    SRL_KEEP(oAMAX); SRL_KEEP(oBC); SRL_KEEP(oWV); SRL_KEEP(oLV); SRL_KEEP(oMISC); SRL_KEEP(oPAIR); SRL_KEEP(vs3);
 #undef SRL_KEEP
 #endif
   }
@@ -78,6 +78,10 @@ struct Lds {
   __device__ __forceinline__ float* WV(int b) const { return sm + oWV + vs3 * b; }
   __device__ __forceinline__ float* LV(int b) const { return sm + oLV + vs3 * b; }
   __device__ __forceinline__ int* MISC() const { return (int*)(sm + oMISC); }
+  // bodies (i < j) of pair id p: an LDS copy of the constant tables (a global load inside the sub-step loop would cost a
+  // lone wave a memory round trip)
+  __device__ __forceinline__ int* PAIR() const { return (int*)(sm + oPAIR); }
+  __device__ __forceinline__ void pair(int p, int& i, int& j) const { const int w = PAIR()[p]; i = w & 0xffff; j = w >> 16; }
 };
 
 // ------------------------------------------------------------------ episode reset (env.py:266-293)
@@ -340,7 +344,7 @@ __device__ __forceinline__ void sat_faces(const DevParams& P, int mesh_a, const 
 __device__ __forceinline__ void narrowphase_slot(const Lds& L, int sl, int gl) {
   const DevParams& P = *L.P;
   int pid = L.POS()[sl];
-  int a = c_pair_i[pid], b = c_pair_j[pid];
+  int a, b; L.pair(pid, a, b);
   const float* bca = L.BC(a);
   const float* bcb = L.BC(b);
   int na = __float_as_int(bca[5]), nb = __float_as_int(bcb[5]);
@@ -493,7 +497,7 @@ __device__ __forceinline__ Point make_pair_point(const Lds& L, int sl, int i) {
   const float* mp = L.MAN(sl);
   if (i >= __float_as_int(mp[0])) return p;
   p.valid = true;
-  p.a = c_pair_i[pid]; p.b = c_pair_j[pid];
+  L.pair(pid, p.a, p.b);
   p.colour = L.COL()[sl];
   p.ima = L.BC(p.a)[0]; p.imb = L.BC(p.b)[0];
   p.mu = P.c.friction_rock * P.c.friction_rock;
@@ -601,7 +605,7 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid) {
   const int npair = nb * (nb - 1) / 2;
   int fl = 0;
   for (int pid = tid; pid < npair; pid += T) {
-    int i = c_pair_i[pid], j = c_pair_j[pid];
+    int i, j; L.pair(pid, i, j);
     v3 ai = ld3(L.AMIN(i)), bi = ld3(L.AMAX(i)), aj = ld3(L.AMIN(j)), bj = ld3(L.AMAX(j));
     bool ov = ai.x <= bj.x && aj.x <= bi.x && ai.y <= bj.y && aj.y <= bi.y && ai.z <= bj.z && aj.z <= bi.z;
     int sl = L.SOP()[pid];
@@ -617,7 +621,7 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid) {
       if (flags & 2) {   // allocate slots for newly close pairs: ascending pair id, lowest free slot first
         for (int pid = 0; pid < npair; ++pid) {
           if (L.SOP()[pid] >= 0) continue;
-          int i = c_pair_i[pid], j = c_pair_j[pid];
+          int i, j; L.pair(pid, i, j);
           v3 ai = ld3(L.AMIN(i)), bi = ld3(L.AMAX(i)), aj = ld3(L.AMIN(j)), bj = ld3(L.AMAX(j));
           bool ov = ai.x <= bj.x && aj.x <= bi.x && ai.y <= bj.y && aj.y <= bi.y && ai.z <= bj.z && aj.z <= bi.z;
           if (!ov) continue;
@@ -638,7 +642,7 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid) {
       for (int sl = 0; sl < P.NS; ++sl) {
         int pid = L.POS()[sl];
         if (pid < 0) continue;
-        int i = c_pair_i[pid], j = c_pair_j[pid];
+        int i, j; L.pair(pid, i, j);
         uint64_t u = used[i] | used[j];
         int c = __ffsll((long long)~u) - 1;
         L.COL()[sl] = c;
@@ -721,7 +725,9 @@ __device__ int newest_contacts(const Lds& L, int nb, int tid, int T) {
   int n = 0;
   for (int sl = tid; sl < L.P->NS; sl += T) {
     int pid = L.POS()[sl];
-    if (pid >= 0 && (c_pair_i[pid] == nb - 1 || c_pair_j[pid] == nb - 1)) n += __float_as_int(L.MAN(sl)[0]);
+    int pi_ = -1, pj_ = -1;
+    if (pid >= 0) L.pair(pid, pi_, pj_);
+    if (pid >= 0 && (pi_ == nb - 1 || pj_ == nb - 1)) n += __float_as_int(L.MAN(sl)[0]);
   }
   if (n) atomicAdd(&misc[M_CNT], n);
   __syncthreads();
@@ -804,6 +810,7 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
 
   // ---- load the persistent blob into LDS
   for (int k = tid; k < P.BLOB; k += T) sm[k] = gblob[k];
+  for (int k = tid; k < P.NP; k += T) L.PAIR()[k] = (int)c_pair_i[k] | ((int)c_pair_j[k] << 16);
   __syncthreads();
 
   // ---- K4: Observer.pose (observer.py:392-421): z = max(H[window] + O | O > 1e-4) - oz/2

@@ -50,7 +50,7 @@ struct DevParams {
   // persistent blob layout (32-bit words)
   int32_t OFF_X, OFF_Q, OFF_V, OFF_W, OFF_PX, OFF_PQ, OFF_MESH, OFF_GM, OFF_MAN, OFF_SOP, OFF_POS, OFF_COL, BLOB;
   // scratch layout (words, after the blob in LDS)
-  int32_t S_R, S_IW, S_AMIN, S_AMAX, S_BC, S_WV, S_LV, S_USED, S_MISC, LDS_WORDS;
+  int32_t S_R, S_IW, S_AMIN, S_AMAX, S_BC, S_WV, S_LV, S_USED, S_MISC, S_PAIR, LDS_WORDS;
   // device pointers
   EnvHdr* hdr;
   float* blob;            // [n_envs][BLOB]

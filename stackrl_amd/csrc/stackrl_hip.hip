@@ -136,6 +136,7 @@ void layout(DevParams& P) {
   s = (s + 1) & ~1;
   P.S_USED = s; s += 2 * SRL_MAX_BODIES;   // colouring scratch (uint64 per body); BLOB is a multiple of 4 words
   P.S_MISC = s; s += M_WORDS;
+  P.S_PAIR = s; s += P.NP;                 // pair id -> (i | j << 16), copied from the constant tables once per launch
   P.LDS_WORDS = P.BLOB + s;
 }
 
