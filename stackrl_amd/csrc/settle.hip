@@ -34,7 +34,7 @@ __constant__ uint8_t c_pair_i[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
 __constant__ uint8_t c_pair_j[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
 
 // misc words in LDS
-enum { M_MODE = 0, M_U, M_V, M_NEXT, M_ZMAX, M_FLAGS, M_NCOL, M_CNT, M_NB, M_PENDING, M_STATUS, M_DONE, M_ORIENT, M_WORDS = 16 };
+enum { M_MODE = 0, M_U, M_V, M_NEXT, M_ZMAX, M_FLAGS, M_NCOL, M_CNT, M_NB, M_PENDING, M_STATUS, M_DONE, M_ORIENT, M_MOVING, M_WORDS = 16 };
 
 struct Lds {
   float* sm;
@@ -709,12 +709,23 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid) {
 
 // simulator.py:322-335: every body's linear speed <= threshold
 __device__ __forceinline__ bool sim_stop(const Lds& L, int nb, int tid) {
+  int* misc = L.MISC();
   bool moving = false;
   if (tid < nb) {
     v3 v = ld3(L.Vl(tid));
     moving = sqrtf(dot(v, v)) > L.P->c.velocity_threshold;
   }
-  return !__syncthreads_or(moving ? 1 : 0);
+  // the bodies are lanes of wave 0 (nb <= 32): one ballot, one LDS word, one barrier.  (__syncthreads_or reads the
+  // workgroup size from the dispatch packet in global memory on every call: a memory round trip per sub-step that a
+  // lone wave cannot hide.)
+  if (tid < 64) {
+    const unsigned long long m = __ballot(moving);
+    if (tid == 0) misc[M_MOVING] = m != 0ull;
+  }
+  __syncthreads();
+  const int any = misc[M_MOVING];
+  __syncthreads();   // the word is rewritten by the next call
+  return !any;
 }
 
 // number of manifold points on the newest body (getContactPoints, simulator.py:340)
