@@ -1,7 +1,7 @@
 // settle.hip — K1 (place / smooth placing / settle) + K4 (Observer.pose) + the episode machine.
 //
-// One workgroup per env: 128 threads (2 waves) for L <= 8 bodies, 256 threads with 1 - 3 contact points per
-// thread above that (srl_k_step / _pp1 / _pp2 / _pp3).  The env's whole persistent state ("blob": poses,
+// One workgroup per env: 128 threads (2 waves) for L <= 8 bodies, 256 threads with 1 - 2 contact points per
+// thread above that, 512 threads with 2 for the longest episodes (srl_k_step / _pp1 / _pp2 / _t512).  The env's whole persistent state ("blob": poses,
 // velocities, ground and body-body manifolds with their warm-start impulses, slot tables) is loaded into
 // LDS once, every sub-step runs out of LDS, and the blob is written back once — HBM traffic per env step
 // is 2 x BLOB words regardless of how many sub-steps the stop criterion takes.
@@ -937,7 +937,9 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
 
 // Variants: T threads per env, PP contact points of body-body manifolds per thread (4 NS <= T PP).
 // L <= 8 runs two waves per env so that four envs per CU (1,024 envs per GPU) are resident together with up to
-// 256 VGPRs per lane; longer episodes use four waves.
+// 256 VGPRs per lane; longer episodes use four waves with one or two points per thread, and eight waves with two
+// points per thread once 4 NS exceeds 512 (three points per thread at four waves spill: 94.5 -> 57.8 ms per launch at
+// 2,048 envs x 32 rocks).
 extern "C" __global__ void __launch_bounds__(128, 2) srl_k_step(const DevParams* __restrict__ Pp,
     const int64_t* __restrict__ action, int force_reset) {
   step_body<128, 1>(Pp, action, force_reset);
@@ -950,9 +952,9 @@ extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp2(const DevPar
     const int64_t* __restrict__ action, int force_reset) {
   step_body<256, 2>(Pp, action, force_reset);
 }
-extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp3(const DevParams* __restrict__ Pp,
+extern "C" __global__ void __launch_bounds__(512, 2) srl_k_step_t512(const DevParams* __restrict__ Pp,
     const int64_t* __restrict__ action, int force_reset) {
-  step_body<256, 3>(Pp, action, force_reset);
+  step_body<512, 2>(Pp, action, force_reset);
 }
 
 // ------------------------------------------------------------------ ParallelEnv.sample (utils.py:534-538)

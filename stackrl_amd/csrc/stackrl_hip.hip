@@ -169,10 +169,10 @@ int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void*
   }
   const DevParams* dP = env->d_P;
   prof_begin(env, st, 0);
-  if (env->step_pp == 0) hipLaunchKernelGGL(srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
+  if (env->step_pp == 3) hipLaunchKernelGGL(srl_k_step_t512, dim3(n), dim3(512), env->step_lds, st, dP, action, force_reset);
+  else if (env->step_pp == 0) hipLaunchKernelGGL(srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
   else if (env->step_pp == 1) hipLaunchKernelGGL(srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
-  else if (env->step_pp == 2) hipLaunchKernelGGL(srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
-  else hipLaunchKernelGGL(srl_k_step_pp3, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
+  else hipLaunchKernelGGL(srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
   prof_end(env, st);
   prof_begin(env, st, 1);
   hipLaunchKernelGGL(srl_k_render, dim3(n), dim3(SRL_RENDER_THREADS), env->render_lds, st, P, (uint8_t*)obs_map, (uint8_t*)obs_obj,
@@ -382,13 +382,14 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   // threads per env / pair-manifold points per thread (settle.hip "Variants")
   if (4 * P.NS <= 128 && 8 * P.c.episode_length <= 128) { env->step_threads = 128; env->step_pp = 0; }
   else { env->step_threads = 256; env->step_pp = (4 * P.NS + 255) / 256; }
+  if (env->step_pp == 3) env->step_threads = 512;   // 4 NS > 512: eight waves, two points per thread (three per thread at 256 spill)
+  HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_t512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   const int res = P.c.overhead_res;
   env->render_lds = render_lds_bytes(res);
   env->objmap_lds = 0;
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
-  HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->render_lds));
   // K3: object maps of the whole pool, once
   hipLaunchKernelGGL(srl_k_objmap, dim3(n_mesh, P.n_orient), dim3(256), env->objmap_lds, 0, P, env->d_objmap, env->d_objmap_u8);
