@@ -578,6 +578,10 @@ __device__ __forceinline__ void solver_sweep(const Lds& L, Point& gp, Point (&pp
 template <int T, int PP>
 __device__ __forceinline__ void substep(const Lds& L, int nb, int tid) {
   const DevParams& P = *L.P;
+  // With two contact points per thread the register file is full: lane-dependent LDS addresses that the compiler
+  // hoists out of the sub-step loop end up spilled to scratch and are reloaded from memory in every sub-step.  An
+  // opaque copy of the thread index keeps them inside the loop, where recomputing one costs an instruction or two.
+  if (PP >= 2) asm volatile("" : "+v"(tid));
 #ifdef SRL_STAMPS
   long long _t0 = wall_clock64();
 #endif
