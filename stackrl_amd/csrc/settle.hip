@@ -178,11 +178,11 @@ __device__ __forceinline__ void body_bounds_ground(const Lds& L, int b, int gl) 
       if (d < thr) cd[j] = d;
     }
   }
-#pragma unroll
-  for (int s = 1; s < 16; s <<= 1) {
-    lo = V(fminf(lo.x, __shfl_xor(lo.x, s, 16)), fminf(lo.y, __shfl_xor(lo.y, s, 16)), fminf(lo.z, __shfl_xor(lo.z, s, 16)));
-    hi = V(fmaxf(hi.x, __shfl_xor(hi.x, s, 16)), fmaxf(hi.y, __shfl_xor(hi.y, s, 16)), fmaxf(hi.z, __shfl_xor(hi.z, s, 16)));
-  }
+#define SRL_BOUNDS_STEP(C)                                                                                   \
+  lo = V(fminf(lo.x, dpp_f<C>(lo.x)), fminf(lo.y, dpp_f<C>(lo.y)), fminf(lo.z, dpp_f<C>(lo.z)));                \
+  hi = V(fmaxf(hi.x, dpp_f<C>(hi.x)), fmaxf(hi.y, dpp_f<C>(hi.y)), fmaxf(hi.z, dpp_f<C>(hi.z)));
+  SRL_BOUNDS_STEP(0xB1) SRL_BOUNDS_STEP(0x4E) SRL_BOUNDS_STEP(0x141) SRL_BOUNDS_STEP(0x140)   // (srl_device.h: dpp_f)
+#undef SRL_BOUNDS_STEP
   float sd[SRL_GMAXP]; int sk[SRL_GMAXP];
   int ns = 0;
 #pragma unroll
@@ -193,12 +193,11 @@ __device__ __forceinline__ void body_bounds_ground(const Lds& L, int b, int gl) 
 #pragma unroll
       for (int j = 0; j < SRL_MAX_VERTS / 16; ++j)
         if (cd[j] < bd) { bd = cd[j]; bk = gl + 16 * j; }   // ascending k: lowest index wins ties
-#pragma unroll
-      for (int s = 1; s < 16; s <<= 1) {
-        const float od = __shfl_xor(bd, s, 16);
-        const int ok = __shfl_xor(bk, s, 16);
-        if (od < bd || (od == bd && ok < bk)) { bd = od; bk = ok; }
-      }
+#define SRL_MIN_STEP(C)                                                                                      \
+      { const float od = dpp_f<C>(bd); const int ok = dpp_i<C>(bk);                                                 \
+        if (od < bd || (od == bd && ok < bk)) { bd = od; bk = ok; } }
+      SRL_MIN_STEP(0xB1) SRL_MIN_STEP(0x4E) SRL_MIN_STEP(0x141) SRL_MIN_STEP(0x140)
+#undef SRL_MIN_STEP
       if (bd < 3.0e38f) {
         sd[r] = bd; sk[r] = bk; ns = r + 1;
 #pragma unroll
@@ -322,12 +321,19 @@ __device__ __forceinline__ void sat_faces(const DevParams& P, int mesh_a, const 
       if (smin > best) { best = smin; border = pass * 1024 + t; bvert = kmin; bn = n; }
     }
   }
-#pragma unroll
-  for (int m = 1; m < G; m <<= 1) {
-    const float ob = __shfl_xor(best, m, G);
-    const int oo = __shfl_xor(border, m, G), ov = __shfl_xor(bvert, m, G);
-    const float nx = __shfl_xor(bn.x, m, G), ny = __shfl_xor(bn.y, m, G), nz = __shfl_xor(bn.z, m, G);
+  static_assert(G == 1 || G == 16 || G == 32, "group reductions are written for 1, 16 or 32 lanes");
+  auto take = [&](float ob, int oo, int ov, float nx, float ny, float nz) {
     if (ob > best || (ob == best && oo < border)) { best = ob; border = oo; bvert = ov; bn = V(nx, ny, nz); }
+  };
+#define SRL_SAT_STEP(C) take(dpp_f<C>(best), dpp_i<C>(border), dpp_i<C>(bvert), dpp_f<C>(bn.x), dpp_f<C>(bn.y), dpp_f<C>(bn.z));
+  if (G >= 16) { SRL_SAT_STEP(0xB1) SRL_SAT_STEP(0x4E) SRL_SAT_STEP(0x141) SRL_SAT_STEP(0x140) }
+#undef SRL_SAT_STEP
+  if (G >= 32) {
+    float b0, b1, x0, x1, y0, y1, z0, z1; int o0, o1, v0, v1;
+    rows_f(best, b0, b1); rows_i(border, o0, o1); rows_i(bvert, v0, v1);
+    rows_f(bn.x, x0, x1); rows_f(bn.y, y0, y1); rows_f(bn.z, z0, z1);
+    best = b0; border = o0; bvert = v0; bn = V(x0, y0, z0);
+    take(b1, o1, v1, x1, y1, z1);
   }
   // (value selects, not two branches writing through pa / pb: the compiler merged those into stores at a computed
   //  scratch offset)

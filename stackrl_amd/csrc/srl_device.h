@@ -274,6 +274,26 @@ __device__ __forceinline__ int simplex_closest(Simplex& s, v3& vout) {
   return 1;
 }
 
+// Exchange steps of symmetric all-reductions over aligned groups of 16 / 32 lanes without LDS traffic (__shfl_xor
+// compiles to ds_bpermute_b32: an LDS round trip per step, which a lone wave cannot hide).  Steps within a row of 16
+// lanes are DPP moves — quad_perm [1,0,3,2] (0xB1), quad_perm [2,3,0,1] (0x4E), row_half_mirror (0x141), row_mirror
+// (0x140): after the first two a quad is uniform, the mirrors then pair quad with quad and half with half — and the step
+// between the two rows of a 32-lane group is v_permlane16_swap_b32 (gfx950), which hands every lane both rows' values at
+// its position.  The pairing differs from xor-butterflies but a reduction by a total order gives the same result
+// (tools/experiments/permlane_swap.hip prints the lane maps).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+__device__ __forceinline__ void rows_i(int v, int& even, int& odd) {
+  const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  even = (int)r[0]; odd = (int)r[1];
+}
+__device__ __forceinline__ void rows_f(float v, float& even, float& odd) {
+  int a, b; rows_i(__float_as_int(v), a, b);
+  even = __int_as_float(a); odd = __int_as_float(b);
+}
+
 // Support vertices of A in direction -v and of B in direction +v (arg max of P[k] . d, lowest index on ties),
 // computed by a group of G adjacent lanes: each lane scans the vertices k = gl, gl + G, ... of both clouds and the
 // group combines both results in the same xor-shuffle rounds.  G = 1 is the plain sequential scan.  The dot
@@ -289,12 +309,22 @@ __device__ __forceinline__ void support_pair(const float* VA, int na, const floa
     if (k < na) { float t = dot(ld3(VA + 3 * k), nv); if (t > da) { da = t; ba = k; } }
     if (k < nb) { float t = dot(ld3(VB + 3 * k), v); if (t > db) { db = t; bb = k; } }
   }
-#pragma unroll
-  for (int m = 1; m < G; m <<= 1) {
-    float oa = __shfl_xor(da, m, G), ob = __shfl_xor(db, m, G);
-    int ka = __shfl_xor(ba, m, G), kb = __shfl_xor(bb, m, G);
+  static_assert(G == 1 || G == 16 || G == 32, "group reductions are written for 1, 16 or 32 lanes");
+  auto take = [&](float oa, float ob, int ka, int kb) {
     if (oa > da || (oa == da && ka < ba)) { da = oa; ba = ka; }
     if (ob > db || (ob == db && kb < bb)) { db = ob; bb = kb; }
+  };
+  if (G >= 16) {
+    take(dpp_f<0xB1>(da), dpp_f<0xB1>(db), dpp_i<0xB1>(ba), dpp_i<0xB1>(bb));
+    take(dpp_f<0x4E>(da), dpp_f<0x4E>(db), dpp_i<0x4E>(ba), dpp_i<0x4E>(bb));
+    take(dpp_f<0x141>(da), dpp_f<0x141>(db), dpp_i<0x141>(ba), dpp_i<0x141>(bb));
+    take(dpp_f<0x140>(da), dpp_f<0x140>(db), dpp_i<0x140>(ba), dpp_i<0x140>(bb));
+  }
+  if (G >= 32) {
+    float da0, da1, db0, db1; int ba0, ba1, bb0, bb1;
+    rows_f(da, da0, da1); rows_f(db, db0, db1); rows_i(ba, ba0, ba1); rows_i(bb, bb0, bb1);
+    da = da0; ba = ba0; db = db0; bb = bb0;
+    take(da1, db1, ba1, bb1);
   }
   ia = ba; ib = bb;
 }
