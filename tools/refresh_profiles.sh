@@ -12,3 +12,9 @@ python tools/ab_render.py --libs ab_libs > gpurun_out/ablation.txt 2>&1 || exit 
 echo ablation done
 bash tools/pmc_ablate.sh > gpurun_out/inst_counts.txt 2>&1 || exit 1
 echo all done
+# settle kernel counters (profiles/r01_settle_pmc.txt)
+cd /tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d gpurun_out/pmc_s1 -- python3 bench.py --no-cpu --steps 18 > gpurun_out/pmc_s1.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/pmc_s2 -- python3 bench.py --no-cpu --steps 18 > gpurun_out/pmc_s2.log 2>&1 || exit 1
+python tools/pmc_insts.py srl_k_step gpurun_out/pmc_s1 gpurun_out/pmc_s2 > gpurun_out/settle_pmc.txt
+echo settle pmc done
