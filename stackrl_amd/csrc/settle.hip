@@ -552,11 +552,14 @@ __device__ __forceinline__ void point_turn(const Lds& L, Point& p) {
   }
 }
 
+// gturns / pturns: the turns this wave needs in a ground / colour phase = 1 + the highest point index any of its lanes
+// holds (a turn no lane takes still costs a lone wave its loop control: 8 + 4 ncol empty turns per sweep were a third
+// of the sub-step's instructions)
 template <bool WARM, int PP>
-__device__ __forceinline__ void solver_sweep(const Lds& L, Point& gp, Point (&pp)[PP], int ncol) {
+__device__ __forceinline__ void solver_sweep(const Lds& L, Point& gp, Point (&pp)[PP], int ncol, int gturns, int pturns) {
   // ground phase: the (up to 8) points of one body are consecutive lanes of one wave and take turns
 #pragma unroll 1
-  for (int i = 0; i < SRL_GMAXP; ++i) {
+  for (int i = 0; i < gturns; ++i) {
     if (gp.valid && gp.idx == i) point_turn<WARM, false>(L, gp);
     __builtin_amdgcn_wave_barrier();
   }
@@ -564,7 +567,7 @@ __device__ __forceinline__ void solver_sweep(const Lds& L, Point& gp, Point (&pp
 #pragma unroll 1
   for (int c = 0; c < ncol; ++c) {
 #pragma unroll 1
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < pturns; ++i) {
 #pragma unroll
       for (int r = 0; r < PP; ++r)
         if (pp[r].valid && pp[r].colour == c && pp[r].idx == i) point_turn<WARM, true>(L, pp[r]);
@@ -683,8 +686,18 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid) {
     for (int r = 0; r < PP; ++r) pp[r] = make_pair_point(L, (tid + r * T) >> 2, tid & 3);
     __syncthreads();   // every lane has read the pre-solve velocities' companions (R, Iw, manifolds)
     STAMP(5);
-    solver_sweep<true, PP>(L, gp, pp, ncol);
-    for (int it = 0; it < P.c.solver_iterations; ++it) solver_sweep<false, PP>(L, gp, pp, ncol);
+    int gturns = 0, pturns = 0;   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < SRL_GMAXP; ++i) if (__ballot(gp.valid && gp.idx == i)) gturns = i + 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < PP; ++r) any |= pp[r].valid && pp[r].idx == i;
+      if (__ballot(any)) pturns = i + 1;
+    }
+    solver_sweep<true, PP>(L, gp, pp, ncol, gturns, pturns);
+    for (int it = 0; it < P.c.solver_iterations; ++it) solver_sweep<false, PP>(L, gp, pp, ncol, gturns, pturns);
     // accumulated impulses back to the manifolds (warm start of the next sub-step)
     if (gp.valid) { float* g = L.GM(gp.a); g[17 + gp.idx] = gp.in; g[25 + gp.idx] = gp.i1; g[33 + gp.idx] = gp.i2; }
 #pragma unroll
