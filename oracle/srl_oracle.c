@@ -1039,6 +1039,18 @@ static void narrowphase_slot(const struct srlo_env* e, env_t* s, int sl) {
 /* one solver row: direction d at arms ra (body A) / rb (body B) */
 typedef struct { v3 va, wa, vb, wb; } vel4;
 
+/* The clamp of an accumulated impulse to [lo, hi] is the median of the three values, as the GPU instruction the kernel
+ * uses defines it for non-NaN inputs (V_MED3_F32: if MAX3 == S0 then MAX(S1, S2), else if MAX3 == S1 then MAX(S0, S2),
+ * else MAX(S0, S1), with MAX ordering -0 below +0).  For lo <= hi this is the usual clamp; the restatement pins which
+ * zero comes back when the value equals a bound of the other sign. */
+static inline float fmax_sz(float a, float b) { if (a > b) return a; if (b > a) return b; return signbit(a) ? b : a; }
+static inline float med3f(float a, float b, float c) {
+  float m = fmax_sz(fmax_sz(a, b), c);
+  if (m == a) return fmax_sz(b, c);
+  if (m == b) return fmax_sz(a, c);
+  return fmax_sz(a, b);
+}
+
 static inline float row_solve(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float imb, const m3* Ib,
                               vel4* u, float target, float* acc, float lo, float hi, int has_b) {
   v3 ca = vcross(ra, d);
@@ -1054,9 +1066,7 @@ static inline float row_solve(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float
   }
   float rk = 1.0f / k;            /* reciprocal effective mass, as the kernel precomputes it per row */
   float dl = (target - vrel) * rk;
-  float na = *acc + dl;
-  if (na < lo) na = lo;
-  if (na > hi) na = hi;
+  float na = med3f(*acc + dl, lo, hi);   /* clamp to [lo, hi] */
   dl = na - *acc;
   *acc = na;
   u->va = vmadd(u->va, d, ima * dl);
