@@ -193,11 +193,15 @@ __device__ __forceinline__ void body_bounds_ground(const Lds& L, int b, int gl) 
 #pragma unroll
       for (int j = 0; j < SRL_MAX_VERTS / 16; ++j)
         if (cd[j] < bd) { bd = cd[j]; bk = gl + 16 * j; }   // ascending k: lowest index wins ties
+      // arg min of (distance, lowest index) over the 16 lanes on a packed key (srl_device.h: dpp_u64); the distance
+      // itself travels along (the key holds it with -0 folded into +0)
+      uint64_t key = ((uint64_t)f2o(bd + 0.0f) << 32) | (uint32_t)bk;
 #define SRL_MIN_STEP(C)                                                                                      \
-      { const float od = dpp_f<C>(bd); const int ok = dpp_i<C>(bk);                                                 \
-        if (od < bd || (od == bd && ok < bk)) { bd = od; bk = ok; } }
+      { const uint64_t ok = dpp_u64<C>(key); const float od = dpp_f<C>(bd);                                        \
+        const bool t = ok < key; key = t ? ok : key; bd = t ? od : bd; }
       SRL_MIN_STEP(0xB1) SRL_MIN_STEP(0x4E) SRL_MIN_STEP(0x141) SRL_MIN_STEP(0x140)
 #undef SRL_MIN_STEP
+      bk = (int)(uint32_t)key;
       if (bd < 3.0e38f) {
         sd[r] = bd; sk[r] = bk; ns = r + 1;
 #pragma unroll

@@ -294,6 +294,21 @@ __device__ __forceinline__ void rows_f(float v, float& even, float& odd) {
   even = __int_as_float(a); odd = __int_as_float(b);
 }
 
+// 64-bit forms of the exchange steps, for reductions on (ordered float << 32 | index) keys: one 64-bit integer
+// compare decides a lexicographic (value, index) order, which keeps the reduction's dependency chain at
+// move -> compare -> select instead of three compares joined by scalar logic
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {
+  return ((uint64_t)(uint32_t)dpp_i<CTRL>((int)(v >> 32)) << 32) | (uint32_t)dpp_i<CTRL>((int)(uint32_t)v);
+}
+__device__ __forceinline__ void rows_u64(uint64_t v, uint64_t& even, uint64_t& odd) {
+  int h0, h1, l0, l1;
+  rows_i((int)(v >> 32), h0, h1); rows_i((int)(uint32_t)v, l0, l1);
+  even = ((uint64_t)(uint32_t)h0 << 32) | (uint32_t)l0; odd = ((uint64_t)(uint32_t)h1 << 32) | (uint32_t)l1;
+}
+// key of (value, index) for "largest value, lowest index on ties" (x + 0 turns -0 into +0: the float order has one zero)
+__device__ __forceinline__ uint64_t key_max_lo(float d, int k) { return ((uint64_t)f2o(d + 0.0f) << 32) | (uint32_t)(0x7fffffff - k); }
+
 // Support vertices of A in direction -v and of B in direction +v (arg max of P[k] . d, lowest index on ties),
 // computed by a group of G adjacent lanes: each lane scans the vertices k = gl, gl + G, ... of both clouds and the
 // group combines both results in the same xor-shuffle rounds.  G = 1 is the plain sequential scan.  The dot
@@ -310,21 +325,19 @@ __device__ __forceinline__ void support_pair(const float* VA, int na, const floa
     if (k < nb) { float t = dot(ld3(VB + 3 * k), v); if (t > db) { db = t; bb = k; } }
   }
   static_assert(G == 1 || G == 16 || G == 32, "group reductions are written for 1, 16 or 32 lanes");
-  auto take = [&](float oa, float ob, int ka, int kb) {
-    if (oa > da || (oa == da && ka < ba)) { da = oa; ba = ka; }
-    if (ob > db || (ob == db && kb < bb)) { db = ob; bb = kb; }
-  };
-  if (G >= 16) {
-    take(dpp_f<0xB1>(da), dpp_f<0xB1>(db), dpp_i<0xB1>(ba), dpp_i<0xB1>(bb));
-    take(dpp_f<0x4E>(da), dpp_f<0x4E>(db), dpp_i<0x4E>(ba), dpp_i<0x4E>(bb));
-    take(dpp_f<0x141>(da), dpp_f<0x141>(db), dpp_i<0x141>(ba), dpp_i<0x141>(bb));
-    take(dpp_f<0x140>(da), dpp_f<0x140>(db), dpp_i<0x140>(ba), dpp_i<0x140>(bb));
-  }
-  if (G >= 32) {
-    float da0, da1, db0, db1; int ba0, ba1, bb0, bb1;
-    rows_f(da, da0, da1); rows_f(db, db0, db1); rows_i(ba, ba0, ba1); rows_i(bb, bb0, bb1);
-    da = da0; ba = ba0; db = db0; bb = bb0;
-    take(da1, db1, ba1, bb1);
+  if (G > 1) {
+    // arg max of (dot, lowest index) over the group on packed keys; the sentinel index 0x7fffffff (no vertex seen) packs
+    // to 0 and loses every tie, as in the sequential scan
+    uint64_t ka = key_max_lo(da, ba), kb = key_max_lo(db, bb);
+#define SRL_SUP_STEP(C) { const uint64_t oa = dpp_u64<C>(ka), ob = dpp_u64<C>(kb); ka = oa > ka ? oa : ka; kb = ob > kb ? ob : kb; }
+    SRL_SUP_STEP(0xB1) SRL_SUP_STEP(0x4E) SRL_SUP_STEP(0x141) SRL_SUP_STEP(0x140)
+#undef SRL_SUP_STEP
+    if (G >= 32) {
+      uint64_t a0, a1, b0, b1;
+      rows_u64(ka, a0, a1); rows_u64(kb, b0, b1);
+      ka = a1 > a0 ? a1 : a0; kb = b1 > b0 ? b1 : b0;
+    }
+    ba = 0x7fffffff - (int)(uint32_t)ka; bb = 0x7fffffff - (int)(uint32_t)kb;
   }
   ia = ba; ib = bb;
 }
