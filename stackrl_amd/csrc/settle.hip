@@ -561,11 +561,14 @@ __device__ __forceinline__ void point_turn(const Lds& L, Point& p) {
 // holds (a turn no lane takes still costs a lone wave its loop control: 8 + 4 ncol empty turns per sweep were a third
 // of the sub-step's instructions)
 template <bool WARM, int PP>
-__device__ __forceinline__ void solver_sweep(const Lds& L, Point& gp, Point (&pp)[PP], int ncol, int gturns, int pturns) {
+__device__ __forceinline__ void solver_sweep(const Lds& L, Point& gp, Point (&pp)[PP], int ncol, int gturns, int pturns,
+                                             int gslot, const int (&pslot)[PP]) {
+  // gslot / pslot: the turn a lane's point takes (ground: its index; colour phases: 4 * colour + index; -1: none), so
+  // that a turn's guard is one compare
   // ground phase: the (up to 8) points of one body are consecutive lanes of one wave and take turns
 #pragma unroll 1
   for (int i = 0; i < gturns; ++i) {
-    if (gp.valid && gp.idx == i) point_turn<WARM, false>(L, gp);
+    if (gslot == i) point_turn<WARM, false>(L, gp);
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
@@ -575,7 +578,7 @@ __device__ __forceinline__ void solver_sweep(const Lds& L, Point& gp, Point (&pp
     for (int i = 0; i < pturns; ++i) {
 #pragma unroll
       for (int r = 0; r < PP; ++r)
-        if (pp[r].valid && pp[r].colour == c && pp[r].idx == i) point_turn<WARM, true>(L, pp[r]);
+        if (pslot[r] == 4 * c + i) point_turn<WARM, true>(L, pp[r]);
       __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
@@ -701,8 +704,12 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid) {
       for (int r = 0; r < PP; ++r) any |= pp[r].valid && pp[r].idx == i;
       if (__ballot(any)) pturns = i + 1;
     }
-    solver_sweep<true, PP>(L, gp, pp, ncol, gturns, pturns);
-    for (int it = 0; it < P.c.solver_iterations; ++it) solver_sweep<false, PP>(L, gp, pp, ncol, gturns, pturns);
+    const int gslot = gp.valid ? gp.idx : -1;
+    int pslot[PP];
+#pragma unroll
+    for (int r = 0; r < PP; ++r) pslot[r] = pp[r].valid ? 4 * pp[r].colour + pp[r].idx : -1;
+    solver_sweep<true, PP>(L, gp, pp, ncol, gturns, pturns, gslot, pslot);
+    for (int it = 0; it < P.c.solver_iterations; ++it) solver_sweep<false, PP>(L, gp, pp, ncol, gturns, pturns, gslot, pslot);
     // accumulated impulses back to the manifolds (warm start of the next sub-step)
     if (gp.valid) { float* g = L.GM(gp.a); g[17 + gp.idx] = gp.in; g[25 + gp.idx] = gp.i1; g[33 + gp.idx] = gp.i2; }
 #pragma unroll
