@@ -1065,14 +1065,16 @@ static inline float row_solve(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float
     vrel = vrel - (vdot(d, u->vb) + vdot(cb, u->wb));
   }
   float rk = 1.0f / k;            /* reciprocal effective mass, as the kernel precomputes it per row */
-  float dl = (target - vrel) * rk;
+  /* (target - vrel) rk as one fused step, and the linear impulses as (d m^-1) dl: each form keeps the solver's
+   * dependency chain one operation shorter than (target - vrel) * rk and d (m^-1 dl); the kernel evaluates the same */
+  float dl = fmaf(-vrel, rk, target * rk);
   float na = med3f(*acc + dl, lo, hi);   /* clamp to [lo, hi] */
   dl = na - *acc;
   *acc = na;
-  u->va = vmadd(u->va, d, ima * dl);
+  u->va = vmadd(u->va, vscale(d, ima), dl);
   u->wa = vmadd(u->wa, aa, dl);
   if (has_b) {
-    u->vb = vmadd(u->vb, d, -(imb * dl));
+    u->vb = vmadd(u->vb, vscale(d, -imb), dl);
     u->wb = vmadd(u->wb, ab, -dl);
   }
   return dl;
@@ -1081,11 +1083,11 @@ static inline float row_solve(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float
 static inline void row_apply(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float imb, const m3* Ib,
                              vel4* u, float imp, int has_b) {
   v3 aa = mmul(Ia, vcross(ra, d));
-  u->va = vmadd(u->va, d, ima * imp);
+  u->va = vmadd(u->va, vscale(d, ima), imp);
   u->wa = vmadd(u->wa, aa, imp);
   if (has_b) {
     v3 ab = mmul(Ib, vcross(rb, d));
-    u->vb = vmadd(u->vb, d, -(imb * imp));
+    u->vb = vmadd(u->vb, vscale(d, -imb), imp);
     u->wb = vmadd(u->wb, ab, -imp);
   }
 }

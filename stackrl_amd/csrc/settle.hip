@@ -429,27 +429,29 @@ __device__ __forceinline__ void row_solve(const Row& r, float ima, float imb, Ve
                                           float lo, float hi) {
   float vrel = dot(r.d, u.va) + dot(r.ca, u.wa);
   if (HAS_B) vrel = vrel - (dot(r.d, u.vb) + dot(r.cb, u.wb));
-  float dl = (target - vrel) * r.rk;
+  // (target - vrel) rk as one fused step and the linear impulses as (d m^-1) dl: the products that do not depend on the
+  // velocities leave the dependency chain (10 dependent operations per row instead of 12; the oracle evaluates the same)
+  float dl = fmaf(-vrel, r.rk, target * r.rk);
   // the accumulated impulse clamped to [lo, hi] as the median of the three (v_med3_f32; the oracle restates its zero
   // handling): one instruction on the solver's dependency chain instead of two compare / select pairs through VCC,
   // each of which costs a lone wave its wait states — 6.68 -> 6.02 ms per launch at the headline shape
   float na = __builtin_amdgcn_fmed3f(acc + dl, lo, hi);
   dl = na - acc;
   acc = na;
-  u.va = madd(u.va, r.d, ima * dl);
+  u.va = madd(u.va, r.d * ima, dl);
   u.wa = madd(u.wa, r.aa, dl);
   if (HAS_B) {
-    u.vb = madd(u.vb, r.d, -(imb * dl));
+    u.vb = madd(u.vb, r.d * (-imb), dl);
     u.wb = madd(u.wb, r.ab, -dl);
   }
 }
 
 template <bool HAS_B>
 __device__ __forceinline__ void row_apply(const Row& r, float ima, float imb, Vel4& u, float imp) {
-  u.va = madd(u.va, r.d, ima * imp);
+  u.va = madd(u.va, r.d * ima, imp);
   u.wa = madd(u.wa, r.aa, imp);
   if (HAS_B) {
-    u.vb = madd(u.vb, r.d, -(imb * imp));
+    u.vb = madd(u.vb, r.d * (-imb), imp);
     u.wb = madd(u.wb, r.ab, -imp);
   }
 }
