@@ -66,15 +66,22 @@ typedef struct srl_config {
   float reward_scale;        /* 1.0; <= 0 means None -> n_objects (rewarder.py:97) */
   int32_t reward_pexp;       /* reward_params: integer exponent, 2; < 0 = None    */
   int32_t reward_oexp;       /* idem for rotation; 2                               */
-  /* --- solver definition (build-owned; Bullet defaults where they exist) --- */
-  int32_t solver_iterations; /* sequential-impulse sweeps per sub-step             */
+  /* --- solver definition: the values pybullet's physics server runs with when the client only calls setTimeStep
+   *     (simulator.py:143; DESIGN.md section 5 lists every value with its source) --- */
+  int32_t solver_iterations; /* cap on sequential-impulse sweeps per sub-step: pybullet numSolverIterations = 50
+                                (Bullet library default 10 = SolverPreset "bullet10")                              */
   float collision_margin;    /* convex-hull margin (pybullet URDF default 0.001)  */
-  float erp;                 /* Baumgarte factor (Bullet m_erp = 0.2)             */
+  float erp;                 /* Baumgarte factor of a penetrating contact (Bullet m_erp = 0.2; applies down to the
+                                split-impulse threshold of -0.04 m, which no resting contact reaches)              */
   float friction_rock;       /* lateral_friction of a rock (template.urdf: 0.6)   */
   float friction_ground;     /* Bullet default body friction 0.5                  */
   float linear_damping;      /* pybullet default 0.04                             */
   float angular_damping;     /* pybullet default 0.04                             */
-  float warmstart;           /* Bullet m_warmstartingFactor 0.85                  */
+  float warmstart;           /* m_warmstartingFactor: pybullet server 0.1 (Bullet library default 0.85)             */
+  float linear_slop;         /* m_linearSlop: pybullet server 1e-5 (library default 0): penetration = distance + slop */
+  float residual_threshold;  /* m_leastSquaresResidualThreshold: pybullet server 1e-7 (library default 0 = never): the
+                                sweeps of a sub-step end once max over rows of (delta impulse x effective-mass
+                                denominator)^2 of a sweep is <= this                                               */
   int32_t place_at_com;      /* 1: resetBasePositionAndOrientation moves the COM frame (reference quirk) */
   /* --- TestStackEnv (Stack-v2), env.py:443-470 --- */
   int32_t orientation_freedom; /* k: the pending rock is observed in 2^k yaw orientations (observer.py:127-140) and the

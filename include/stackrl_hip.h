@@ -88,6 +88,9 @@ int srl_sync_status(srl_env* env, void* stream);
 int srl_get_state(srl_env* env, float* poses, int32_t* n_bodies, int32_t* substeps, int32_t* status);
 /* `Observer.state` (observer.py:365-368) float[n][H*W], float[n][2^orientation_freedom][h*w]; `Rewarder` goal rect int32[n][4]. */
 int srl_get_maps(srl_env* env, float* height, float* object_map, int32_t* goal_rect);
+/* solver telemetry int32[n]: sequential-impulse sweeps run by the last step of each env, all its sub-steps together
+ * (each sub-step runs at most solver_iterations sweeps and ends them early on the residual threshold) */
+int srl_get_sweeps(srl_env* env, int32_t* sweeps);
 /* velocities float[n][SRL_MAX_BODIES][8] = lin xyz 0, ang xyz 0 */
 int srl_get_velocities(srl_env* env, float* vel);
 /* contact telemetry: deepest penetration (m) and number of manifold points per env */

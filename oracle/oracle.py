@@ -114,6 +114,11 @@ class OracleEnv(object):
     self.L.srlo_get_contacts(self.h, _p(mp), _p(npts))
     return mp, npts
 
+  def sweeps(self):
+    sw = np.zeros(self.n, np.int32)
+    self.L.srlo_get_sweeps(self.h, _p(sw))
+    return sw
+
   def maps(self):
     Hm = np.zeros((self.n, self.H, self.H), np.float32)
     Om = np.zeros((self.n, self.h_, self.h_) if self.no == 1 else (self.n, self.no, self.h_, self.h_), np.float32)

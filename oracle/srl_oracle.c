@@ -196,6 +196,7 @@ typedef struct {
   int goal[4];                      /* u, v, h, w */
   float prev_metric;
   int substeps[2];
+  int sweeps;                       /* solver sweeps of the last step (telemetry) */
   int status;
   int has_script; int script_ids[MAXB]; int script_goal[4];
   float* H;                         /* [res*res] */
@@ -1077,7 +1078,9 @@ static inline float row_solve(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float
     u->vb = vmadd(u->vb, vscale(d, -imb), dl);
     u->wb = vmadd(u->wb, ab, -dl);
   }
-  return dl;
+  /* the row's residual as Bullet's resolveSingleConstraintRow* returns it: the applied (clamped) delta impulse times
+   * the effective-mass denominator (deltaImpulse / m_jacDiagABInv), i.e. the velocity change it stands for */
+  return fabsf(dl * k);
 }
 
 static inline void row_apply(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float imb, const m3* Ib,
@@ -1094,14 +1097,16 @@ static inline void row_apply(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float 
 
 static inline float contact_target(const struct srlo_env* e, float dist) {
   float inv_dt = 1.0f / e->c.sim_time_step;
-  /* Bullet setupContactConstraint restated: separated points may close the gap in one step,
-   * penetrating points are pushed out with erp */
-  return dist > 0.0f ? -(dist * inv_dt) : -((dist * e->c.erp) * inv_dt);
+  /* Bullet setupContactConstraint restated: penetration = distance + m_linearSlop; separated points may close the gap
+   * in one step, penetrating points are pushed out with erp */
+  float pen = dist + e->c.linear_slop;
+  return pen > 0.0f ? -(pen * inv_dt) : -((pen * e->c.erp) * inv_dt);
 }
 
-static void solve_ground(const struct srlo_env* e, env_t* s, int b, int warm) {
+static float solve_ground(const struct srlo_env* e, env_t* s, int b, int warm) {
   gmanifold_t* g = &s->gm[b];
-  if (g->np == 0) return;
+  float res = 0.0f;
+  if (g->np == 0) return res;
   const mesh_t* M = &e->mesh[s->mesh[b]];
   float mu = e->c.friction_rock * e->c.friction_ground;
   vel4 u; u.va = s->v[b]; u.wa = s->w[b]; u.vb = V(0, 0, 0); u.wb = V(0, 0, 0);
@@ -1117,18 +1122,20 @@ static void solve_ground(const struct srlo_env* e, env_t* s, int b, int warm) {
       row_apply(t1, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, g->it1[i], 0);
       row_apply(t2, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, g->it2[i], 0);
     } else {
-      row_solve(n, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, contact_target(e, g->dist[i]), &g->in[i], 0.0f, 1e30f, 0);
+      res = fmaxf(res, row_solve(n, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, contact_target(e, g->dist[i]), &g->in[i], 0.0f, 1e30f, 0));
       float lim = mu * g->in[i];
-      row_solve(t1, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, 0.0f, &g->it1[i], -lim, lim, 0);
-      row_solve(t2, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, 0.0f, &g->it2[i], -lim, lim, 0);
+      res = fmaxf(res, row_solve(t1, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, 0.0f, &g->it1[i], -lim, lim, 0));
+      res = fmaxf(res, row_solve(t2, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, 0.0f, &g->it2[i], -lim, lim, 0));
     }
   }
   s->v[b] = u.va; s->w[b] = u.wa;
+  return res;
 }
 
-static void solve_slot(const struct srlo_env* e, env_t* s, int sl, int warm) {
+static float solve_slot(const struct srlo_env* e, env_t* s, int sl, int warm) {
   manifold_t* m = &s->man[sl];
-  if (m->np == 0) return;
+  float res = 0.0f;
+  if (m->np == 0) return res;
   int a = s->slot_a[sl], b = s->slot_b[sl];
   const mesh_t* MA = &e->mesh[s->mesh[a]];
   const mesh_t* MB = &e->mesh[s->mesh[b]];
@@ -1146,20 +1153,25 @@ static void solve_slot(const struct srlo_env* e, env_t* s, int sl, int warm) {
       row_apply(t1, ra, rb, MA->inv_mass, &s->Iw[a], MB->inv_mass, &s->Iw[b], &u, p->it1, 1);
       row_apply(t2, ra, rb, MA->inv_mass, &s->Iw[a], MB->inv_mass, &s->Iw[b], &u, p->it2, 1);
     } else {
-      row_solve(p->n, ra, rb, MA->inv_mass, &s->Iw[a], MB->inv_mass, &s->Iw[b], &u, contact_target(e, p->dist), &p->in, 0.0f, 1e30f, 1);
+      res = fmaxf(res, row_solve(p->n, ra, rb, MA->inv_mass, &s->Iw[a], MB->inv_mass, &s->Iw[b], &u, contact_target(e, p->dist), &p->in, 0.0f, 1e30f, 1));
       float lim = mu * p->in;
-      row_solve(t1, ra, rb, MA->inv_mass, &s->Iw[a], MB->inv_mass, &s->Iw[b], &u, 0.0f, &p->it1, -lim, lim, 1);
-      row_solve(t2, ra, rb, MA->inv_mass, &s->Iw[a], MB->inv_mass, &s->Iw[b], &u, 0.0f, &p->it2, -lim, lim, 1);
+      res = fmaxf(res, row_solve(t1, ra, rb, MA->inv_mass, &s->Iw[a], MB->inv_mass, &s->Iw[b], &u, 0.0f, &p->it1, -lim, lim, 1));
+      res = fmaxf(res, row_solve(t2, ra, rb, MA->inv_mass, &s->Iw[a], MB->inv_mass, &s->Iw[b], &u, 0.0f, &p->it2, -lim, lim, 1));
     }
   }
   s->v[a] = u.va; s->w[a] = u.wa; s->v[b] = u.vb; s->w[b] = u.wb;
+  return res;
 }
 
-static void solver_sweep(const struct srlo_env* e, env_t* s, int warm) {
-  for (int b = 0; b < s->nb; ++b) solve_ground(e, s, b, warm);
+/* one Gauss-Seidel sweep over every contact row of the env; returns the largest row residual of the sweep (the
+ * maximum is order-independent, so the kernel's parallel sweep reports the same bits) */
+static float solver_sweep(const struct srlo_env* e, env_t* s, int warm) {
+  float res = 0.0f;
+  for (int b = 0; b < s->nb; ++b) res = fmaxf(res, solve_ground(e, s, b, warm));
   for (int c = 0; c < s->ncolour; ++c)
     for (int sl = 0; sl < MAXSLOT; ++sl)
-      if (s->pair_of_slot[sl] >= 0 && s->colour[sl] == c) solve_slot(e, s, sl, warm);
+      if (s->pair_of_slot[sl] >= 0 && s->colour[sl] == c) res = fmaxf(res, solve_slot(e, s, sl, warm));
+  return res;
 }
 
 static void substep(const struct srlo_env* e, env_t* s) {
@@ -1176,7 +1188,13 @@ static void substep(const struct srlo_env* e, env_t* s) {
   for (int sl = 0; sl < MAXSLOT; ++sl)
     if (s->pair_of_slot[sl] >= 0) narrowphase_slot(e, s, sl);
   solver_sweep(e, s, 1);
-  for (int it = 0; it < e->c.solver_iterations; ++it) solver_sweep(e, s, 0);
+  /* btSequentialImpulseConstraintSolver::solveGroupCacheFriendlyIterations restated: at most numIterations sweeps,
+   * ended early once the largest squared row residual of a sweep is <= m_leastSquaresResidualThreshold */
+  for (int it = 0; it < e->c.solver_iterations; ++it) {
+    float res = solver_sweep(e, s, 0);
+    s->sweeps++;
+    if (res * res <= e->c.residual_threshold) break;
+  }
   /* integrate */
   for (int b = 0; b < s->nb; ++b) {
     s->x[b] = vmadd(s->x[b], s->v[b], dt);
@@ -1216,6 +1234,7 @@ static int sim_drop(const struct srlo_env* e, const env_t* s) {
 /* Simulator.step, simulator.py:190-258 */
 static void sim_step(const struct srlo_env* e, env_t* s, v3 pos, int oi) {
   int counter = 0, diverged = 0;
+  s->sweeps = 0;
   if (s->pending >= 0) {             /* _place, simulator.py:310-320 */
     int b = s->nb;
     const mesh_t* M = &e->mesh[s->pending];
@@ -1490,6 +1509,11 @@ int srlo_get_contacts(srlo_env* e, float* max_pen, int32_t* n_points) {
     if (max_pen) max_pen[i] = mp;
     if (n_points) n_points[i] = np;
   }
+  return SRL_OK;
+}
+
+int srlo_get_sweeps(srlo_env* e, int32_t* sweeps) {
+  for (int i = 0; i < e->c.n_envs; ++i) sweeps[i] = e->env[i].sweeps;
   return SRL_OK;
 }
 

@@ -61,6 +61,8 @@ int srlo_get_maps(srlo_env* e, float* height, float* object_map, int32_t* goal_r
 int srlo_get_velocities(srlo_env* e, float* vel /* [n, SRL_MAX_BODIES, 8] lin xyz0 ang xyz0 */);
 /* manifold telemetry for invariants: max penetration depth (metres, >= 0) per env */
 int srlo_get_contacts(srlo_env* e, float* max_penetration, int32_t* n_points);
+/* solver sweeps run by the last step of each env (all its sub-steps together) */
+int srlo_get_sweeps(srlo_env* e, int32_t* sweeps);
 
 /* Pure functions (closed-form units) ---------------------------------------------- */
 /* Render the overhead height map for explicit poses: poses [n_bodies, 7] (COM frame),

@@ -13,6 +13,13 @@ MAX_BODIES = 32
 MAX_VERTS = 128
 MAX_TRIS = 252
 
+# Named solver definitions: 'pybullet' = the defaults above (what the reference runs: it only calls setTimeStep,
+# simulator.py:143); 'bullet10' = the Bullet library defaults (btContactSolverInfo) that round 1 was measured on.
+SOLVER_PRESETS = {
+  'pybullet': dict(solver_iterations=50, warmstart=0.1, linear_slop=1e-5, residual_threshold=1e-7),
+  'bullet10': dict(solver_iterations=10, warmstart=0.85, linear_slop=0.0, residual_threshold=0.0),
+}
+
 METRICS = {'iou': 0, 'or': 1, 'diou': 2, 'dor': 3}  # rewarder.py:7-14
 
 # return codes, include/srl_types.h
@@ -48,6 +55,8 @@ class CConfig(ctypes.Structure):
     ('linear_damping', ctypes.c_float),
     ('angular_damping', ctypes.c_float),
     ('warmstart', ctypes.c_float),
+    ('linear_slop', ctypes.c_float),
+    ('residual_threshold', ctypes.c_float),
     ('place_at_com', ctypes.c_int32),
     ('orientation_freedom', ctypes.c_int32),
     ('ordering_freedom', ctypes.c_int32),
@@ -76,15 +85,18 @@ class StackConfig:
   flat_action: bool = True
   dtype: str = 'uint8'                # Stack-v0 registry kwarg
   max_substeps: int = 0               # 0 -> int(300/time_step), simulator.py:46
-  # solver definition (DESIGN.md "settle solver")
-  solver_iterations: int = 10
+  # solver definition: what pybullet's physics server runs with when the client only sets the
+  # time step (simulator.py:143).  SOLVER_PRESETS['bullet10'] holds the Bullet *library* defaults of round 1.
+  solver_iterations: int = 50         # pybullet numSolverIterations default
   collision_margin: float = 0.001
   erp: float = 0.2
   friction_rock: float = 0.6          # template.urdf lateral_friction, generator.py:250
   friction_ground: float = 0.5
   linear_damping: float = 0.04
   angular_damping: float = 0.04
-  warmstart: float = 0.85
+  warmstart: float = 0.1              # pybullet server m_warmstartingFactor
+  linear_slop: float = 1e-5           # pybullet server m_linearSlop
+  residual_threshold: float = 1e-7    # pybullet server m_leastSquaresResidualThreshold (0 = no early exit)
   place_at_com: bool = True
   orientation_freedom: int = 0        # TestStackEnv (Stack-v2, env.py:443-470): 2**k yaw orientations; 0 = Stack-v0
   ordering_freedom: bool = False      # TestStackEnv: all rocks on show from the start, the action picks the next one
@@ -174,6 +186,7 @@ class StackConfig:
       collision_margin=self.collision_margin, erp=self.erp, friction_rock=self.friction_rock,
       friction_ground=self.friction_ground, linear_damping=self.linear_damping,
       angular_damping=self.angular_damping, warmstart=self.warmstart,
+      linear_slop=self.linear_slop, residual_threshold=self.residual_threshold,
       place_at_com=int(bool(self.place_at_com)),
       orientation_freedom=int(self.orientation_freedom),
       ordering_freedom=int(bool(self.ordering_freedom)),

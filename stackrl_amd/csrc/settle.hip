@@ -34,7 +34,7 @@ __constant__ uint8_t c_pair_i[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
 __constant__ uint8_t c_pair_j[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
 
 // misc words in LDS
-enum { M_MODE = 0, M_U, M_V, M_NEXT, M_ZMAX, M_FLAGS, M_NCOL, M_CNT, M_NB, M_PENDING, M_STATUS, M_DONE, M_ORIENT, M_MOVING, M_WORDS = 16 };
+enum { M_MODE = 0, M_U, M_V, M_NEXT, M_ZMAX, M_FLAGS, M_NCOL, M_CNT, M_NB, M_PENDING, M_STATUS, M_DONE, M_ORIENT, M_MOVING, M_RES0, M_RES1, M_WORDS = 16 };
 
 struct Lds {
   float* sm;
@@ -404,7 +404,7 @@ __device__ __forceinline__ void narrowphase_slot(const Lds& L, int sl, int gl) {
 // ------------------------------------------------------------------ sequential impulses (lane = contact point)
 // One solver row in precomputed form: direction d, ca = ra x d, aa = Ia ca (and cb, ab for body B),
 // k = effective mass denominator.  Same expression trees as the sequential definition.
-struct Row { v3 d, ca, aa, cb, ab; float rk; };   // rk = 1 / effective mass denominator
+struct Row { v3 d, ca, aa, cb, ab; float rk, k; };   // k = effective mass denominator, rk = 1 / k
 struct Vel4 { v3 va, wa, vb, wb; };
 
 template <bool HAS_B>
@@ -421,12 +421,15 @@ __device__ __forceinline__ Row make_row(v3 d, v3 ra, v3 rb, float ima, const m3&
     k = k + (imb + dot(cross(r.ab, rb), d));
   }
   r.rk = 1.0f / k;
+  r.k = k;
   return r;
 }
 
+// res: running maximum of the rows' residuals |delta impulse x k| (Bullet: deltaImpulse / m_jacDiagABInv) — off the
+// velocities' dependency chain
 template <bool HAS_B>
 __device__ __forceinline__ void row_solve(const Row& r, float ima, float imb, Vel4& u, float target, float& acc,
-                                          float lo, float hi) {
+                                          float lo, float hi, float& res) {
   float vrel = dot(r.d, u.va) + dot(r.ca, u.wa);
   if (HAS_B) vrel = vrel - (dot(r.d, u.vb) + dot(r.cb, u.wb));
   // (target - vrel) rk as one fused step and the linear impulses as (d m^-1) dl: the products that do not depend on the
@@ -438,6 +441,7 @@ __device__ __forceinline__ void row_solve(const Row& r, float ima, float imb, Ve
   float na = __builtin_amdgcn_fmed3f(acc + dl, lo, hi);
   dl = na - acc;
   acc = na;
+  res = fmaxf(res, fabsf(dl * r.k));
   u.va = madd(u.va, r.d * ima, dl);
   u.wa = madd(u.wa, r.aa, dl);
   if (HAS_B) {
@@ -458,7 +462,8 @@ __device__ __forceinline__ void row_apply(const Row& r, float ima, float imb, Ve
 
 __device__ __forceinline__ float contact_target(const DevParams& P, float dist) {
   float inv_dt = 1.0f / P.c.sim_time_step;
-  return dist > 0.0f ? -(dist * inv_dt) : -((dist * P.c.erp) * inv_dt);
+  float pen = dist + P.c.linear_slop;   // Bullet: penetration = distance + m_linearSlop
+  return pen > 0.0f ? -(pen * inv_dt) : -((pen * P.c.erp) * inv_dt);
 }
 
 // A contact point owned by one lane for the duration of a sub-step's solve
@@ -531,7 +536,7 @@ __device__ __forceinline__ Point make_pair_point(const Lds& L, int sl, int i) {
 
 // one turn of a point: read the velocities of its bodies, three rows, write them back
 template <bool WARM, bool HAS_B>
-__device__ __forceinline__ void point_turn(const Lds& L, Point& p) {
+__device__ __forceinline__ void point_turn(const Lds& L, Point& p, float& res) {
   const float ws = L.P->c.warmstart;
   Vel4 u;
   {   // 16-byte LDS reads (vectors are stored with a stride of 4 words)
@@ -548,10 +553,10 @@ __device__ __forceinline__ void point_turn(const Lds& L, Point& p) {
     row_apply<HAS_B>(p.t1, p.ima, p.imb, u, p.i1);
     row_apply<HAS_B>(p.t2, p.ima, p.imb, u, p.i2);
   } else {
-    row_solve<HAS_B>(p.n, p.ima, p.imb, u, p.target, p.in, 0.0f, 1e30f);
+    row_solve<HAS_B>(p.n, p.ima, p.imb, u, p.target, p.in, 0.0f, 1e30f, res);
     const float lim = p.mu * p.in;
-    row_solve<HAS_B>(p.t1, p.ima, p.imb, u, 0.0f, p.i1, -lim, lim);
-    row_solve<HAS_B>(p.t2, p.ima, p.imb, u, 0.0f, p.i2, -lim, lim);
+    row_solve<HAS_B>(p.t1, p.ima, p.imb, u, 0.0f, p.i1, -lim, lim, res);
+    row_solve<HAS_B>(p.t2, p.ima, p.imb, u, 0.0f, p.i2, -lim, lim, res);
   }
   *(float4*)L.Vl(p.a) = make_float4(u.va.x, u.va.y, u.va.z, 0.0f); *(float4*)L.Wl(p.a) = make_float4(u.wa.x, u.wa.y, u.wa.z, 0.0f);
   if (HAS_B) {
@@ -562,29 +567,41 @@ __device__ __forceinline__ void point_turn(const Lds& L, Point& p) {
 // gturns / pturns: the turns this wave needs in a ground / colour phase = 1 + the highest point index any of its lanes
 // holds (a turn no lane takes still costs a lone wave its loop control: 8 + 4 ncol empty turns per sweep were a third
 // of the sub-step's instructions)
+// A sweep ends with a block barrier; before it every wave that still holds a row whose squared residual exceeds the
+// threshold writes the sweep's number `gsweep` (counted over the whole launch, so a stale word never matches) into the
+// LDS word of the sweep's parity; after the barrier every thread reads that word: `true` = some row has not converged
+// (Bullet's m_leastSquaresResidual > m_leastSquaresResidualThreshold; the maximum over rows is order-independent, so
+// the parallel sweep decides exactly as the sequential definition).  The word of the other parity is the one the
+// next sweep writes, so a fast wave cannot disturb a slow wave's read.
 template <bool WARM, int PP>
-__device__ __forceinline__ void solver_sweep(const Lds& L, Point& gp, Point (&pp)[PP], int ncol, int gturns, int pturns,
-                                             int gslot, const int (&pslot)[PP]) {
+__device__ __forceinline__ bool solver_sweep(const Lds& L, Point& gp, Point (&pp)[PP], int ncol, int gturns, int pturns,
+                                             int gslot, const int (&pslot)[PP], int gsweep) {
   // gslot / pslot: the turn a lane's point takes (ground: its index; colour phases: 4 * colour + index; -1: none), so
   // that a turn's guard is one compare
   // ground phase: the (up to 8) points of one body are consecutive lanes of one wave and take turns
+  float res = 0.0f;
 #pragma unroll 1
   for (int i = 0; i < gturns; ++i) {
-    if (gslot == i) point_turn<WARM, false>(L, gp);
+    if (gslot == i) point_turn<WARM, false>(L, gp, res);
     __builtin_amdgcn_wave_barrier();
   }
-  __syncthreads();
 #pragma unroll 1
   for (int c = 0; c < ncol; ++c) {
+    __syncthreads();
 #pragma unroll 1
     for (int i = 0; i < pturns; ++i) {
 #pragma unroll
       for (int r = 0; r < PP; ++r)
-        if (pslot[r] == 4 * c + i) point_turn<WARM, true>(L, pp[r]);
+        if (pslot[r] == 4 * c + i) point_turn<WARM, true>(L, pp[r], res);
       __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
   }
+  int* word = L.MISC() + M_RES0 + (gsweep & 1);
+  if (!WARM) {
+    if (__ballot(res * res > L.P->c.residual_threshold) != 0ull && (threadIdx.x & 63) == 0) *word = gsweep;
+  }
+  __syncthreads();
+  return WARM ? true : *word == gsweep;
 }
 
 // ------------------------------------------------------------------ one sub-step (block-wide)
@@ -595,7 +612,7 @@ __device__ __forceinline__ void solver_sweep(const Lds& L, Point& gp, Point (&pp
 #endif
 
 template <int T, int PP>
-__device__ __forceinline__ void substep(const Lds& L, int nb, int tid) {
+__device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gsweep) {
   const DevParams& P = *L.P;
   // With two contact points per thread the register file is full: lane-dependent LDS addresses that the compiler
   // hoists out of the sub-step loop end up spilled to scratch and are reloaded from memory in every sub-step.  An
@@ -710,8 +727,13 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid) {
     int pslot[PP];
 #pragma unroll
     for (int r = 0; r < PP; ++r) pslot[r] = pp[r].valid ? 4 * pp[r].colour + pp[r].idx : -1;
-    solver_sweep<true, PP>(L, gp, pp, ncol, gturns, pturns, gslot, pslot);
-    for (int it = 0; it < P.c.solver_iterations; ++it) solver_sweep<false, PP>(L, gp, pp, ncol, gturns, pturns, gslot, pslot);
+    solver_sweep<true, PP>(L, gp, pp, ncol, gturns, pturns, gslot, pslot, 0);
+    // at most solver_iterations sweeps, ended early once a sweep's largest squared residual is <= the threshold
+    // (btSequentialImpulseConstraintSolver::solveGroupCacheFriendlyIterations)
+    for (int it = 0; it < P.c.solver_iterations; ++it) {
+      gsweep++;
+      if (!solver_sweep<false, PP>(L, gp, pp, ncol, gturns, pturns, gslot, pslot, gsweep)) break;
+    }
     // accumulated impulses back to the manifolds (warm start of the next sub-step)
     if (gp.valid) { float* g = L.GM(gp.a); g[17 + gp.idx] = gp.in; g[25 + gp.idx] = gp.i1; g[33 + gp.idx] = gp.i2; }
 #pragma unroll
@@ -841,6 +863,7 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
         misc[M_NCOL] = h->ncolour;
         misc[M_STATUS] = h->status;
         misc[M_ZMAX] = (int)f2o(-1e30f);
+        misc[M_RES0] = -1; misc[M_RES1] = -1;
       }
     }
     h->mode = mode;
@@ -927,13 +950,14 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
   //   SETTLE : step until _stop (simulator.py:239-245)
   enum { PH_PLACE = 0, PH_SMOOTH = 1, PH_ENTER = 2, PH_SETTLE = 3 };
   int counter = 0, phase = PH_PLACE, s_a = 0;
+  int gsweep = 0;   // solver sweeps of this launch (block-uniform); the residual words start at -1
   bool diverged = false;
   for (;;) {
     if (phase == PH_SMOOTH) {
       if (tid == 0) { st3(L.Vl(nb - 1), V(0, 0, 0)); st3(L.Wl(nb - 1), V(0, 0, 0)); }   // resetBaseVelocity
       __syncthreads();
     }
-    substep<T, PP>(L, nb, tid);
+    substep<T, PP>(L, nb, tid, gsweep);
     counter++;
     if (phase != PH_PLACE && counter > P.max_substeps) diverged = true;
     if (phase == PH_PLACE) phase = P.c.smooth_placing ? PH_SMOOTH : PH_ENTER;
@@ -966,6 +990,7 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
     h->ncolour = misc[M_NCOL];
     h->substeps[0] = s_a;
     h->substeps[1] = counter - s_a;
+    h->sweeps = gsweep;
     int st = misc[M_STATUS] | (diverged ? SRL_ST_DIVERGED : 0);
     h->status = st;
     if (diverged) atomicOr(P.flags, 2);

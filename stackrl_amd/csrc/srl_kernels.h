@@ -25,6 +25,7 @@ struct EnvHdr {
   int32_t goal[4];              // u, v, h, w (rewarder.py:255-257)
   float prev_metric;            // Rewarder._memory[metric]
   int32_t substeps[2];          // Simulator.n_steps
+  int32_t sweeps;               // solver sweeps of the last step, all its sub-steps together (telemetry)
   int32_t status;               // SRL_ST_* bits
   int32_t ncolour;              // contact-graph colours, -1 = recolour
   int32_t has_script;

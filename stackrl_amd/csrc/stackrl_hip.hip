@@ -200,9 +200,9 @@ int srl_config_default(srl_config* c) {
   c->smooth_placing = 1; c->max_substeps = 0;
   c->metric = SRL_METRIC_IOU; c->goal_size_ratio = 0.25f; c->reward_scale = 1.0f;
   c->reward_pexp = 2; c->reward_oexp = 2;   // Stack-v0 registry: reward_params=2
-  c->solver_iterations = 10; c->collision_margin = 0.001f; c->erp = 0.2f;
+  c->solver_iterations = 50; c->collision_margin = 0.001f; c->erp = 0.2f;
   c->friction_rock = 0.6f; c->friction_ground = 0.5f;
-  c->linear_damping = 0.04f; c->angular_damping = 0.04f; c->warmstart = 0.85f;
+  c->linear_damping = 0.04f; c->angular_damping = 0.04f; c->warmstart = 0.1f; c->linear_slop = 1e-5f; c->residual_threshold = 1e-7f;
   c->place_at_com = 1;
   c->orientation_freedom = 0;
   c->ordering_freedom = 0;
@@ -498,6 +498,16 @@ int srl_get_state(srl_env* env, float* poses, int32_t* n_bodies, int32_t* subste
     if (substeps) { substeps[2 * i] = h[i].substeps[0]; substeps[2 * i + 1] = h[i].substeps[1]; }
     if (status) status[i] = h[i].status;
   }
+  return SRL_OK;
+}
+
+int srl_get_sweeps(srl_env* env, int32_t* sweeps) {
+  if (!env || !sweeps) return fail(SRL_EINVAL, "null argument");
+  const int n = env->P.c.n_envs;
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<EnvHdr> h((size_t)n);
+  HIP_TRY(hipMemcpy(h.data(), env->P.hdr, sizeof(EnvHdr) * (size_t)n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i) sweeps[i] = h[i].sweeps;
   return SRL_OK;
 }
 

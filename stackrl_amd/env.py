@@ -232,6 +232,12 @@ class VecStackEnv(object):
     _check(self._lib.srl_get_velocities(self._h, _np_ptr(v)))
     return v
 
+  def sweeps(self):
+    """Solver sweeps run by the last step of each env (telemetry)."""
+    sw = np.zeros(self._B, np.int32)
+    _check(self._lib.srl_get_sweeps(self._h, _np_ptr(sw)))
+    return sw
+
   def contacts(self):
     mp = np.zeros(self._B, np.float32)
     npts = np.zeros(self._B, np.int32)
