@@ -88,6 +88,13 @@ int srl_sync_status(srl_env* env, void* stream);
 int srl_get_state(srl_env* env, float* poses, int32_t* n_bodies, int32_t* substeps, int32_t* status);
 /* `Observer.state` (observer.py:365-368) float[n][H*W], float[n][2^orientation_freedom][h*w]; `Rewarder` goal rect int32[n][4]. */
 int srl_get_maps(srl_env* env, float* height, float* object_map, int32_t* goal_rect);
+/* State injection for closed-form physics tests (host pointers, synchronises; either pointer may be NULL = leave as is):
+ * `pb.resetBasePositionAndOrientation` (simulator.py:313) and `pb.resetBaseVelocity` (simulator.py:214) for every placed
+ * body of every env, in the layouts srl_get_state / srl_get_velocities return (the mesh-id column is ignored). */
+int srl_set_body_state(srl_env* env, const float* poses, const float* velocities);
+/* `pb.stepSimulation` (simulator.py:219, :240, :320) x n_substeps on every env: no placement, no stop criterion, no
+ * render — the raw sub-step the three loops of `Simulator.step` are built from. */
+int srl_step_simulation(srl_env* env, int32_t n_substeps, void* stream);
 /* solver telemetry int32[n]: sequential-impulse sweeps run by the last step of each env, all its sub-steps together
  * (each sub-step runs at most solver_iterations sweeps and ends them early on the residual threshold) */
 int srl_get_sweeps(srl_env* env, int32_t* sweeps);

@@ -114,6 +114,14 @@ class OracleEnv(object):
     self.L.srlo_get_contacts(self.h, _p(mp), _p(npts))
     return mp, npts
 
+  def set_body_state(self, poses=None, velocities=None):
+    p = None if poses is None else np.ascontiguousarray(poses, np.float32)
+    v = None if velocities is None else np.ascontiguousarray(velocities, np.float32)
+    self.L.srlo_set_body_state(self.h, _p(p), _p(v))
+
+  def step_simulation(self, n=1):
+    self.L.srlo_step_simulation(self.h, ctypes.c_int32(int(n)))
+
   def sweeps(self):
     sw = np.zeros(self.n, np.int32)
     self.L.srlo_get_sweeps(self.h, _p(sw))

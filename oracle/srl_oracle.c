@@ -1551,6 +1551,34 @@ int srlo_render_object(srlo_env* e, int32_t mesh_id, float* object_map) {
 }
 
 /* debug / invariant hook: run `n` raw sub-steps on env `i` (no stop criterion) */
+int srlo_set_body_state(srlo_env* e, const float* poses, const float* vel) {
+  for (int i = 0; i < e->c.n_envs; ++i) {
+    env_t* s = &e->env[i];
+    for (int b = 0; b < s->nb; ++b) {
+      if (poses) {
+        const float* p = poses + ((size_t)i * MAXB + b) * 8;
+        s->x[b] = V(p[0], p[1], p[2]);
+        s->q[b].x = p[3]; s->q[b].y = p[4]; s->q[b].z = p[5]; s->q[b].w = p[6];
+      }
+      if (vel) {
+        const float* p = vel + ((size_t)i * MAXB + b) * 8;
+        s->v[b] = V(p[0], p[1], p[2]); s->w[b] = V(p[4], p[5], p[6]);
+      }
+    }
+  }
+  return SRL_OK;
+}
+
+int srlo_step_simulation(srlo_env* e, int32_t n) {
+  for (int i = 0; i < e->c.n_envs; ++i) {
+    env_t* s = &e->env[i];
+    if (s->nb == 0) continue;
+    s->sweeps = 0;
+    for (int k = 0; k < n; ++k) substep(e, s);
+  }
+  return SRL_OK;
+}
+
 int srlo_debug_substeps(srlo_env* e, int32_t i, int32_t n) {
   if (i < 0 || i >= e->c.n_envs) return fail(SRL_EINVAL, "env index");
   for (int k = 0; k < n; ++k) substep(e, &e->env[i]);

@@ -84,6 +84,10 @@ uint32_t srlo_rng(uint32_t key, uint32_t episode, uint32_t stream, uint32_t draw
 void srlo_goal_from_rng(const srl_config* cfg, uint32_t key, uint32_t episode, int32_t* rect);
 float srlo_acosf(float x);
 int srlo_debug_substeps(srlo_env* e, int32_t env_index, int32_t n);
+/* resetBasePositionAndOrientation / resetBaseVelocity of every placed body (layouts of srlo_get_state /
+ * srlo_get_velocities; NULL = leave as is) and n raw sub-steps on every env: the hooks of the closed-form physics tests */
+int srlo_set_body_state(srlo_env* e, const float* poses, const float* velocities);
+int srlo_step_simulation(srlo_env* e, int32_t n);
 
 #ifdef __cplusplus
 }

@@ -822,7 +822,13 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
 
   if (tid == 0) {
     int mode;
-    if (!force_reset && action[e] == (int64_t)SRL_ACTION_HOLD) {
+    if (force_reset < 0) {                    // srl_step_simulation: -force_reset raw sub-steps, no placement
+      mode = h->nb > 0 ? 4 : 3;
+      misc[M_NB] = h->nb;
+      misc[M_NCOL] = h->ncolour;
+      misc[M_STATUS] = h->status;
+      misc[M_RES0] = -1; misc[M_RES1] = -1;
+    } else if (!force_reset && action[e] == (int64_t)SRL_ACTION_HOLD) {
       mode = 3;                               // this env sits the call out (srl_types.h)
     } else if (force_reset || h->done) {     // env.py:235-236 auto-reset
       env_reset(P, h, e);
@@ -887,7 +893,7 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
   // ---- K4: Observer.pose (observer.py:392-421): z = max(H[window] + O | O > 1e-4) - oz/2
   const int u = misc[M_U], v = misc[M_V], pending = misc[M_PENDING];
   int nb = misc[M_NB];
-  {
+  if (mode == 0) {
     const int res = P.c.overhead_res, r = P.c.object_res;
     const float* Hm = P.H + (size_t)e * res * res;
     const float* Om = P.objmap + ((size_t)pending * P.n_orient + misc[M_ORIENT]) * r * r;
@@ -903,7 +909,7 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
     atomicMax((uint32_t*)&misc[M_ZMAX], best);
   }
   __syncthreads();
-  if (tid == 0) {   // _place (simulator.py:310-320): teleport the pending rock, zero velocity
+  if (tid == 0 && mode == 0) {   // _place (simulator.py:310-320): teleport the pending rock, zero velocity
     float z = o2f((uint32_t)misc[M_ZMAX]);
     float half = ((float)P.c.object_res * P.px) * 0.5f;
     v3 pos = V((float)u * P.px + half, (float)v * P.px + half, z - half);
@@ -923,7 +929,7 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
     st3(L.Vl(b), V(0, 0, 0)); st3(L.Wl(b), V(0, 0, 0));
     L.GM(b)[0] = __int_as_float(0);
   }
-  nb += 1;
+  if (mode == 0) nb += 1;
   __syncthreads();
   for (int b = tid; b < nb; b += T) {
     int m = L.MESH()[b];
@@ -952,6 +958,12 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
   int counter = 0, phase = PH_PLACE, s_a = 0;
   int gsweep = 0;   // solver sweeps of this launch (block-uniform); the residual words start at -1
   bool diverged = false;
+  if (mode == 4) {   // stepSimulation x n (srl_step_simulation): no placement, no stop criterion
+    for (int k = 0; k < -force_reset; ++k) substep<T, PP>(L, nb, tid, gsweep);
+    for (int k = tid; k < P.BLOB; k += T) gblob[k] = sm[k];
+    if (tid == 0) { h->ncolour = misc[M_NCOL]; h->status = misc[M_STATUS]; h->sweeps = gsweep; }
+    return;
+  }
   for (;;) {
     if (phase == PH_SMOOTH) {
       if (tid == 0) { st3(L.Vl(nb - 1), V(0, 0, 0)); st3(L.Wl(nb - 1), V(0, 0, 0)); }   // resetBaseVelocity

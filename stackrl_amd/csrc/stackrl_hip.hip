@@ -174,6 +174,10 @@ int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void*
   else if (env->step_pp == 1) hipLaunchKernelGGL(srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
   else hipLaunchKernelGGL(srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
   prof_end(env, st);
+  if (force_reset < 0) {   // srl_step_simulation: sub-steps only
+    HIP_TRY(hipGetLastError());
+    return SRL_OK;
+  }
   prof_begin(env, st, 1);
   hipLaunchKernelGGL(srl_k_render, dim3(n), dim3(SRL_RENDER_THREADS), env->render_lds, st, P, (uint8_t*)obs_map, (uint8_t*)obs_obj,
                      reward, done, (const float*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr,
@@ -449,6 +453,38 @@ int srl_step(srl_env* env, const int64_t* action, void* obs_map, void* obs_obj, 
              void* stream) {
   if (!env || !action || !obs_map || !obs_obj || !reward || !done) return fail(SRL_EINVAL, "null argument");
   return launch_step_render(env, action, obs_map, obs_obj, reward, done, (hipStream_t)stream, 0);
+}
+
+int srl_step_simulation(srl_env* env, int32_t n_substeps, void* stream) {
+  if (!env || n_substeps < 1 || n_substeps > 100000) return fail(SRL_EINVAL, "n_substeps must be in [1, 100000]");
+  return launch_step_render(env, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream, -n_substeps);
+}
+
+int srl_set_body_state(srl_env* env, const float* poses, const float* vel) {
+  if (!env) return fail(SRL_EINVAL, "null env");
+  const DevParams& P = env->P;
+  const int n = P.c.n_envs;
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<EnvHdr> h((size_t)n);
+  HIP_TRY(hipMemcpy(h.data(), P.hdr, sizeof(EnvHdr) * (size_t)n, hipMemcpyDeviceToHost));
+  std::vector<float> blob((size_t)n * P.BLOB);
+  HIP_TRY(hipMemcpy(blob.data(), P.blob, sizeof(float) * blob.size(), hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i) {
+    float* gb = blob.data() + (size_t)i * P.BLOB;
+    for (int b = 0; b < h[i].nb; ++b) {
+      if (poses) {
+        const float* p = poses + ((size_t)i * SRL_MAX_BODIES + b) * 8;
+        for (int k = 0; k < 3; ++k) gb[P.OFF_X + 4 * b + k] = p[k];
+        for (int k = 0; k < 4; ++k) gb[P.OFF_Q + 4 * b + k] = p[3 + k];
+      }
+      if (vel) {
+        const float* p = vel + ((size_t)i * SRL_MAX_BODIES + b) * 8;
+        for (int k = 0; k < 3; ++k) { gb[P.OFF_V + 4 * b + k] = p[k]; gb[P.OFF_W + 4 * b + k] = p[4 + k]; }
+      }
+    }
+  }
+  HIP_TRY(hipMemcpy(P.blob, blob.data(), sizeof(float) * blob.size(), hipMemcpyHostToDevice));
+  return SRL_OK;
 }
 
 int srl_sample(srl_env* env, int64_t* action, void* stream) {

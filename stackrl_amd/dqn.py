@@ -86,6 +86,15 @@ class DQN(object):
       if self.device.type == 'cuda' and hasattr(self._q_net, 'correlation'):
         from stackrl_amd import qops
         self._q_net.correlation = qops.correlation(qops.BF16X3 if xcorr == 'bf16x3' else qops.BF16)
+    self._pg = process_group
+    self._world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+    if self._world > 1:
+      # replicas must start from the same weights whatever seed each rank built its net with: rank 0's are broadcast
+      # (the gradient all-reduce keeps them equal from then on)
+      src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+      with torch.no_grad():
+        for t in list(self._q_net.parameters()) + list(self._q_net.buffers()):
+          dist.broadcast(t, src=src, group=process_group)
     import copy
     self._target_q_net = copy.deepcopy(self._q_net)                 # clone + set_weights, dqn.py:116-117
     for p in self._target_q_net.parameters():
@@ -157,8 +166,6 @@ class DQN(object):
     self._gen = torch.Generator(device=self.device)
     if seed is not None:
       self._gen.manual_seed(int(seed) + 1)
-    self._pg = process_group
-    self._world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
     self._policy_op = policy_op     # optional fused rollout head (stackrl_amd.qops.FusedPolicy)
     # graphs: replay the no-grad target evaluations of the update from hipGraphs (HIP device only)
     self._graphs = bool(graphs) and self.device.type == 'cuda'
@@ -289,6 +296,9 @@ class DQN(object):
     else:
       loss, mtd = self._update()
     self._iterations += 1
+    # consumers that cache re-packed weights (qops.FastFeatures) key on this: a graph replay changes the parameters
+    # without bumping any tensor version
+    self._q_net._weights_epoch = self._iterations
     if self._iterations % self._target_update_period == 0:           # dqn.py:478-484
       self._target_q_net.load_state_dict(self._target_sync_source())
     return loss, mtd
@@ -340,6 +350,7 @@ class DQN(object):
     self._target_q_net.load_state_dict(d['target_q_net'])
     self._optimizer.load_state_dict(d['optimizer'])
     self._iterations = int(d['iterations'])
+    self._q_net._weights_epoch = -self._iterations - 1               # restored weights: never equal to a cached epoch
     self._gen.set_state(d['gen'].cpu())
     if 'replay_memory' in d:
       self._replay_memory.load_state_dict(d['replay_memory'])

@@ -232,6 +232,21 @@ class VecStackEnv(object):
     _check(self._lib.srl_get_velocities(self._h, _np_ptr(v)))
     return v
 
+  def set_body_state(self, poses=None, velocities=None):
+    """`resetBasePositionAndOrientation` / `resetBaseVelocity` (simulator.py:313, :214) for every placed body, in the
+    layouts of `state()[0]` / `velocities()`.  Test hook of the closed-form physics cases."""
+    p = None if poses is None else np.ascontiguousarray(poses, np.float32)
+    v = None if velocities is None else np.ascontiguousarray(velocities, np.float32)
+    for a in (p, v):
+      if a is not None and a.shape != (self._B, _config.MAX_BODIES, 8):
+        raise ValueError('expected an array of shape ({}, {}, 8)'.format(self._B, _config.MAX_BODIES))
+    _check(self._lib.srl_set_body_state(self._h, None if p is None else _np_ptr(p), None if v is None else _np_ptr(v)))
+
+  def step_simulation(self, n=1):
+    """`pb.stepSimulation` x n on every env (no placement, no stop criterion, no render)."""
+    _check(self._lib.srl_step_simulation(self._h, int(n), self._stream()))
+    _check(self._lib.srl_sync_status(self._h, self._stream()))
+
   def sweeps(self):
     """Solver sweeps run by the last step of each env (telemetry)."""
     sw = np.zeros(self._B, np.int32)

@@ -25,6 +25,8 @@ _SIGS = {
   'srl_get_maps': (ctypes.c_int, [_VP, _VP, _VP, _VP]),
   'srl_get_velocities': (ctypes.c_int, [_VP, _VP]),
   'srl_get_sweeps': (ctypes.c_int, [_VP, _VP]),
+  'srl_set_body_state': (ctypes.c_int, [_VP, _VP, _VP]),
+  'srl_step_simulation': (ctypes.c_int, [_VP, ctypes.c_int32, _VP]),
   'srl_get_contacts': (ctypes.c_int, [_VP, _VP, _VP]),
   'srl_render_heightmap': (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
   'srl_get_object_map': (ctypes.c_int, [_VP, ctypes.c_int32, _VP]),

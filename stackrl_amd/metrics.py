@@ -8,41 +8,40 @@ import torch
 
 
 class Timer(object):
-  """Context manager accumulating the time spent inside `with` blocks; calling it returns the average block time
-  since the last reset (None before the first block), metrics.py:33-49."""
+  """Times `with` blocks.  `timer()` gives the mean duration of the blocks finished since the last reset (None when
+  there is none) and, unless `reset=False`, starts a new averaging window — the `CollectTime` / `TrainTime` columns of
+  train.csv (training.py:495-505).  Only the surface of the reference's `metrics.Timer` is kept (context manager + call);
+  durations are measured per block with a monotonic clock."""
 
   def __init__(self, clock=None):
-    if clock is None:
-      self.clock = time.perf_counter
-    elif isinstance(clock, str):
-      self.clock = getattr(time, clock)
-    elif callable(clock):
-      self.clock = clock
-    else:
-      raise TypeError('Invalid type {} for argument clock.'.format(type(clock)))
-    self.reset()
-
-  def __call__(self, reset=True):
-    if self.ready:
-      result = self.time / self.n
-      if reset:
-        self.reset()
-      return result
-    return None
-
-  def __enter__(self):
-    self.ready = False
-    self.time -= self.clock()
-
-  def __exit__(self, type, value, tb):
-    self.time += self.clock()
-    self.n += 1
-    self.ready = True
+    if isinstance(clock, str):
+      clock = getattr(time, clock)
+    if clock is not None and not callable(clock):
+      raise TypeError('clock must be None, the name of a function of the time module, or a callable')
+    self._clock = clock or time.perf_counter
+    self._t0 = None
+    self.total, self.n = 0.0, 0
 
   def reset(self):
-    self.ready = False
-    self.time = 0.
-    self.n = 0
+    self.total, self.n = 0.0, 0
+
+  def __enter__(self):
+    self._t0 = self._clock()
+    return self
+
+  def __exit__(self, *exc):
+    self.total += self._clock() - self._t0
+    self.n += 1
+    self._t0 = None
+    return False
+
+  def __call__(self, reset=True):
+    if self.n == 0:
+      return None
+    mean = self.total / self.n
+    if reset:
+      self.reset()
+    return mean
 
 
 class AverageMetric(object):

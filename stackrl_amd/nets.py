@@ -34,8 +34,10 @@ def _init_conv(m, gen):
     he_normal_(w, fan_in, gen)
     nn.init.zeros_(m.bias)
   elif isinstance(m, nn.ConvTranspose2d):
-    w = m.weight                                # [in, out, kh, kw]; Keras Conv2DTranspose fan_in = kh*kw*in
-    fan_in = w.shape[0] * w.shape[2] * w.shape[3]
+    # torch [in, out, kh, kw]; the Keras Conv2DTranspose kernel is (kh, kw, out, in) and `_compute_fans` takes
+    # fan_in = shape[-2] * receptive field = out_channels * kh * kw (layers.py:9-18 he_normal on that kernel)
+    w = m.weight
+    fan_in = w.shape[1] * w.shape[2] * w.shape[3]
     he_normal_(w, fan_in, gen)
     nn.init.zeros_(m.bias)
 

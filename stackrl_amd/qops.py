@@ -333,7 +333,9 @@ class FastFeatures(object):
     self._posbuf = {}
 
   def _refresh(self):
-    key = tuple(p._version for p in self.net.parameters()) + (id(self.net),)
+    # `_weights_epoch` is bumped by whoever updates the parameters outside ATen's sight: a hipGraph replay of the
+    # optimiser step (DQN._train_graphed) changes the weights without touching any tensor's version counter
+    key = tuple(p._version for p in self.net.parameters()) + (id(self.net), getattr(self.net, '_weights_epoch', 0))
     if key == self._key:
       return
     self._w = {}

@@ -20,6 +20,8 @@ from stackrl_amd import metrics
 
 
 class Trainer(object):
+  LOSS_HISTORY = 4096   # `run` returns the losses of at most this many last iterations
+
   def __init__(self, env, agent, eval_env=None, directory=None, log_interval=100, eval_interval=10000,
                checkpoint_interval=10000, eval_seed=None, train_reward_buffer_length=10, eval_reward_buffer_length=10,
                save_evaluated_policies=False, log_to_file=True, checkpoint_memory=True, goal_check_interval=1000):
@@ -66,6 +68,10 @@ class Trainer(object):
     self._collect_timer, self._train_timer = metrics.Timer(), metrics.Timer()
     self.collect_time = self.train_time = 0.0          # cumulative, for the benchmarks
     self._train_file = self._eval_file = self._log_file = self._ckpt_file = None
+    # one writer per directory: with one process per GPU only rank 0 writes logs, weights and checkpoints (every rank
+    # still restores from the shared checkpoint)
+    import torch.distributed as dist
+    self._rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
     if directory is not None:
       os.makedirs(directory, exist_ok=True)
       self._train_file = os.path.join(directory, 'train.csv')
@@ -99,6 +105,8 @@ class Trainer(object):
 
   def log(self, line):
     """training.py:577-588: timestamped line to train.log (or stdout)."""
+    if self._rank != 0:
+      return
     line = '{}: {}\n'.format(datetime.now(), line)
     if self._log_file is not None:
       with open(self._log_file, 'a') as f:
@@ -122,8 +130,12 @@ class Trainer(object):
     if self._ckpt_file is not None and os.path.isfile(self._ckpt_file):
       self.log('Restoring checkpoint.')
       self.restore()
-      self._initialized = True
-      return
+      # a checkpoint written with checkpoint_memory=False (an extension: the reference always saves the memory) leaves
+      # the replay memory empty: sampling it would return unwritten slots, so the initial collect runs again
+      if len(agent._replay_memory) >= agent._minibatch_size:
+        self._initialized = True
+        return
+      self.log('Checkpoint holds no replay memory.')
     self.log('Collecting initial experience...')
     num_steps = num_steps or agent.replay_memory_size
     policy = policy or (lambda o: env.sample())
@@ -153,7 +165,8 @@ class Trainer(object):
     if not self._initialized:
       self.initialize()
     env = self._env
-    losses = []
+    import collections
+    losses = collections.deque(maxlen=self.LOSS_HISTORY)   # bounded: a real run lasts millions of iterations
     step = None
     try:
       step = env.reset()
@@ -204,7 +217,7 @@ class Trainer(object):
         step()
       if self._directory is not None:
         self.checkpoint()
-    return torch.stack(losses) if losses else torch.zeros(0)
+    return torch.stack(list(losses)) if losses else torch.zeros(0)
 
   # ------------------------------------------------------------------ eval (training.py:398-452)
   def eval(self):
@@ -228,7 +241,7 @@ class Trainer(object):
     values = torch.stack(values)                                   # [steps, B, A]
     row = (self.iterations, float(self._eval_reward.result), float(values.amax(dim=-1).mean()), float(values.mean()),
            float(values.std(unbiased=False)), float(values.min()), float(values.max()))
-    if self._eval_file is not None:
+    if self._eval_file is not None and self._rank == 0:
       header = '' if os.path.isfile(self._eval_file) else 'Iter,Return,Value,MeanValue,StdValue,MinValue,MaxValue\n'
       with open(self._eval_file, 'a') as f:
         f.write(header + '{},{},{},{},{},{},{}\n'.format(*row))
@@ -257,7 +270,7 @@ class Trainer(object):
     """training.py:526-546: goal reached when the training return exceeds goal * (1 - epsilon)."""
     if not self._complete and float(self._reward.result) > self._current_goal * (1 - self._agent.exploration):
       self.log('Goal reward achieved.')
-      if self._curriculum_file is not None:
+      if self._curriculum_file is not None and self._rank == 0:
         header = '' if os.path.isfile(self._curriculum_file) else 'EndIter,Goal\n'
         with open(self._curriculum_file, 'a') as f:
           f.write(header + '{},{}\n'.format(self.iterations, self._current_goal))
@@ -275,7 +288,7 @@ class Trainer(object):
     """training.py:487-509: one train.csv row."""
     iters = self.iterations
     reward, loss, merr = float(self._reward.result), float(self._loss.result), float(self._mean_error.result)
-    if self._train_file is not None:
+    if self._train_file is not None and self._rank == 0:
       header = '' if os.path.isfile(self._train_file) else 'Iter,Return,Loss,MeanError,CollectTime,TrainTime\n'
       with open(self._train_file, 'a') as f:
         f.write(header + '{},{},{},{},{},{}\n'.format(iters, reward, loss, merr, self._collect_timer(), self._train_timer()))
@@ -284,7 +297,7 @@ class Trainer(object):
   def save(self):
     """training.py:454-465: the current Q-net weights under saved_weights/<iter>/weights."""
     iters = self.iterations
-    if iters != self._last_save_iter and self._directory is not None:
+    if iters != self._last_save_iter and self._directory is not None and self._rank == 0:
       self.log("Saving Q network's weights...")
       path = os.path.join(self._directory, 'saved_weights', str(iters), 'weights')
       os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -295,7 +308,7 @@ class Trainer(object):
   def checkpoint(self):
     """training.py:467-485: agent (nets, optimiser, counters, replay memory) + the training-return metric."""
     iters = self.iterations
-    if iters != self._last_checkpoint_iter and self._ckpt_file is not None:
+    if iters != self._last_checkpoint_iter and self._ckpt_file is not None and self._rank == 0:
       self.log('Saving checkpoint...')
       os.makedirs(os.path.dirname(self._ckpt_file), exist_ok=True)
       tmp = self._ckpt_file + '.tmp'

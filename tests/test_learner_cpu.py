@@ -37,6 +37,10 @@ def test_net_matches_reference_architecture():
   w = w.detach()
   assert abs(float(w.std()) - math.sqrt(2 / fan_in)) < 0.1 * math.sqrt(2 / fan_in)
   assert float(w.abs().max()) <= 2 * math.sqrt(2 / fan_in) / .8796 + 1e-6
+  # transposed convolutions: Keras' Conv2DTranspose kernel is (kh, kw, out, in) and its fan_in is out * kh * kw
+  up = nets.DeepQSiamFCN(seed=1).left.up[0]
+  fan_in = up.out_channels * up.kernel_size[0] * up.kernel_size[1]
+  assert abs(float(up.weight.detach().std()) - math.sqrt(2 / fan_in)) < 0.1 * math.sqrt(2 / fan_in)
 
 
 def test_forward_shapes_scaling_and_dueling():
@@ -221,7 +225,7 @@ def _rank_main(rank, world, port, out):
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
   dist.init_process_group('gloo', rank=rank, world_size=world)
   torch.manual_seed(0)
-  net = _small_net(seed=7)                                     # identical replicas
+  net = _small_net(seed=7 + rank)                              # replicas built from DIFFERENT seeds: DQN broadcasts rank 0's
   agent = DQN(net, learning_rate=1e-2, minibatch_size=4, replay_memory_size=2 * 10, collect_batch_size=2, exploration=0.3,
               double=True, seed=100 + rank)                    # rank-local replay shard and sampling stream
   rng = np.random.RandomState(50 + rank)                       # rank-local env shard

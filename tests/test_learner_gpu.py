@@ -267,3 +267,34 @@ def test_update_with_mfma_xcorr_and_graphs_tracks_library_update(ref_pool):
   assert float((la - lb).abs().max()) <= 1e-3 * max(1e-6, float(la.abs().max()))
   for p, q in zip(wa, wb):
     assert float((p - q).abs().max()) <= 1e-3                  # 5 Adam steps of lr 6.25e-5: at most ~3e-4 per weight
+
+
+def test_fast_rollout_follows_graph_replayed_updates(ref_pool):
+  """The bf16 fast rollout (`FusedPolicy(autocast=bf16)` -> `FastFeatures`) caches re-packed weights; once the update is
+  replayed from a hipGraph no tensor version counter moves any more, so the cache must follow the agent's weights epoch:
+  after more than _GRAPH_WARMUP + 2 updates its features equal those of a cache built afresh from the current weights."""
+  from stackrl_amd import env as envs, nets, qops
+  from stackrl_amd.dqn import DQN, PolynomialDecay
+  from stackrl_amd.training import Trainer
+  B, L = 8, 4
+  env = envs.make('Stack-v0', n_parallel=B, seed=5, pool=ref_pool, episode_length=L)
+  net = nets.DeepQSiamFCN(env.observation_spec, seed=2).cuda()
+  pol = qops.FusedPolicy(autocast=torch.bfloat16)
+  agent = DQN(net, learning_rate=1e-3, adam_betas=(0.95, 0.95), minibatch_size=8, replay_memory_size=B * 16,
+              discount_factor=.966667, collect_batch_size=B, exploration=0.5, prioritization=0.6,
+              priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=9,
+              policy_op=pol, xcorr='bf16x3', graphs=True)
+  tr = Trainer(env, agent)
+  tr.initialize(num_steps=10)
+  tr.run(DQN._GRAPH_WARMUP + 4)
+  assert agent._train_graph is not None                         # the last updates were graph replays
+  obs = env.reset()()[0]
+  w_before = [p.detach().clone() for p in net.parameters()]
+  xa, wa = pol._ff(obs)
+  tr.run(3)                                                     # three more replayed updates, no ATen op on the weights
+  assert any(not torch.equal(a, b) for a, b in zip(w_before, net.parameters()))
+  obs = env.reset()()[0]
+  xb, wb = pol._ff(obs)                                         # the policy's own cache ...
+  xc, wc = qops.FastFeatures(net)(obs)                          # ... against one built from the current weights
+  assert torch.equal(xb, xc) and torch.equal(wb, wc)
+  env.close()

@@ -164,10 +164,11 @@ def test_episode_state_machine(oracle_mod, ref_pool):
 def test_physics_invariants(oracle_mod, ref_pool):
   """Tier C invariants of the settle solver: rest speed below threshold, rocks above ground,
   bounded penetration, nothing diverged."""
-  n, L = 16, 12
+  n, L = 64, 12
   cfg = StackConfig(n_envs=n, episode_length=L)
   env = oracle_mod.OracleEnv(cfg, ref_pool, seed=11)
   env.reset()
+  pens = []
   for k in range(L):
     env.step(env.sample())
     poses, nb, sub, st = env.state()
@@ -177,7 +178,16 @@ def test_physics_invariants(oracle_mod, ref_pool):
     assert (st == 0).all()
     assert (sub.sum(1) < 3000).all()
     mp, npts = env.contacts()
-    assert mp.max() < 0.006                                       # < 1.5 pixels of interpenetration
+    pens.append(mp)
     assert (poses[:, :k + 1, 2] > 0.005).all() and (poses[:, :k + 1, 2] < 0.375).all()
     q = poses[:, :k + 1, 3:7]
     assert np.abs(np.linalg.norm(q, axis=-1) - 1).max() < 1e-5
+  # Penetration left when the stop criterion fires (simulator.py:322-335 looks at linear speeds only).  A contact at
+  # rest is pushed out at erp x depth / dt, so a depth above velocity_threshold x dt / erp = 0.5 mm keeps its bodies
+  # moving: the bulk sits below 1 mm.  The tail is not a solver residue (it is the same with 10 or 50 sweeps): `Observer.pose`
+  # releases a rock by pixel-centre samples of both maps (observer.py:405-413), which on sloped faces starts it up to
+  # half a pixel x slope inside its neighbours, and a rock wedged between two others cannot be pushed out of both.
+  pens = np.stack(pens)
+  assert np.quantile(pens, 0.99) <= 1e-3
+  assert (pens > 1e-3).mean() <= 0.02
+  assert pens.max() < 0.006
