@@ -1,44 +1,123 @@
 #!/usr/bin/env python3
-"""bench.py — env steps/sec of the batched Stack-v0 hot path (BASELINE.json metric).
+"""bench.py — env steps/sec of the batched Stack-v0 hot path (BASELINE.json metric) + the DQN rollout/update leg.
 
-A "step" is one vectorised `env.step` over the per-GPU batch (settle kernel + render kernel).
-N = 1 workload = BASELINE.json configs[1]: Stack-v0, 1024 vectorised envs, 8 rocks, random policy on
-device, physics + render kernels only.  N > 1: every rank owns its own 1024 envs (weak scaling; envs are
-independent, utils.py:424-448, so there is no data-path collective).
+  python bench.py --gpus N --steps K --warmup W [--config 1|2|3|4]
 
-`value` = placements performed by all ranks / max-over-ranks wall time of the K timed steps (auto-reset
-calls, env.py:235-236, are stepped and timed but are not placements).  Inputs are resident in HBM.
+Launch.  `--gpus N` with N > 1 starts N fresh child processes itself (one per GPU, rendezvous on 127.0.0.1; the
+parent never touches the GPU and never execs); under `python -m torch.distributed.run` (RANK / WORLD_SIZE already in
+the environment) the process is a rank and starts nothing.  Rank 0 prints ONE JSON line.
 
-Extra objects on the JSON line: `roofline` (render kernel K2, HBM-bound: algorithmic bytes / HIP-event
-time), `settle` (K1 launch statistics), `cpu_baseline` (the CPU oracle timed on this
-host's cores on a bounded sample of the same workload), `reward_mse_vs_cpu`.
+Workloads (BASELINE.json `configs`):
+  leg A  configs[1] — Stack-v0, 1,024 vectorised envs per GPU, 8 rocks, random policy on device, physics + render
+         kernels only.  A "step" is one vectorised `env.step` (settle kernel + render kernel).  This is the
+         configuration the metric's target is quoted on (>= 50 k env steps/s on one MI355X at >= 40 % of the HBM roofline
+         for the render kernel) and it is `value` by default: placements of all ranks / max-over-ranks wall time of the
+         K timed steps (auto-reset calls, env.py:235-236, are stepped and timed but are not placements).  Weak scaling:
+         every rank owns its own 1,024 envs; envs are independent (utils.py:424-448), no data-path collective.
+  leg B  the DQN configs — rollout (Q-net forward on every env) + one minibatch-32 update per iteration
+         (training.py:338-380), reported under "dqn": configs[2] (4,096 envs x 16 rocks) at N = 1, configs[3]'s per-GPU
+         shard (2,048 x 16) at N = 2 / 4, configs[4]'s (2,048 x 32 rocks, 64 x 64 maps) at N = 8; the one collective is
+         the RCCL all-reduce of the flat gradient bucket.  Rollout in fp32 (the reference's dtype) and, as a second
+         labelled entry, bf16.  `--config 2|3|4` makes that leg the headline `value` instead.
+
+Extra objects on the JSON line: `roofline` (render kernel K2, HBM-bound: algorithmic bytes / HIP-event time measured in
+the timed region), `settle` (K1 launch statistics), `cpu_baseline` (the CPU oracle timed on this
+host's cores on a bounded sample of leg A's workload), `reward_mse_vs_cpu`, `dqn` (leg B incl. its own `roofline` with
+bound "mfma").
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}   # dense MFMA peaks, same guide (fp32 matrix = fp32 vector rate)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+def parse_args(argv=None):
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=54)
+  ap.add_argument('--warmup', type=int, default=9)
+  ap.add_argument('--config', type=int, default=1, choices=[1, 2, 3, 4],
+                  help='BASELINE.json configs[i] whose throughput is the headline `value` (1 = env only)')
+  ap.add_argument('--envs', type=int, default=None, help='leg A: envs per GPU (default 1024)')
+  ap.add_argument('--rocks', type=int, default=None, help='leg A: episode_length (default 8)')
+  ap.add_argument('--res', type=int, default=128, choices=[64, 128], help='leg A: overhead map side')
+  ap.add_argument('--solver', default='pybullet', help="solver definition: 'pybullet' (default) or 'bullet10'")
+  ap.add_argument('--seed', type=int, default=11)
+  ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline / reward-MSE legs')
+  ap.add_argument('--no-dqn', action='store_true', help='skip leg B')
+  ap.add_argument('--dqn-iters', type=int, default=12)
+  ap.add_argument('--dqn-warmup', type=int, default=6)
+  ap.add_argument('--dqn-envs', type=int, default=None, help='leg B: envs per GPU (default by --gpus, see above)')
+  ap.add_argument('--dqn-rocks', type=int, default=None)
+  ap.add_argument('--dqn-res', type=int, default=None, choices=[64, 128])
+  ap.add_argument('--dqn-slots', type=int, default=16, help='replay capacity in transitions per env')
+  ap.add_argument('--rollout', default='both', choices=['f32', 'bf16', 'both'])
+  ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL; gloo for rehearsals')
+  ap.add_argument('--same-device', action='store_true', help='rehearsal: every rank uses device 0 (needs --backend gloo)')
+  ap.add_argument('--launch-only', action='store_true',
+                  help='rehearsal without a GPU: spawn, rendezvous, barriers and aggregation only; value is null')
+  return ap.parse_args(argv)
 
 
+# ----------------------------------------------------------------------------------------------- launcher
+def free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def launch(args, argv):
+  """Start one fresh child per rank (plain subprocesses of this same script: nothing here has touched the GPU, and the
+  children are started, not exec'd into) and wait for them; rank 0's stdout is this process's stdout."""
+  port = free_port()
+  procs = []
+  for r in range(args.gpus):
+    env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if args.same_device else r), WORLD_SIZE=str(args.gpus),
+               LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               SRL_BENCH_CHILD='1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    out = None if r == 0 else subprocess.DEVNULL
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
+  rc = 0
+  deadline = None
+  while any(p.poll() is None for p in procs):
+    time.sleep(0.2)
+    failed = [p for p in procs if p.poll() not in (None, 0)]
+    if failed and deadline is None:
+      deadline = time.time() + 20.0          # a rank died: give the others a moment, then end exactly those we started
+    if deadline is not None and time.time() > deadline:
+      for p in procs:
+        if p.poll() is None:
+          p.kill()
+  for p in procs:
+    rc = rc or (p.returncode or 0)
+  return rc
+
+
+# ----------------------------------------------------------------------------------------------- helpers
 def alg_bytes_per_env(res, r, nb):
   """H f32 + obs u8 (H,W,2) + O f32 + obs u8 (h,w,1) + 1,404 B per placed rock."""
   return 6 * res * res + 5 * r * r + 1404 * nb
 
 
-def _cpu_worker(args):
-  n, L, seed, offset, episodes = args
+def _cpu_worker(a):
+  n, L, seed, offset, episodes, kw = a
   from oracle.oracle import OracleEnv
   from stackrl_amd import assets
   from stackrl_amd.config import StackConfig
   pool = assets.default_pool()
-  env = OracleEnv(StackConfig(n_envs=n, episode_length=L, env_index_offset=offset), pool, seed=seed)
+  env = OracleEnv(StackConfig(n_envs=n, episode_length=L, env_index_offset=offset, **kw), pool, seed=seed)
   env.reset()
   t0 = time.perf_counter()
   for _ in range(episodes * L):
@@ -46,23 +125,23 @@ def _cpu_worker(args):
   return n * L * episodes, time.perf_counter() - t0
 
 
-def cpu_baseline(L, seed, budget_envs=64, episodes=3):
-  """The oracle on this host's cores: `cores` processes x `budget_envs` envs x `episodes` episodes."""
+def cpu_baseline(L, seed, kw, budget_envs=48, episodes=2):
+  """The oracle (oracle/srl_oracle.c, built -O3 at the x86-64-v3 level, oracle/Makefile) on this host's cores: `cores` processes x `budget_envs`
+  envs x `episodes` episodes of the same workload, forked before this process touches the GPU."""
   import multiprocessing as mp
   cores = min(os.cpu_count() or 1, 16)
-  # one-thread figure first (same sample size per worker)
-  n1, t1 = _cpu_worker((budget_envs, L, seed, 0, episodes))
-  ctx = mp.get_context('fork')    # forked before this process touches the GPU
+  n1, t1 = _cpu_worker((budget_envs, L, seed, 0, episodes, kw))     # one-thread figure first
+  ctx = mp.get_context('fork')
   t0 = time.perf_counter()
   with ctx.Pool(cores) as pool:
-    res = pool.map(_cpu_worker, [(budget_envs, L, seed, i * budget_envs, episodes) for i in range(cores)])
+    res = pool.map(_cpu_worker, [(budget_envs, L, seed, i * budget_envs, episodes, kw) for i in range(cores)])
   wall = time.perf_counter() - t0
   placed = sum(r[0] for r in res)
   busy = max(r[1] for r in res)
   return {
     'value': placed / busy, 'unit': 'env_steps/s', 'cores': cores, 'kind': 'port',
-    'sample': '{} procs x {} envs x {} episode(s) of {} placements (oracle/srl_oracle.c, same pool and RNG keys); '
-              'wall incl. process start {:.1f}s'.format(cores, budget_envs, episodes, L, wall),
+    'sample': '{} procs x {} envs x {} episode(s) of {} placements (oracle/srl_oracle.c -O3 x86-64-v3, same pool, '
+              'RNG keys and solver definition); wall incl. process start {:.1f}s'.format(cores, budget_envs, episodes, L, wall),
     'single_thread_value': n1 / t1,
   }
 
@@ -80,55 +159,39 @@ def aggregate(dt, placed, world, device):
   return float(t.item()), float(tot.item())
 
 
-def main():
-  ap = argparse.ArgumentParser()
-  ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=54)
-  ap.add_argument('--warmup', type=int, default=9)
-  ap.add_argument('--envs', type=int, default=1024, help='envs per GPU')
-  ap.add_argument('--rocks', type=int, default=8, help='episode_length')
-  ap.add_argument('--seed', type=int, default=11)
-  ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
-  args = ap.parse_args()
+def traffic_record(B, L, res):
+  """HBM bytes per render launch from the PMC counters.  They come from separate `rocprofv3 --pmc` passes of this very
+  command (counter collection cannot run inside the timed process), summarised by tools/pmc_summary.py into
+  profiles/rNN_render_pmc.json; the line names the file and the commit that last touched it."""
+  import glob
+  if not (B == 1024 and L == 8 and res == 128):
+    return None, None
+  pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_render_pmc.json')))
+  if not pmcs:
+    return None, None
+  with open(pmcs[-1]) as f:
+    traffic = json.load(f).get('traffic_bytes_per_launch')
+  rel = os.path.relpath(pmcs[-1], ROOT)
+  try:
+    commit = subprocess.check_output(['git', '-C', ROOT, 'log', '-1', '--format=%h', '--', rel],
+                                     stderr=subprocess.DEVNULL).decode().strip() or None
+  except Exception:
+    commit = None
+  return traffic, {'file': rel, 'commit': commit, 'how': 'separate rocprofv3 --pmc passes of bench.py (FETCH_SIZE, WRITE_SIZE)'}
 
-  rank = int(os.environ.get('RANK', '0'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit('--gpus {} needs torch.distributed.run with --nproc-per-node {}'.format(args.gpus, args.gpus))
-  B, L = args.envs, args.rocks
 
-  from stackrl_amd import assets
-  pool = assets.default_pool()           # synthetic rocks, generator seed 11 (cached)
-
-  cpu = None
-  if rank == 0 and args.gpus == 1 and not args.no_cpu:
-    from oracle import oracle as _o
-    _o.build()
-    cpu = cpu_baseline(L, args.seed)     # before any GPU initialisation in this process
-
+# ----------------------------------------------------------------------------------------------- leg A
+def env_leg(args, rank, world, pool, barrier, solver_kw):
+  import numpy as np
   import torch
-  import torch.distributed as dist
-  torch.cuda.set_device(local_rank)
-  use_dist = world > 1 or os.environ.get('SRL_BENCH_FORCE_DIST') == '1'   # the latter: rehearse the RCCL calls on one GPU
-  if use_dist:
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29511')
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-
   from stackrl_amd import env as envs
+  B, L = args.envs or 1024, args.rocks or 8
+  kw = dict(solver_kw)
+  if args.res == 64:
+    kw['resolution_factor'] = 4
   env = envs.VecStackEnv(n_parallel=B, seed=args.seed, pool=pool, block=False, episode_length=L,
-                         env_index_offset=rank * B)
-
-  def barrier():
-    torch.cuda.synchronize()
-    if use_dist:
-      dist.barrier()
-    torch.cuda.synchronize()
-
-  # lock-step bookkeeping: which calls are placements and how many rocks each render launch sees
-  phase = {'k': 0}   # calls since reset(): 1..L placements, L+1 auto-reset
+                         env_index_offset=rank * B, **kw)
+  phase = {'k': 0}   # lock-step bookkeeping: calls since reset(): 1..L placements, L+1 auto-reset
 
   def do_step():
     out = env.step(env.sample())
@@ -158,77 +221,277 @@ def main():
   last()     # raises if any env diverged / action invalid
   ms, nl = env.kernel_times()
   env.set_profiling(False)
-  # sub-step statistics of one further (untimed) episode: what the stop criterion asked of the settle kernel
-  subs = []
+  # statistics of one further (untimed) episode: what the stop criterion and the residual threshold asked of the kernel
+  subs, sweeps = [], []
   while phase['k'] != 0:
     do_step()[0]()
   for _ in range(L):
     do_step()[0]()
     subs.append(env.state()[2].sum(1))
+    sweeps.append(env.sweeps())
   do_step()[0]()
-  sub = np.stack(subs)
+  sub, sw = np.stack(subs), np.stack(sweeps)
+  out = dict(B=B, L=L, res=res, r=r, dt=dt, placed=placed, alg=alg, ms=ms, nl=nl, sub=sub, sw=sw, config=env.config)
+  env.close()
+  torch.cuda.synchronize()
+  return out
 
-  dt_max, placed_all = aggregate(dt, placed, world, 'cuda')
+
+def reward_mse(args, pool, L, solver_kw):
+  """Reward parity on identical seeds: 64 envs, one episode, HIP vs the CPU oracle."""
+  import numpy as np
+  from oracle.oracle import OracleEnv
+  from stackrl_amd import env as envs
+  from stackrl_amd.config import StackConfig
+  g = envs.VecStackEnv(n_parallel=64, seed=args.seed + 1, pool=pool, block=True, episode_length=L, **solver_kw)
+  o = OracleEnv(StackConfig(n_envs=64, episode_length=L, **solver_kw), pool, seed=args.seed + 1)
+  g.reset(); o.reset()
+  se, cnt, ok = 0.0, 0, True
+  for _ in range(L):
+    a = g.sample()
+    (gm, go), gr, gd = g.step(a)
+    (om, oo), orr, od = o.step(a.cpu().numpy())
+    se += float(((gr.cpu().numpy().astype(np.float64) - orr) ** 2).sum()); cnt += 64
+    ok &= bool(np.array_equal(gm.cpu().numpy(), om) and np.array_equal(gd.cpu().numpy(), od))
+  g.close()
+  return {'value': se / cnt, 'envs': 64, 'steps': L, 'obs_and_done_bit_exact': ok}
+
+
+# ----------------------------------------------------------------------------------------------- leg B
+def dqn_shape(args):
+  """Per-GPU shard of the BASELINE DQN configs: configs[2] at N = 1, configs[3] at N = 2 / 4, configs[4] at N = 8."""
+  if args.config in (2, 3, 4):
+    B, L, res = {2: (4096, 16, 128), 3: (2048, 16, 128), 4: (2048, 32, 64)}[args.config]
+    name = 'configs[{}]'.format(args.config)
+  elif args.gpus >= 8:
+    B, L, res, name = 2048, 32, 64, 'configs[4]'
+  elif args.gpus >= 2:
+    B, L, res, name = 2048, 16, 128, 'configs[3]'
+  else:
+    B, L, res, name = 4096, 16, 128, 'configs[2]'
+  return args.dqn_envs or B, args.dqn_rocks or L, args.dqn_res or res, name
+
+
+def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
+  """`Training.run` (training.py:338-380) for --dqn-iters iterations after --dqn-warmup: per iteration one rollout forward
+  over the rank's envs (`agent.collect`), one non-blocking vectorised env step on a side stream, one minibatch-32 update
+  (`agent.train`, with the gradient all-reduce when world > 1)."""
+  import torch
+  import torch.distributed as dist
+  from stackrl_amd import env as envs, nets, qops
+  from stackrl_amd.dqn import DQN, PolynomialDecay
+  from stackrl_amd.training import Trainer
+  B, L, res, name = dqn_shape(args)
+  # as the headline (--config 2|3|4) the leg follows the contract's K timed / W warm-up steps; the three eager updates
+  # and the graph capture of the update (DQN._GRAPH_WARMUP) then run before those, as part of the setup
+  iters, warm, pre = (args.steps, args.warmup, 5) if args.config != 1 else (args.dqn_iters, args.dqn_warmup, 0)
+  kw = dict(solver_kw)
+  if res == 64:
+    kw['resolution_factor'] = 4
+  env = envs.make('Stack-v0', n_parallel=B, seed=args.seed, pool=pool, episode_length=L, side_stream=True,
+                  env_index_offset=rank * B, **kw)
+  net = nets.DeepQSiamFCN(env.observation_spec, seed=1).cuda()
+  agent = DQN(net, learning_rate=6.25e-5, adam_betas=(0.95, 0.95), minibatch_size=32,
+              replay_memory_size=B * args.dqn_slots, discount_factor=.966667, collect_batch_size=B,
+              exploration=PolynomialDecay(1.0, 400000, .1), prioritization=0.6,
+              priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=7 + rank,
+              policy_op=qops.FusedPolicy(autocast=torch.bfloat16 if dtype == 'bf16' else None),
+              xcorr='bf16x3', graphs=True)                     # config.gin:55-112
+  tr = Trainer(env, agent)
+  tr.initialize(num_steps=4)
+  if pre:
+    tr.run(pre)
+  ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(iters)]
+  step = env.reset()
+  agent.acknowledge_reset()
+  t0 = None
+  for it in range(warm + iters):
+    if it == warm:
+      step = step() if callable(step) else step
+      barrier()
+      t0 = time.perf_counter()
+    k = it - warm
+    if callable(step):
+      step = step()
+    if k >= 0:
+      ev[k][0].record()
+    action = agent.collect(*step)
+    if k >= 0:
+      ev[k][1].record()
+    step = env.step(action)                # side stream: overlaps the update below
+    if k >= 0:
+      ev[k][2].record()
+    agent.train()
+    if k >= 0:
+      ev[k][3].record()
+  step = step() if callable(step) else step
+  barrier()
+  dt = time.perf_counter() - t0
+  fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev)
+  upd_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / len(ev)
+  # all-reduce of the gradient bucket, timed on its own after the loop (inside the update it hides in upd_ms)
+  ar_ms = None
+  if world > 1:
+    g = agent._flat_grad
+    for _ in range(3):
+      dist.all_reduce(g)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+      dist.all_reduce(g)
+    b.record()
+    torch.cuda.synchronize()
+    ar_ms = a.elapsed_time(b) / 10
+  macs = sum(nets.forward_macs(H=res, h=res // 4).values())
+  dt_max, steps_all = aggregate(dt, B * iters, world, 'cuda')
+  flops_fwd = 2.0 * macs * B
+  out = {
+    'workload': 'Stack-v0, {} envs per GPU x {} rocks, {}x{} maps, DQN rollout + minibatch-32 update per iteration '
+                '(BASELINE {} per-GPU shard)'.format(B, L, res, res, name),
+    'rollout_dtype': dtype, 'update_dtype': 'f32 (cross-correlation as bf16x3 split on MFMA)',
+    'iterations': iters, 'warmup': warm,
+    'env_steps_per_s': steps_all / dt_max, 'iters_per_s': iters / dt_max, 'ms_per_iter': 1e3 * dt_max / iters,
+    'rollout_forward_ms': fwd_ms, 'update_ms': upd_ms, 'allreduce_ms': ar_ms,
+    'grad_bucket_bytes': int(agent._flat_grad.numel() * 4), 'update_graphed': agent._train_graph is not None,
+    'roofline': {
+      'kernel': 'Q-net rollout forward (DeepQSiamFCN, {} samples)'.format(B), 'bound': 'mfma',
+      'achieved': flops_fwd / (fwd_ms * 1e-3) / 1e12, 'peak': PEAK_TFLOPS[dtype], 'unit': 'TFLOP/s',
+      'frac': flops_fwd / (fwd_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 'traffic': None,
+      'alg_flops_per_launch': flops_fwd, 'avg_launch_ms': fwd_ms,
+      'note': 'model-level: 2 x {:.1f} M MAC per sample (SURVEY.md N1) x samples / HIP-event time of agent.collect in '
+              'the timed region; peak = dense {} MFMA'.format(macs / 1e6, dtype),
+    },
+  }
+  env.close()
+  del agent, net, tr
+  torch.cuda.empty_cache()
+  return out
+
+
+# ----------------------------------------------------------------------------------------------- worker
+def worker(args):
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  if world != args.gpus:
+    raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+  from stackrl_amd.config import SOLVER_PRESETS
+  solver_kw = dict(SOLVER_PRESETS[args.solver])
+  L = args.rocks or 8
+
+  if args.launch_only:
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(args.backend, rank=rank, world_size=world)
+    dist.barrier()
+    dt, placed = aggregate(1.0 + 0.5 * rank, 100 * (rank + 1), world, 'cpu')
+    dist.barrier()
+    if rank == 0:
+      print(json.dumps({'metric': 'env steps/sec (batched Stack-v0)', 'value': None, 'unit': 'env_steps/s',
+                        'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup, 'launch_only': True,
+                        'note': 'rehearsal of spawn + rendezvous + aggregation; no GPU work was done',
+                        'aggregate_check': {'max_dt': dt, 'sum_placed': placed}}))
+    dist.destroy_process_group()
+    return
+
+  from stackrl_amd import assets
+  pool = assets.default_pool()           # synthetic rocks, generator seed 11 (cached)
+
+  cpu = None
+  if rank == 0 and not args.no_cpu:
+    from oracle import oracle as _o
+    _o.build()
+    cpu = cpu_baseline(L, args.seed, solver_kw)     # before any GPU initialisation in this process
+
+  import torch
+  import torch.distributed as dist
+  dev = 0 if args.same_device else local_rank
+  torch.cuda.set_device(dev)
+  use_dist = world > 1 or os.environ.get('SRL_BENCH_FORCE_DIST') == '1'   # the latter: rehearse the RCCL calls on one GPU
+  if use_dist:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29511')
+    if args.backend == 'nccl':
+      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev))
+    else:
+      dist.init_process_group('gloo', rank=rank, world_size=world)
+
+  def barrier():
+    torch.cuda.synchronize()
+    if use_dist:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  a = env_leg(args, rank, world, pool, barrier, solver_kw)
+  dt_max, placed_all = aggregate(a['dt'], a['placed'], world, 'cuda')
+
+  dqn = None
+  if not args.no_dqn:
+    dqn = {}
+    for dtype in (['f32', 'bf16'] if args.rollout == 'both' else [args.rollout]):
+      dqn[dtype] = dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype)
 
   mse = None
-  if rank == 0 and args.gpus == 1 and not args.no_cpu:
-    # reward parity on identical seeds: 64 envs, one episode
-    from oracle.oracle import OracleEnv
-    from stackrl_amd.config import StackConfig
-    g = envs.VecStackEnv(n_parallel=64, seed=args.seed + 1, pool=pool, block=True, episode_length=L)
-    o = OracleEnv(StackConfig(n_envs=64, episode_length=L), pool, seed=args.seed + 1)
-    g.reset(); o.reset()
-    se, cnt, idx_ok = 0.0, 0, True
-    for _ in range(L):
-      a = g.sample()
-      (gm, go), gr, gd = g.step(a)
-      (om, oo), orr, od = o.step(a.cpu().numpy())
-      se += float(((gr.cpu().numpy().astype(np.float64) - orr) ** 2).sum()); cnt += 64
-      idx_ok &= bool(np.array_equal(gm.cpu().numpy(), om) and np.array_equal(gd.cpu().numpy(), od))
-    mse = {'value': se / cnt, 'envs': 64, 'steps': L, 'obs_and_done_bit_exact': idx_ok}
-    g.close()
+  if rank == 0 and not args.no_cpu:
+    mse = reward_mse(args, pool, L, solver_kw)
 
-  traffic = None
-  # HBM bytes per launch from the PMC counters: separate rocprofv3 --pmc passes of this command (they cannot run inside
-  # this process), summarised by tools/pmc_summary.py into profiles/rNN_render_pmc.json; the latest round's file is used
-  import glob
-  pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_render_pmc.json')))
-  if pmcs and B == 1024 and L == 8:
-    with open(pmcs[-1]) as f:
-      traffic = json.load(f).get('traffic_bytes_per_launch')
   if rank == 0:
+    B, res, ms, nl, sub, sw = a['B'], a['res'], a['ms'], a['nl'], a['sub'], a['sw']
+    traffic, traffic_source = traffic_record(B, a['L'], res)
     render_s = float(ms[1]) / 1e3
+    cfg = a['config']
     line = {
       'metric': 'env steps/sec (batched Stack-v0)', 'value': placed_all / dt_max, 'unit': 'env_steps/s',
       'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt_max / args.steps,
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
       'config': {
         'workload': 'Stack-v0, {} vectorised envs per GPU, {} rocks, random policy on device, physics+render '
-                    'kernels only (BASELINE configs[1])'.format(B, L),
-        'envs_per_gpu': B, 'episode_length': L, 'heightmap': res, 'sim_time_step': env.config.sim_time_step,
-        'solver_iterations': env.config.solver_iterations, 'parallelism': 'env-shard x{}'.format(args.gpus),
+                    'kernels only (BASELINE configs[1])'.format(B, a['L']),
+        'envs_per_gpu': B, 'episode_length': a['L'], 'heightmap': res, 'sim_time_step': cfg.sim_time_step,
+        'solver': args.solver, 'solver_iterations': cfg.solver_iterations, 'warmstart': cfg.warmstart,
+        'linear_slop': cfg.linear_slop, 'residual_threshold': cfg.residual_threshold,
+        'parallelism': 'env-shard x{}'.format(args.gpus),
         'mesh_pool': '{} synthetic rocks (generator seed 11)'.format(len(pool)),
       },
       'step_calls_per_s': args.steps * B * args.gpus / dt_max,
       'roofline': {
-        'kernel': 'srl_k_render', 'bound': 'hbm', 'achieved': alg / render_s / 1e9 if render_s > 0 else None,
+        'kernel': 'srl_k_render', 'bound': 'hbm', 'achieved': a['alg'] / render_s / 1e9 if render_s > 0 else None,
         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': (alg / render_s / 1e9) / HBM_PEAK_GBS if render_s > 0 else None, 'traffic': traffic,
+        'frac': (a['alg'] / render_s / 1e9) / HBM_PEAK_GBS if render_s > 0 else None, 'traffic': traffic,
+        'traffic_source': traffic_source,
         'avg_launch_us': 1e3 * float(ms[1]) / max(int(nl[1]), 1), 'launches': int(nl[1]),
-        'alg_bytes_per_launch': alg / max(int(nl[1]), 1),
+        'alg_bytes_per_launch': a['alg'] / max(int(nl[1]), 1),
       },
       'settle': {
         'kernel': 'srl_k_step', 'avg_launch_ms': float(ms[0]) / max(int(nl[0]), 1), 'launches': int(nl[0]),
-        'share_of_wall': float(ms[0]) / 1e3 / dt, 'substeps_mean': float(sub.mean()),
+        'share_of_wall': float(ms[0]) / 1e3 / a['dt'], 'substeps_mean': float(sub.mean()),
         'substeps_mean_of_per_step_max': float(sub.max(1).mean()), 'substeps_max': int(sub.max()),
+        'sweeps_per_substep_mean': float(sw.sum() / max(sub.sum(), 1)),
+        'sweeps_mean': float(sw.mean()), 'sweeps_mean_of_per_step_max': float(sw.max(1).mean()),
         'note': 'latency-bound: one launch lasts as long as its slowest env (stop criterion simulator.py:322-335)',
       },
-      'cpu_baseline': cpu, 'reward_mse_vs_cpu': mse,
+      'cpu_baseline': cpu, 'reward_mse_vs_cpu': mse, 'dqn': dqn,
     }
+    if args.config != 1 and dqn:
+      # the DQN leg as the headline: fp32 rollout (the reference's dtype) when it was run
+      d = dqn.get('f32') or next(iter(dqn.values()))
+      line.update(value=d['env_steps_per_s'], steps=d['iterations'], warmup=d['warmup'], ms_per_step=d['ms_per_iter'],
+                  dtype=d['rollout_dtype'], env_only={'value': placed_all / dt_max, 'steps': args.steps,
+                                                      'warmup': args.warmup, 'ms_per_step': 1e3 * dt_max / args.steps})
+      line['config'] = dict(line['config'], workload=d['workload'], note='leg A (config keys above) is reported under env_only')
     print(json.dumps(line))
-  env.close()
   if use_dist:
+    dist.barrier()
     dist.destroy_process_group()
+
+
+def main(argv=None):
+  argv = list(sys.argv[1:] if argv is None else argv)
+  args = parse_args(argv)
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(launch(args, argv))
+  worker(args)
 
 
 if __name__ == '__main__':

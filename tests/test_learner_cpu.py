@@ -535,3 +535,22 @@ def test_keras_weight_import_layouts_and_names():
   bad = dict(w); bad['extra/kernel:0'] = np.zeros(3)
   with pytest.raises(ValueError):
     kw.load_keras_weights(nets.DeepQSiamFCN(seed=3), bad)
+
+
+def test_bench_spawns_its_own_ranks_world_size_2_gloo():
+  """`python bench.py --gpus 2` must start its two ranks itself (the driver calls it exactly so) and rank 0 must print
+  one JSON line.  No GPU here: `--launch-only` runs spawn + rendezvous (gloo, 127.0.0.1) + barriers + the MAX / SUM
+  aggregation and nothing else."""
+  import json
+  import subprocess
+  import sys
+  env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--launch-only', '--backend', 'gloo',
+                      '--steps', '7', '--warmup', '2'], env=env, capture_output=True, text=True, timeout=300)
+  assert p.returncode == 0, p.stderr[-2000:]
+  lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 2 and d['steps'] == 7 and d['warmup'] == 2 and d['value'] is None and d['launch_only']
+  assert d['aggregate_check'] == {'max_dt': 1.5, 'sum_placed': 300.0}
