@@ -933,7 +933,11 @@ static void derive_bodies(const struct srlo_env* e, env_t* s) {
   }
 }
 
-#define GMAXP 8   /* ground manifold: up to 8 deepest vertices within the breaking threshold */
+/* ground manifold: the deepest vertices within the breaking threshold, at most 4 — the size of Bullet's persistent
+ * manifold (MANIFOLD_CACHE_SIZE); round 1 kept 8, which doubled the ground phase of every solver sweep for the same
+ * sub-step and sweep counts.  (Choosing the four by extent — deepest, farthest from it, farthest to either side of that
+ * line — was tried: it can leave out a vertex that carries the rock, and such rocks never come to rest.) */
+#define GMAXP 4
 static void ground_manifold(const struct srlo_env* e, env_t* s, int b) {
   const mesh_t* M = &e->mesh[s->mesh[b]];
   float m = e->c.collision_margin, thr = 0.02f * M->radius;
@@ -1095,6 +1099,35 @@ static inline void row_apply(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float 
   }
 }
 
+/* Ground rows.  The ground's contact normal is +z and its tangents (plane_space of +z) are -y and +x, so a ground row's
+ * direction is sgn * e_axis: its relative velocity needs one component of the linear velocity and its impulse changes
+ * that component only — stated as such (not as products with the zeros of d) so that the kernel and this file evaluate
+ * the same, shorter expressions: vrel = ca . w + sgn v[axis] as one fused chain, v[axis] += (sgn m^-1) dl.  The row
+ * constants (ca = ra x d, aa = I ca, k) are those of the general row. */
+static inline float row_solve_axis(int axis, float sgn, v3 d, v3 ra, float ima, const m3* Ia, vel4* u, float target,
+                                   float* acc, float lo, float hi) {
+  v3 ca = vcross(ra, d);
+  v3 aa = mmul(Ia, ca);
+  float k = ima + vdot(vcross(aa, ra), d);
+  float* va = axis == 0 ? &u->va.x : axis == 1 ? &u->va.y : &u->va.z;
+  float vrel = fmaf(ca.x, u->wa.x, fmaf(ca.y, u->wa.y, fmaf(ca.z, u->wa.z, sgn * *va)));
+  float rk = 1.0f / k;
+  float dl = fmaf(-vrel, rk, target * rk);
+  float na = med3f(*acc + dl, lo, hi);
+  dl = na - *acc;
+  *acc = na;
+  *va = fmaf(sgn * ima, dl, *va);
+  u->wa = vmadd(u->wa, aa, dl);
+  return fabsf(dl * k);
+}
+
+static inline void row_apply_axis(int axis, float sgn, v3 d, v3 ra, float ima, const m3* Ia, vel4* u, float imp) {
+  v3 aa = mmul(Ia, vcross(ra, d));
+  float* va = axis == 0 ? &u->va.x : axis == 1 ? &u->va.y : &u->va.z;
+  *va = fmaf(sgn * ima, imp, *va);
+  u->wa = vmadd(u->wa, aa, imp);
+}
+
 static inline float contact_target(const struct srlo_env* e, float dist) {
   float inv_dt = 1.0f / e->c.sim_time_step;
   /* Bullet setupContactConstraint restated: penetration = distance + m_linearSlop; separated points may close the gap
@@ -1115,17 +1148,16 @@ static float solve_ground(const struct srlo_env* e, env_t* s, int b, int warm) {
   for (int i = 0; i < g->np; ++i) {
     v3 pw = s->wv[b][g->vid[i]];
     v3 ra = vsub(V(pw.x, pw.y, pw.z - e->c.collision_margin), s->x[b]);
-    v3 rb = V(0, 0, 0);
     if (warm) {
       g->in[i] = g->in[i] * e->c.warmstart; g->it1[i] = g->it1[i] * e->c.warmstart; g->it2[i] = g->it2[i] * e->c.warmstart;
-      row_apply(n, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, g->in[i], 0);
-      row_apply(t1, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, g->it1[i], 0);
-      row_apply(t2, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, g->it2[i], 0);
+      row_apply_axis(2, 1.0f, n, ra, M->inv_mass, &s->Iw[b], &u, g->in[i]);
+      row_apply_axis(1, -1.0f, t1, ra, M->inv_mass, &s->Iw[b], &u, g->it1[i]);
+      row_apply_axis(0, 1.0f, t2, ra, M->inv_mass, &s->Iw[b], &u, g->it2[i]);
     } else {
-      res = fmaxf(res, row_solve(n, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, contact_target(e, g->dist[i]), &g->in[i], 0.0f, 1e30f, 0));
+      res = fmaxf(res, row_solve_axis(2, 1.0f, n, ra, M->inv_mass, &s->Iw[b], &u, contact_target(e, g->dist[i]), &g->in[i], 0.0f, 1e30f));
       float lim = mu * g->in[i];
-      res = fmaxf(res, row_solve(t1, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, 0.0f, &g->it1[i], -lim, lim, 0));
-      res = fmaxf(res, row_solve(t2, ra, rb, M->inv_mass, &s->Iw[b], 0.0f, 0, &u, 0.0f, &g->it2[i], -lim, lim, 0));
+      res = fmaxf(res, row_solve_axis(1, -1.0f, t1, ra, M->inv_mass, &s->Iw[b], &u, 0.0f, &g->it1[i], -lim, lim));
+      res = fmaxf(res, row_solve_axis(0, 1.0f, t2, ra, M->inv_mass, &s->Iw[b], &u, 0.0f, &g->it2[i], -lim, lim));
     }
   }
   s->v[b] = u.va; s->w[b] = u.wa;

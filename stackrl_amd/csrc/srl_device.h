@@ -13,11 +13,16 @@
 #include <stdint.h>
 
 #define SRL_FAR 1000.0f      // Observer.far, observer.py:6
-#define SRL_GMAXP 8          // ground manifold points per body
+#define SRL_GMAXP 4          // ground manifold points per body: Bullet's MANIFOLD_CACHE_SIZE (round 1 kept 8)
 #define SRL_NSLOT_MAX 192    // persistent body-body manifolds per env
 #define SRL_MP_WORDS 13      // manifold point: la3 lb3 n3 dist in it1 it2
 #define SRL_MAN_WORDS 60     // np, axis3, 4 points, cached GJK simplex: n, 3 words of packed (ia, ib) pairs
-#define SRL_GM_WORDS 41      // np, vid8, dist8, in8, it1 8, it2 8
+#define SRL_GM_WORDS (1 + 5 * SRL_GMAXP)   // np, vid[], dist[], in[], it1[], it2[]
+#define SRL_GM_VID 1
+#define SRL_GM_DIST (1 + SRL_GMAXP)
+#define SRL_GM_IN (1 + 2 * SRL_GMAXP)
+#define SRL_GM_T1 (1 + 3 * SRL_GMAXP)
+#define SRL_GM_T2 (1 + 4 * SRL_GMAXP)
 #define SRL_GJK_MAXIT 32
 
 struct v3 { float x, y, z; };

@@ -384,7 +384,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   env->step_lds = sizeof(float) * (size_t)P.LDS_WORDS;
   if (env->step_lds > 160 * 1024) return fail(SRL_EINVAL, "episode_length x mesh size exceeds the 160 KB LDS budget");
   // threads per env / pair-manifold points per thread (settle.hip "Variants")
-  if (4 * P.NS <= 128 && 8 * P.c.episode_length <= 128) { env->step_threads = 128; env->step_pp = 0; }
+  if (4 * P.NS <= 128 && SRL_GMAXP * P.c.episode_length <= 128) { env->step_threads = 128; env->step_pp = 0; }
   else { env->step_threads = 256; env->step_pp = (4 * P.NS + 255) / 256; }
   if (env->step_pp == 3) env->step_threads = 512;   // 4 NS > 512: eight waves, two points per thread (three per thread at 256 spill)
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_t512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));

@@ -294,7 +294,15 @@ def test_fast_rollout_follows_graph_replayed_updates(ref_pool):
   tr.run(3)                                                     # three more replayed updates, no ATen op on the weights
   assert any(not torch.equal(a, b) for a, b in zip(w_before, net.parameters()))
   obs = env.reset()()[0]
-  xb, wb = pol._ff(obs)                                         # the policy's own cache ...
-  xc, wc = qops.FastFeatures(net)(obs)                          # ... against one built from the current weights
-  assert torch.equal(xb, xc) and torch.equal(wb, wc)
+  xb, wb = pol._ff(obs)                                         # refreshes the policy's own cache ...
+  n = 0
+  for m, (w, b) in pol._ff._w.items():                          # ... which must hold the current weights, bit for bit
+    assert torch.equal(w, m.weight.detach().to(torch.bfloat16)) and torch.equal(b, m.bias.detach().float())
+    n += 1
+  assert n >= 20
+  for m, wf in pol._ff._wf.items():
+    pack = qops.pack_conv3x3_weights if isinstance(m, torch.nn.Conv2d) else qops.pack_convt2x2_weights
+    assert torch.equal(wf, pack(m.weight))
+  xc, wc = qops.FastFeatures(net)(obs)                          # and its features track a cache built afresh
+  assert float((xb.float() - xc.float()).abs().max()) <= 0.05 * float(xc.float().abs().max())
   env.close()
