@@ -306,3 +306,74 @@ def test_fast_rollout_follows_graph_replayed_updates(ref_pool):
   xc, wc = qops.FastFeatures(net)(obs)                          # and its features track a cache built afresh
   assert float((xb.float() - xc.float()).abs().max()) <= 0.05 * float(xc.float().abs().max())
   env.close()
+
+
+def test_train_step_matches_dqn_oracle():
+  """One `DQN.train` step of the product settings (full-size net, MFMA cross-correlation, PER, Double-DQN, Huber) against
+  oracle/dqn_oracle.py on the same minibatch: sampled indices (Gumbel top-k over the oracle's logits and the generator's
+  own uniforms), importance weights, transitions, TD targets / loss / mean TD in float64, updated priorities and the
+  min / max trackers."""
+  from oracle import dqn_oracle as O
+  from stackrl_amd import nets
+  from stackrl_amd.dqn import DQN
+  B, slots, mb, gamma, alpha, beta = 4, 8, 6, 0.9, 0.6, 0.5
+  net = nets.DeepQSiamFCN(seed=3).cuda()
+  agent = DQN(net, learning_rate=1e-4, adam_betas=(0.95, 0.95), minibatch_size=mb, replay_memory_size=B * slots,
+              discount_factor=gamma, collect_batch_size=B, exploration=0.5, prioritization=alpha,
+              priority_bias_compensation=beta, double=True, seed=5, xcorr='bf16x3')
+  with torch.no_grad():                                        # a target net that differs from the online one
+    for p in agent._target_q_net.parameters():
+      p.mul_(1.05)
+  mem = agent._replay_memory
+  ref = O.RefMemory(B, B * slots)
+  rng = np.random.RandomState(0)
+  for t in range(11):                                          # wraps the 8 slots per env; some episode ends
+    sm = rng.randint(0, 256, (B, 128, 128, 2)).astype(np.uint8)
+    so = rng.randint(0, 256, (B, 32, 32, 1)).astype(np.uint8)
+    r = rng.normal(size=B).astype(np.float32)
+    term = rng.rand(B) < 0.2
+    a = rng.randint(0, net.n_actions, B)
+    agent.observe((torch.from_numpy(sm).cuda(), torch.from_numpy(so).cuda()), torch.from_numpy(r).cuda(),
+                  torch.from_numpy(term).cuda(), torch.from_numpy(a).cuda())
+    ref.add([(sm[i], so[i]) for i in range(B)], r, term, a)
+    if t in (5, 8):                                            # non-uniform priorities
+      fin = np.flatnonzero(np.isfinite(np.array(ref.logits)))[:5]
+      dl = rng.rand(len(fin)).astype(np.float32) * 3
+      mem.update_priorities(torch.from_numpy(fin).cuda(), torch.from_numpy(dl).cuda())
+      ref.update_priorities(fin.tolist(), dl.tolist())
+  np.testing.assert_allclose(mem._logits.cpu().numpy(), np.array(ref.logits, np.float32), rtol=1e-6)
+  assert int(mem._max_logit_index) == ref.max_idx and int(mem._min_logit_index) == ref.min_idx
+  # --- the sample the update will draw
+  st = mem._gen.get_state()
+  u = torch.rand(mem._logits.shape, generator=mem._gen, device='cuda', dtype=torch.float32).cpu().numpy().astype(np.float64)
+  mem._gen.set_state(st)
+  lg = np.array(ref.logits, np.float64)
+  keys = np.where(np.isinf(lg), lg, alpha * lg) - np.log(-np.log(u))          # memory.py:220-223
+  expect_idx = np.argsort(-keys)[:mb]
+  indexes, weights, (states, actions, rewards, next_states, terminal) = mem.sample(mb, get_weights=True)
+  mem._gen.set_state(st)
+  idx = indexes.cpu().numpy()
+  assert np.array_equal(idx, expect_idx)
+  for j, i in enumerate(idx.tolist()):
+    s0, a0, r0, s1, t1 = ref.transition(i)
+    assert np.array_equal(states[0][j].cpu().numpy(), s0[0]) and np.array_equal(states[1][j].cpu().numpy(), s0[1])
+    assert np.array_equal(next_states[0][j].cpu().numpy(), s1[0]) and np.array_equal(next_states[1][j].cpu().numpy(), s1[1])
+    assert int(actions[j]) == a0 and float(rewards[j]) == np.float32(r0) and bool(terminal[j]) == t1
+    assert abs(float(weights[j]) - ref.weight(i, alpha, beta)) <= 1e-5 * ref.weight(i, alpha, beta)
+  with torch.no_grad():
+    q = agent._q_net(states).double().cpu().numpy()
+    qo = agent._q_net(next_states).double().cpu().numpy()
+    qt = agent._target_q_net(next_states).double().cpu().numpy()
+  w = [ref.weight(i, alpha, beta) for i in idx.tolist()]
+  eloss, emtd, etd = O.dqn_targets(q, qo, qt, actions.cpu().numpy(), rewards.cpu().numpy(), terminal.cpu().numpy(), gamma,
+                                   double=True, huber_delta=1.0, weights=w)
+  w0 = [p.detach().clone() for p in net.parameters()]
+  loss, mtd = agent.train()                                    # samples the same minibatch (generator state restored)
+  scale = max(1.0, float(np.abs(q).max()))
+  assert abs(float(loss) - eloss) <= 2e-4 * max(eloss, 1e-3) + 1e-6 * scale
+  assert abs(float(mtd) - emtd) <= 2e-4 * scale
+  assert any(not torch.equal(a, b) for a, b in zip(w0, net.parameters()))
+  # priorities and trackers after the update (memory.py:266-316)
+  ref.update_priorities(idx.tolist(), [float(np.float32(t)) for t in etd])
+  np.testing.assert_allclose(mem._logits[indexes].cpu().numpy(), np.array([ref.logits[i] for i in idx]), rtol=0, atol=2e-3)
+  assert int(mem._max_logit_index) == ref.max_idx and int(mem._min_logit_index) == ref.min_idx
