@@ -108,6 +108,58 @@ int srl_baseline_select(const double* values_dev, const uint8_t* mask_dev, int32
 
 const char* srl_qnet_last_error(void);
 
+/* ---- update path (csrc/learner.hip).  Device pointers, contiguous, `stream` a hipStream_t; nothing is allocated, so a
+ * captured hipGraph can replay every call.
+ *
+ * srl_td_epilogue = the loss of `DQN.train` (stackrl/agents/dqn.py:408-469) and its gradient in one pass over the
+ * minibatch: y = r [x reward_scale] + (terminal ? 0 : gamma Q_target(s', a*)), a* = argmax_a Q_online(s', a)
+ * (use_double, ties to the lowest index) or argmax_a Q_target(s', a); td = Q(s, action) - y; Huber with `huber_delta`
+ * (< 0: plain 0.5 td^2) times the importance weight (weights may be NULL); outputs: loss = mean, mtd = mean td,
+ * td_abs[mb], logits[mb] = log(|td| + prio_eps) (the new replay priorities, memory.py:272), and grad_q[mb][A] (may be
+ * NULL) = d loss / d Q(s, .): zero except at the taken action.  scratch: 2 mb floats; ticket: one int32, zero before the
+ * first call (the kernel leaves it zero). */
+int srl_td_epilogue(const float* q_dev, const float* q_next_online_dev, const float* q_next_target_dev,
+                    const int64_t* actions_dev, const float* rewards_dev, const uint8_t* terminal_dev,
+                    const float* weights_dev, float gamma, float huber_delta, float reward_scale, int32_t use_double,
+                    float prio_eps, int32_t mb, int32_t A, float* loss_dev, float* mean_td_dev, float* td_abs_dev,
+                    float* logits_dev, float* grad_q_dev, float* scratch_dev, int32_t* ticket_dev, void* stream);
+
+/* Keras Adam (`optimizer.apply_gradients`, dqn.py:473; config.gin:90-93) over one flat fp32 bucket of n elements
+ * (16-byte aligned): m += (g - m)(1 - beta1); v += (g^2 - v)(1 - beta2); p -= lr_t m / (sqrt(v) + eps) with
+ * lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t).  state: 4 device floats {t, beta1^t, beta2^t, lr_t}, {0, 1, 1, 0} before
+ * the first step, advanced on the device by every call. */
+int srl_adam_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, int64_t n, float* state_dev,
+                  float lr, float beta1, float beta2, float eps, void* stream);
+
+/* K7 — prioritised sampling without replacement (`ReplayMemory.sample`, memory.py:220-223): the k largest of
+ * key_i = alpha logit_i - log(-log(u_i)) over n slots (logit = -inf: not sampleable), indices in descending key order,
+ * the lower index first among equal keys; out_key = the keys (-inf where fewer than k slots were sampleable).
+ * alpha is read from device memory.  scratch: srl_gumbel_topk_scratch_bytes(n, k) bytes. */
+int64_t srl_gumbel_topk_scratch_bytes(int64_t n, int32_t k);
+int srl_gumbel_topk(const float* logits_dev, const float* u_dev, const float* alpha_dev, int64_t n, int32_t k,
+                    int64_t* out_idx_dev, float* out_key_dev, void* scratch_dev, int64_t scratch_bytes, void* stream);
+
+/* K8 — `ReplayMemory.add` (memory.py:153-161): transition b of the B collected ones goes to row b part_len + slot of
+ * the two state tensors (rows of bytes0 / bytes1 bytes, multiples of 16) and of reward / terminal / action; its logit
+ * becomes -inf (not sampleable until its successor exists). */
+int srl_replay_scatter(const uint8_t* state0_dev, const uint8_t* state1_dev, int64_t bytes0, int64_t bytes1,
+                       const float* reward_dev, const uint8_t* terminal_dev, const int64_t* action_dev, int32_t B,
+                       int64_t slot, int64_t part_len, uint8_t* mem0_dev, uint8_t* mem1_dev, float* mem_reward_dev,
+                       uint8_t* mem_terminal_dev, int64_t* mem_action_dev, float* mem_logits_dev, void* stream);
+/* K8 — the minibatch of `ReplayMemory.sample` (memory.py:232-260) for mb sampled rows: state and next state (the row
+ * n_steps on inside the partition of part_len rows; literal_next = 1: the formula of memory.py:239-242 as written),
+ * action, reward and terminal flag of the next row, and (weight_dev != NULL) the importance weight
+ * exp(beta alpha (min_logit - logit)); alpha, beta, min_logit are device scalars; next_dev (may be NULL) receives the
+ * next-row indices. */
+int srl_replay_gather(const int64_t* idx_dev, int32_t mb, int64_t part_len, int64_t n_steps, int32_t literal_next,
+                      int64_t* next_dev, const uint8_t* mem0_dev, const uint8_t* mem1_dev, int64_t bytes0, int64_t bytes1,
+                      const float* mem_reward_dev, const uint8_t* mem_terminal_dev, const int64_t* mem_action_dev,
+                      const float* mem_logits_dev, const float* alpha_dev, const float* beta_dev,
+                      const float* min_logit_dev, uint8_t* state0_dev, uint8_t* state1_dev, uint8_t* next0_dev,
+                      uint8_t* next1_dev, int64_t* action_dev, float* reward_dev, uint8_t* terminal_dev,
+                      float* weight_dev, void* stream);
+const char* srl_learner_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

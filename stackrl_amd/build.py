@@ -22,7 +22,8 @@ def stale():
 
 
 QLIB = os.path.join(HERE, 'libstackrl_qnet.so')
-QDEPS = ['qnet.hip', 'heuristics.hip', 'xcorr_mfma.hip', 'epilogue.hip', 'conv_mfma.hip', os.path.join('..', '..', 'include', 'stackrl_qnet.h')]
+QSRC = ['qnet.hip', 'heuristics.hip', 'xcorr_mfma.hip', 'epilogue.hip', 'conv_mfma.hip', 'learner.hip']
+QDEPS = QSRC + [ os.path.join('..', '..', 'include', 'stackrl_qnet.h')]
 # the Q-net ops are ordinary fp32 kernels compared against a torch fp32 reference with a stated tolerance
 QFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wall', '-Wno-unused-function',
           '-Wno-unused-value', '-Wno-unused-result']
@@ -43,7 +44,7 @@ def build(force=False, verbose=False):
       print(' '.join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
   if force or qstale():
-    cmd = [hipcc] + QFLAGS + [os.path.join(CSRC, 'qnet.hip'), os.path.join(CSRC, 'heuristics.hip'), os.path.join(CSRC, 'xcorr_mfma.hip'), os.path.join(CSRC, 'epilogue.hip'), os.path.join(CSRC, 'conv_mfma.hip'), '-o', QLIB]
+    cmd = [hipcc] + QFLAGS + [os.path.join(CSRC, f) for f in QSRC] + ['-o', QLIB]
     if verbose:
       print(' '.join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

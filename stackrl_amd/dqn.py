@@ -31,6 +31,49 @@ class PolynomialDecay(object):
 EXPLORATION_MODES = ['epsilon-greedy', 'boltzmann']     # dqn.py:23-28
 
 
+class KerasAdam(object):
+  """`keras.optimizers.Adam` as the reference applies it (dqn.py:473; config.gin:90-93) over ONE flat fp32 bucket:
+  m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); p -= lr_t m / (sqrt(v) + eps), lr_t = lr sqrt(1 - b2^t) / (1 - b1^t)
+  (epsilon outside the bias correction, unlike torch.optim.Adam).  The parameters are re-pointed to views of the
+  bucket, so a step is one launch of `srl_adam_step` (csrc/learner.hip) on a HIP device — capturable, the step counter
+  and its powers live in device memory — and the same formula in torch on the CPU (host-logic tests)."""
+
+  def __init__(self, params, lr=0.001, betas=(0.9, 0.999), eps=1e-7):
+    self.params = list(params)
+    dev = self.params[0].device
+    self.lr, (self.b1, self.b2), self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+    n = sum(p.numel() for p in self.params)
+    self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+    o = 0
+    with torch.no_grad():
+      for p in self.params:
+        self.flat[o:o + p.numel()].copy_(p.detach().reshape(-1))
+        p.data = self.flat[o:o + p.numel()].view_as(p)
+        o += p.numel()
+    self.m = torch.zeros_like(self.flat)
+    self.v = torch.zeros_like(self.flat)
+    self.state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float32, device=dev)   # t, b1^t, b2^t, lr_t
+
+  @torch.no_grad()
+  def step(self, flat_grad):
+    if self.flat.is_cuda:
+      from stackrl_amd import qops
+      qops.adam_step(self.flat, flat_grad, self.m, self.v, self.state, self.lr, self.b1, self.b2, self.eps)
+      return
+    st = self.state
+    st[0] += 1.0; st[1] *= self.b1; st[2] *= self.b2
+    st[3] = self.lr * torch.sqrt(1.0 - st[2]) / (1.0 - st[1])
+    self.m += (flat_grad - self.m) * (1.0 - self.b1)
+    self.v += (flat_grad * flat_grad - self.v) * (1.0 - self.b2)
+    self.flat -= (st[3] * self.m) / (torch.sqrt(self.v) + self.eps)
+
+  def state_dict(self):
+    return {'m': self.m.clone(), 'v': self.v.clone(), 'state': self.state.clone()}
+
+  def load_state_dict(self, d):
+    self.m.copy_(d['m']); self.v.copy_(d['v']); self.state.copy_(d['state'])
+
+
 class GraphedEval(object):
   """`net(inputs)` without grad, replayed from a hipGraph (torch.cuda.CUDAGraph) for a fixed input signature.
   The target evaluations of the update are ~200 launches of microsecond kernels each; as a graph each is one launch.
@@ -107,12 +150,11 @@ class DQN(object):
       p.grad = self._flat_grad[o:o + p.numel()].view_as(p)
       o += p.numel()
     self._params = params
-    if optimizer is None:                                            # dqn.py:127-130
-      optimizer = torch.optim.Adam(params, lr=learning_rate or 0.00025, betas=adam_betas, eps=1e-7,
-                                   capturable=bool(graphs) and self.device.type == 'cuda')
+    if optimizer is None:                                            # dqn.py:127-130: Adam with Keras' defaults
+      optimizer = KerasAdam(params, lr=learning_rate or 0.00025, betas=adam_betas, eps=1e-7)
     elif callable(optimizer) and not isinstance(optimizer, torch.optim.Optimizer):
       optimizer = optimizer(params, lr=learning_rate or 0.00025)
-    elif not isinstance(optimizer, torch.optim.Optimizer):
+    elif not isinstance(optimizer, (torch.optim.Optimizer, KerasAdam)):
       raise TypeError('Invalid type {} for argument optimizer.'.format(type(optimizer)))
     self._optimizer = optimizer
     self._iterations = 0
@@ -173,6 +215,9 @@ class DQN(object):
     self._g_online = GraphedEval(self._q_net) if self._graphs else None
     self._train_graph = None
     self._graph_calls = 0
+    # the loss and its gradient as one hand-written kernel (csrc/learner.hip) on a HIP device
+    self._fused = self.device.type == 'cuda'
+    self._ws = {}
 
   def __call__(self, state, reward, terminal, action=None):
     return self.collect(state, reward, terminal) if action is None else self.observe(state, reward, terminal, action)
@@ -272,21 +317,41 @@ class DQN(object):
         weights = None
     else:
       states, actions, rewards, next_states, terminal = self._replay_memory.sample(self._minibatch_size)
-    y = self.td_targets(rewards, next_states, terminal)
-    q = self._q_net(states).gather(1, actions[:, None])[:, 0]        # one_hot . sum, dqn.py:410-417
-    td = q - y
-    mtd = td.mean().detach()
-    td_abs = td.abs()
-    loss = self.loss_from_td(td_abs, weights)
-    self._flat_grad.zero_()
-    loss.backward()
+    new_logits = None
+    if self._fused and not (self._gamma == 0 and not self._n_step):
+      # target evaluations, then loss, mean TD, |TD|, new priorities and d loss / d Q(s, .) in one kernel (dqn.py:408-469)
+      from stackrl_amd import qops
+      with torch.no_grad():
+        tq = self._g_target(next_states) if self._graphs else self._target_q_net(next_states)
+        qo = (self._g_online(next_states) if self._graphs else self._q_net(next_states)) if self._double else None
+        if self._n_step:
+          rewards = (self._gamma_r * rewards).sum(dim=-1)
+      q_all = self._q_net(states)
+      loss, mtd, td_abs, new_logits, grad_q = qops.td_epilogue(
+        q_all.detach(), qo, tq, actions, rewards, terminal, weights, self._gamma, self._huber_delta, self._reward_scale,
+        self._double, self._replay_memory.epsilon, self._ws)
+      self._flat_grad.zero_()
+      q_all.backward(grad_q)
+    else:
+      y = self.td_targets(rewards, next_states, terminal)
+      q = self._q_net(states).gather(1, actions[:, None])[:, 0]      # one_hot . sum, dqn.py:410-417
+      td = q - y
+      mtd = td.mean().detach()
+      td_abs = td.abs()
+      loss = self.loss_from_td(td_abs, weights)
+      self._flat_grad.zero_()
+      loss.backward()
+      loss, td_abs = loss.detach(), td_abs.detach()
     if self._world > 1:                                              # the one collective of the update
       dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM, group=self._pg)
       self._flat_grad.div_(self._world)
-    self._optimizer.step()
+    if isinstance(self._optimizer, KerasAdam):
+      self._optimizer.step(self._flat_grad)
+    else:
+      self._optimizer.step()
     if self._prioritized:
-      self._replay_memory.update_priorities(indexes, td_abs.detach())   # dqn.py:475-476
-    return loss.detach(), mtd
+      self._replay_memory.update_priorities(indexes, td_abs, logits=new_logits)   # dqn.py:475-476
+    return loss, mtd
 
   _GRAPH_WARMUP = 3   # eager updates before the capture (library solver search, optimiser state, lazy initialisations)
 

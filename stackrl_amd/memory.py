@@ -58,6 +58,11 @@ class ReplayMemory(object):
     self._min_logit = torch.zeros((), dtype=torch.float32, device=self.device)
     self._min_logit_index = torch.zeros((), dtype=torch.int64, device=self.device)
     self.check = False      # True: raise like the reference's tf.debugging asserts (costs a device sync)
+    # on a HIP device the scatter of `add`, the Gumbel top-k and the minibatch gather of `sample` are the hand-written
+    # kernels of csrc/learner.hip (K7 / K8); they need two state tensors with rows of a multiple of 16 bytes
+    self._fused = self.device.type == 'cuda' and len(self._states) == 2 and \
+        all((s[0].numel() * s.element_size()) % 16 == 0 for s in self._states)
+    self._ws = {}
     # schedule values as device scalars for a hipGraph-replayed update (refreshed by `refresh_schedules`)
     self._alpha_t = torch.zeros((), dtype=torch.float32, device=self.device)
     self._beta_t = torch.zeros((), dtype=torch.float32, device=self.device)
@@ -113,13 +118,18 @@ class ReplayMemory(object):
 
   def add(self, state, reward, terminal, action):
     L = self._max_length
-    idx = self._offsets + self._insert_index % L                   # memory.py:153
-    for var, upd in zip(self._states, state):
-      var.index_copy_(0, idx, upd.to(var.dtype))
-    self._rewards.index_copy_(0, idx, reward.to(torch.float32))
-    self._terminal.index_copy_(0, idx, terminal.to(torch.bool))
-    self._actions.index_copy_(0, idx, action.to(torch.int64))
-    self._logits.index_fill_(0, idx, -math.inf)                    # unsampleable until the next state exists
+    if self._fused:
+      from stackrl_amd import qops
+      qops.replay_scatter(tuple(u.to(v.dtype) for u, v in zip(state, self._states)), reward, terminal, action,
+                          self._insert_index % L, L, self._states, self._rewards, self._terminal, self._actions, self._logits)
+    else:
+      idx = self._offsets + self._insert_index % L                 # memory.py:153
+      for var, upd in zip(self._states, state):
+        var.index_copy_(0, idx, upd.to(var.dtype))
+      self._rewards.index_copy_(0, idx, reward.to(torch.float32))
+      self._terminal.index_copy_(0, idx, terminal.to(torch.bool))
+      self._actions.index_copy_(0, idx, action.to(torch.int64))
+      self._logits.index_fill_(0, idx, -math.inf)                  # unsampleable until the next state exists
     if self._insert_index > 0:
       slot = self._insert_index % L
       # tf.reduce_any(index == indexes) (memory.py:164, :168): the tracked slot was just overwritten -> recompute
@@ -160,6 +170,8 @@ class ReplayMemory(object):
   def sample(self, minibatch_size, get_weights=False):
     alpha = self._alpha_t if self.tensor_schedules else self.alpha
     u = torch.rand(self._logits.shape, generator=self._gen, device=self.device, dtype=torch.float32)
+    if self._fused:
+      return self._sample_fused(u, minibatch_size, get_weights)
     z = -torch.log(-torch.log(u))                                  # Gumbel-max trick, memory.py:220-222
     keys = torch.where(torch.isinf(self._logits), self._logits, alpha * self._logits) + z
     values, indexes = torch.topk(keys, minibatch_size)
@@ -179,9 +191,33 @@ class ReplayMemory(object):
       return indexes, weights, (states, actions, rewards, next_states, terminal)
     return states, actions, rewards, next_states, terminal
 
+  def _sample_fused(self, u, minibatch_size, get_weights):
+    """`sample` on the kernels of csrc/learner.hip: K7 (top-k of alpha logit + Gumbel(u)) and K8 (minibatch gather with
+    the next-row arithmetic and the importance weights); the same draws `u` as the library formulation."""
+    from stackrl_amd import qops
+    if not self.tensor_schedules:
+      self.refresh_schedules()
+    indexes, keys = qops.gumbel_topk(self._logits, u, self._alpha_t, minibatch_size, self._ws)
+    if self.check and not bool(torch.isfinite(keys).all()):
+      raise FloatingPointError('Not enough elements to sample')    # memory.py:227-230
+    if self._n_steps != 1:                                          # n-step rewards are gathered by the library path
+      states = tuple(s[indexes] for s in self._states)
+      nxt = self.next_indexes(indexes, self._n_steps)
+      batch = (states, self._actions[indexes], self._rewards[self.next_indexes(indexes[:, None], self._n_range[None, :])],
+               tuple(s[nxt] for s in self._states), self._terminal[nxt])
+      weights = torch.exp(self._beta_t * self._alpha_t * (self._min_logit - self._logits[indexes])) if get_weights else None
+    else:
+      batch, weights = qops.replay_gather(indexes, self._max_length, 1, self._reference_next_index, self._states, self._rewards,
+                                          self._terminal, self._actions, self._logits,
+                                          *((self._alpha_t, self._beta_t, self._min_logit) if get_weights else ()))
+    if get_weights:
+      return indexes, weights, batch
+    return batch
+
   # ------------------------------------------------------------------ update_priorities (memory.py:266-316)
-  def update_priorities(self, indexes, deltas):
-    logits = torch.log(deltas.to(torch.float32) + self.epsilon)    # memory.py:272
+  def update_priorities(self, indexes, deltas, logits=None):
+    if logits is None:
+      logits = torch.log(deltas.to(torch.float32) + self.epsilon)  # memory.py:272
     self._logits.index_copy_(0, indexes, logits)
     max_logit, amax = torch.max(logits, dim=0); min_logit, amin = torch.min(logits, dim=0)
     imax = indexes.gather(0, amax.view(1))[0]; imin = indexes.gather(0, amin.view(1))[0]

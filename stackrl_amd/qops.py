@@ -46,6 +46,20 @@ def load():
     L.srl_policy_head.restype = ctypes.c_int
     L.srl_policy_head.argtypes = [VP, VP, VP, ctypes.c_float, VP, ctypes.c_int32, ctypes.c_int32, VP]
     L.srl_qnet_last_error.restype = ctypes.c_char_p
+    I32, I64, F = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    L.srl_td_epilogue.restype = ctypes.c_int
+    L.srl_td_epilogue.argtypes = [VP] * 7 + [F, F, F, I32, F, I32, I32] + [VP] * 7 + [VP]
+    L.srl_adam_step.restype = ctypes.c_int
+    L.srl_adam_step.argtypes = [VP, VP, VP, VP, I64, VP, F, F, F, F, VP]
+    L.srl_gumbel_topk_scratch_bytes.restype = I64
+    L.srl_gumbel_topk_scratch_bytes.argtypes = [I64, I32]
+    L.srl_gumbel_topk.restype = ctypes.c_int
+    L.srl_gumbel_topk.argtypes = [VP, VP, VP, I64, I32, VP, VP, VP, I64, VP]
+    L.srl_replay_scatter.restype = ctypes.c_int
+    L.srl_replay_scatter.argtypes = [VP, VP, I64, I64, VP, VP, VP, I32, I64, I64] + [VP] * 6 + [VP]
+    L.srl_replay_gather.restype = ctypes.c_int
+    L.srl_replay_gather.argtypes = [VP, I32, I64, I64, I32, VP, VP, VP, I64, I64] + [VP] * 15 + [VP]
+    L.srl_learner_last_error.restype = ctypes.c_char_p
     _LIB = L
   return _LIB
 
@@ -481,3 +495,95 @@ class FusedPolicy(object):
       adv = self._ff.pos(corr) if self.fast else net.pos(corr).flatten(1)
       out[s:e] = policy_head(adv, u[s:e], rnd[s:e], epsilon)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ update path (csrc/learner.hip)
+def _lchk(rc):
+  if rc:
+    raise RuntimeError(load().srl_learner_last_error().decode())
+
+
+def _ptr(t):
+  return None if t is None else t.data_ptr()
+
+
+def td_epilogue(q, q_next_online, q_next_target, actions, rewards, terminal, weights, gamma, huber_delta, reward_scale,
+                double, prio_eps, ws):
+  """Loss, mean TD, |TD|, new priorities and d loss / d Q(s, .) of `DQN.train` (dqn.py:408-476) in one launch.
+  q, q_next_*: float32 [mb, A]; ws: a dict the caller keeps (scratch and the ticket word live at fixed addresses)."""
+  mb, A = q.shape
+  dev = q.device
+  if 'ticket' not in ws or ws['mb'] != mb:
+    ws.update(mb=mb, ticket=torch.zeros(1, dtype=torch.int32, device=dev), scratch=torch.empty(2 * mb, dtype=torch.float32, device=dev))
+  out = torch.empty(2, dtype=torch.float32, device=dev)
+  td_abs = torch.empty(mb, dtype=torch.float32, device=dev)
+  logits = torch.empty(mb, dtype=torch.float32, device=dev)
+  grad_q = torch.empty((mb, A), dtype=torch.float32, device=dev)
+  q = q.contiguous(); qt = q_next_target.contiguous()
+  qo = q_next_online.contiguous() if q_next_online is not None else None
+  term = terminal.contiguous().view(torch.uint8)
+  act = actions.contiguous(); rew = rewards.contiguous().float()
+  wts = weights.contiguous().float() if weights is not None else None
+  with torch.cuda.device(dev):
+    _lchk(load().srl_td_epilogue(q.data_ptr(), _ptr(qo), qt.data_ptr(), act.data_ptr(), rew.data_ptr(), term.data_ptr(),
+                                 _ptr(wts), float(gamma),
+                                 -1.0 if huber_delta is None else float(huber_delta), float(reward_scale or 0.0), int(bool(double)),
+                                 float(prio_eps), mb, A, out.data_ptr(), out[1:].data_ptr(), td_abs.data_ptr(), logits.data_ptr(),
+                                 grad_q.data_ptr(), ws['scratch'].data_ptr(), ws['ticket'].data_ptr(), _stream(q)))
+  return out[0], out[1], td_abs, logits, grad_q
+
+
+def adam_step(params, grads, m, v, state, lr, beta1, beta2, eps):
+  """Keras Adam over flat fp32 buckets, in place; `state` = 4 device floats {t, beta1^t, beta2^t, lr_t}."""
+  with torch.cuda.device(params.device):
+    _lchk(load().srl_adam_step(params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), params.numel(), state.data_ptr(),
+                               float(lr), float(beta1), float(beta2), float(eps), _stream(params)))
+
+
+def gumbel_topk(logits, u, alpha_t, k, ws):
+  """K7: indices (int64 [k], descending key) and keys of the k largest alpha * logit + Gumbel(u)."""
+  n = logits.numel()
+  need = load().srl_gumbel_topk_scratch_bytes(n, k)
+  if ws.get('topk_n') != (n, k):
+    ws['topk_n'] = (n, k)
+    ws['topk_scratch'] = torch.empty(need, dtype=torch.uint8, device=logits.device)
+  idx = torch.empty(k, dtype=torch.int64, device=logits.device)
+  key = torch.empty(k, dtype=torch.float32, device=logits.device)
+  with torch.cuda.device(logits.device):
+    _lchk(load().srl_gumbel_topk(logits.data_ptr(), u.data_ptr(), alpha_t.data_ptr(), n, k, idx.data_ptr(), key.data_ptr(),
+                                 ws['topk_scratch'].data_ptr(), need, _stream(logits)))
+  return idx, key
+
+
+def replay_scatter(state, reward, terminal, action, slot, part_len, mem_states, mem_reward, mem_terminal, mem_action, mem_logits):
+  """K8: one transition per env into row b * part_len + slot of the replay tensors (memory.py:153-161)."""
+  s0, s1 = (t.contiguous() for t in state)
+  B = s0.shape[0]
+  b0, b1 = s0[0].numel() * s0.element_size(), s1[0].numel() * s1.element_size()
+  r = reward.contiguous().float(); t = terminal.contiguous().to(torch.bool).view(torch.uint8); a = action.contiguous().to(torch.int64)
+  with torch.cuda.device(s0.device):
+    _lchk(load().srl_replay_scatter(s0.data_ptr(), s1.data_ptr(), b0, b1, r.data_ptr(), t.data_ptr(), a.data_ptr(), B, int(slot),
+                                    int(part_len), mem_states[0].data_ptr(), mem_states[1].data_ptr(), mem_reward.data_ptr(),
+                                    mem_terminal.data_ptr(), mem_action.data_ptr(), mem_logits.data_ptr(), _stream(s0)))
+
+
+def replay_gather(idx, part_len, n_steps, literal_next, mem_states, mem_reward, mem_terminal, mem_action, mem_logits,
+                  alpha_t=None, beta_t=None, min_logit=None):
+  """K8: the minibatch for the sampled rows (memory.py:232-260): (states, actions, rewards, next_states, terminal), weights."""
+  mb = idx.numel()
+  m0, m1 = mem_states
+  dev = m0.device
+  b0, b1 = m0[0].numel() * m0.element_size(), m1[0].numel() * m1.element_size()
+  s0 = torch.empty((mb,) + tuple(m0.shape[1:]), dtype=m0.dtype, device=dev); n0 = torch.empty_like(s0)
+  s1 = torch.empty((mb,) + tuple(m1.shape[1:]), dtype=m1.dtype, device=dev); n1 = torch.empty_like(s1)
+  act = torch.empty(mb, dtype=torch.int64, device=dev)
+  rew = torch.empty(mb, dtype=torch.float32, device=dev)
+  term = torch.empty(mb, dtype=torch.bool, device=dev)
+  w = torch.empty(mb, dtype=torch.float32, device=dev) if alpha_t is not None else None
+  with torch.cuda.device(dev):
+    _lchk(load().srl_replay_gather(idx.data_ptr(), mb, int(part_len), int(n_steps), int(bool(literal_next)), None, m0.data_ptr(),
+                                   m1.data_ptr(), b0, b1, mem_reward.data_ptr(), mem_terminal.data_ptr(), mem_action.data_ptr(),
+                                   mem_logits.data_ptr(), _ptr(alpha_t), _ptr(beta_t), _ptr(min_logit), s0.data_ptr(), s1.data_ptr(),
+                                   n0.data_ptr(), n1.data_ptr(), act.data_ptr(), rew.data_ptr(), term.data_ptr(), _ptr(w),
+                                   _stream(m0)))
+  return ((s0, s1), act, rew, (n0, n1), term), w

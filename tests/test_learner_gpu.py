@@ -3,6 +3,7 @@ rollout policy against `DQN.policy`, and an end-to-end collect -> step -> train 
 import numpy as np
 import pytest
 
+import math
 torch = pytest.importorskip('torch')
 
 pytestmark = pytest.mark.gpu
@@ -377,3 +378,122 @@ def test_train_step_matches_dqn_oracle():
   ref.update_priorities(idx.tolist(), [float(np.float32(t)) for t in etd])
   np.testing.assert_allclose(mem._logits[indexes].cpu().numpy(), np.array([ref.logits[i] for i in idx]), rtol=0, atol=2e-3)
   assert int(mem._max_logit_index) == ref.max_idx and int(mem._min_logit_index) == ref.min_idx
+
+
+# ---------------------------------------------------------------------------- update-path kernels (csrc/learner.hip)
+@pytest.mark.parametrize('double,huber,use_w', [(True, 1.0, True), (False, 1.0, False), (True, None, True), (True, 0.05, False)])
+def test_td_epilogue_matches_torch_autograd(double, huber, use_w):
+  """Loss, mean TD, |TD|, new priorities and d loss / d Q of dqn.py:408-476: the fused kernel against the same
+  expressions in torch fp32 with autograd (and the loss against float64)."""
+  from stackrl_amd import qops
+  g = torch.Generator(device='cuda').manual_seed(3)
+  mb, A, gamma, eps = 32, 9409, 0.966667, 1e-3
+  q = (torch.randn(mb, A, generator=g, device='cuda') * 2).requires_grad_(True)
+  qo = torch.randn(mb, A, generator=g, device='cuda')
+  qt = torch.randn(mb, A, generator=g, device='cuda')
+  qo[3, 17] = qo[3, 4000] = 9.0                                # a tie: the lowest index wins (like argmax)
+  a = torch.randint(A, (mb,), generator=g, device='cuda')
+  r = torch.randn(mb, generator=g, device='cuda')
+  term = torch.rand(mb, generator=g, device='cuda') < 0.3
+  w = torch.rand(mb, generator=g, device='cuda') if use_w else None
+  loss, mtd, td_abs, logits, grad_q = qops.td_epilogue(q.detach(), qo if double else None, qt, a, r, term, w, gamma, huber, None,
+                                                       double, eps, {})
+  astar = (qo if double else qt).argmax(-1)
+  assert int(astar[3]) == 17 or not double
+  y = r + torch.where(term, torch.zeros_like(r), gamma * qt.gather(1, astar[:, None])[:, 0])
+  td = q.gather(1, a[:, None])[:, 0] - y
+  ad = td.abs()
+  if huber is not None:
+    quad = torch.clamp(ad, max=huber); l = 0.5 * quad ** 2 + huber * (ad - quad)
+  else:
+    l = 0.5 * ad ** 2
+  if w is not None:
+    l = l * w
+  ref = l.mean()
+  ref.backward()
+  assert abs(float(loss) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+  assert abs(float(mtd) - float(td.mean())) <= 1e-6
+  assert torch.equal(td_abs, ad.detach())
+  np.testing.assert_allclose(logits.cpu().numpy(), torch.log(ad.detach() + eps).cpu().numpy(), rtol=2e-6, atol=2e-6)
+  np.testing.assert_allclose(grad_q.cpu().numpy(), q.grad.cpu().numpy(), rtol=1e-6, atol=1e-9)
+  assert int((grad_q != 0).sum()) <= mb
+
+
+def test_adam_step_is_keras_adam():
+  """`srl_adam_step` against Keras' Adam formula in float64 over several steps (epsilon outside the bias correction), and
+  against the CPU path of `KerasAdam` (the same formula in torch)."""
+  from stackrl_amd.dqn import KerasAdam
+  rng = np.random.RandomState(0)
+  n, lr, b1, b2, eps = 100003, 6.25e-5, 0.95, 0.95, 1e-7        # an odd size: exercises the scalar tail
+  p0 = rng.normal(size=n).astype(np.float32)
+  pg = torch.nn.Parameter(torch.from_numpy(p0.copy()).cuda())
+  pc = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+  og, oc = KerasAdam([pg], lr, (b1, b2), eps), KerasAdam([pc], lr, (b1, b2), eps)
+  p = p0.astype(np.float64); m = np.zeros(n); v = np.zeros(n)
+  for t in range(1, 8):
+    gnp = (rng.normal(size=n) * (10.0 ** rng.uniform(-4, 1))).astype(np.float32)
+    og.step(torch.from_numpy(gnp).cuda()); oc.step(torch.from_numpy(gnp))
+    g = gnp.astype(np.float64)
+    m += (g - m) * (1 - b1); v += (g * g - v) * (1 - b2)
+    p -= lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m / (np.sqrt(v) + eps)
+  np.testing.assert_allclose(pg.detach().cpu().numpy(), p, rtol=0, atol=2e-6)
+  np.testing.assert_allclose(pc.detach().numpy(), p, rtol=0, atol=2e-6)
+  assert float(og.state[0]) == 7.0 and pg.data_ptr() == og.flat.data_ptr()
+
+
+@pytest.mark.parametrize('n,k', [(1000, 8), (65536, 32), (262144, 32), (5000, 64)])
+def test_gumbel_topk_matches_torch_topk(n, k):
+  """K7 against `torch.topk` of alpha * logit + Gumbel(u) (memory.py:220-223): same indices in the same order wherever
+  the float32 keys are not within rounding of each other, unsampleable (-inf) slots never returned."""
+  from stackrl_amd import qops
+  g = torch.Generator(device='cuda').manual_seed(n + k)
+  logits = torch.randn(n, generator=g, device='cuda') * 2
+  logits[torch.rand(n, generator=g, device='cuda') < 0.3] = -math.inf
+  u = torch.rand(n, generator=g, device='cuda')
+  alpha = torch.tensor(0.6, device='cuda')
+  idx, key = qops.gumbel_topk(logits, u, alpha, k, {})
+  keys = torch.where(torch.isinf(logits), logits, alpha * logits) - torch.log(-torch.log(u))
+  tv, ti = torch.topk(keys, k)
+  assert bool(torch.isfinite(logits[idx]).all()) and len(set(idx.tolist())) == k
+  np.testing.assert_allclose(key.cpu().numpy(), tv.cpu().numpy(), rtol=1e-5, atol=1e-5)
+  np.testing.assert_allclose(keys[idx].cpu().numpy(), key.cpu().numpy(), rtol=1e-5, atol=1e-5)
+  gaps = (tv[:-1] - tv[1:]).min()
+  if float(gaps) > 1e-4:
+    assert torch.equal(idx, ti)
+  # fewer sampleable slots than k: the missing entries are flagged by a -inf key
+  logits2 = torch.full((n,), -math.inf, device='cuda'); logits2[5] = 0.0; logits2[n - 1] = 1.0
+  idx2, key2 = qops.gumbel_topk(logits2, u, alpha, k, {})
+  assert sorted(idx2[:2].tolist()) == [5, n - 1] and bool(torch.isinf(key2[2:]).all()) and bool(torch.isfinite(key2[:2]).all())
+
+
+@pytest.mark.parametrize('literal', [False, True])
+def test_replay_kernels_match_the_library_formulation(literal):
+  """K8 (scatter of `add`, gather of `sample`) + K7 inside `ReplayMemory`: a memory on the hand-written kernels against one
+  forced onto the index_copy / topk / gather formulation, same data and same generator seed."""
+  from stackrl_amd.memory import ReplayMemory
+  B, slots, mb = 6, 9, 8
+  spec = (((B, 128, 128, 2), torch.uint8), ((B, 32, 32, 1), torch.uint8))
+  mk = lambda: ReplayMemory(spec, B * slots, alpha=0.6, beta=0.7, seed=11, device='cuda', reference_next_index=literal)
+  a, b = mk(), mk()
+  assert a._fused
+  b._fused = False
+  g = torch.Generator(device='cuda').manual_seed(1)
+  for t in range(13):
+    st = (torch.randint(0, 256, (B, 128, 128, 2), generator=g, device='cuda', dtype=torch.uint8),
+          torch.randint(0, 256, (B, 32, 32, 1), generator=g, device='cuda', dtype=torch.uint8))
+    r = torch.randn(B, generator=g, device='cuda')
+    term = torch.rand(B, generator=g, device='cuda') < 0.2
+    act = torch.randint(0, 9409, (B,), generator=g, device='cuda')
+    a.add(st, r, term, act); b.add(st, r, term, act)
+    if t in (6, 9):
+      ia, wa, _ = a.sample(4, get_weights=True); ib, wb, _ = b.sample(4, get_weights=True)
+      d = torch.rand(4, generator=g, device='cuda') * 2
+      a.update_priorities(ia, d); b.update_priorities(ib, d)
+  for k in ('_rewards', '_terminal', '_actions', '_logits', '_max_logit', '_min_logit', '_max_logit_index', '_min_logit_index'):
+    assert torch.equal(getattr(a, k), getattr(b, k)), k
+  assert all(torch.equal(x, y) for x, y in zip(a._states, b._states))
+  ia, wa, (sa, aa, ra, na, ta) = a.sample(mb, get_weights=True)
+  ib, wb, (sb, ab, rb, nb_, tb) = b.sample(mb, get_weights=True)
+  assert torch.equal(ia, ib) and torch.equal(aa, ab) and torch.equal(ra, rb) and torch.equal(ta, tb)
+  assert all(torch.equal(x, y) for x, y in zip(sa + na, sb + nb_))
+  np.testing.assert_allclose(wa.cpu().numpy(), wb.cpu().numpy(), rtol=2e-6)
