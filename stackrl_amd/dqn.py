@@ -307,8 +307,9 @@ class DQN(object):
       loss = loss * weights
     return loss.mean()
 
-  def _update(self):
-    """One minibatch update (dqn.py:397-476) without the host-side bookkeeping; returns (loss, mean TD error)."""
+  def _forward_backward(self):
+    """First half of one minibatch update (dqn.py:397-469): sample, target evaluations, forward, loss, backward into the
+    flat gradient bucket.  Returns (loss, mean TD error, indexes, |TD|, new priorities or None)."""
     weights = indexes = None
     if self._prioritized:
       indexes, weights, (states, actions, rewards, next_states, terminal) = \
@@ -342,8 +343,15 @@ class DQN(object):
       self._flat_grad.zero_()
       loss.backward()
       loss, td_abs = loss.detach(), td_abs.detach()
-    if self._world > 1:                                              # the one collective of the update
-      dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM, group=self._pg)
+    return loss, mtd, indexes, td_abs, new_logits
+
+  def _all_reduce(self):
+    """The one collective of the update: the flat gradient bucket summed over the ranks (RCCL over xGMI)."""
+    dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM, group=self._pg)
+
+  def _apply(self, indexes, td_abs, new_logits):
+    """Second half (dqn.py:470-476): average over the ranks, optimiser step, new replay priorities."""
+    if self._world > 1:
       self._flat_grad.div_(self._world)
     if isinstance(self._optimizer, KerasAdam):
       self._optimizer.step(self._flat_grad)
@@ -351,12 +359,19 @@ class DQN(object):
       self._optimizer.step()
     if self._prioritized:
       self._replay_memory.update_priorities(indexes, td_abs, logits=new_logits)   # dqn.py:475-476
+
+  def _update(self):
+    """One minibatch update (dqn.py:397-476) without the host-side bookkeeping; returns (loss, mean TD error)."""
+    loss, mtd, indexes, td_abs, new_logits = self._forward_backward()
+    if self._world > 1:
+      self._all_reduce()
+    self._apply(indexes, td_abs, new_logits)
     return loss, mtd
 
   _GRAPH_WARMUP = 3   # eager updates before the capture (library solver search, optimiser state, lazy initialisations)
 
   def train(self):
-    if self._graphs and self._world == 1:
+    if self._graphs:
       loss, mtd = self._train_graphed()
     else:
       loss, mtd = self._update()
@@ -372,11 +387,13 @@ class DQN(object):
     return self._q_net.state_dict()
 
   def _train_graphed(self):
-    """The whole update — prioritised sampling, target evaluation, forward, backward, Adam, priority update: ~1,100
+    """The whole update — prioritised sampling, target evaluation, forward, backward, Adam, priority update: hundreds of
     launches of mostly microsecond kernels — replayed as one hipGraph.  Everything it reads or writes lives at fixed
-    addresses (replay tensors, trackers, flat gradient bucket, capturable Adam state, schedule scalars), the sampling
+    addresses (replay tensors, trackers, flat gradient and parameter buckets, Adam state, schedule scalars), the sampling
     generator is registered with the graph, and the nets' parameters are updated in place, so target syncs and
-    checkpoints need no re-capture."""
+    checkpoints need no re-capture.  With more than one rank the update is two graphs around the eager all-reduce of the
+    gradient bucket (sample .. backward | all-reduce | average, Adam, priorities): the collective stays an ordinary
+    stream-ordered call of whatever backend the process group has, and the launch-bound halves are still one launch each."""
     mem = self._replay_memory
     mem.refresh_schedules()
     if self._train_graph is None:
@@ -389,12 +406,27 @@ class DQN(object):
       g_eval = self._graphs
       self._graphs = False                 # the target evaluations are part of this graph, not graphs of their own
       try:
-        with torch.cuda.graph(g):
-          self._graph_out = self._update()
+        if self._world == 1:
+          with torch.cuda.graph(g):
+            self._graph_out = self._update()
+        else:
+          with torch.cuda.graph(g):
+            loss, mtd, indexes, td_abs, new_logits = self._forward_backward()
+          self._graph_out = (loss, mtd)
+          g2 = torch.cuda.CUDAGraph()
+          with torch.cuda.graph(g2, pool=g.pool()):
+            self._apply(indexes, td_abs, new_logits)
+          self._apply_graph = g2
       finally:
         self._graphs = g_eval
       self._train_graph = g
+    return self._replay_update()
+
+  def _replay_update(self):
     self._train_graph.replay()
+    if self._world > 1:
+      self._all_reduce()
+      self._apply_graph.replay()
     loss, mtd = self._graph_out
     return loss.clone(), mtd.clone()
 
