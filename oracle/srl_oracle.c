@@ -1104,29 +1104,30 @@ static inline void row_apply(v3 d, v3 ra, v3 rb, float ima, const m3* Ia, float 
  * that component only — stated as such (not as products with the zeros of d) so that the kernel and this file evaluate
  * the same, shorter expressions: vrel = ca . w + sgn v[axis] as one fused chain, v[axis] += (sgn m^-1) dl.  The row
  * constants (ca = ra x d, aa = I ca, k) are those of the general row. */
-static inline float row_solve_axis(int axis, float sgn, v3 d, v3 ra, float ima, const m3* Ia, vel4* u, float target,
-                                   float* acc, float lo, float hi) {
-  v3 ca = vcross(ra, d);
-  v3 aa = mmul(Ia, ca);
-  float k = ima + vdot(vcross(aa, ra), d);
-  float* va = axis == 0 ? &u->va.x : axis == 1 ? &u->va.y : &u->va.z;
-  float vrel = fmaf(ca.x, u->wa.x, fmaf(ca.y, u->wa.y, fmaf(ca.z, u->wa.z, sgn * *va)));
-  float rk = 1.0f / k;
-  float dl = fmaf(-vrel, rk, target * rk);
-  float na = med3f(*acc + dl, lo, hi);
-  dl = na - *acc;
-  *acc = na;
-  *va = fmaf(sgn * ima, dl, *va);
-  u->wa = vmadd(u->wa, aa, dl);
-  return fabsf(dl * k);
+#define ROW_AXIS_FUNCS(NAME, COMP)                                                                                    \
+static inline float row_solve_##NAME(float sgn, v3 d, v3 ra, float ima, const m3* Ia, vel4* u, float target,         \
+                                     float* acc, float lo, float hi) {                                               \
+  v3 ca = vcross(ra, d);                                                                                             \
+  v3 aa = mmul(Ia, ca);                                                                                              \
+  float k = ima + vdot(vcross(aa, ra), d);                                                                           \
+  float vrel = fmaf(ca.x, u->wa.x, fmaf(ca.y, u->wa.y, fmaf(ca.z, u->wa.z, sgn * u->va.COMP)));                       \
+  float rk = 1.0f / k;                                                                                               \
+  float dl = fmaf(-vrel, rk, target * rk);                                                                           \
+  float na = med3f(*acc + dl, lo, hi);                                                                               \
+  dl = na - *acc;                                                                                                    \
+  *acc = na;                                                                                                         \
+  u->va.COMP = fmaf(sgn * ima, dl, u->va.COMP);                                                                      \
+  u->wa = vmadd(u->wa, aa, dl);                                                                                      \
+  return fabsf(dl * k);                                                                                              \
+}                                                                                                                    \
+static inline void row_apply_##NAME(float sgn, v3 d, v3 ra, float ima, const m3* Ia, vel4* u, float imp) {           \
+  v3 aa = mmul(Ia, vcross(ra, d));                                                                                   \
+  u->va.COMP = fmaf(sgn * ima, imp, u->va.COMP);                                                                     \
+  u->wa = vmadd(u->wa, aa, imp);                                                                                     \
 }
-
-static inline void row_apply_axis(int axis, float sgn, v3 d, v3 ra, float ima, const m3* Ia, vel4* u, float imp) {
-  v3 aa = mmul(Ia, vcross(ra, d));
-  float* va = axis == 0 ? &u->va.x : axis == 1 ? &u->va.y : &u->va.z;
-  *va = fmaf(sgn * ima, imp, *va);
-  u->wa = vmadd(u->wa, aa, imp);
-}
+ROW_AXIS_FUNCS(x, x)
+ROW_AXIS_FUNCS(y, y)
+ROW_AXIS_FUNCS(z, z)
 
 static inline float contact_target(const struct srlo_env* e, float dist) {
   float inv_dt = 1.0f / e->c.sim_time_step;
@@ -1150,14 +1151,14 @@ static float solve_ground(const struct srlo_env* e, env_t* s, int b, int warm) {
     v3 ra = vsub(V(pw.x, pw.y, pw.z - e->c.collision_margin), s->x[b]);
     if (warm) {
       g->in[i] = g->in[i] * e->c.warmstart; g->it1[i] = g->it1[i] * e->c.warmstart; g->it2[i] = g->it2[i] * e->c.warmstart;
-      row_apply_axis(2, 1.0f, n, ra, M->inv_mass, &s->Iw[b], &u, g->in[i]);
-      row_apply_axis(1, -1.0f, t1, ra, M->inv_mass, &s->Iw[b], &u, g->it1[i]);
-      row_apply_axis(0, 1.0f, t2, ra, M->inv_mass, &s->Iw[b], &u, g->it2[i]);
+      row_apply_z(1.0f, n, ra, M->inv_mass, &s->Iw[b], &u, g->in[i]);
+      row_apply_y(-1.0f, t1, ra, M->inv_mass, &s->Iw[b], &u, g->it1[i]);
+      row_apply_x(1.0f, t2, ra, M->inv_mass, &s->Iw[b], &u, g->it2[i]);
     } else {
-      res = fmaxf(res, row_solve_axis(2, 1.0f, n, ra, M->inv_mass, &s->Iw[b], &u, contact_target(e, g->dist[i]), &g->in[i], 0.0f, 1e30f));
+      res = fmaxf(res, row_solve_z(1.0f, n, ra, M->inv_mass, &s->Iw[b], &u, contact_target(e, g->dist[i]), &g->in[i], 0.0f, 1e30f));
       float lim = mu * g->in[i];
-      res = fmaxf(res, row_solve_axis(1, -1.0f, t1, ra, M->inv_mass, &s->Iw[b], &u, 0.0f, &g->it1[i], -lim, lim));
-      res = fmaxf(res, row_solve_axis(0, 1.0f, t2, ra, M->inv_mass, &s->Iw[b], &u, 0.0f, &g->it2[i], -lim, lim));
+      res = fmaxf(res, row_solve_y(-1.0f, t1, ra, M->inv_mass, &s->Iw[b], &u, 0.0f, &g->it1[i], -lim, lim));
+      res = fmaxf(res, row_solve_x(1.0f, t2, ra, M->inv_mass, &s->Iw[b], &u, 0.0f, &g->it2[i], -lim, lim));
     }
   }
   s->v[b] = u.va; s->w[b] = u.wa;
