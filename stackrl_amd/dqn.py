@@ -38,18 +38,27 @@ class KerasAdam(object):
   bucket, so a step is one launch of `srl_adam_step` (csrc/learner.hip) on a HIP device — capturable, the step counter
   and its powers live in device memory — and the same formula in torch on the CPU (host-logic tests)."""
 
+  ALIGN = 64   # every parameter starts on a 256-byte boundary of the bucket (library kernels load weights in vectors)
+
+  @classmethod
+  def layout(cls, params):
+    """Offsets of the parameters in a flat bucket and the bucket's length (elements)."""
+    offs, o = [], 0
+    for p in params:
+      offs.append(o)
+      o += (p.numel() + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
+    return offs, o
+
   def __init__(self, params, lr=0.001, betas=(0.9, 0.999), eps=1e-7):
     self.params = list(params)
     dev = self.params[0].device
     self.lr, (self.b1, self.b2), self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
-    n = sum(p.numel() for p in self.params)
-    self.flat = torch.empty(n, dtype=torch.float32, device=dev)
-    o = 0
+    offs, n = self.layout(self.params)
+    self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
     with torch.no_grad():
-      for p in self.params:
+      for p, o in zip(self.params, offs):
         self.flat[o:o + p.numel()].copy_(p.detach().reshape(-1))
         p.data = self.flat[o:o + p.numel()].view_as(p)
-        o += p.numel()
     self.m = torch.zeros_like(self.flat)
     self.v = torch.zeros_like(self.flat)
     self.state = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float32, device=dev)   # t, b1^t, b2^t, lr_t
@@ -144,11 +153,10 @@ class DQN(object):
       p.requires_grad_(False)
     # one flat gradient bucket; every p.grad is a view into it
     params = [p for p in self._q_net.parameters() if p.requires_grad]
-    self._flat_grad = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=self.device)
-    o = 0
-    for p in params:
+    offs, n = KerasAdam.layout(params)        # the same (256-byte aligned) layout as the optimiser's parameter bucket
+    self._flat_grad = torch.zeros(n, dtype=torch.float32, device=self.device)
+    for p, o in zip(params, offs):
       p.grad = self._flat_grad[o:o + p.numel()].view_as(p)
-      o += p.numel()
     self._params = params
     if optimizer is None:                                            # dqn.py:127-130: Adam with Keras' defaults
       optimizer = KerasAdam(params, lr=learning_rate or 0.00025, betas=adam_betas, eps=1e-7)
