@@ -34,7 +34,7 @@ __constant__ uint8_t c_pair_i[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
 __constant__ uint8_t c_pair_j[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
 
 // misc words in LDS
-enum { M_MODE = 0, M_U, M_V, M_NEXT, M_ZMAX, M_FLAGS, M_NCOL, M_CNT, M_NB, M_PENDING, M_STATUS, M_DONE, M_ORIENT, M_MOVING, M_RES0, M_RES1, M_WORDS = 16 };
+enum { M_MODE = 0, M_U, M_V, M_NEXT, M_ZMAX, M_FLAGS, M_NCOL, M_CNT, M_NB, M_PENDING, M_STATUS, M_DONE, M_ORIENT, M_MOVING, M_RES0, M_RES1, M_SOLO, M_WORDS = 20 };
 
 struct Lds {
   float* sm;
@@ -631,7 +631,11 @@ __device__ __forceinline__ void point_turn(const Lds& L, Point& p, float& res) {
 // (Bullet's m_leastSquaresResidual > m_leastSquaresResidualThreshold; the maximum over rows is order-independent, so
 // the parallel sweep decides exactly as the sequential definition).  The word of the other parity is the one the
 // next sweep writes, so a fast wave cannot disturb a slow wave's read.
-template <bool WARM, int PP>
+// SOLO: every contact point of the env sits in wave 0 (the common case with few rocks: the ground points are the first
+// lanes, and manifold slots are handed out lowest first), so the sweep is wave 0's alone: the phases follow each other in
+// program order — the LDS serves one wave's accesses in order — without a single block barrier, and the residual is a
+// ballot.  The other waves skip the sweeps and wait at the barrier that ends the solve.
+template <bool WARM, int PP, bool SOLO>
 __device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, Point (&pp)[PP], int ncol, int gturns, int pturns,
                                              int gslot, const int (&pslot)[PP], int gsweep) {
   // gslot / pslot: the turn a lane's point takes (ground: its index; colour phases: 4 * colour + index; -1: none), so
@@ -645,7 +649,7 @@ __device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, Point (&p
   }
 #pragma unroll 1
   for (int c = 0; c < ncol; ++c) {
-    __syncthreads();
+    if (!SOLO) __syncthreads();
 #pragma unroll 1
     for (int i = 0; i < pturns; ++i) {
 #pragma unroll
@@ -654,6 +658,7 @@ __device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, Point (&p
       __builtin_amdgcn_wave_barrier();
     }
   }
+  if (SOLO) return WARM ? true : __ballot(res * res > L.P->c.residual_threshold) != 0ull;
   int* word = L.MISC() + M_RES0 + (gsweep & 1);
   if (!WARM) {
     if (__ballot(res * res > L.P->c.residual_threshold) != 0ull && (threadIdx.x & 63) == 0) *word = gsweep;
@@ -682,7 +687,7 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
   int* misc = L.MISC();
   // (1) lane = body: damping, gravity, frame
   if (tid < nb) body_frame(L, tid);
-  if (tid == 0) misc[M_FLAGS] = 0;
+  if (tid == 0) { misc[M_FLAGS] = 0; misc[M_SOLO] = 1; }
   __syncthreads();
   STAMP(0);
   // (2) lane = (body, vertex): world vertices
@@ -769,8 +774,15 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
     Point pp[PP];
 #pragma unroll
     for (int r = 0; r < PP; ++r) pp[r] = make_pair_point(L, (tid + r * T) >> 2, tid & 3);
+    {   // a wave other than the first that holds a contact point rules the solo sweep out
+      bool mine = gp.valid;
+#pragma unroll
+      for (int r = 0; r < PP; ++r) mine |= pp[r].valid;
+      if (tid >= 64 && __ballot(mine) != 0ull && (tid & 63) == 0) misc[M_SOLO] = 0;
+    }
     __syncthreads();   // every lane has read the pre-solve velocities' companions (R, Iw, manifolds)
     STAMP(5);
+    const bool solo = PP == 1 && misc[M_SOLO] != 0;   // (the variants with two points per thread are out of registers as it is)
     int gturns = 0, pturns = 0;   // wave-uniform
 #pragma unroll
     for (int i = 0; i < SRL_GMAXP; ++i) if (__ballot(gp.valid && gp.idx == i)) gturns = i + 1;
@@ -785,12 +797,26 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
     int pslot[PP];
 #pragma unroll
     for (int r = 0; r < PP; ++r) pslot[r] = pp[r].valid ? 4 * pp[r].colour + pp[r].idx : -1;
-    solver_sweep<true, PP>(L, gp, pp, ncol, gturns, pturns, gslot, pslot, 0);
     // at most solver_iterations sweeps, ended early once a sweep's largest squared residual is <= the threshold
     // (btSequentialImpulseConstraintSolver::solveGroupCacheFriendlyIterations)
-    for (int it = 0; it < P.c.solver_iterations; ++it) {
-      gsweep++;
-      if (!solver_sweep<false, PP>(L, gp, pp, ncol, gturns, pturns, gslot, pslot, gsweep)) break;
+    if (solo) {
+      int done = 0;
+      if (tid < 64) {
+        solver_sweep<true, PP, PP == 1>(L, gp, pp, ncol, gturns, pturns, gslot, pslot, 0);
+        for (int it = 0; it < P.c.solver_iterations; ++it) {
+          done++;
+          if (!solver_sweep<false, PP, PP == 1>(L, gp, pp, ncol, gturns, pturns, gslot, pslot, 0)) break;
+        }
+        if (tid == 0) misc[M_CNT] = done;   // (M_CNT is free between the calls of newest_contacts)
+      }
+      __syncthreads();
+      gsweep += misc[M_CNT];
+    } else {
+      solver_sweep<true, PP, false>(L, gp, pp, ncol, gturns, pturns, gslot, pslot, 0);
+      for (int it = 0; it < P.c.solver_iterations; ++it) {
+        gsweep++;
+        if (!solver_sweep<false, PP, false>(L, gp, pp, ncol, gturns, pturns, gslot, pslot, gsweep)) break;
+      }
     }
     // accumulated impulses back to the manifolds (warm start of the next sub-step)
     if (gp.valid) { float* g = L.GM(gp.a); g[SRL_GM_IN + gp.idx] = gp.in; g[SRL_GM_T1 + gp.idx] = gp.i1; g[SRL_GM_T2 + gp.idx] = gp.i2; }
