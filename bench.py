@@ -331,7 +331,7 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
   upd_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / len(ev)
   # all-reduce of the gradient bucket, timed on its own after the loop (inside the update it hides in upd_ms)
   ar_ms = None
-  if world > 1:
+  if dist.is_available() and dist.is_initialized():     # (world 1 under SRL_BENCH_FORCE_DIST=1: exercises the RCCL call itself)
     g = agent._flat_grad
     for _ in range(3):
       dist.all_reduce(g)
@@ -371,6 +371,16 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
 
 # ----------------------------------------------------------------------------------------------- worker
 def worker(args):
+  # stdout carries the ONE JSON line and nothing else: libraries that print banners to stdout (RCCL's version block)
+  # are sent to stderr for the whole run, the line is written to the saved descriptor at the end
+  sys.stdout.flush()
+  json_fd = os.dup(1)
+  os.dup2(2, 1)
+
+  def emit(line):
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(line) + '\n').encode())
+
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -388,10 +398,10 @@ def worker(args):
     dt, placed = aggregate(1.0 + 0.5 * rank, 100 * (rank + 1), world, 'cpu')
     dist.barrier()
     if rank == 0:
-      print(json.dumps({'metric': 'env steps/sec (batched Stack-v0)', 'value': None, 'unit': 'env_steps/s',
-                        'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup, 'launch_only': True,
-                        'note': 'rehearsal of spawn + rendezvous + aggregation; no GPU work was done',
-                        'aggregate_check': {'max_dt': dt, 'sum_placed': placed}}))
+      emit({'metric': 'env steps/sec (batched Stack-v0)', 'value': None, 'unit': 'env_steps/s',
+            'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup, 'launch_only': True,
+            'note': 'rehearsal of spawn + rendezvous + aggregation; no GPU work was done',
+            'aggregate_check': {'max_dt': dt, 'sum_placed': placed}})
     dist.destroy_process_group()
     return
 
@@ -480,7 +490,7 @@ def worker(args):
                   dtype=d['rollout_dtype'], env_only={'value': placed_all / dt_max, 'steps': args.steps,
                                                       'warmup': args.warmup, 'ms_per_step': 1e3 * dt_max / args.steps})
       line['config'] = dict(line['config'], workload=d['workload'], note='leg A (config keys above) is reported under env_only')
-    print(json.dumps(line))
+    emit(line)
   if use_dist:
     dist.barrier()
     dist.destroy_process_group()
