@@ -295,7 +295,7 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
               replay_memory_size=B * args.dqn_slots, discount_factor=.966667, collect_batch_size=B,
               exploration=PolynomialDecay(1.0, 400000, .1), prioritization=0.6,
               priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=7 + rank,
-              policy_op=qops.FusedPolicy(autocast=torch.bfloat16 if dtype == 'bf16' else None),
+              policy_op=qops.FusedPolicy(autocast=torch.bfloat16 if dtype == 'bf16' else None, fast=True),
               xcorr='bf16x3', graphs=True)                     # config.gin:55-112
   tr = Trainer(env, agent)
   tr.initialize(num_steps=4)
@@ -440,7 +440,17 @@ def worker(args):
   if not args.no_dqn:
     dqn = {}
     for dtype in (['f32', 'bf16'] if args.rollout == 'both' else [args.rollout]):
-      dqn[dtype] = dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype)
+      # leg B must not take the headline down with it: an exception is recorded, not raised (with the DQN leg as the
+      # headline, --config 2|3|4, it is raised)
+      try:
+        dqn[dtype] = dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype)
+      except Exception as e:   # noqa: BLE001
+        if args.config != 1:
+          raise
+        import traceback
+        traceback.print_exc()
+        dqn[dtype] = {'error': '{}: {}'.format(type(e).__name__, e)}
+        torch.cuda.synchronize()
 
   mse = None
   if rank == 0 and not args.no_cpu:

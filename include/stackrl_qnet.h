@@ -52,6 +52,11 @@ int srl_bias_act(const void* in_dev, void* out_dev, const float* bias_dev, int64
                  int32_t out_offset, int32_t nchw_hw, int32_t relu, void* stream);
 int srl_bias_act_pool(const void* in_dev, void* skip_dev, void* pooled_dev, const float* bias_dev, int32_t B, int32_t H,
                       int32_t W, int32_t C, int32_t skip_stride, int32_t skip_offset, void* stream);
+/* The same two passes on float32 tensors (the fp32 rollout, the reference's dtype). */
+int srl_bias_act_f32(const float* in_dev, float* out_dev, const float* bias_dev, int64_t npix, int32_t C,
+                     int32_t out_stride, int32_t out_offset, int32_t nchw_hw, int32_t relu, void* stream);
+int srl_bias_act_pool_f32(const float* in_dev, float* skip_dev, float* pooled_dev, const float* bias_dev, int32_t B,
+                          int32_t H, int32_t W, int32_t C, int32_t skip_stride, int32_t skip_offset, void* stream);
 const char* srl_epilogue_last_error(void);
 
 /* 3 x 3 convolution (stride 1, SAME) + bias + ReLU on the matrix cores for the thin, wide layers of `layers.unet`

@@ -36,9 +36,25 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// in [npix][C] bf16; out: channels-last slice (pixel stride ostride, channel offset ooff) or, when nchw_hw > 0,
+// element types: bf16 (uint16_t, 16 bytes per 8 channels) or float (the fp32 rollout of the reference's dtype, 32 bytes)
+__device__ __forceinline__ void load8(const uint16_t* p, float* v) { unpack8(*(const uint4*)p, v); }
+__device__ __forceinline__ void load8(const float* p, float* v) {
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(uint16_t* p, const float* v) { *(uint4*)p = pack8(v); }
+__device__ __forceinline__ void store8(float* p, const float* v) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store1(uint16_t* p, float v) { *p = (uint16_t)e_bf16_rne(v); }
+__device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+__device__ __forceinline__ float stored(const uint16_t*, float v) { return __uint_as_float(e_bf16_rne(v) << 16); }   // the value as stored
+__device__ __forceinline__ float stored(const float*, float v) { return v; }
+
+// in [npix][C]; out: channels-last slice (pixel stride ostride, channel offset ooff) or, when nchw_hw > 0,
 // [B][C][nchw_hw] with npix = B * nchw_hw
-__global__ void __launch_bounds__(256) k_bias_act(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+template <typename E>
+__global__ void __launch_bounds__(256) k_bias_act(const E* __restrict__ in, E* __restrict__ out,
                                                   const float* __restrict__ bias, long long npix, int C, int ostride,
                                                   int ooff, int nchw_hw, int relu) {
   const int cg = C / 8;
@@ -48,7 +64,7 @@ __global__ void __launch_bounds__(256) k_bias_act(const uint16_t* __restrict__ i
   if (nchw_hw > 0) { g = (int)(idx / npix); pix = idx - (long long)g * npix; }   // adjacent lanes = adjacent pixels
   else { pix = idx / cg; g = (int)(idx - pix * cg); }
   float v[8];
-  unpack8(*(const uint4*)(in + pix * C + g * 8), v);
+  load8(in + pix * C + g * 8, v);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     v[k] += bias[g * 8 + k];
@@ -56,17 +72,18 @@ __global__ void __launch_bounds__(256) k_bias_act(const uint16_t* __restrict__ i
   }
   if (nchw_hw > 0) {
     const long long b = pix / nchw_hw, p = pix - b * nchw_hw;
-    uint16_t* o = out + (b * C + g * 8) * nchw_hw + p;
+    E* o = out + (b * C + g * 8) * nchw_hw + p;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[(long long)k * nchw_hw] = (uint16_t)e_bf16_rne(v[k]);
+    for (int k = 0; k < 8; ++k) store1(o + (long long)k * nchw_hw, v[k]);
   } else {
-    *(uint4*)(out + pix * ostride + ooff + g * 8) = pack8(v);
+    store8(out + pix * ostride + ooff + g * 8, v);
   }
 }
 
-// in [B][H][W][C] bf16 (H, W even); skip out: channels-last slice as above; pooled [B][H/2][W/2][C]
-__global__ void __launch_bounds__(256) k_bias_act_pool(const uint16_t* __restrict__ in, uint16_t* __restrict__ skip,
-                                                       uint16_t* __restrict__ pooled, const float* __restrict__ bias,
+// in [B][H][W][C] (H, W even); skip out: channels-last slice as above; pooled [B][H/2][W/2][C]
+template <typename E>
+__global__ void __launch_bounds__(256) k_bias_act_pool(const E* __restrict__ in, E* __restrict__ skip,
+                                                       E* __restrict__ pooled, const float* __restrict__ bias,
                                                        int B, int H, int W, int C, int ostride, int ooff) {
   const int cg = C / 8, H2 = H / 2, W2 = W / 2;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -85,17 +102,14 @@ __global__ void __launch_bounds__(256) k_bias_act_pool(const uint16_t* __restric
     for (int dx = 0; dx < 2; ++dx) {
       const long long pix = (b * H + 2 * y2 + dy) * W + 2 * x2 + dx;
       float v[8];
-      unpack8(*(const uint4*)(in + pix * C + g * 8), v);
+      load8(in + pix * C + g * 8, v);
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + bz[k], 0.0f);
-      const uint4 pk = pack8(v);
-      *(uint4*)(skip + pix * ostride + ooff + g * 8) = pk;
-      float r[8];
-      unpack8(pk, r);   // pool the rounded values, like MaxPool2D on the stored tensor
+      store8(skip + pix * ostride + ooff + g * 8, v);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], r[k]);
+      for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], stored(in, v[k]));   // pool the values as stored, like MaxPool2D on the tensor
     }
-  *(uint4*)(pooled + ((b * H2 + y2) * W2 + x2) * C + g * 8) = pack8(m);
+  store8(pooled + ((b * H2 + y2) * W2 + x2) * C + g * 8, m);
 }
 
 thread_local char e_err[256] = "";
@@ -120,9 +134,22 @@ int srl_bias_act(const void* in, void* out, const float* bias, int64_t npix, int
     return 1;
   }
   const long long n = npix * (C / 8);
-  hipLaunchKernelGGL(k_bias_act, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in,
+  hipLaunchKernelGGL(k_bias_act<uint16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in,
                      (uint16_t*)out, bias, (long long)npix, C, out_stride, out_offset, nchw_hw, relu);
   return finish("srl_bias_act");
+}
+
+int srl_bias_act_f32(const float* in, float* out, const float* bias, int64_t npix, int32_t C, int32_t out_stride,
+                     int32_t out_offset, int32_t nchw_hw, int32_t relu, void* stream) {
+  if (!in || !out || !bias || npix < 1 || C < 8 || C % 8 || out_stride % 8 || out_offset % 8 ||
+      (nchw_hw > 0 && npix % nchw_hw)) {
+    snprintf(e_err, sizeof e_err, "srl_bias_act_f32: bad arguments (channel counts, strides and offsets must be multiples of 8)");
+    return 1;
+  }
+  const long long n = npix * (C / 8);
+  hipLaunchKernelGGL(k_bias_act<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, bias,
+                     (long long)npix, C, out_stride, out_offset, nchw_hw, relu);
+  return finish("srl_bias_act_f32");
 }
 
 int srl_bias_act_pool(const void* in, void* skip, void* pooled, const float* bias, int32_t B, int32_t H, int32_t W,
@@ -133,9 +160,22 @@ int srl_bias_act_pool(const void* in, void* skip, void* pooled, const float* bia
     return 1;
   }
   const long long n = (long long)B * (H / 2) * (W / 2) * (C / 8);
-  hipLaunchKernelGGL(k_bias_act_pool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_bias_act_pool<uint16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const uint16_t*)in, (uint16_t*)skip, (uint16_t*)pooled, bias, B, H, W, C, skip_stride, skip_offset);
   return finish("srl_bias_act_pool");
+}
+
+int srl_bias_act_pool_f32(const float* in, float* skip, float* pooled, const float* bias, int32_t B, int32_t H, int32_t W,
+                          int32_t C, int32_t skip_stride, int32_t skip_offset, void* stream) {
+  if (!in || !skip || !pooled || !bias || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 8 || C % 8 ||
+      skip_stride % 8 || skip_offset % 8) {
+    snprintf(e_err, sizeof e_err, "srl_bias_act_pool_f32: bad arguments");
+    return 1;
+  }
+  const long long n = (long long)B * (H / 2) * (W / 2) * (C / 8);
+  hipLaunchKernelGGL(k_bias_act_pool<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, skip,
+                     pooled, bias, B, H, W, C, skip_stride, skip_offset);
+  return finish("srl_bias_act_pool_f32");
 }
 
 }  // extern "C"

@@ -29,6 +29,10 @@ def load():
     L.srl_bias_act.argtypes = [VP, VP, VP, ctypes.c_int64] + [ctypes.c_int32] * 5 + [VP]
     L.srl_bias_act_pool.restype = ctypes.c_int
     L.srl_bias_act_pool.argtypes = [VP, VP, VP, VP] + [ctypes.c_int32] * 6 + [VP]
+    L.srl_bias_act_f32.restype = ctypes.c_int
+    L.srl_bias_act_f32.argtypes = [VP, VP, VP, ctypes.c_int64] + [ctypes.c_int32] * 5 + [VP]
+    L.srl_bias_act_pool_f32.restype = ctypes.c_int
+    L.srl_bias_act_pool_f32.argtypes = [VP, VP, VP, VP] + [ctypes.c_int32] * 6 + [VP]
     L.srl_epilogue_last_error.restype = ctypes.c_char_p
     L.srl_conv3x3_wfrag_elems.restype = ctypes.c_int32
     L.srl_conv3x3_wfrag_elems.argtypes = [ctypes.c_int32] * 2
@@ -196,9 +200,10 @@ def _cl(t):
 
 
 def bias_act(y, bias, out=None, out_offset=0, relu=True, nchw=False):
-  """relu(y + bias[c]) in one pass (csrc/epilogue.hip).  y: bf16 [B,C,H,W] channels-last.  out: None = in place; a
-  channels-last bf16 tensor with >= C channels = write into its channel slice [out_offset, out_offset + C); nchw=True
-  returns a new NCHW-contiguous tensor (the layout the cross-correlation kernel reads)."""
+  """relu(y + bias[c]) in one pass (csrc/epilogue.hip).  y: bf16 or float32 [B,C,H,W] channels-last.  out: None = in
+  place; a channels-last tensor of the same dtype with >= C channels = write into its channel slice
+  [out_offset, out_offset + C); nchw=True returns a new NCHW-contiguous tensor (the layout the cross-correlation kernel
+  reads)."""
   B, C, H, W = y.shape
   if nchw:
     dst = torch.empty((B, C, H, W), dtype=y.dtype, device=y.device)
@@ -206,9 +211,9 @@ def bias_act(y, bias, out=None, out_offset=0, relu=True, nchw=False):
   else:
     dst = y if out is None else out
     stride, hw = dst.shape[1], 0
+  fn = load().srl_bias_act_f32 if y.dtype == torch.float32 else load().srl_bias_act
   with torch.cuda.device(y.device):
-    rc = load().srl_bias_act(y.data_ptr(), dst.data_ptr(), bias.data_ptr(), B * H * W, C, stride, out_offset, hw,
-                             int(relu), _stream(y))
+    rc = fn(y.data_ptr(), dst.data_ptr(), bias.data_ptr(), B * H * W, C, stride, out_offset, hw, int(relu), _stream(y))
   if rc:
     raise RuntimeError(load().srl_epilogue_last_error().decode())
   return dst
@@ -218,9 +223,9 @@ def bias_act_pool(y, bias, skip, skip_offset):
   """relu(y + bias[c]) into the channel slice [skip_offset, skip_offset + C) of `skip`, plus its 2 x 2 max-pool."""
   B, C, H, W = y.shape
   pooled = torch.empty((B, C, H // 2, W // 2), dtype=y.dtype, device=y.device, memory_format=_CL)
+  fn = load().srl_bias_act_pool_f32 if y.dtype == torch.float32 else load().srl_bias_act_pool
   with torch.cuda.device(y.device):
-    rc = load().srl_bias_act_pool(y.data_ptr(), skip.data_ptr(), pooled.data_ptr(), bias.data_ptr(), B, H, W, C,
-                                  skip.shape[1], skip_offset, _stream(y))
+    rc = fn(y.data_ptr(), skip.data_ptr(), pooled.data_ptr(), bias.data_ptr(), B, H, W, C, skip.shape[1], skip_offset, _stream(y))
   if rc:
     raise RuntimeError(load().srl_epilogue_last_error().decode())
   return pooled
@@ -336,9 +341,12 @@ class FastFeatures(object):
   csrc/epilogue.hip instead of separate bias / ReLU / max-pool / concatenate / layout kernels.  Returns the left and
   right feature maps NCHW-contiguous, ready for the MFMA cross-correlation."""
 
-  def __init__(self, net, mfma_conv=True):
+  def __init__(self, net, mfma_conv=True, dtype=torch.bfloat16):
     self.net = net
-    self.mfma_conv = bool(mfma_conv)   # hand-written MFMA kernel for the 16- / 32-channel 3 x 3 layers
+    # dtype float32 = the reference's dtype: library fp32 convolutions without bias + the fused fp32 epilogues (the
+    # MFMA convolution kernels are bf16 and stay out of this path)
+    self.dtype = dtype
+    self.mfma_conv = bool(mfma_conv) and dtype == torch.bfloat16   # hand-written MFMA kernel for the 16- / 32-channel 3 x 3 layers
     self._key = None
     self._w = {}
     self._wf = {}
@@ -357,7 +365,7 @@ class FastFeatures(object):
     self._wt = {}
     for m in self.net.modules():
       if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
-        self._w[m] = (m.weight.detach().to(torch.bfloat16).contiguous(memory_format=_CL), m.bias.detach().float().contiguous())
+        self._w[m] = (m.weight.detach().to(self.dtype).contiguous(memory_format=_CL), m.bias.detach().float().contiguous())
         if self.mfma_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.in_channels in (16, 32, 64) and m.out_channels in (16, 32):
           self._wf[m] = pack_conv3x3_weights(m.weight)
@@ -393,7 +401,7 @@ class FastFeatures(object):
         y = conv3x3_thin(obs, self._wt[blk[0]], self._w[blk[0]][1])      # /255 and the cast happen in the kernel
       elif x is None:
         # uint8 NHWC / 255 (models.py:144-147); the NHWC memory is exactly a channels-last NCHW tensor
-        x = (obs.float() / 255.0).to(torch.bfloat16).permute(0, 3, 1, 2)
+        x = (obs.float() / 255.0).to(self.dtype).permute(0, 3, 1, 2)
         y, b = self._conv(blk[0], x)
         bias_act(y, b)
       elif self._mine(blk[0], x):
@@ -470,7 +478,8 @@ class FusedPolicy(object):
   def __init__(self, chunk=512, autocast=None, fast=None):
     self.chunk = int(chunk)      # rollout batches are processed in chunks to bound activation memory
     self.autocast = autocast     # None = fp32 like the reference; torch.bfloat16 runs the library convs on MFMA
-    self.fast = (autocast == torch.bfloat16) if fast is None else bool(fast)   # fused epilogues (bf16 only)
+    # fused epilogues around bias-free library convolutions (bf16: + the MFMA convolution kernels; fp32: epilogues only)
+    self.fast = (autocast == torch.bfloat16) if fast is None else bool(fast)
     self._ff = None
 
   @torch.no_grad()
@@ -484,7 +493,7 @@ class FusedPolicy(object):
       e = min(B, s + self.chunk)
       if self.fast:
         if self._ff is None or self._ff.net is not net:
-          self._ff = FastFeatures(net)
+          self._ff = FastFeatures(net, dtype=torch.bfloat16 if self.autocast == torch.bfloat16 else torch.float32)
         x, w = self._ff((xm[s:e], xo[s:e]))
       elif self.autocast is not None:
         with torch.autocast('cuda', dtype=self.autocast):

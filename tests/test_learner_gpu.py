@@ -497,3 +497,27 @@ def test_replay_kernels_match_the_library_formulation(literal):
   assert torch.equal(ia, ib) and torch.equal(aa, ab) and torch.equal(ra, rb) and torch.equal(ta, tb)
   assert all(torch.equal(x, y) for x, y in zip(sa + na, sb + nb_))
   np.testing.assert_allclose(wa.cpu().numpy(), wb.cpu().numpy(), rtol=2e-6)
+
+
+def test_fast_features_fp32_match_the_module():
+  """The fp32 fast rollout (`FastFeatures(dtype=float32)`: bias-free library fp32 convolutions + the fused fp32 epilogues
+  of csrc/epilogue.hip instead of separate bias / ReLU / max-pool / concatenate / layout kernels) against the stock fp32
+  module: the same arithmetic up to where the bias is added, so fp32-level agreement (1e-5 of the feature scale), and the
+  policy built on it picks the actions of `DQN.policy` at epsilon 0."""
+  from stackrl_amd import nets, qops
+  from stackrl_amd.dqn import DQN
+  net = nets.DeepQSiamFCN(seed=5).cuda().eval()
+  g = torch.Generator(device='cuda').manual_seed(4)
+  xm = torch.randint(0, 256, (6, 128, 128, 2), generator=g, device='cuda', dtype=torch.uint8)
+  xo = torch.randint(0, 256, (6, 32, 32, 1), generator=g, device='cuda', dtype=torch.uint8)
+  fx, fw = qops.FastFeatures(net, dtype=torch.float32)((xm, xo))
+  with torch.no_grad():
+    ex, _, ew = net.features((xm, xo))
+  for got, ref in ((fx, ex), (fw, ew)):
+    assert got.shape == ref.shape and got.dtype == torch.float32 and got.is_contiguous()
+    assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+  agent = DQN(net, collect_batch_size=6, replay_memory_size=6 * 4, exploration=0.0)
+  a_ref = agent.policy((xm, xo), exploration=True)
+  pol = qops.FusedPolicy(autocast=None, fast=True)
+  a = pol(net, (xm, xo), 0.0, torch.Generator(device='cuda').manual_seed(1))
+  assert torch.equal(a, a_ref)
