@@ -432,13 +432,23 @@ def test_adam_step_is_keras_adam():
   p = p0.astype(np.float64); m = np.zeros(n); v = np.zeros(n)
   for t in range(1, 8):
     gnp = (rng.normal(size=n) * (10.0 ** rng.uniform(-4, 1))).astype(np.float32)
-    og.step(torch.from_numpy(gnp).cuda()); oc.step(torch.from_numpy(gnp))
+    gfull = torch.zeros(og.flat.numel()); gfull[:n] = torch.from_numpy(gnp)   # the bucket pads every parameter to 256 bytes
+    og.step(gfull.cuda()); oc.step(gfull)
     g = gnp.astype(np.float64)
     m += (g - m) * (1 - b1); v += (g * g - v) * (1 - b2)
     p -= lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m / (np.sqrt(v) + eps)
   np.testing.assert_allclose(pg.detach().cpu().numpy(), p, rtol=0, atol=2e-6)
   np.testing.assert_allclose(pc.detach().numpy(), p, rtol=0, atol=2e-6)
   assert float(og.state[0]) == 7.0 and pg.data_ptr() == og.flat.data_ptr()
+  # the kernel itself on an odd length (scalar tail), one step from zero state: p -= lr sqrt(1-b2)/(1-b1) m / (sqrt(v) + eps)
+  from stackrl_amd import qops
+  n2 = 1027
+  P = torch.from_numpy(p0[:n2].copy()).cuda(); G = torch.from_numpy(gnp[:n2].copy()).cuda()
+  M = torch.zeros(n2, device='cuda'); V = torch.zeros(n2, device='cuda'); S = torch.tensor([0., 1., 1., 0.], device='cuda')
+  qops.adam_step(P, G, M, V, S, lr, b1, b2, eps)
+  g = gnp[:n2].astype(np.float64)
+  ref = p0[:n2].astype(np.float64) - lr * np.sqrt(1 - b2) / (1 - b1) * (g * (1 - b1)) / (np.sqrt(g * g * (1 - b2)) + eps)
+  np.testing.assert_allclose(P.cpu().numpy(), ref, rtol=0, atol=2e-6)
 
 
 @pytest.mark.parametrize('n,k', [(1000, 8), (65536, 32), (262144, 32), (5000, 64)])
