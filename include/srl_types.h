@@ -25,7 +25,10 @@ extern "C" {
 #define SRL_MAX_ORIENT 16      /* 2^orientation_freedom <= 16                     */
 
 /* Reward metrics, rewarder.py:7-14. */
-enum { SRL_METRIC_IOU = 0, SRL_METRIC_OR = 1, SRL_METRIC_DIOU = 2, SRL_METRIC_DOR = 3 };
+/* 'all' (rewarder.py:157-158): the four metrics' rewards at once, reward is float[n][4] in this order; 'eval'
+ * (rewarder.py:147-156): float[n][2] = the IoU reward and 'AD', the change of the average discount of all rocks
+ * (not scaled). */
+enum { SRL_METRIC_IOU = 0, SRL_METRIC_OR = 1, SRL_METRIC_DIOU = 2, SRL_METRIC_DOR = 3, SRL_METRIC_ALL = 4, SRL_METRIC_EVAL = 5 };
 
 /* Return codes (the Python shim maps them to the reference's exception types:
  * AssertionError env.py:238, RuntimeError simulator.py:221-224, ValueError env.py:169). */
@@ -61,7 +64,7 @@ typedef struct srl_config {
   int32_t smooth_placing;    /* 1                                                 */
   int32_t max_substeps;      /* int(MAX_STEP_TIME/time_step), simulator.py:46; 0 = derive */
   /* --- Rewarder, rewarder.py:17-27 --- */
-  int32_t metric;            /* SRL_METRIC_*; None -> IoU (rewarder.py:113-114)   */
+  int32_t metric;            /* SRL_METRIC_*; None -> IoU (rewarder.py:113-114); ALL / EVAL: several rewards per env */
   float goal_size_ratio;     /* 0.25 (scalar-area branch rewarder.py:225-237)     */
   float reward_scale;        /* 1.0; <= 0 means None -> n_objects (rewarder.py:97) */
   int32_t reward_pexp;       /* reward_params: integer exponent, 2; < 0 = None    */

@@ -63,7 +63,8 @@ int srl_set_script(srl_env* env, const int32_t* mesh_ids, const int32_t* goal_re
  * form of the reference's shrinking list (env.py:596-608). */
 int srl_reset(srl_env* env, void* obs_map_dev, void* obs_obj_dev, void* stream);
 
-/* `ParallelEnv.step` (utils.py:468-486): action int64[n]; reward float[n]; done uint8[n].
+/* `ParallelEnv.step` (utils.py:468-486): action int64[n]; reward float[n] (float[n][4] with metric 'all' = IoU, OR, DIoU,
+ * DOR; float[n][2] with 'eval' = IoU, AD: the dict of rewarder.py:147-158 as columns); done uint8[n].
  * Auto-reset semantics of env.py:235-236 are kept: a step on a finished env returns the reset
  * observation, reward 0, done 0.  With orientation_freedom > 0 the action is orientation * A + pixel
  * (the reference's `(index, action)` tuple, env.py:485-494) and the rock is placed in that orientation.  With

@@ -57,7 +57,8 @@ class OracleEnv(object):
     self.obs_map = np.zeros((self.n, self.H, self.H, 2), np.uint8)
     self.no = cfg.n_object_maps        # TestStackEnv: one object map per observable orientation (and unplaced rock)
     self.obs_obj = np.zeros((self.n, self.h_, self.h_, 1) if self.no == 1 else (self.n, self.no, self.h_, self.h_, 1), np.uint8)
-    self.reward = np.zeros(self.n, np.float32)
+    keys = cfg.reward_keys            # 'all' / 'eval': several rewards per env (rewarder.py:147-158)
+    self.reward = np.zeros(self.n if keys is None else (self.n, len(keys)), np.float32)
     self.done = np.zeros(self.n, np.uint8)
     if seed is not None:
       self.seed(seed)
@@ -82,7 +83,7 @@ class OracleEnv(object):
     rc = self.L.srlo_reset(self.h, _p(self.obs_map), _p(self.obs_obj))
     if rc:
       raise RuntimeError(self.L.srlo_last_error().decode())
-    return (self.obs_map.copy(), self.obs_obj.copy()), np.zeros(self.n, np.float32), np.zeros(self.n, bool)
+    return (self.obs_map.copy(), self.obs_obj.copy()), np.zeros_like(self.reward), np.zeros(self.n, bool)
 
   def step(self, action):
     action = np.ascontiguousarray(action, np.int64)

@@ -194,7 +194,7 @@ typedef struct {
   int ids[MAXB]; int list_pos;
   int pending;                      /* mesh id waiting at the spawn pose, -1 = none */
   int goal[4];                      /* u, v, h, w */
-  float prev_metric;
+  float prev_metric[4];             /* Rewarder._memory */
   int substeps[2];
   int sweeps;                       /* solver sweeps of the last step (telemetry) */
   int status;
@@ -1311,42 +1311,79 @@ static void sim_step(const struct srlo_env* e, env_t* s, v3 pos, int oi) {
 }
 
 /* ------------------------------------------------------------------ reward (rewarder.py:162-179, :261-295) */
-static float metric_value(const struct srlo_env* e, env_t* s) {
+/* discount of one body (rewarder.py:261-269) */
+static float body_discount(const struct srlo_env* e, const env_t* s, int b) {
   const srl_config* c = &e->c;
-  if (c->metric == SRL_METRIC_IOU || c->metric == SRL_METRIC_OR) {
-    float inter, uni;
-    srlo_iou_sums(c, s->H, s->goal, &inter, &uni);
-    if (c->metric == SRL_METRIC_OR) return inter / ((float)(s->goal[2] * s->goal[3]) * e->goal_z);
-    return inter / uni;
-  }
   float pmax = (float)c->object_res * e->px;     /* rewarder.py:126 */
   float omax = 3.14159265358979f;
+  v3 dp = vsub(s->place_x[b], s->x[b]);
+  float perr = sqrtf(vdot(dp, dp));
+  q4 a = s->place_q[b], q = s->q[b];
+  float dw = fabsf((a.x * q.x + a.y * q.y) + (a.z * q.z + a.w * q.w));
+  float oerr = 2.0f * srlo_acosf(fminf(dw, 1.0f));
+  float disc = 1.0f;
+  if (c->reward_pexp >= 0) {
+    float t = perr / pmax, pw = 1.0f;
+    for (int k = 0; k < c->reward_pexp; ++k) pw = pw * t;
+    disc = disc * fmaxf(0.0f, 1.0f - pw);
+  }
+  if (c->reward_oexp >= 0) {
+    float t = oerr / omax, pw = 1.0f;
+    for (int k = 0; k < c->reward_oexp; ++k) pw = pw * t;
+    disc = disc * fmaxf(0.0f, 1.0f - pw);
+  }
+  return disc;
+}
+
+/* the current value of one metric (rewarder.py:162-175) */
+static float metric_value(const struct srlo_env* e, env_t* s, int metric) {
+  const srl_config* c = &e->c;
+  if (metric == SRL_METRIC_IOU || metric == SRL_METRIC_OR) {
+    float inter, uni;
+    srlo_iou_sums(c, s->H, s->goal, &inter, &uni);
+    if (metric == SRL_METRIC_OR) return inter / ((float)(s->goal[2] * s->goal[3]) * e->goal_z);
+    return inter / uni;
+  }
   float r = 0.0f; int nout = 0;
   for (int b = 0; b < s->nb; ++b) {
     float fu = floorf(s->x[b].x / e->px), fv = floorf(s->x[b].y / e->px); /* xy_to_pixel: // */
     int in = fu >= (float)s->goal[0] && fv >= (float)s->goal[1] &&
              fu < (float)(s->goal[0] + s->goal[2]) && fv < (float)(s->goal[1] + s->goal[3]);
     if (!in) { nout++; continue; }
-    v3 dp = vsub(s->place_x[b], s->x[b]);
-    float perr = sqrtf(vdot(dp, dp));
-    q4 a = s->place_q[b], q = s->q[b];
-    float dw = fabsf((a.x * q.x + a.y * q.y) + (a.z * q.z + a.w * q.w));
-    float oerr = 2.0f * srlo_acosf(fminf(dw, 1.0f));
-    float disc = 1.0f;
-    if (c->reward_pexp >= 0) {
-      float t = perr / pmax, pw = 1.0f;
-      for (int k = 0; k < c->reward_pexp; ++k) pw = pw * t;
-      disc = disc * fmaxf(0.0f, 1.0f - pw);
-    }
-    if (c->reward_oexp >= 0) {
-      float t = oerr / omax, pw = 1.0f;
-      for (int k = 0; k < c->reward_oexp; ++k) pw = pw * t;
-      disc = disc * fmaxf(0.0f, 1.0f - pw);
-    }
-    r = r + disc;
+    r = r + body_discount(e, s, b);
   }
-  if (c->metric == SRL_METRIC_DOR) return r / (float)c->episode_length;
+  if (metric == SRL_METRIC_DOR) return r / (float)c->episode_length;
   return r / (float)(c->episode_length + nout);
+}
+
+/* average discount of all rocks, inside the goal or not (`_discounted(intersection=False)`, rewarder.py:149-151) */
+static float average_discount(const struct srlo_env* e, env_t* s) {
+  float d = 0.0f;
+  for (int b = 0; b < s->nb; ++b) d = d + body_discount(e, s, b);
+  return d / (float)s->nb;
+}
+
+/* Rewarder.__call__ (rewarder.py:144-160): the step's reward(s) into out[0 .. n_rewards) */
+static void step_rewards(const struct srlo_env* e, env_t* s, float* out) {
+  const srl_config* c = &e->c;
+  if (c->metric == SRL_METRIC_ALL) {
+    for (int m = 0; m < 4; ++m) {
+      float mv = metric_value(e, s, m);
+      out[m] = (mv - s->prev_metric[m]) * e->scale;      /* rewarder.py:176-179 */
+      s->prev_metric[m] = mv;
+    }
+  } else if (c->metric == SRL_METRIC_EVAL) {
+    float mv = metric_value(e, s, SRL_METRIC_IOU);
+    out[0] = (mv - s->prev_metric[0]) * e->scale;
+    s->prev_metric[0] = mv;
+    float ad = average_discount(e, s);
+    out[1] = ad - s->prev_metric[3];                     /* memory[-1] of a 4-entry array, not scaled */
+    s->prev_metric[3] = ad;
+  } else {
+    float mv = metric_value(e, s, c->metric);
+    out[0] = (mv - s->prev_metric[c->metric]) * e->scale;
+    s->prev_metric[c->metric] = mv;
+  }
 }
 
 /* ------------------------------------------------------------------ episode machine */
@@ -1402,7 +1439,7 @@ static void env_reset(struct srlo_env* e, int i) {
   s->ncolour = -1;
   s->pending = s->ids[0];
   s->list_pos = c->ordering_freedom ? L : 1;   /* with ordering freedom: the number of rocks still unplaced, ids[0 .. list_pos) */
-  s->prev_metric = 0.0f;                                                  /* rewarder.py:191-194 */
+  for (int k = 0; k < 4; ++k) s->prev_metric[k] = 0.0f;                   /* rewarder.py:191-194 */
   s->substeps[0] = 0; s->substeps[1] = 0;
   s->status = 0;
   render_heightmap(e, 0, s->mesh, s->x, s->q, s->H);
@@ -1427,16 +1464,18 @@ int srlo_step(srlo_env* e, const int64_t* action, uint8_t* obs_map, uint8_t* obs
   const srl_config* c = &e->c;
   size_t nm = (size_t)c->overhead_res * c->overhead_res * 2, no = (size_t)c->object_res * c->object_res * e->n_slots;
   int rc = SRL_OK;
+  const int K = c->metric == SRL_METRIC_ALL ? 4 : c->metric == SRL_METRIC_EVAL ? 2 : 1;   /* rewards per env */
   for (int i = 0; i < c->n_envs; ++i) {
     env_t* s = &e->env[i];
+    for (int k = 0; k < K; ++k) reward[(size_t)i * K + k] = 0.0f;
     if (action[i] == (int64_t)SRL_ACTION_HOLD) {         /* the env sits this call out (srl_types.h) */
-      reward[i] = 0.0f; done[i] = 0;
+      done[i] = 0;
       pack_obs(e, s, obs_map + nm * i, obs_obj + no * i);
       continue;
     }
     if (s->done) {                                       /* env.py:235-236 */
       env_reset(e, i);
-      reward[i] = 0.0f; done[i] = 0;
+      done[i] = 0;
       pack_obs(e, s, obs_map + nm * i, obs_obj + no * i);
       continue;
     }
@@ -1451,7 +1490,7 @@ int srlo_step(srlo_env* e, const int64_t* action, uint8_t* obs_map, uint8_t* obs
     }
     if (a < 0 || a >= (int64_t)e->A) {                   /* env.py:238 */
       s->status |= SRL_ST_BAD_ACTION;
-      reward[i] = 0.0f; done[i] = 0;
+      done[i] = 0;
       pack_obs(e, s, obs_map + nm * i, obs_obj + no * i);
       rc = SRL_EINVAL_ACTION;
       continue;
@@ -1474,9 +1513,7 @@ int srlo_step(srlo_env* e, const int64_t* action, uint8_t* obs_map, uint8_t* obs
     s->pending = next;                                   /* _load, simulator.py:258 */
     render_heightmap(e, s->nb, s->mesh, s->x, s->q, s->H);
     observe_objects(e, s);
-    float mv = metric_value(e, s);
-    reward[i] = (mv - s->prev_metric) * e->scale;        /* rewarder.py:176-179 */
-    s->prev_metric = mv;
+    step_rewards(e, s, reward + (size_t)i * K);
     done[i] = (uint8_t)s->done;
     pack_obs(e, s, obs_map + nm * i, obs_obj + no * i);
     if ((s->status & SRL_ST_DIVERGED) && rc == SRL_OK) rc = SRL_ESIM_DIVERGED;

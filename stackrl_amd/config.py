@@ -20,7 +20,8 @@ SOLVER_PRESETS = {
   'bullet10': dict(solver_iterations=10, warmstart=0.85, linear_slop=0.0, residual_threshold=0.0),
 }
 
-METRICS = {'iou': 0, 'or': 1, 'diou': 2, 'dor': 3}  # rewarder.py:7-14
+METRICS = {'iou': 0, 'or': 1, 'diou': 2, 'dor': 3, 'all': 4, 'eval': 5}  # rewarder.py:7-14
+REWARD_KEYS = {4: ('IoU', 'OR', 'DIoU', 'DOR'), 5: ('IoU', 'AD')}      # the dict keys of rewarder.py:147-158
 
 # return codes, include/srl_types.h
 OK, EINVAL, EINVAL_ACTION, ESIM_DIVERGED, EHIP, ENOMESH = range(6)
@@ -152,9 +153,15 @@ class StackConfig:
       if m.lower() not in METRICS:
         raise ValueError('Invalid value {} for argument metric.'.format(m))
       return METRICS[m.lower()]
-    if m not in (0, 1, 2, 3):
+    if m not in (0, 1, 2, 3, 4, 5):
       raise ValueError('Invalid value {} for argument metric.'.format(m))
     return int(m)
+
+  @property
+  def reward_keys(self):
+    """None for a scalar reward; for 'all' / 'eval' the keys of the dict the reference returns (rewarder.py:147-158) —
+    here the columns of the reward tensor [B, K]."""
+    return REWARD_KEYS.get(self.metric_id)
 
   def exponents(self):
     p = self.reward_params                                   # rewarder.py:129-142

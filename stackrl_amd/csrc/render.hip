@@ -97,10 +97,32 @@ __device__ __forceinline__ bool pixel_range(float lo, float hi, float inv_px, in
   return true;
 }
 
-// Rewarder.call (rewarder.py:162-179) for the discounted metrics, thread 0 only
-__device__ float discounted_metric(const DevParams& P, const EnvHdr* h, const float* gb) {
-  float pmax = (float)P.c.object_res * P.px;   // rewarder.py:126
-  float omax = 3.14159265358979f;
+// discount of one body (rewarder.py:261-269), thread 0 only
+__device__ float body_discount(const DevParams& P, const float* gb, int b) {
+  const float pmax = (float)P.c.object_res * P.px;   // rewarder.py:126
+  const float omax = 3.14159265358979f;
+  const v3 dp = ld3(gb + P.OFF_PX + 4 * b) - ld3(gb + P.OFF_X + 4 * b);
+  const float perr = sqrtf(dot(dp, dp));
+  const float* a = gb + P.OFF_PQ + 4 * b;
+  const float* q = gb + P.OFF_Q + 4 * b;
+  const float dw = fabsf((a[0] * q[0] + a[1] * q[1]) + (a[2] * q[2] + a[3] * q[3]));
+  const float oerr = 2.0f * srl_acosf(fminf(dw, 1.0f));
+  float disc = 1.0f;
+  if (P.c.reward_pexp >= 0) {
+    float t = perr / pmax, pw = 1.0f;
+    for (int k = 0; k < P.c.reward_pexp; ++k) pw = pw * t;
+    disc = disc * fmaxf(0.0f, 1.0f - pw);
+  }
+  if (P.c.reward_oexp >= 0) {
+    float t = oerr / omax, pw = 1.0f;
+    for (int k = 0; k < P.c.reward_oexp; ++k) pw = pw * t;
+    disc = disc * fmaxf(0.0f, 1.0f - pw);
+  }
+  return disc;
+}
+
+// Rewarder.call (rewarder.py:162-179) for the discounted metrics (DOR or DIoU), thread 0 only
+__device__ float discounted_metric(const DevParams& P, const EnvHdr* h, const float* gb, int metric) {
   float r = 0.0f; int nout = 0;
   for (int b = 0; b < h->nb; ++b) {
     v3 x = ld3(gb + P.OFF_X + 4 * b);
@@ -108,27 +130,17 @@ __device__ float discounted_metric(const DevParams& P, const EnvHdr* h, const fl
     bool in = fu >= (float)h->goal[0] && fv >= (float)h->goal[1] && fu < (float)(h->goal[0] + h->goal[2]) &&
               fv < (float)(h->goal[1] + h->goal[3]);
     if (!in) { nout++; continue; }
-    v3 dp = ld3(gb + P.OFF_PX + 4 * b) - x;
-    float perr = sqrtf(dot(dp, dp));
-    const float* a = gb + P.OFF_PQ + 4 * b;
-    const float* q = gb + P.OFF_Q + 4 * b;
-    float dw = fabsf((a[0] * q[0] + a[1] * q[1]) + (a[2] * q[2] + a[3] * q[3]));
-    float oerr = 2.0f * srl_acosf(fminf(dw, 1.0f));
-    float disc = 1.0f;
-    if (P.c.reward_pexp >= 0) {
-      float t = perr / pmax, pw = 1.0f;
-      for (int k = 0; k < P.c.reward_pexp; ++k) pw = pw * t;
-      disc = disc * fmaxf(0.0f, 1.0f - pw);
-    }
-    if (P.c.reward_oexp >= 0) {
-      float t = oerr / omax, pw = 1.0f;
-      for (int k = 0; k < P.c.reward_oexp; ++k) pw = pw * t;
-      disc = disc * fmaxf(0.0f, 1.0f - pw);
-    }
-    r = r + disc;
+    r = r + body_discount(P, gb, b);
   }
-  if (P.c.metric == SRL_METRIC_DOR) return r / (float)P.c.episode_length;
+  if (metric == SRL_METRIC_DOR) return r / (float)P.c.episode_length;
   return r / (float)(P.c.episode_length + nout);
+}
+
+// average discount of all rocks (`_discounted(intersection=False)`, rewarder.py:149-151), thread 0 only
+__device__ float average_discount(const DevParams& P, const EnvHdr* h, const float* gb) {
+  float d = 0.0f;
+  for (int b = 0; b < h->nb; ++b) d = d + body_discount(P, gb, b);
+  return d / (float)h->nb;
 }
 
 // row of the codec table (DevParams::codec) for a ray-cast height z > 0: n - k with k the index of t = fl(FAR - z) on the
@@ -310,10 +322,9 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   }
   const int nb = ext ? nb_ext[e] : h->nb;
   int g0 = 0, g1 = 0, g2 = 0, g3 = 0, pending = -1, mode = 0, hdone = 0;
-  float prev_metric = 0.0f;
   if (!ext) {
     g0 = h->goal[0]; g1 = h->goal[1]; g2 = h->goal[2]; g3 = h->goal[3]; pending = h->pending;
-    mode = h->mode; hdone = h->done; prev_metric = h->prev_metric;
+    mode = h->mode; hdone = h->done;
   }
   const int rr = P.c.object_res * P.c.object_res * P.n_orient;   // all observable orientations of the pending rock
   {
@@ -727,17 +738,32 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     for (int s = 32; s >= 1; s >>= 1) { sum_i = sum_i + __shfl_down(sum_i, s); sum_u = sum_u + __shfl_down(sum_u, s); }   // p[t] += p[t+s], t < s
   }
   // ---- K5: reward = scale * (metric_t - metric_{t-1})  (rewarder.py:176-179)
+  //      'all' (rewarder.py:157-158): the four metrics at once, reward[e][4]; 'eval' (rewarder.py:147-156): reward[e][2] = the
+  //      IoU reward and the change of the average discount ('AD', memory slot -1 = 3, not scaled)
   if (tid == 0) {
+    const int K = P.c.metric == SRL_METRIC_ALL ? 4 : P.c.metric == SRL_METRIC_EVAL ? 2 : 1;
+    float* rw = reward + (size_t)e * K;
     if (mode == 0) {
-      float mv;
-      if (P.c.metric == SRL_METRIC_IOU) mv = sum_i / sum_u;
-      else if (P.c.metric == SRL_METRIC_OR) mv = sum_i / ((float)(g2 * g3) * gz);
-      else mv = discounted_metric(P, h, gb);
-      reward[e] = (mv - prev_metric) * P.scale;
-      h->prev_metric = mv;
+      const float iou = sum_i / sum_u, orr = sum_i / ((float)(g2 * g3) * gz);
+      if (P.c.metric == SRL_METRIC_ALL) {
+        const float mv[4] = {iou, orr, discounted_metric(P, h, gb, SRL_METRIC_DIOU), discounted_metric(P, h, gb, SRL_METRIC_DOR)};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { rw[m] = (mv[m] - h->prev_metric[m]) * P.scale; h->prev_metric[m] = mv[m]; }
+      } else if (P.c.metric == SRL_METRIC_EVAL) {
+        rw[0] = (iou - h->prev_metric[0]) * P.scale; h->prev_metric[0] = iou;
+        const float ad = average_discount(P, h, gb);
+        rw[1] = ad - h->prev_metric[3]; h->prev_metric[3] = ad;
+      } else {
+        float mv;
+        if (P.c.metric == SRL_METRIC_IOU) mv = iou;
+        else if (P.c.metric == SRL_METRIC_OR) mv = orr;
+        else mv = discounted_metric(P, h, gb, P.c.metric);
+        rw[0] = (mv - h->prev_metric[P.c.metric]) * P.scale;
+        h->prev_metric[P.c.metric] = mv;
+      }
       done[e] = (uint8_t)hdone;
     } else {   // reset step (env.py:235-236) or rejected action
-      reward[e] = 0.0f;
+      for (int m = 0; m < K; ++m) rw[m] = 0.0f;
       done[e] = 0;
     }
   }

@@ -130,7 +130,7 @@ __device__ void env_reset(const DevParams& P, EnvHdr* h, int e) {
   h->ncolour = -1;
   h->pending = h->ids[0];
   h->list_pos = P.c.ordering_freedom ? L : 1;   // ordering freedom: the rocks still unplaced are ids[0 .. list_pos)
-  h->prev_metric = 0.0f;   // rewarder.py:191-194
+  for (int k = 0; k < 4; ++k) h->prev_metric[k] = 0.0f;   // rewarder.py:191-194
   h->substeps[0] = 0; h->substeps[1] = 0;
   h->status = 0;
   h->done = 0;

@@ -23,7 +23,7 @@ struct EnvHdr {
   int32_t pending;              // mesh id waiting at the spawn pose, -1 = none (Simulator._new)
   int32_t mode;                 // what the last step did: 0 placement, 1 reset, 2 rejected action
   int32_t goal[4];              // u, v, h, w (rewarder.py:255-257)
-  float prev_metric;            // Rewarder._memory[metric]
+  float prev_metric[4];         // Rewarder._memory (rewarder.py:100)
   int32_t substeps[2];          // Simulator.n_steps
   int32_t sweeps;               // solver sweeps of the last step, all its sub-steps together (telemetry)
   int32_t status;               // SRL_ST_* bits

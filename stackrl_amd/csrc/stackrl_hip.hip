@@ -72,7 +72,7 @@ int derive(DevParams& P) {
     return fail(SRL_EINVAL, "n_envs/episode_length out of range");
   if (c.overhead_res < c.object_res || c.object_res < 2 || c.overhead_res > 256 || (c.overhead_res % 8) != 0)
     return fail(SRL_EINVAL, "bad resolutions (overhead_res must be a multiple of 8, <= 256)");
-  if (c.metric < 0 || c.metric > 3) return fail(SRL_EINVAL, "Invalid value for argument metric");
+  if (c.metric < 0 || c.metric > SRL_METRIC_EVAL) return fail(SRL_EINVAL, "Invalid value for argument metric");
   P.px = c.object_max_dimension / (float)c.object_res;
   P.inv_px = (float)c.object_res / c.object_max_dimension;
   P.lin_damp = (float)pow(1.0 - (double)c.linear_damping, (double)c.sim_time_step);
@@ -442,7 +442,7 @@ int srl_reset(srl_env* env, void* obs_map, void* obs_obj, void* stream) {
   const int n = env->P.c.n_envs;
   if (scratch_n < n) {
     (void)hipFree(scratch_r); (void)hipFree(scratch_d);
-    HIP_TRY(hipMalloc((void**)&scratch_r, sizeof(float) * (size_t)n));
+    HIP_TRY(hipMalloc((void**)&scratch_r, sizeof(float) * 4 * (size_t)n));   // up to 4 rewards per env (metric 'all')
     HIP_TRY(hipMalloc((void**)&scratch_d, (size_t)n));
     scratch_n = n;
   }

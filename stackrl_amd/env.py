@@ -179,7 +179,8 @@ class VecStackEnv(object):
     with torch.cuda.device(self._device):
       _check(self._lib.srl_reset(self._h, om.data_ptr(), oo.data_ptr(), self._stream()))
     self._left = self.config.episode_length
-    out = ((om, oo), torch.zeros(self._B, dtype=torch.float32, device=self._device),
+    keys = self.config.reward_keys
+    out = ((om, oo), torch.zeros(self._B if keys is None else (self._B, len(keys)), dtype=torch.float32, device=self._device),
            torch.zeros(self._B, dtype=torch.bool, device=self._device))     # utils.py:545-552
     wait = self._finish(out)
     block = self._block if block is None else block
@@ -192,7 +193,8 @@ class VecStackEnv(object):
     if action.shape != (self._B,):
       raise ValueError('action must have shape [{}]'.format(self._B))
     om, oo = self._new_obs()
-    reward = torch.empty(self._B, dtype=torch.float32, device=self._device)
+    keys = self.config.reward_keys       # 'all' / 'eval': one column per key of the reference's dict (rewarder.py:147-158)
+    reward = torch.empty(self._B if keys is None else (self._B, len(keys)), dtype=torch.float32, device=self._device)
     done = torch.empty(self._B, dtype=torch.uint8, device=self._device)
     self._fork()
     with torch.cuda.device(self._device):

@@ -191,3 +191,36 @@ def test_physics_invariants(oracle_mod, ref_pool):
   assert np.quantile(pens, 0.95) <= 1e-3
   assert (pens > 1e-3).mean() <= 0.02
   assert pens.max() < 0.006
+
+
+def test_all_and_eval_metrics(oracle_mod, ref_pool):
+  """`Rewarder` with metric 'all' / 'eval' (rewarder.py:147-160): 'all' returns the four metrics' rewards at once — each
+  column equals the reward of a run with that single metric on the same script; 'eval' returns the IoU reward and 'AD',
+  the change of the average discount of ALL rocks (unscaled): with a goal that covers the whole map every rock is inside
+  it, so the running average discount times the number of rocks equals the running DOR times the episode length."""
+  n, L = 3, 6
+  rng = np.random.RandomState(2)
+  ids = np.stack([rng.choice(len(ref_pool), size=L, replace=False) for _ in range(n)]).astype(np.int32)
+  rect = np.array([[0, 0, 128, 128]] * n, np.int32)
+  acts = rng.randint(0, 9409, size=(L, n)).astype(np.int64)
+
+  def run(metric, scale=2.0):
+    env = oracle_mod.OracleEnv(StackConfig(n_envs=n, episode_length=L, rewarder=metric, reward_scale=scale), ref_pool, seed=3)
+    env.set_script(ids, rect)
+    _, r0, _ = env.reset()
+    out = [env.step(acts[k])[1] for k in range(L)]
+    _, rr, _ = env.step(acts[0])                     # the auto-reset call: zeros in every column
+    assert not rr.any() and r0.shape == rr.shape
+    return np.stack(out)
+  single = {m: run(m) for m in ('iou', 'or', 'diou', 'dor')}
+  allr = run('all')
+  assert allr.shape == (L, n, 4) and StackConfig(rewarder='all').reward_keys == ('IoU', 'OR', 'DIoU', 'DOR')
+  for col, m in enumerate(('iou', 'or', 'diou', 'dor')):
+    assert np.array_equal(allr[..., col], single[m]), m
+  ev = run('eval')
+  assert ev.shape == (L, n, 2) and StackConfig(rewarder='eval').reward_keys == ('IoU', 'AD')
+  assert np.array_equal(ev[..., 0], single['iou'])
+  ad = np.cumsum(ev[..., 1], axis=0)                 # running average discount (not scaled)
+  dor = np.cumsum(single['dor'], axis=0) / 2.0       # running DOR (undo the scale)
+  k = np.arange(1, L + 1, dtype=np.float64)[:, None]
+  np.testing.assert_allclose(ad * k, dor * L, rtol=0, atol=2e-5)

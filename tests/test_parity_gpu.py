@@ -74,6 +74,8 @@ def test_render_explicit_poses(ref_pool, oracle_mod):
   (8, 8, dict(sim_time_step=0.0125, rewarder='dor', reward_scale=None)),   # root config.gin env overrides
   (16, 8, dict(rewarder='diou')),
   (4, 4, dict(rewarder='or', smooth_placing=False)),
+  (6, 6, dict(rewarder='all', reward_scale=2.0)),      # rewarder.py:157-158: the four metrics at once, reward [B, 4]
+  (6, 6, dict(rewarder='eval')),                       # rewarder.py:147-156: IoU reward + average-discount change, [B, 2]
 ])
 def test_scripted_episodes(ref_pool, oracle_mod, L, n, kw):
   g, o = _mk(ref_pool, oracle_mod, n, L, **kw)
@@ -96,6 +98,7 @@ def test_scripted_episodes(ref_pool, oracle_mod, L, n, kw):
       assert oout[2].all() and gout[2].all()
     if k == L:
       assert not oout[2].any() and float(gout[1].abs().max()) == 0.0
+    assert tuple(gout[1].shape) == tuple(oout[1].shape)
   print('max pose diff', worst)
 
 
