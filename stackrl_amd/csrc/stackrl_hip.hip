@@ -1,6 +1,7 @@
 // stackrl_hip.hip — C-ABI of libstackrl_hip.so (include/stackrl_hip.h): host side.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC (see stackrl_amd/build.py).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <math.h>
 #include <stdio.h>
@@ -147,16 +148,20 @@ hipEvent_t get_event(srl_env* env) {
   return e;
 }
 
-void prof_begin(srl_env* env, hipStream_t st, int which) {
-  if (!env->profiling) return;
-  EventPair p; p.a = get_event(env); p.b = get_event(env); p.which = which;
-  (void)hipEventRecord(p.a, st);
-  env->pending.push_back(p);
+// Per-kernel timing (bench.py's roofline leg): the two events are attached to the dispatch itself (hipExtLaunchKernelGGL),
+// so they carry the kernel's own begin / end timestamps on its stream — what rocprofv3 reports for the dispatch — and not
+// the two marker packets of hipEventRecord calls around it (about 3 us on a 44 us kernel).
+EventPair prof_pair(srl_env* env, int which) {
+  EventPair p; p.a = nullptr; p.b = nullptr; p.which = which;
+  if (env->profiling) { p.a = get_event(env); p.b = get_event(env); env->pending.push_back(p); }
+  return p;
 }
-void prof_end(srl_env* env, hipStream_t st) {
-  if (!env->profiling) return;
-  (void)hipEventRecord(env->pending.back().b, st);
-}
+#define SRL_LAUNCH(env_, which_, kernel_, grid_, block_, lds_, st_, ...)                                           \
+  do {                                                                                                             \
+    const EventPair ev_ = prof_pair(env_, which_);                                                                 \
+    if (ev_.a) hipExtLaunchKernelGGL(kernel_, grid_, block_, lds_, st_, ev_.a, ev_.b, 0, __VA_ARGS__);             \
+    else hipLaunchKernelGGL(kernel_, grid_, block_, lds_, st_, __VA_ARGS__);                                       \
+  } while (0)
 
 int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void* obs_obj, float* reward, uint8_t* done,
                        hipStream_t st, int force_reset) {
@@ -168,21 +173,16 @@ int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void*
     env->P_dirty = false;
   }
   const DevParams* dP = env->d_P;
-  prof_begin(env, st, 0);
-  if (env->step_pp == 3) hipLaunchKernelGGL(srl_k_step_t512, dim3(n), dim3(512), env->step_lds, st, dP, action, force_reset);
-  else if (env->step_pp == 0) hipLaunchKernelGGL(srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
-  else if (env->step_pp == 1) hipLaunchKernelGGL(srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
-  else hipLaunchKernelGGL(srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
-  prof_end(env, st);
+  if (env->step_pp == 3) SRL_LAUNCH(env, 0, srl_k_step_t512, dim3(n), dim3(512), env->step_lds, st, dP, action, force_reset);
+  else if (env->step_pp == 0) SRL_LAUNCH(env, 0, srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
+  else if (env->step_pp == 1) SRL_LAUNCH(env, 0, srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
+  else SRL_LAUNCH(env, 0, srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
   if (force_reset < 0) {   // srl_step_simulation: sub-steps only
     HIP_TRY(hipGetLastError());
     return SRL_OK;
   }
-  prof_begin(env, st, 1);
-  hipLaunchKernelGGL(srl_k_render, dim3(n), dim3(SRL_RENDER_THREADS), env->render_lds, st, P, (uint8_t*)obs_map, (uint8_t*)obs_obj,
-                     reward, done, (const float*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr,
-                     (float*)nullptr);
-  prof_end(env, st);
+  SRL_LAUNCH(env, 1, srl_k_render, dim3(n), dim3(SRL_RENDER_THREADS), env->render_lds, st, P, (uint8_t*)obs_map, (uint8_t*)obs_obj,
+             reward, done, (const float*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (float*)nullptr);
   HIP_TRY(hipGetLastError());
   return SRL_OK;
 }
@@ -626,10 +626,8 @@ int srl_render_heightmap(srl_env* env, const float* poses, const int32_t* mesh_i
   if (!env || !poses || !mesh_ids || !n_bodies || !height) return fail(SRL_EINVAL, "null argument");
   if (!env->d_mh) return fail(SRL_ENOMESH, "srl_load_meshes must be called first");
   hipStream_t st = (hipStream_t)stream;
-  prof_begin(env, st, 1);
-  hipLaunchKernelGGL(srl_k_render, dim3(env->P.c.n_envs), dim3(SRL_RENDER_THREADS), env->render_lds, st, env->P, (uint8_t*)nullptr,
-                     (uint8_t*)nullptr, (float*)nullptr, (uint8_t*)nullptr, poses, mesh_ids, n_bodies, height);
-  prof_end(env, st);
+  SRL_LAUNCH(env, 1, srl_k_render, dim3(env->P.c.n_envs), dim3(SRL_RENDER_THREADS), env->render_lds, st, env->P, (uint8_t*)nullptr,
+             (uint8_t*)nullptr, (float*)nullptr, (uint8_t*)nullptr, poses, mesh_ids, n_bodies, height);
   HIP_TRY(hipGetLastError());
   return SRL_OK;
 }
