@@ -70,6 +70,13 @@ int32_t srl_conv3x3_wfrag_elems(int32_t cin, int32_t cout);
 int srl_conv3x3_bias_relu(const void* in_dev, const void* wfrag_dev, const float* bias_dev, void* out_dev, void* pooled_dev,
                           int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t out_stride,
                           int32_t out_offset, int32_t nchw, void* stream);
+/* The same layer in fp32-class precision (the fp32 rollout, the reference's dtype): float32 channels-last in and out,
+ * cin, cout in {16, 32}; every product is hi hi + hi lo + lo hi of bfloat16 halves on the matrix cores, fp32 accumulation
+ * ("bf16x3").  wfrag: 2 x srl_conv3x3_wfrag_elems(cin, cout) bfloat16 elements — the fragments of bf16(w), then those of
+ * bf16(w - bf16(w)), each in the order described above.  pooled (may be NULL) float32 [B][H/2][W/2][cout]. */
+int srl_conv3x3_bias_relu_f32(const float* in_dev, const void* wfrag_dev, const float* bias_dev, float* out_dev,
+                              float* pooled_dev, int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                              int32_t out_stride, int32_t out_offset, int32_t nchw, void* stream);
 /* The thin first layers (1 or 2 input channels -> 16) on the vector ALU: in uint8 (in_dtype 0: the env's observation
  * bytes, scaled by 1/255 as in models.py:144-147) or float32 (in_dtype 1) channels-last [B][H][W][cin]; w float32
  * [16][cin][3][3], bias float32 [16]; out bfloat16 channels-last [B][Hp][Wp][16] with Hp >= H, Wp >= W (only the H x W

@@ -173,6 +173,121 @@ k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, c
   }
 }
 
+// The same convolution in fp32-class precision for the fp32 rollout (the reference's dtype): float32 channels-last in and
+// out, every operand split into a high and a low bfloat16 part (x = hi + lo up to 2^-17 |x|) and the product taken as
+// hi hi + hi lo + lo hi on the matrix cores with fp32 accumulation ("bf16x3": relative error ~2^-16 per product, the
+// split the cross-correlation kernel uses) — a third of the bf16 MFMA rate, which these HBM-bound layers do not miss.
+// The input tile is split once while it is staged (two bf16 planes in LDS), the weights arrive pre-split (hi fragments,
+// then lo fragments) and stay in registers.  CIN in {16, 32} (CIN = 64 would need 93 KB of LDS per workgroup).
+template <int CIN, int COUT, int MT_W>
+__global__ void __launch_bounds__(256, 2)
+k_conv3x3_x3(const float* __restrict__ in, const uint16_t* __restrict__ wfrag, const float* __restrict__ bias,
+             float* __restrict__ out, float* __restrict__ pooled, int H, int W, int ostride, int ooff, int nchw) {
+  typedef ConvCfg<CIN> G;
+  constexpr int MT = COUT / 16;
+  constexpr int WM = MT / MT_W;
+  constexpr int RW = 16 / (4 / WM);
+  constexpr int PLANE = G::TW * G::TW * G::PS;
+  extern __shared__ uint16_t tile[];   // [2][18][18][PS]: hi plane, lo plane
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = W / 16;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  const int x0 = 16 * tx, y0 = 16 * ty;
+  const int mt0 = (wave % WM) * MT_W, row0 = (wave / WM) * RW;
+  bf16x8 wh[G::KS][MT_W], wl[G::KS][MT_W];
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < MT_W; ++mt) {
+      wh[ks][mt] = ((const bf16x8*)wfrag)[(ks * MT + mt0 + mt) * 64 + lane];
+      wl[ks][mt] = ((const bf16x8*)wfrag)[((G::KS + ks) * MT + mt0 + mt) * 64 + lane];
+    }
+  {
+    constexpr int CPP = CIN / 8;   // 8-channel chunks per pixel
+    const float* src = in + (size_t)b * H * W * CIN;
+    for (int k = tid; k < G::TW * G::TW * CPP; k += 256) {
+      const int p = k / CPP, ch = k - p * CPP;
+      const int py = p / G::TW, px = p - py * G::TW;
+      const int y = y0 + py - 1, x = x0 + px - 1;
+      float v[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      if (y >= 0 && y < H && x >= 0 && x < W) {
+        const float4 a = *(const float4*)(src + ((size_t)y * W + x) * CIN + ch * 8);
+        const float4 c = *(const float4*)(src + ((size_t)y * W + x) * CIN + ch * 8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+      }
+      uint32_t hi[4], lo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t h0 = c_bf16_rne(v[2 * j]), h1 = c_bf16_rne(v[2 * j + 1]);
+        const uint32_t l0 = c_bf16_rne(v[2 * j] - __uint_as_float(h0 << 16)), l1 = c_bf16_rne(v[2 * j + 1] - __uint_as_float(h1 << 16));
+        hi[j] = h0 | (h1 << 16); lo[j] = l0 | (l1 << 16);
+      }
+      *(uint4*)(tile + p * G::PS + ch * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      *(uint4*)(tile + PLANE + p * G::PS + ch * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+  }
+  __syncthreads();
+  f32x4 acc[RW][MT_W];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int mt = 0; mt < MT_W; ++mt) acc[r][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks) {
+    int tap, ci0;
+    k_of<CIN>(ks, g, tap, ci0);
+    if (tap > 8) tap = 8;
+    const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int off = ((row0 + r + dy) * G::TW + n + dx) * G::PS + ci0;
+      const bf16x8 xh = *(const bf16x8*)(tile + off), xl = *(const bf16x8*)(tile + PLANE + off);
+#pragma unroll
+      for (int mt = 0; mt < MT_W; ++mt) {
+        // small terms first: lo hi + hi lo, then the leading product
+        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks][mt], xh, acc[r][mt], 0, 0, 0);
+        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][mt], xl, acc[r][mt], 0, 0, 0);
+        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][mt], xh, acc[r][mt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT_W; ++mt) {
+    const int co = 16 * (mt0 + mt) + 4 * g;
+    const float4 bz = *(const float4*)(bias + co);
+    float4 val[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      val[r] = make_float4(fmaxf(acc[r][mt][0] + bz.x, 0.0f), fmaxf(acc[r][mt][1] + bz.y, 0.0f),
+                           fmaxf(acc[r][mt][2] + bz.z, 0.0f), fmaxf(acc[r][mt][3] + bz.w, 0.0f));
+      const int y = y0 + row0 + r, x = x0 + n;
+      if (nchw) {
+        float* o = out + ((size_t)b * COUT + co) * H * W + (size_t)y * W + x;
+        o[0] = val[r].x; o[(size_t)H * W] = val[r].y; o[(size_t)2 * H * W] = val[r].z; o[(size_t)3 * H * W] = val[r].w;
+      } else {
+        *(float4*)(out + (((size_t)b * H + y) * W + x) * ostride + ooff + co) = val[r];
+      }
+    }
+    if (pooled) {   // 2 x 2 max: rows in registers, the neighbouring column (lane n ^ 1) by a DPP quad permute
+#pragma unroll
+      for (int rp = 0; rp < RW / 2; ++rp) {
+        float m[4] = {fmaxf(val[2 * rp].x, val[2 * rp + 1].x), fmaxf(val[2 * rp].y, val[2 * rp + 1].y),
+                      fmaxf(val[2 * rp].z, val[2 * rp + 1].z), fmaxf(val[2 * rp].w, val[2 * rp + 1].w)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float other = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m[q]), __float_as_int(m[q]), 0xb1, 0xf, 0xf, false));
+          m[q] = fmaxf(m[q], other);
+        }
+        if (!(n & 1)) {
+          const int y2 = (y0 + row0) / 2 + rp, x2 = (x0 + n) / 2;
+          *(float4*)(pooled + (((size_t)b * (H / 2) + y2) * (W / 2) + x2) * COUT + co) = make_float4(m[0], m[1], m[2], m[3]);
+        }
+      }
+    }
+  }
+}
+
 // 3 x 3 convolution + bias + ReLU from 1 or 2 input channels to 16 (the first layer of each U-Net and of
 // `pos_layers`): K = 9 or 18 is too thin for the matrix cores, the layer is bound by its 32-byte-per-pixel output.
 // One thread per output pixel, fp32 math, weights in LDS (broadcast reads), bf16 channels-last output into a buffer
@@ -273,11 +388,38 @@ int launch(const void* in, const void* wfrag, const float* bias, void* out, void
   return 0;
 }
 
+template <int CIN, int COUT>
+int launch_x3(const float* in, const void* wfrag, const float* bias, float* out, float* pooled, int B, int H, int W, int ostride,
+              int ooff, int nchw, hipStream_t st) {
+  const size_t lds = 2 * sizeof(uint16_t) * ConvCfg<CIN>::TW * ConvCfg<CIN>::TW * ConvCfg<CIN>::PS;
+  constexpr int MT_W = COUT / 16;
+  hipLaunchKernelGGL((k_conv3x3_x3<CIN, COUT, MT_W>), dim3((W / 16) * (H / 16), B), dim3(256), lds, st, in, (const uint16_t*)wfrag,
+                     bias, out, pooled, H, W, ostride, ooff, nchw);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "srl_conv3x3_bias_relu_f32: %s", hipGetErrorString(e)); return 2; }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* srl_conv_last_error(void) { return c_err; }
+
+int srl_conv3x3_bias_relu_f32(const float* in, const void* wfrag, const float* bias, float* out, float* pooled, int32_t B,
+                              int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset,
+                              int32_t nchw, void* stream) {
+  if (!in || !wfrag || !bias || !out || B < 1 || H < 16 || W < 16 || H % 16 || W % 16 || out_stride % 4 || out_offset % 4 ||
+      (cin != 16 && cin != 32) || (cout != 16 && cout != 32) || (pooled && nchw)) {
+    snprintf(c_err, sizeof c_err, "srl_conv3x3_bias_relu_f32: bad arguments (H, W multiples of 16; cin, cout in {16, 32})");
+    return 1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (cin == 16 && cout == 16) return launch_x3<16, 16>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+  if (cin == 16 && cout == 32) return launch_x3<16, 32>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+  if (cin == 32 && cout == 16) return launch_x3<32, 16>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+  return launch_x3<32, 32>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+}
 
 int32_t srl_conv3x3_wfrag_elems(int32_t cin, int32_t cout) {
   if ((cin != 16 && cin != 32 && cin != 64) || (cout != 16 && cout != 32)) return -1;

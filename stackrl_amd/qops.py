@@ -38,6 +38,8 @@ def load():
     L.srl_conv3x3_wfrag_elems.argtypes = [ctypes.c_int32] * 2
     L.srl_conv3x3_bias_relu.restype = ctypes.c_int
     L.srl_conv3x3_bias_relu.argtypes = [VP] * 5 + [ctypes.c_int32] * 8 + [VP]
+    L.srl_conv3x3_bias_relu_f32.restype = ctypes.c_int
+    L.srl_conv3x3_bias_relu_f32.argtypes = [VP] * 5 + [ctypes.c_int32] * 8 + [VP]
     L.srl_conv_last_error.restype = ctypes.c_char_p
     L.srl_convt2x2_wfrag_elems.restype = ctypes.c_int32
     L.srl_convt2x2_wfrag_elems.argtypes = [ctypes.c_int32] * 2
@@ -256,6 +258,15 @@ def pack_conv3x3_weights(w):
   return out
 
 
+def pack_conv3x3_weights_x3(w):
+  """Conv2d weight [cout, cin, 3, 3] (cin, cout in {16, 32}) -> the two bf16 fragment sets of the fp32-class kernel
+  (srl_conv3x3_bias_relu_f32): the fragments of bf16(w), then those of bf16(w - bf16(w))."""
+  w = w.detach().float()
+  hi = w.to(torch.bfloat16)
+  lo = (w - hi.float()).to(torch.bfloat16)
+  return torch.cat([pack_conv3x3_weights(hi.float()), pack_conv3x3_weights(lo.float())]).contiguous()
+
+
 def conv3x3_bias_relu(x, wfrag, bias, cout, out=None, out_offset=0, pool=False, nchw=False):
   """relu(conv3x3(x) + bias) on the matrix cores (csrc/conv_mfma.hip).  x: bf16 [B,cin,H,W] channels-last.  Returns
   the output (a new channels-last tensor, or `out` whose channel slice [out_offset, out_offset + cout) was written, or
@@ -268,10 +279,11 @@ def conv3x3_bias_relu(x, wfrag, bias, cout, out=None, out_offset=0, pool=False, 
     dst = out if out is not None else torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=_CL)
     stride = dst.shape[1]
   pooled = torch.empty((B, cout, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=_CL) if pool else None
+  # float32 tensors take the fp32-class kernel (bf16x3 products, wfrag from pack_conv3x3_weights_x3)
+  fn = load().srl_conv3x3_bias_relu_f32 if x.dtype == torch.float32 else load().srl_conv3x3_bias_relu
   with torch.cuda.device(x.device):
-    rc = load().srl_conv3x3_bias_relu(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), dst.data_ptr(),
-                                      pooled.data_ptr() if pool else None, B, H, W, cin, cout, stride, out_offset,
-                                      int(nchw), _stream(x))
+    rc = fn(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), dst.data_ptr(), pooled.data_ptr() if pool else None, B, H, W, cin,
+            cout, stride, out_offset, int(nchw), _stream(x))
   if rc:
     raise RuntimeError(load().srl_conv_last_error().decode())
   return (dst, pooled) if pool else dst
@@ -341,12 +353,15 @@ class FastFeatures(object):
   csrc/epilogue.hip instead of separate bias / ReLU / max-pool / concatenate / layout kernels.  Returns the left and
   right feature maps NCHW-contiguous, ready for the MFMA cross-correlation."""
 
-  def __init__(self, net, mfma_conv=True, dtype=torch.bfloat16):
+  def __init__(self, net, mfma_conv=True, dtype=torch.bfloat16, x3_conv=True):
     self.net = net
-    # dtype float32 = the reference's dtype: library fp32 convolutions without bias + the fused fp32 epilogues (the
-    # MFMA convolution kernels are bf16 and stay out of this path)
+    # dtype float32 = the reference's dtype: library fp32 convolutions without bias + the fused fp32 epilogues, and
+    # (x3_conv) the 16- / 32-channel 3 x 3 layers on the matrix cores in fp32-class precision (bf16x3 products,
+    # csrc/conv_mfma.hip k_conv3x3_x3); the thin first layers, the transposed convolutions and the position head stay
+    # library fp32 in this mode
     self.dtype = dtype
     self.mfma_conv = bool(mfma_conv) and dtype == torch.bfloat16   # hand-written MFMA kernel for the 16- / 32-channel 3 x 3 layers
+    self.x3_conv = bool(x3_conv) and dtype == torch.float32
     self._key = None
     self._w = {}
     self._wf = {}
@@ -369,6 +384,9 @@ class FastFeatures(object):
         if self.mfma_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.in_channels in (16, 32, 64) and m.out_channels in (16, 32):
           self._wf[m] = pack_conv3x3_weights(m.weight)
+        if self.x3_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
+           m.in_channels in (16, 32) and m.out_channels in (16, 32):
+          self._wf[m] = pack_conv3x3_weights_x3(m.weight)
         if self.mfma_conv and isinstance(m, torch.nn.ConvTranspose2d) and m.kernel_size == (2, 2) and \
            (m.in_channels, m.out_channels) in ((32, 16), (64, 32)):
           self._wf[m] = pack_convt2x2_weights(m.weight)

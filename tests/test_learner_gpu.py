@@ -509,6 +509,30 @@ def test_replay_kernels_match_the_library_formulation(literal):
   np.testing.assert_allclose(wa.cpu().numpy(), wb.cpu().numpy(), rtol=2e-6)
 
 
+@pytest.mark.parametrize('cin,cout,H', [(16, 16, 32), (16, 32, 16), (32, 16, 48), (32, 32, 16)])
+def test_conv3x3_bf16x3_matches_torch_fp64(cin, cout, H):
+  """The fp32-class MFMA convolution (`k_conv3x3_x3`: bf16 hi/lo split, hi hi + hi lo + lo hi, fp32 accumulation) + bias +
+  ReLU against float64 torch: 3e-5 of the output scale (the split's 2^-16 per product; fp32 itself sits at 1e-6 here), for
+  the plain, concat-slice + pooled and channel-major outputs."""
+  from stackrl_amd import qops
+  g = torch.Generator(device='cuda').manual_seed(cin * 100 + cout)
+  B, W = 3, H
+  x = torch.randn(B, cin, H, W, generator=g, device='cuda').contiguous(memory_format=torch.channels_last)
+  w = torch.randn(cout, cin, 3, 3, generator=g, device='cuda') / (3 * cin ** 0.5)
+  b = torch.randn(cout, generator=g, device='cuda') * 0.1
+  ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1))
+  wf = qops.pack_conv3x3_weights_x3(w)
+  y = qops.conv3x3_bias_relu(x, wf, b, cout)
+  scale = float(ref.abs().max())
+  assert y.dtype == torch.float32 and float((y.double() - ref).abs().max()) <= 3e-5 * scale
+  cat = torch.zeros((B, 2 * cout, H, W), device='cuda').contiguous(memory_format=torch.channels_last)
+  _, pooled = qops.conv3x3_bias_relu(x, wf, b, cout, out=cat, out_offset=cout, pool=True)
+  assert float((cat[:, cout:].double() - ref).abs().max()) <= 3e-5 * scale and float(cat[:, :cout].abs().max()) == 0.0
+  assert torch.equal(pooled, torch.nn.functional.max_pool2d(cat[:, cout:], 2))
+  yn = qops.conv3x3_bias_relu(x, wf, b, cout, nchw=True)
+  assert yn.is_contiguous() and torch.equal(yn, y.contiguous())
+
+
 def test_fast_features_fp32_match_the_module():
   """The fp32 fast rollout (`FastFeatures(dtype=float32)`: bias-free library fp32 convolutions + the fused fp32 epilogues
   of csrc/epilogue.hip instead of separate bias / ReLU / max-pool / concatenate / layout kernels) against the stock fp32
@@ -520,14 +544,22 @@ def test_fast_features_fp32_match_the_module():
   g = torch.Generator(device='cuda').manual_seed(4)
   xm = torch.randint(0, 256, (6, 128, 128, 2), generator=g, device='cuda', dtype=torch.uint8)
   xo = torch.randint(0, 256, (6, 32, 32, 1), generator=g, device='cuda', dtype=torch.uint8)
-  fx, fw = qops.FastFeatures(net, dtype=torch.float32)((xm, xo))
   with torch.no_grad():
     ex, _, ew = net.features((xm, xo))
+  # (a) epilogues only: the same fp32 arithmetic up to where the bias is added
+  fx, fw = qops.FastFeatures(net, dtype=torch.float32, x3_conv=False)((xm, xo))
   for got, ref in ((fx, ex), (fw, ew)):
     assert got.shape == ref.shape and got.dtype == torch.float32 and got.is_contiguous()
     assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+  # (b) + the 16- / 32-channel layers on the matrix cores as bf16x3 products: fp32-class, 2e-4 of the feature scale after
+  #     the whole U-Net (2^-16 per product, a dozen layers deep)
+  gx, gw = qops.FastFeatures(net, dtype=torch.float32)((xm, xo))
+  for got, ref in ((gx, ex), (gw, ew)):
+    assert got.dtype == torch.float32 and float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
   agent = DQN(net, collect_batch_size=6, replay_memory_size=6 * 4, exploration=0.0)
-  a_ref = agent.policy((xm, xo), exploration=True)
+  a_ref, q_ref = agent.policy((xm, xo), exploration=True, values=True)
   pol = qops.FusedPolicy(autocast=None, fast=True)
   a = pol(net, (xm, xo), 0.0, torch.Generator(device='cuda').manual_seed(1))
-  assert torch.equal(a, a_ref)
+  # the same greedy actions, or actions whose Q-value is within the fp32-class tolerance of the maximum
+  qa = q_ref.gather(1, a[:, None])[:, 0]
+  assert bool((q_ref.amax(-1) - qa <= 2e-4 * q_ref.abs().amax(-1)).all())
