@@ -17,10 +17,10 @@ def run(B, dtype):
   g = torch.Generator(device='cuda').manual_seed(0)
   xm = torch.randint(0, 256, (B, 128, 128, 2), generator=g, device='cuda', dtype=torch.uint8)
   xo = torch.randint(0, 256, (B, 32, 32, 1), generator=g, device='cuda', dtype=torch.uint8)
-  ac = {'fp32': None, 'bf16': torch.bfloat16, 'fp16': torch.float16}[dtype]
+  ac = {'fp32': None, 'fp32-stock': None, 'bf16': torch.bfloat16, 'fp16': torch.float16}[dtype]
   if ac is not None:
     net = net.to(memory_format=torch.channels_last)
-  pol = qops.FusedPolicy(chunk=min(B, 512), autocast=ac)
+  pol = qops.FusedPolicy(chunk=min(B, 512), autocast=ac, fast=(dtype != 'fp32-stock'))
   with torch.no_grad():
     for _ in range(3): pol(net, (xm, xo), 0.1, g)
     torch.cuda.synchronize()
