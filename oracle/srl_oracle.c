@@ -987,7 +987,8 @@ static void update_slots(const struct srlo_env* e, env_t* s) {
                s->amin[i].z <= s->amax[j].z && s->amin[j].z <= s->amax[i].z;
       if (ov && s->slot_of_pair[pid] < 0) {
         int sl = -1;
-        for (int k = 0; k < MAXSLOT; ++k) if (s->pair_of_slot[k] < 0) { sl = k; break; }
+        const int cap = e->c.episode_length <= 16 ? 64 : 128;   /* manifold slots per env, as the kernels lay them out */
+        for (int k = 0; k < MAXSLOT && k < cap; ++k) if (s->pair_of_slot[k] < 0) { sl = k; break; }
         if (sl < 0) { s->status |= SRL_ST_PAIR_OVERFLOW; continue; }
         s->slot_of_pair[pid] = (int16_t)sl; s->pair_of_slot[sl] = (int16_t)pid;
         s->slot_a[sl] = (uint8_t)i; s->slot_b[sl] = (uint8_t)j;

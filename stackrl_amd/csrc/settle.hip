@@ -730,7 +730,7 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
           if (!ov) continue;
           int sl = -1;
           for (int k = 0; k < P.NS; ++k) if (L.POS()[k] < 0) { sl = k; break; }
-          if (sl < 0) { misc[M_STATUS] |= SRL_ST_PAIR_OVERFLOW; continue; }
+          if (sl < 0) { misc[M_STATUS] |= SRL_ST_PAIR_OVERFLOW; atomicOr(P.flags, 4); continue; }
           L.SOP()[pid] = sl; L.POS()[sl] = pid;
           float* mp = L.MAN(sl);
           mp[0] = __int_as_float(0);
@@ -1093,11 +1093,10 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
   }
 }
 
-// Variants: T threads per env, PP contact points of body-body manifolds per thread (4 NS <= T PP).
-// L <= 8 runs two waves per env so that four envs per CU (1,024 envs per GPU) are resident together with up to
-// 256 VGPRs per lane; longer episodes use four waves with one or two points per thread, and eight waves with two
-// points per thread once 4 NS exceeds 512 (three points per thread at four waves spill: 94.5 -> 57.8 ms per launch at
-// 2,048 envs x 32 rocks).
+// Variants: T threads per env, one contact point of the body-body manifolds per thread (4 NS <= T; NS = 28 / 64 / 128
+// slots up to 8 / 16 / 32 rocks, stackrl_hip.hip nslots).  L <= 8 runs two waves per env so that four envs per CU (1,024
+// envs per GPU) are resident together with up to 256 VGPRs per lane; up to 16 rocks four waves, above eight.  (Round 1
+// kept a slot for every pair up to 16 rocks and 192 above, which needed two points per thread and 256 VGPRs + scratch.)
 extern "C" __global__ void __launch_bounds__(128, 2) srl_k_step(const DevParams* __restrict__ Pp,
     const int64_t* __restrict__ action, int force_reset) {
   step_body<128, 1>(Pp, action, force_reset);
@@ -1106,13 +1105,9 @@ extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp1(const DevPar
     const int64_t* __restrict__ action, int force_reset) {
   step_body<256, 1>(Pp, action, force_reset);
 }
-extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp2(const DevParams* __restrict__ Pp,
+extern "C" __global__ void __launch_bounds__(512, 1) srl_k_step_t512(const DevParams* __restrict__ Pp,
     const int64_t* __restrict__ action, int force_reset) {
-  step_body<256, 2>(Pp, action, force_reset);
-}
-extern "C" __global__ void __launch_bounds__(512, 2) srl_k_step_t512(const DevParams* __restrict__ Pp,
-    const int64_t* __restrict__ action, int force_reset) {
-  step_body<512, 2>(Pp, action, force_reset);
+  step_body<512, 1>(Pp, action, force_reset);
 }
 
 // ------------------------------------------------------------------ ParallelEnv.sample (utils.py:534-538)

@@ -60,10 +60,15 @@ struct srl_env {
 
 namespace {
 
+// Manifold slots per env: every pair up to 8 rocks (28), 64 up to 16 rocks, 128 above — one contact point per thread in
+// every kernel variant (4 lanes per slot).  Pairs whose AABBs overlap at the same time: at most 36 over 512 random
+// 16-rock episodes, 85 over 24 32-rock ones (the oracle's statistics); an env that needs more reports
+// SRL_ST_PAIR_OVERFLOW and srl_sync_status fails, as it did at the old cap of 192.
 int nslots(int L) {
   int np = L * (L - 1) / 2;
   if (np < 1) np = 1;
-  return np < SRL_NSLOT_MAX ? np : SRL_NSLOT_MAX;
+  const int cap = L <= 16 ? 64 : 128;
+  return np < cap ? np : cap;
 }
 
 // derived constants: identical expressions to the oracle's derive() so both sides round alike
@@ -175,8 +180,7 @@ int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void*
   const DevParams* dP = env->d_P;
   if (env->step_pp == 3) SRL_LAUNCH(env, 0, srl_k_step_t512, dim3(n), dim3(512), env->step_lds, st, dP, action, force_reset);
   else if (env->step_pp == 0) SRL_LAUNCH(env, 0, srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
-  else if (env->step_pp == 1) SRL_LAUNCH(env, 0, srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
-  else SRL_LAUNCH(env, 0, srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
+  else SRL_LAUNCH(env, 0, srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
   if (force_reset < 0) {   // srl_step_simulation: sub-steps only
     HIP_TRY(hipGetLastError());
     return SRL_OK;
@@ -384,16 +388,16 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   env->step_lds = sizeof(float) * (size_t)P.LDS_WORDS;
   if (env->step_lds > 160 * 1024) return fail(SRL_EINVAL, "episode_length x mesh size exceeds the 160 KB LDS budget");
   // threads per env / pair-manifold points per thread (settle.hip "Variants")
+  // one contact point per thread: 128 threads up to 8 rocks, 256 up to 16, 512 above (settle.hip "Variants")
   if (4 * P.NS <= 128 && SRL_GMAXP * P.c.episode_length <= 128) { env->step_threads = 128; env->step_pp = 0; }
-  else { env->step_threads = 256; env->step_pp = (4 * P.NS + 255) / 256; }
-  if (env->step_pp == 3) env->step_threads = 512;   // 4 NS > 512: eight waves, two points per thread (three per thread at 256 spill)
+  else if (4 * P.NS <= 256) { env->step_threads = 256; env->step_pp = 1; }
+  else { env->step_threads = 512; env->step_pp = 3; }
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_t512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   const int res = P.c.overhead_res;
   env->render_lds = render_lds_bytes(res);
   env->objmap_lds = 0;
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
-  HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->render_lds));
   // K3: object maps of the whole pool, once
   hipLaunchKernelGGL(srl_k_objmap, dim3(n_mesh, P.n_orient), dim3(256), env->objmap_lds, 0, P, env->d_objmap, env->d_objmap_u8);
@@ -504,6 +508,7 @@ int srl_sync_status(srl_env* env, void* stream) {
   if (f) HIP_TRY(hipMemset(env->P.flags, 0, sizeof f));
   if (f & 1) return fail(SRL_EINVAL_ACTION, "Invalid action.");
   if (f & 2) return fail(SRL_ESIM_DIVERGED, "Maximum number of simulator steps reached. This may be caused by incorrect behaviour due to a large time step value");
+  if (f & 4) return fail(SRL_ESIM_DIVERGED, "More close rock pairs than manifold slots in some env (SRL_ST_PAIR_OVERFLOW): the step is not valid");
   return SRL_OK;
 }
 
