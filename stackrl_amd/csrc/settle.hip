@@ -1097,11 +1097,14 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
 // slots up to 8 / 16 / 32 rocks, stackrl_hip.hip nslots).  L <= 8 runs two waves per env so that four envs per CU (1,024
 // envs per GPU) are resident together with up to 256 VGPRs per lane; up to 16 rocks four waves, above eight.  (Round 1
 // kept a slot for every pair up to 16 rocks and 192 above, which needed two points per thread and 256 VGPRs + scratch.)
+// The 16-rock variant is built for three waves per SIMD (168 VGPRs, 62 spilled to scratch): its shapes (2,048 - 4,096
+// envs x 16 rocks) are throughput-bound, and a third workgroup per CU is worth more than the spills cost — 60.7 -> 50.1 ms
+// per launch at 4,096 envs; four waves per SIMD (128 VGPRs) spill 108 registers and lose: 80 ms.
 extern "C" __global__ void __launch_bounds__(128, 2) srl_k_step(const DevParams* __restrict__ Pp,
     const int64_t* __restrict__ action, int force_reset) {
   step_body<128, 1>(Pp, action, force_reset);
 }
-extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp1(const DevParams* __restrict__ Pp,
+extern "C" __global__ void __launch_bounds__(256, 3) srl_k_step_pp1(const DevParams* __restrict__ Pp,
     const int64_t* __restrict__ action, int force_reset) {
   step_body<256, 1>(Pp, action, force_reset);
 }
