@@ -54,7 +54,7 @@ def parse_args(argv=None):
   ap.add_argument('--seed', type=int, default=11)
   ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline / reward-MSE legs')
   ap.add_argument('--no-dqn', action='store_true', help='skip leg B')
-  ap.add_argument('--dqn-iters', type=int, default=12)
+  ap.add_argument('--dqn-iters', type=int, default=None, help='leg B: timed iterations (default: one whole episode, L + 1 calls)')
   ap.add_argument('--dqn-warmup', type=int, default=6)
   ap.add_argument('--dqn-envs', type=int, default=None, help='leg B: envs per GPU (default by --gpus, see above)')
   ap.add_argument('--dqn-rocks', type=int, default=None)
@@ -284,7 +284,8 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
   B, L, res, name = dqn_shape(args)
   # as the headline (--config 2|3|4) the leg follows the contract's K timed / W warm-up steps; the three eager updates
   # and the graph capture of the update (DQN._GRAPH_WARMUP) then run before those, as part of the setup
-  iters, warm, pre = (args.steps, args.warmup, 5) if args.config != 1 else (args.dqn_iters, args.dqn_warmup, 0)
+  # (default: one whole episode of L placements + the auto-reset call, so that every fill level of the scene is in the window)
+  iters, warm, pre = (args.steps, args.warmup, 5) if args.config != 1 else (args.dqn_iters or L + 1, args.dqn_warmup, 0)
   kw = dict(solver_kw)
   if res == 64:
     kw['resolution_factor'] = 4
