@@ -1,7 +1,7 @@
 // settle.hip — K1 (place / smooth placing / settle) + K4 (Observer.pose) + the episode machine.
 //
-// One workgroup per env: 128 threads (2 waves) for L <= 8 bodies, 256 threads with 1 - 2 contact points per
-// thread above that, 512 threads with 2 for the longest episodes (srl_k_step / _pp1 / _pp2 / _t512).  The env's whole persistent state ("blob": poses,
+// One workgroup per env: 128 threads (2 waves) for L <= 8 bodies, 256 threads with one contact point per thread up to
+// 16, 256 threads with two above (srl_k_step / _pp1 / _pp2).  The env's whole persistent state ("blob": poses,
 // velocities, ground and body-body manifolds with their warm-start impulses, slot tables) is loaded into
 // LDS once, every sub-step runs out of LDS, and the blob is written back once — HBM traffic per env step
 // is 2 x BLOB words regardless of how many sub-steps the stop criterion takes.
@@ -695,7 +695,10 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
     const int b = it / P.VS, k = it - b * P.VS;
     if (k < __float_as_int(L.BC(b)[5])) {
       const m3 R = ldm(L.R(b));
-      st3(L.WV(b) + 3 * k, mmul_add(R, ld3(L.LV(b) + 3 * k), ld3(L.X(b))));
+      v3 lv;
+      if (P.S_LV >= 0) lv = ld3(L.LV(b) + 3 * k);
+      else { const float4 g4 = P.mv[__float_as_int(L.BC(b)[6]) + k]; lv = V(g4.x, g4.y, g4.z); }   // no LDS copy: the L2-resident mesh table
+      st3(L.WV(b) + 3 * k, mmul_add(R, lv, ld3(L.X(b))));
     }
   }
   __syncthreads();
@@ -1023,7 +1026,9 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
     bc[5] = __int_as_float(mh.nv); bc[6] = __int_as_float(mh.vo); bc[7] = __int_as_float(m);
   }
   __syncthreads();
-  // local (COM-frame) vertices of every body into LDS, once per step
+  // local (COM-frame) vertices of every body into LDS, once per step (the 32-rock variant reads them from the mesh table
+  // instead: without this copy two of its workgroups fit a CU)
+  if (P.S_LV >= 0)
   for (int it = tid; it < nb * P.VS; it += T) {
     const int b = it / P.VS, k = it - b * P.VS;
     const float* bc = L.BC(b);
@@ -1095,7 +1100,7 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
 
 // Variants: T threads per env, one contact point of the body-body manifolds per thread (4 NS <= T; NS = 28 / 64 / 128
 // slots up to 8 / 16 / 32 rocks, stackrl_hip.hip nslots).  L <= 8 runs two waves per env so that four envs per CU (1,024
-// envs per GPU) are resident together with up to 256 VGPRs per lane; up to 16 rocks four waves, above eight.  (Round 1
+// envs per GPU) are resident together with up to 256 VGPRs per lane; up to 16 rocks four waves; above: srl_k_step_pp2.  (Round 1
 // kept a slot for every pair up to 16 rocks and 192 above, which needed two points per thread and 256 VGPRs + scratch.)
 // The 16-rock variant is built for three waves per SIMD (168 VGPRs, 62 spilled to scratch): its shapes (2,048 - 4,096
 // envs x 16 rocks) are throughput-bound, and a third workgroup per CU is worth more than the spills cost — 60.7 -> 50.1 ms
@@ -1108,9 +1113,12 @@ extern "C" __global__ void __launch_bounds__(256, 3) srl_k_step_pp1(const DevPar
     const int64_t* __restrict__ action, int force_reset) {
   step_body<256, 1>(Pp, action, force_reset);
 }
-extern "C" __global__ void __launch_bounds__(512, 1) srl_k_step_t512(const DevParams* __restrict__ Pp,
+// Above 16 rocks: four waves with two points per thread (128 slots) and no LDS copy of the local vertices — 70 KB per env,
+// two workgroups per CU.  (Eight waves with one point per thread and the vertex copy, 97 KB and one workgroup per CU:
+// 145.5 against 104.9 ms per launch at 2,048 envs x 32 rocks.)
+extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp2(const DevParams* __restrict__ Pp,
     const int64_t* __restrict__ action, int force_reset) {
-  step_body<512, 1>(Pp, action, force_reset);
+  step_body<256, 2>(Pp, action, force_reset);
 }
 
 // ------------------------------------------------------------------ ParallelEnv.sample (utils.py:534-538)

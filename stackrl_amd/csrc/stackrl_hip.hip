@@ -138,7 +138,9 @@ void layout(DevParams& P) {
   P.S_AMAX = s; s += 3 * L;
   P.S_BC = s; s += 8 * L;
   P.S_WV = s; s += 3 * P.VS * L;
-  P.S_LV = s; s += 3 * P.VS * L;
+  // above 16 rocks the local vertices are read from the (L2-resident) mesh table instead of an LDS copy: 70 instead of
+  // 97 KB per env, so that two workgroups share a CU
+  if (L > 16) P.S_LV = -1; else { P.S_LV = s; s += 3 * P.VS * L; }
   s = (s + 1) & ~1;
   P.S_USED = s; s += 2 * SRL_MAX_BODIES;   // colouring scratch (uint64 per body); BLOB is a multiple of 4 words
   P.S_MISC = s; s += M_WORDS;
@@ -178,8 +180,8 @@ int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void*
     env->P_dirty = false;
   }
   const DevParams* dP = env->d_P;
-  if (env->step_pp == 3) SRL_LAUNCH(env, 0, srl_k_step_t512, dim3(n), dim3(512), env->step_lds, st, dP, action, force_reset);
-  else if (env->step_pp == 0) SRL_LAUNCH(env, 0, srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
+  if (env->step_pp == 0) SRL_LAUNCH(env, 0, srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
+  else if (env->step_pp == 2) SRL_LAUNCH(env, 0, srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
   else SRL_LAUNCH(env, 0, srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
   if (force_reset < 0) {   // srl_step_simulation: sub-steps only
     HIP_TRY(hipGetLastError());
@@ -388,16 +390,17 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   env->step_lds = sizeof(float) * (size_t)P.LDS_WORDS;
   if (env->step_lds > 160 * 1024) return fail(SRL_EINVAL, "episode_length x mesh size exceeds the 160 KB LDS budget");
   // threads per env / pair-manifold points per thread (settle.hip "Variants")
-  // one contact point per thread: 128 threads up to 8 rocks, 256 up to 16, 512 above (settle.hip "Variants")
+  // 128 threads up to 8 rocks, 256 up to 16 (one contact point per thread), 256 with two points per thread above
+  // (settle.hip "Variants")
   if (4 * P.NS <= 128 && SRL_GMAXP * P.c.episode_length <= 128) { env->step_threads = 128; env->step_pp = 0; }
   else if (4 * P.NS <= 256) { env->step_threads = 256; env->step_pp = 1; }
-  else { env->step_threads = 512; env->step_pp = 3; }
-  HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_t512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
+  else { env->step_threads = 256; env->step_pp = 2; }
   const int res = P.c.overhead_res;
   env->render_lds = render_lds_bytes(res);
   env->objmap_lds = 0;
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->render_lds));
   // K3: object maps of the whole pool, once
   hipLaunchKernelGGL(srl_k_objmap, dim3(n_mesh, P.n_orient), dim3(256), env->objmap_lds, 0, P, env->d_objmap, env->d_objmap_u8);
