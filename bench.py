@@ -410,7 +410,7 @@ def worker(args):
   pool = assets.default_pool()           # synthetic rocks, generator seed 11 (cached)
 
   cpu = None
-  if rank == 0 and not args.no_cpu:
+  if rank == 0 and args.gpus == 1 and not args.no_cpu:      # the CPU legs belong to the N = 1 run
     from oracle import oracle as _o
     _o.build()
     cpu = cpu_baseline(L, args.seed, solver_kw)     # before any GPU initialisation in this process
@@ -454,7 +454,7 @@ def worker(args):
         torch.cuda.synchronize()
 
   mse = None
-  if rank == 0 and not args.no_cpu:
+  if rank == 0 and args.gpus == 1 and not args.no_cpu:
     mse = reward_mse(args, pool, L, solver_kw)
 
   if rank == 0:
