@@ -71,7 +71,7 @@ int srl_conv3x3_bias_relu(const void* in_dev, const void* wfrag_dev, const float
                           int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t out_stride,
                           int32_t out_offset, int32_t nchw, void* stream);
 /* The same layer in fp32-class precision (the fp32 rollout, the reference's dtype): float32 channels-last in and out,
- * cin, cout in {16, 32}; every product is hi hi + hi lo + lo hi of bfloat16 halves on the matrix cores, fp32 accumulation
+ * cin in {16, 32, 64}, cout in {16, 32}; every product is hi hi + hi lo + lo hi of bfloat16 halves on the matrix cores, fp32 accumulation
  * ("bf16x3").  wfrag: 2 x srl_conv3x3_wfrag_elems(cin, cout) bfloat16 elements — the fragments of bf16(w), then those of
  * bf16(w - bf16(w)), each in the order described above.  pooled (may be NULL) float32 [B][H/2][W/2][cout]. */
 int srl_conv3x3_bias_relu_f32(const float* in_dev, const void* wfrag_dev, const float* bias_dev, float* out_dev,
@@ -83,11 +83,18 @@ int srl_conv3x3_bias_relu_f32(const float* in_dev, const void* wfrag_dev, const 
  * region is written: a zero-initialised margin stays zero). */
 int srl_conv3x3_thin(const void* in_dev, int32_t in_dtype, const float* w_dev, const float* bias_dev, void* out_dev,
                      int32_t B, int32_t H, int32_t W, int32_t cin, int32_t Hp, int32_t Wp, void* stream);
+/* The same with float32 output [B][Hp][Wp][16] (the fp32 rollout; the arithmetic is fp32 in both). */
+int srl_conv3x3_thin_f32(const void* in_dev, int32_t in_dtype, const float* w_dev, const float* bias_dev, float* out_dev,
+                         int32_t B, int32_t H, int32_t W, int32_t cin, int32_t Hp, int32_t Wp, void* stream);
 /* conv3x3 16 -> 16 + bias + ReLU followed by the 1 x 1 convolution to one channel, in one kernel (the tail of
  * `pos_layers`, layers.py:439-472): in bfloat16 [B][H][W][16] (H, W multiples of 16), out float32 [B][Hv][Wv]. */
 int srl_conv3x3_relu_project(const void* in_dev, const void* wfrag_dev, const float* bias_dev, const float* proj_w_dev,
                              float proj_b, float* out_dev, int32_t B, int32_t H, int32_t W, int32_t Hv, int32_t Wv,
                              void* stream);
+/* The same in fp32-class precision: in float32 [B][H][W][16], wfrag as for srl_conv3x3_bias_relu_f32 (16 -> 16). */
+int srl_conv3x3_relu_project_f32(const float* in_dev, const void* wfrag_dev, const float* bias_dev, const float* proj_w_dev,
+                                 float proj_b, float* out_dev, int32_t B, int32_t H, int32_t W, int32_t Hv, int32_t Wv,
+                                 void* stream);
 /* Transposed convolution 2 x 2, stride 2 + bias + ReLU on the matrix cores (`up{i}` of layers.unet, layers.py:222-229),
  * (cin, cout) in {(32, 16), (64, 32)}: in bfloat16 [B][H][W][cin] (W a multiple of 16) -> the channel slice
  * [out_offset, out_offset + cout) of a channels-last buffer [B][2H][2W][out_stride].  wfrag: the ConvTranspose2d weight
@@ -98,6 +105,11 @@ int32_t srl_convt2x2_wfrag_elems(int32_t cin, int32_t cout);
 int srl_convt2x2_bias_relu(const void* in_dev, const void* wfrag_dev, const float* bias_dev, void* out_dev, int32_t B,
                            int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset,
                            void* stream);
+/* The same in fp32-class precision (bf16x3 products): float32 in and out; wfrag: 2 x srl_convt2x2_wfrag_elems(cin, cout)
+ * bfloat16 elements, the fragments of bf16(w), then those of bf16(w - bf16(w)). */
+int srl_convt2x2_bias_relu_f32(const float* in_dev, const void* wfrag_dev, const float* bias_dev, float* out_dev, int32_t B,
+                               int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset,
+                               void* stream);
 const char* srl_conv_last_error(void);
 
 /* adv float32 [B][A]; u float32 [B] uniform(0,1); rnd int64 [B] uniform {0..A-1}; actions int64 [B] */

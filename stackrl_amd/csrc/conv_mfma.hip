@@ -25,6 +25,7 @@ namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t c_bf16_rne(float f) {
   const uint32_t u = __float_as_uint(f);
@@ -178,12 +179,19 @@ k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, c
 // hi hi + hi lo + lo hi on the matrix cores with fp32 accumulation ("bf16x3": relative error ~2^-16 per product, the
 // split the cross-correlation kernel uses) — a third of the bf16 MFMA rate, which these HBM-bound layers do not miss.
 // The input tile is split once while it is staged (two bf16 planes in LDS), the weights arrive pre-split (hi fragments,
-// then lo fragments) and stay in registers.  CIN in {16, 32} (CIN = 64 would need 93 KB of LDS per workgroup).
-template <int CIN, int COUT, int MT_W>
+// then lo fragments) and stay in registers.  CIN in {16, 32, 64}; 64 input channels (the decoder's 32 + 32 concat
+// buffer) go through in two passes of 32 — stage, load that half's weights, accumulate — so the tile stays at 52 KB
+// of LDS and the weights at 144 VGPRs.
+// PROJ: the fused 1 x 1 projection of `pos_layers`, as in k_conv3x3.
+template <int CIN, int COUT, int MT_W, bool PROJ>
 __global__ void __launch_bounds__(256, 2)
 k_conv3x3_x3(const float* __restrict__ in, const uint16_t* __restrict__ wfrag, const float* __restrict__ bias,
-             float* __restrict__ out, float* __restrict__ pooled, int H, int W, int ostride, int ooff, int nchw) {
-  typedef ConvCfg<CIN> G;
+             float* __restrict__ out, float* __restrict__ pooled, int H, int W, int ostride, int ooff, int nchw,
+             const float* __restrict__ pw, float pb, float* __restrict__ proj_out, int Hv, int Wv) {
+  constexpr int CB = CIN > 32 ? 32 : CIN;   // channels per pass
+  constexpr int NP = CIN / CB;              // passes
+  typedef ConvCfg<CB> G;
+  constexpr int KST = G::KS * NP;           // K steps of the whole layer (fragment order: tap-major, 32-channel block minor)
   constexpr int MT = COUT / 16;
   constexpr int WM = MT / MT_W;
   constexpr int RW = 16 / (4 / WM);
@@ -194,63 +202,91 @@ k_conv3x3_x3(const float* __restrict__ in, const uint16_t* __restrict__ wfrag, c
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
   const int x0 = 16 * tx, y0 = 16 * ty;
   const int mt0 = (wave % WM) * MT_W, row0 = (wave / WM) * RW;
-  bf16x8 wh[G::KS][MT_W], wl[G::KS][MT_W];
-#pragma unroll
-  for (int ks = 0; ks < G::KS; ++ks)
-#pragma unroll
-    for (int mt = 0; mt < MT_W; ++mt) {
-      wh[ks][mt] = ((const bf16x8*)wfrag)[(ks * MT + mt0 + mt) * 64 + lane];
-      wl[ks][mt] = ((const bf16x8*)wfrag)[((G::KS + ks) * MT + mt0 + mt) * 64 + lane];
-    }
-  {
-    constexpr int CPP = CIN / 8;   // 8-channel chunks per pixel
-    const float* src = in + (size_t)b * H * W * CIN;
-    for (int k = tid; k < G::TW * G::TW * CPP; k += 256) {
-      const int p = k / CPP, ch = k - p * CPP;
-      const int py = p / G::TW, px = p - py * G::TW;
-      const int y = y0 + py - 1, x = x0 + px - 1;
-      float v[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-      if (y >= 0 && y < H && x >= 0 && x < W) {
-        const float4 a = *(const float4*)(src + ((size_t)y * W + x) * CIN + ch * 8);
-        const float4 c = *(const float4*)(src + ((size_t)y * W + x) * CIN + ch * 8 + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
-      }
-      uint32_t hi[4], lo[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t h0 = c_bf16_rne(v[2 * j]), h1 = c_bf16_rne(v[2 * j + 1]);
-        const uint32_t l0 = c_bf16_rne(v[2 * j] - __uint_as_float(h0 << 16)), l1 = c_bf16_rne(v[2 * j + 1] - __uint_as_float(h1 << 16));
-        hi[j] = h0 | (h1 << 16); lo[j] = l0 | (l1 << 16);
-      }
-      *(uint4*)(tile + p * G::PS + ch * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-      *(uint4*)(tile + PLANE + p * G::PS + ch * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-    }
-  }
-  __syncthreads();
+  const int n = lane & 15, g = lane >> 4;
   f32x4 acc[RW][MT_W];
 #pragma unroll
   for (int r = 0; r < RW; ++r)
 #pragma unroll
     for (int mt = 0; mt < MT_W; ++mt) acc[r][mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-  const int n = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int ks = 0; ks < G::KS; ++ks) {
-    int tap, ci0;
-    k_of<CIN>(ks, g, tap, ci0);
-    if (tap > 8) tap = 8;
-    const int dy = tap / 3, dx = tap - 3 * dy;
+  for (int ps = 0; ps < NP; ++ps) {
+    bf16x8 wh[G::KS][MT_W], wl[G::KS][MT_W];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
-      const int off = ((row0 + r + dy) * G::TW + n + dx) * G::PS + ci0;
-      const bf16x8 xh = *(const bf16x8*)(tile + off), xl = *(const bf16x8*)(tile + PLANE + off);
+    for (int ks = 0; ks < G::KS; ++ks)
 #pragma unroll
       for (int mt = 0; mt < MT_W; ++mt) {
-        // small terms first: lo hi + hi lo, then the leading product
-        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks][mt], xh, acc[r][mt], 0, 0, 0);
-        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][mt], xl, acc[r][mt], 0, 0, 0);
-        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][mt], xh, acc[r][mt], 0, 0, 0);
+        const int kg = ks * NP + ps;
+        wh[ks][mt] = ((const bf16x8*)wfrag)[(kg * MT + mt0 + mt) * 64 + lane];
+        wl[ks][mt] = ((const bf16x8*)wfrag)[((KST + kg) * MT + mt0 + mt) * 64 + lane];
+      }
+    if (ps) __syncthreads();   // the previous pass has read its tile
+    {
+      constexpr int CPP = CB / 8;   // 8-channel chunks per pixel
+      const float* src = in + (size_t)b * H * W * CIN + ps * CB;
+      for (int k = tid; k < G::TW * G::TW * CPP; k += 256) {
+        const int p = k / CPP, ch = k - p * CPP;
+        const int py = p / G::TW, px = p - py * G::TW;
+        const int y = y0 + py - 1, x = x0 + px - 1;
+        float v[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+          const float4 a = *(const float4*)(src + ((size_t)y * W + x) * CIN + ch * 8);
+          const float4 c = *(const float4*)(src + ((size_t)y * W + x) * CIN + ch * 8 + 4);
+          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+        }
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t h0 = c_bf16_rne(v[2 * j]), h1 = c_bf16_rne(v[2 * j + 1]);
+          const uint32_t l0 = c_bf16_rne(v[2 * j] - __uint_as_float(h0 << 16)), l1 = c_bf16_rne(v[2 * j + 1] - __uint_as_float(h1 << 16));
+          hi[j] = h0 | (h1 << 16); lo[j] = l0 | (l1 << 16);
+        }
+        *(uint4*)(tile + p * G::PS + ch * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *(uint4*)(tile + PLANE + p * G::PS + ch * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
       }
     }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      int tap, ci0;
+      k_of<CB>(ks, g, tap, ci0);
+      if (tap > 8) tap = 8;
+      const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int off = ((row0 + r + dy) * G::TW + n + dx) * G::PS + ci0;
+        const bf16x8 xh = *(const bf16x8*)(tile + off), xl = *(const bf16x8*)(tile + PLANE + off);
+#pragma unroll
+        for (int mt = 0; mt < MT_W; ++mt) {
+          // small terms first: lo hi + hi lo, then the leading product
+          acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks][mt], xh, acc[r][mt], 0, 0, 0);
+          acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][mt], xl, acc[r][mt], 0, 0, 0);
+          acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][mt], xh, acc[r][mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (PROJ) {
+    static_assert(!PROJ || MT_W == MT, "the projection epilogue needs all channels in one wave");
+    float part[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) part[r] = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < MT_W; ++mt) {
+      const int co = 16 * mt + 4 * g;
+      const float4 bz = *(const float4*)(bias + co), wz = *(const float4*)(pw + co);
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+        part[r] += (wz.x * fmaxf(acc[r][mt][0] + bz.x, 0.0f) + wz.y * fmaxf(acc[r][mt][1] + bz.y, 0.0f)) +
+                   (wz.z * fmaxf(acc[r][mt][2] + bz.z, 0.0f) + wz.w * fmaxf(acc[r][mt][3] + bz.w, 0.0f));
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      part[r] += __shfl_xor(part[r], 16);
+      part[r] += __shfl_xor(part[r], 32);
+      const int y = y0 + row0 + r, x = x0 + n;
+      if (g == 0 && y < Hv && x < Wv) proj_out[((size_t)b * Hv + y) * Wv + x] = part[r] + pb;
+    }
+    return;
   }
 #pragma unroll
   for (int mt = 0; mt < MT_W; ++mt) {
@@ -288,45 +324,107 @@ k_conv3x3_x3(const float* __restrict__ in, const uint16_t* __restrict__ wfrag, c
   }
 }
 
+// what one tap of the thin convolution loads: the pixel's CIN values in one register (pair)
+template <int CIN, typename TIN> struct ThinRaw;
+template <> struct ThinRaw<1, uint8_t> {
+  typedef uint32_t type;
+  static __device__ __forceinline__ type load(const uint8_t* p) { return *p; }
+  static __device__ __forceinline__ float get(type r, int) { return (float)(r & 0xffu); }
+};
+template <> struct ThinRaw<2, uint8_t> {
+  typedef uint32_t type;
+  static __device__ __forceinline__ type load(const uint8_t* p) { return *(const uint16_t*)p; }
+  static __device__ __forceinline__ float get(type r, int c) { return (float)((r >> (8 * c)) & 0xffu); }
+};
+template <> struct ThinRaw<1, float> {
+  typedef float type;
+  static __device__ __forceinline__ type load(const float* p) { return *p; }
+  static __device__ __forceinline__ float get(type r, int) { return r; }
+};
+template <> struct ThinRaw<2, float> {
+  typedef uint64_t type;
+  static __device__ __forceinline__ type load(const float* p) { return *(const uint64_t*)p; }
+  static __device__ __forceinline__ float get(type r, int c) { return __uint_as_float((uint32_t)(r >> (32 * c))); }
+};
+
 // 3 x 3 convolution + bias + ReLU from 1 or 2 input channels to 16 (the first layer of each U-Net and of
 // `pos_layers`): K = 9 or 18 is too thin for the matrix cores, the layer is bound by its 32-byte-per-pixel output.
-// One thread per output pixel, fp32 math, weights in LDS (broadcast reads), bf16 channels-last output into a buffer
+// One thread per output pixel, fp32 math, weights in SGPRs (scalar loads), bf16 channels-last output into a buffer
 // of Hp x Wp pixels (>= H x W; the margin is left untouched: zero for the padded maps the MFMA kernel reads).
 // TIN = uint8_t: the env's observation bytes, scaled by 1/255 here (models.py:144-147); float: as is.
-template <int CIN, typename TIN>
+// TOUT = uint16_t: bf16 output; float: the fp32 rollout (the arithmetic is fp32 either way).
+template <int CIN, typename TIN, typename TOUT>
 __global__ void __launch_bounds__(256)
 k_conv3x3_thin(const TIN* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
-               uint16_t* __restrict__ out, int H, int W, int Hp, int Wp) {
-  __shared__ float sw[16 * CIN * 9 + 16];
-  for (int k = threadIdx.x; k < 16 * CIN * 9; k += 256) sw[k] = w[k];
-  if (threadIdx.x < 16) sw[16 * CIN * 9 + threadIdx.x] = bias[threadIdx.x];
-  __syncthreads();
+               TOUT* __restrict__ out, int H, int W, int Hp, int Wp) {
+  constexpr int WPP = 16 * sizeof(TOUT) / 4;   // 32-bit words per output pixel
+  constexpr int NQ = WPP / 4;                  // 16-byte quads per pixel = lanes that share a pixel when storing
+  constexpr int LS = WPP + 4;                  // LDS pixel stride in words (16-byte aligned, de-phased banks)
+  __shared__ uint32_t xch[256 * LS];
   const int b = blockIdx.y;
   const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= H * W) return;
-  const int y = p / W, x = p - y * W;
+  const int y = p / W, x = p - y * W;          // p >= H W: every tap is out of range, the result is not stored
   const float scale = sizeof(TIN) == 1 ? 1.0f / 255.0f : 1.0f;
-  float v[9][CIN];
+  // unconditional loads from clamped coordinates, all in flight together, zeroed afterwards (SAME padding); the two
+  // bytes of a 2-channel uint8 pixel come as one 16-bit load
+  typedef typename ThinRaw<CIN, TIN>::type RAW;
+  RAW raw[9];
+  bool ok[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-    const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) v[t][c] = ok ? (float)in[(((size_t)b * H + yy) * W + xx) * CIN + c] * scale : 0.0f;
+    ok[t] = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+    raw[t] = ThinRaw<CIN, TIN>::load(in + ((size_t)b * H * W + (unsigned)(yc * W + xc)) * CIN);
   }
-  uint32_t pk[8];
+  // one fence for the nine values: keeps the loads out of the selects' branches without serialising them
+  asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]),
+               "+v"(raw[7]), "+v"(raw[8]));
+  float v[9][CIN];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) v[t][c] = ok[t] ? ThinRaw<CIN, TIN>::get(raw[t], c) * scale : 0.0f;
+  float r[16];
 #pragma unroll
   for (int co = 0; co < 16; ++co) {
-    float a = sw[16 * CIN * 9 + co];
+    // uniform addresses: the weights and biases arrive by scalar loads and are SGPR operands of the FMAs; two partial
+    // sums over alternate k so that the FMAs pair up as v_pk_fma_f32 (weights w[k], w[k + 1] are adjacent SGPRs)
+    const float* wk = w + co * CIN * 9;
+    f32x2 a = {bias[co], 0.0f};
 #pragma unroll
-    for (int c = 0; c < CIN; ++c)
-#pragma unroll
-      for (int t = 0; t < 9; ++t) a = fmaf(sw[(co * CIN + c) * 9 + t], v[t][c], a);
-    const uint32_t h = c_bf16_rne(fmaxf(a, 0.0f));
-    if (co & 1) pk[co >> 1] |= h << 16; else pk[co >> 1] = h;
+    for (int k = 0; k + 1 < 9 * CIN; k += 2) {
+      const f32x2 wv = {wk[k], wk[k + 1]};
+      const f32x2 xv = {v[k % 9][k / 9], v[(k + 1) % 9][(k + 1) / 9]};
+      a = __builtin_elementwise_fma(wv, xv, a);
+    }
+    float sum = a[0] + a[1];
+    if ((9 * CIN) & 1) sum = fmaf(wk[9 * CIN - 1], v[8][CIN - 1], sum);
+    r[co] = fmaxf(sum, 0.0f);
   }
-  uint4* o = (uint4*)(out + (((size_t)b * Hp + y) * Wp + x) * 16);
-  o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]); o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+  // a thread's pixel is 32 or 64 contiguous bytes: exchanged through LDS so that every store instruction of a wave
+  // writes one contiguous kilobyte (NQ adjacent lanes = the quads of one pixel)
+  uint32_t* mine = xch + threadIdx.x * LS;
+  if (sizeof(TOUT) == 4) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(float4*)(mine + 4 * q) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+  } else {
+    uint32_t pk[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) pk[q] = c_bf16_rne(r[2 * q]) | (c_bf16_rne(r[2 * q + 1]) << 16);
+    *(uint4*)mine = make_uint4(pk[0], pk[1], pk[2], pk[3]); *(uint4*)(mine + 4) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+  }
+  __syncthreads();
+  const int wave0 = threadIdx.x & ~63, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int t = wave0 + i * (64 / NQ) + lane / NQ, q = lane % NQ;   // source thread (pixel) and quad
+    const int pp = blockIdx.x * 256 + t;
+    if (pp < H * W) {
+      const int py = pp / W, px = pp - py * W;
+      *(uint4*)((uint32_t*)(out + (((size_t)b * Hp + py) * Wp + px) * 16) + 4 * q) = *(const uint4*)(xch + t * LS + 4 * q);
+    }
+  }
 }
 
 // Transposed convolution 2 x 2, stride 2 (`up{i}` of layers.unet, layers.py:222-229) + bias + ReLU: every input pixel
@@ -373,6 +471,63 @@ k_convt2x2(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, 
   }
 }
 
+// The transposed convolution in fp32-class precision (float32 in and out, bf16x3 products like k_conv3x3_x3): the lane's
+// 8 input channels (32 bytes) are split into hi / lo parts in registers, the weights arrive pre-split (hi fragments, then
+// lo fragments; 128 VGPRs for 64 -> 32); 16-byte stores of 4 consecutive output channels.
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256, 2)
+k_convt2x2_x3(const float* __restrict__ in, const uint16_t* __restrict__ wfrag, const float* __restrict__ bias,
+              float* __restrict__ out, int H, int W, int ostride, int ooff, long long ntiles) {
+  constexpr int MT = 4 * COUT / 16, KS = CIN / 32;
+  const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+  bf16x8 wh[KS][MT], wl[KS][MT];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      wh[ks][mt] = ((const bf16x8*)wfrag)[(ks * MT + mt) * 64 + lane];
+      wl[ks][mt] = ((const bf16x8*)wfrag)[((KS + ks) * MT + mt) * 64 + lane];
+    }
+  const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // 16 consecutive input pixels (W % 16 == 0)
+  if (tile >= ntiles) return;
+  const long long pix0 = tile * 16;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const float* src = in + (pix0 + n) * CIN + 32 * ks + 8 * g;
+    const float4 a = *(const float4*)src, c = *(const float4*)(src + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+    bf16x8 xh, xl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t h = c_bf16_rne(v[j]);
+      xh[j] = (short)h;
+      xl[j] = (short)c_bf16_rne(v[j] - __uint_as_float(h << 16));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks][mt], xh, acc[mt], 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][mt], xl, acc[mt], 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][mt], xh, acc[mt], 0, 0, 0);
+    }
+  }
+  const long long p = pix0 + n;
+  const int x = (int)(p % W);
+  const long long by = p / W;          // b * H + y
+  const long long b = by / H; const int y = (int)(by - b * H);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = 16 * mt + 4 * g;     // row of the GEMM = (dy, dx, co)
+    const int q = m / COUT, co = m - q * COUT, dy = q >> 1, dx = q & 1;
+    const float4 bz = *(const float4*)(bias + co);
+    *(float4*)(out + (((b * 2 * H + 2 * y + dy) * 2 * W) + 2 * x + dx) * ostride + ooff + co) =
+        make_float4(fmaxf(acc[mt][0] + bz.x, 0.0f), fmaxf(acc[mt][1] + bz.y, 0.0f), fmaxf(acc[mt][2] + bz.z, 0.0f),
+                    fmaxf(acc[mt][3] + bz.w, 0.0f));
+  }
+}
+
 thread_local char c_err[256] = "";
 
 template <int CIN, int COUT>
@@ -391,12 +546,31 @@ int launch(const void* in, const void* wfrag, const float* bias, void* out, void
 template <int CIN, int COUT>
 int launch_x3(const float* in, const void* wfrag, const float* bias, float* out, float* pooled, int B, int H, int W, int ostride,
               int ooff, int nchw, hipStream_t st) {
-  const size_t lds = 2 * sizeof(uint16_t) * ConvCfg<CIN>::TW * ConvCfg<CIN>::TW * ConvCfg<CIN>::PS;
+  typedef ConvCfg<(CIN > 32 ? 32 : CIN)> G;   // 64 input channels: two passes of 32
+  const size_t lds = 2 * sizeof(uint16_t) * G::TW * G::TW * G::PS;
   constexpr int MT_W = COUT / 16;
-  hipLaunchKernelGGL((k_conv3x3_x3<CIN, COUT, MT_W>), dim3((W / 16) * (H / 16), B), dim3(256), lds, st, in, (const uint16_t*)wfrag,
-                     bias, out, pooled, H, W, ostride, ooff, nchw);
+  hipLaunchKernelGGL((k_conv3x3_x3<CIN, COUT, MT_W, false>), dim3((W / 16) * (H / 16), B), dim3(256), lds, st, in, (const uint16_t*)wfrag,
+                     bias, out, pooled, H, W, ostride, ooff, nchw, (const float*)nullptr, 0.0f, (float*)nullptr, 0, 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "srl_conv3x3_bias_relu_f32: %s", hipGetErrorString(e)); return 2; }
+  return 0;
+}
+
+template <typename TOUT>
+int launch_thin(const char* what, const void* in, int32_t in_dtype, const float* w, const float* bias, TOUT* o, int32_t B,
+                int32_t H, int32_t W, int32_t cin, int32_t Hp, int32_t Wp, hipStream_t st) {
+  if (!in || !w || !bias || !o || B < 1 || H < 1 || W < 1 || Hp < H || Wp < W || (cin != 1 && cin != 2) ||
+      (in_dtype != 0 && in_dtype != 1)) {
+    snprintf(c_err, sizeof c_err, "%s: bad arguments (cin in {1, 2}; in_dtype 0 = uint8 / 255, 1 = float32)", what);
+    return 1;
+  }
+  const dim3 grid((H * W + 255) / 256, B), blk(256);
+  if (cin == 1 && in_dtype == 0) hipLaunchKernelGGL((k_conv3x3_thin<1, uint8_t, TOUT>), grid, blk, 0, st, (const uint8_t*)in, w, bias, o, H, W, Hp, Wp);
+  else if (cin == 1) hipLaunchKernelGGL((k_conv3x3_thin<1, float, TOUT>), grid, blk, 0, st, (const float*)in, w, bias, o, H, W, Hp, Wp);
+  else if (in_dtype == 0) hipLaunchKernelGGL((k_conv3x3_thin<2, uint8_t, TOUT>), grid, blk, 0, st, (const uint8_t*)in, w, bias, o, H, W, Hp, Wp);
+  else hipLaunchKernelGGL((k_conv3x3_thin<2, float, TOUT>), grid, blk, 0, st, (const float*)in, w, bias, o, H, W, Hp, Wp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "%s: %s", what, hipGetErrorString(e)); return 2; }
   return 0;
 }
 
@@ -410,15 +584,17 @@ int srl_conv3x3_bias_relu_f32(const float* in, const void* wfrag, const float* b
                               int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset,
                               int32_t nchw, void* stream) {
   if (!in || !wfrag || !bias || !out || B < 1 || H < 16 || W < 16 || H % 16 || W % 16 || out_stride % 4 || out_offset % 4 ||
-      (cin != 16 && cin != 32) || (cout != 16 && cout != 32) || (pooled && nchw)) {
-    snprintf(c_err, sizeof c_err, "srl_conv3x3_bias_relu_f32: bad arguments (H, W multiples of 16; cin, cout in {16, 32})");
+      srl_conv3x3_wfrag_elems(cin, cout) < 0 || (pooled && nchw)) {
+    snprintf(c_err, sizeof c_err, "srl_conv3x3_bias_relu_f32: bad arguments (H, W multiples of 16; cin in {16, 32, 64}, cout in {16, 32})");
     return 1;
   }
   hipStream_t st = (hipStream_t)stream;
   if (cin == 16 && cout == 16) return launch_x3<16, 16>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
   if (cin == 16 && cout == 32) return launch_x3<16, 32>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
   if (cin == 32 && cout == 16) return launch_x3<32, 16>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
-  return launch_x3<32, 32>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+  if (cin == 32 && cout == 32) return launch_x3<32, 32>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+  if (cin == 64 && cout == 16) return launch_x3<64, 16>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
+  return launch_x3<64, 32>(in, wfrag, bias, out, pooled, B, H, W, out_stride, out_offset, nchw, st);
 }
 
 int32_t srl_conv3x3_wfrag_elems(int32_t cin, int32_t cout) {
@@ -445,21 +621,12 @@ int srl_conv3x3_bias_relu(const void* in, const void* wfrag, const float* bias, 
 
 int srl_conv3x3_thin(const void* in, int32_t in_dtype, const float* w, const float* bias, void* out, int32_t B, int32_t H,
                      int32_t W, int32_t cin, int32_t Hp, int32_t Wp, void* stream) {
-  if (!in || !w || !bias || !out || B < 1 || H < 1 || W < 1 || Hp < H || Wp < W || (cin != 1 && cin != 2) ||
-      (in_dtype != 0 && in_dtype != 1)) {
-    snprintf(c_err, sizeof c_err, "srl_conv3x3_thin: bad arguments (cin in {1, 2}; in_dtype 0 = uint8 / 255, 1 = float32)");
-    return 1;
-  }
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((H * W + 255) / 256, B), blk(256);
-  uint16_t* o = (uint16_t*)out;
-  if (cin == 1 && in_dtype == 0) hipLaunchKernelGGL((k_conv3x3_thin<1, uint8_t>), grid, blk, 0, st, (const uint8_t*)in, w, bias, o, H, W, Hp, Wp);
-  else if (cin == 1) hipLaunchKernelGGL((k_conv3x3_thin<1, float>), grid, blk, 0, st, (const float*)in, w, bias, o, H, W, Hp, Wp);
-  else if (in_dtype == 0) hipLaunchKernelGGL((k_conv3x3_thin<2, uint8_t>), grid, blk, 0, st, (const uint8_t*)in, w, bias, o, H, W, Hp, Wp);
-  else hipLaunchKernelGGL((k_conv3x3_thin<2, float>), grid, blk, 0, st, (const float*)in, w, bias, o, H, W, Hp, Wp);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "srl_conv3x3_thin: %s", hipGetErrorString(e)); return 2; }
-  return 0;
+  return launch_thin("srl_conv3x3_thin", in, in_dtype, w, bias, (uint16_t*)out, B, H, W, cin, Hp, Wp, (hipStream_t)stream);
+}
+
+int srl_conv3x3_thin_f32(const void* in, int32_t in_dtype, const float* w, const float* bias, float* out, int32_t B, int32_t H,
+                         int32_t W, int32_t cin, int32_t Hp, int32_t Wp, void* stream) {
+  return launch_thin("srl_conv3x3_thin_f32", in, in_dtype, w, bias, out, B, H, W, cin, Hp, Wp, (hipStream_t)stream);
 }
 
 int32_t srl_convt2x2_wfrag_elems(int32_t cin, int32_t cout) {
@@ -481,6 +648,38 @@ int srl_convt2x2_bias_relu(const void* in, const void* wfrag, const float* bias,
   else hipLaunchKernelGGL((k_convt2x2<64, 32>), grid, blk, 0, st, (const uint16_t*)in, (const uint16_t*)wfrag, bias, (uint16_t*)out, H, W, out_stride, out_offset, ntiles);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "srl_convt2x2_bias_relu: %s", hipGetErrorString(e)); return 2; }
+  return 0;
+}
+
+int srl_convt2x2_bias_relu_f32(const float* in, const void* wfrag, const float* bias, float* out, int32_t B, int32_t H, int32_t W,
+                               int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset, void* stream) {
+  if (!in || !wfrag || !bias || !out || B < 1 || H < 1 || W < 16 || W % 16 || out_stride % 4 || out_offset % 4 ||
+      srl_convt2x2_wfrag_elems(cin, cout) < 0) {
+    snprintf(c_err, sizeof c_err, "srl_convt2x2_bias_relu_f32: bad arguments (W a multiple of 16; 32 -> 16 or 64 -> 32 channels)");
+    return 1;
+  }
+  const long long ntiles = (long long)B * H * W / 16;
+  const dim3 grid((unsigned)((ntiles + 3) / 4)), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (cin == 32) hipLaunchKernelGGL((k_convt2x2_x3<32, 16>), grid, blk, 0, st, in, (const uint16_t*)wfrag, bias, out, H, W, out_stride, out_offset, ntiles);
+  else hipLaunchKernelGGL((k_convt2x2_x3<64, 32>), grid, blk, 0, st, in, (const uint16_t*)wfrag, bias, out, H, W, out_stride, out_offset, ntiles);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "srl_convt2x2_bias_relu_f32: %s", hipGetErrorString(e)); return 2; }
+  return 0;
+}
+
+int srl_conv3x3_relu_project_f32(const float* in, const void* wfrag, const float* bias, const float* proj_w, float proj_b,
+                                 float* out, int32_t B, int32_t H, int32_t W, int32_t Hv, int32_t Wv, void* stream) {
+  if (!in || !wfrag || !bias || !proj_w || !out || B < 1 || H < 16 || W < 16 || H % 16 || W % 16 || Hv < 1 || Hv > H ||
+      Wv < 1 || Wv > W) {
+    snprintf(c_err, sizeof c_err, "srl_conv3x3_relu_project_f32: bad arguments");
+    return 1;
+  }
+  const size_t lds = 2 * sizeof(uint16_t) * ConvCfg<16>::TW * ConvCfg<16>::TW * ConvCfg<16>::PS;
+  hipLaunchKernelGGL((k_conv3x3_x3<16, 16, 1, true>), dim3((W / 16) * (H / 16), B), dim3(256), lds, (hipStream_t)stream, in,
+                     (const uint16_t*)wfrag, bias, (float*)nullptr, (float*)nullptr, H, W, 16, 0, 0, proj_w, proj_b, out, Hv, Wv);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "srl_conv3x3_relu_project_f32: %s", hipGetErrorString(e)); return 2; }
   return 0;
 }
 

@@ -47,6 +47,12 @@ def load():
     L.srl_convt2x2_bias_relu.argtypes = [VP] * 4 + [ctypes.c_int32] * 7 + [VP]
     L.srl_conv3x3_thin.restype = ctypes.c_int
     L.srl_conv3x3_thin.argtypes = [VP, ctypes.c_int32, VP, VP, VP] + [ctypes.c_int32] * 6 + [VP]
+    L.srl_conv3x3_thin_f32.restype = ctypes.c_int
+    L.srl_conv3x3_thin_f32.argtypes = L.srl_conv3x3_thin.argtypes
+    L.srl_convt2x2_bias_relu_f32.restype = ctypes.c_int
+    L.srl_convt2x2_bias_relu_f32.argtypes = L.srl_convt2x2_bias_relu.argtypes
+    L.srl_conv3x3_relu_project_f32.restype = ctypes.c_int
+    L.srl_conv3x3_relu_project_f32.argtypes = [VP, VP, VP, VP, ctypes.c_float, VP] + [ctypes.c_int32] * 5 + [VP]
     L.srl_conv3x3_relu_project.restype = ctypes.c_int
     L.srl_conv3x3_relu_project.argtypes = [VP, VP, VP, VP, ctypes.c_float, VP] + [ctypes.c_int32] * 5 + [VP]
     L.srl_policy_head.restype = ctypes.c_int
@@ -259,7 +265,7 @@ def pack_conv3x3_weights(w):
 
 
 def pack_conv3x3_weights_x3(w):
-  """Conv2d weight [cout, cin, 3, 3] (cin, cout in {16, 32}) -> the two bf16 fragment sets of the fp32-class kernel
+  """Conv2d weight [cout, cin, 3, 3] (cin in {16, 32, 64}, cout in {16, 32}) -> the two bf16 fragment sets of the fp32-class kernel
   (srl_conv3x3_bias_relu_f32): the fragments of bf16(w), then those of bf16(w - bf16(w))."""
   w = w.detach().float()
   hi = w.to(torch.bfloat16)
@@ -308,27 +314,38 @@ def pack_convt2x2_weights(w):
   return out
 
 
+def pack_convt2x2_weights_x3(w):
+  """ConvTranspose2d weight -> the hi and lo bf16 fragment sets of the fp32-class kernel (srl_convt2x2_bias_relu_f32)."""
+  w = w.detach().float()
+  hi = w.to(torch.bfloat16)
+  lo = (w - hi.float()).to(torch.bfloat16)
+  return torch.cat([pack_convt2x2_weights(hi.float()), pack_convt2x2_weights(lo.float())]).contiguous()
+
+
 def convt2x2_bias_relu(x, wfrag, bias, cout, out, out_offset=0):
   """relu(conv_transpose2d(x, k=2, s=2) + bias) into the channel slice [out_offset, out_offset + cout) of `out`
-  (bf16 channels-last, twice the spatial size of x), csrc/conv_mfma.hip."""
+  (channels-last, twice the spatial size of x), csrc/conv_mfma.hip.  bf16 tensors: bf16 MFMA; float32 tensors: the
+  fp32-class kernel (wfrag from pack_convt2x2_weights_x3)."""
   B, cin, H, W = x.shape
+  fn = load().srl_convt2x2_bias_relu_f32 if x.dtype == torch.float32 else load().srl_convt2x2_bias_relu
   with torch.cuda.device(x.device):
-    rc = load().srl_convt2x2_bias_relu(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, cin, cout,
+    rc = fn(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, cin, cout,
                                        out.shape[1], out_offset, _stream(x))
   if rc:
     raise RuntimeError(load().srl_conv_last_error().decode())
   return out
 
 
-def conv3x3_thin(x, w, bias, out=None):
+def conv3x3_thin(x, w, bias, out=None, dtype=torch.bfloat16):
   """relu(conv3x3(x) + bias) for 1 or 2 input channels -> 16 (csrc/conv_mfma.hip, vector ALU).  x: uint8 (scaled by
-  1/255) or float32, channels-last memory [B,H,W,cin].  Returns bf16 [B,16,Hp,Wp] channels-last; `out` (optional) is a
-  larger zero-margined buffer of that kind whose top-left H x W region is written."""
+  1/255) or float32, channels-last memory [B,H,W,cin].  Returns bf16 (or float32, per `dtype` / `out`) [B,16,Hp,Wp]
+  channels-last; `out` (optional) is a larger zero-margined buffer of that kind whose top-left H x W region is written."""
   B, H, W, cin = x.shape
   if out is None:
-    out = torch.empty((B, 16, H, W), dtype=torch.bfloat16, device=x.device, memory_format=_CL)
+    out = torch.empty((B, 16, H, W), dtype=dtype, device=x.device, memory_format=_CL)
+  fn = load().srl_conv3x3_thin_f32 if out.dtype == torch.float32 else load().srl_conv3x3_thin
   with torch.cuda.device(x.device):
-    rc = load().srl_conv3x3_thin(x.data_ptr(), int(x.dtype != torch.uint8), w.data_ptr(), bias.data_ptr(), out.data_ptr(),
+    rc = fn(x.data_ptr(), int(x.dtype != torch.uint8), w.data_ptr(), bias.data_ptr(), out.data_ptr(),
                                  B, H, W, cin, out.shape[2], out.shape[3], _stream(x))
   if rc:
     raise RuntimeError(load().srl_conv_last_error().decode())
@@ -339,8 +356,9 @@ def conv3x3_relu_project(x, wfrag, bias, proj_w, proj_b, hv, wv):
   """sum_c proj_w[c] relu(conv3x3(x)[c] + bias[c]) + proj_b, float32 [B,hv,wv]: the last two layers of `pos_layers`."""
   B, _, H, W = x.shape
   out = torch.empty((B, hv, wv), dtype=torch.float32, device=x.device)
+  fn = load().srl_conv3x3_relu_project_f32 if x.dtype == torch.float32 else load().srl_conv3x3_relu_project
   with torch.cuda.device(x.device):
-    rc = load().srl_conv3x3_relu_project(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), proj_w.data_ptr(), float(proj_b),
+    rc = fn(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), proj_w.data_ptr(), float(proj_b),
                                          out.data_ptr(), B, H, W, hv, wv, _stream(x))
   if rc:
     raise RuntimeError(load().srl_conv_last_error().decode())
@@ -355,10 +373,11 @@ class FastFeatures(object):
 
   def __init__(self, net, mfma_conv=True, dtype=torch.bfloat16, x3_conv=True):
     self.net = net
-    # dtype float32 = the reference's dtype: library fp32 convolutions without bias + the fused fp32 epilogues, and
-    # (x3_conv) the 16- / 32-channel 3 x 3 layers on the matrix cores in fp32-class precision (bf16x3 products,
-    # csrc/conv_mfma.hip k_conv3x3_x3); the thin first layers, the transposed convolutions and the position head stay
-    # library fp32 in this mode
+    # dtype float32 = the reference's dtype: (x3_conv) the same hand-written layers as the bf16 mode, in fp32-class
+    # precision — the 16- / 32-output-channel 3 x 3 layers, the 32 -> 16 / 64 -> 32 transposed convolutions and the
+    # position head with bf16x3 products on the matrix cores (csrc/conv_mfma.hip k_conv3x3_x3, k_convt2x2_x3), the thin
+    # first layers in fp32 on the vector ALU; the >= 64-output-channel layers are library fp32 convolutions without bias
+    # + the fused fp32 epilogues
     self.dtype = dtype
     self.mfma_conv = bool(mfma_conv) and dtype == torch.bfloat16   # hand-written MFMA kernel for the 16- / 32-channel 3 x 3 layers
     self.x3_conv = bool(x3_conv) and dtype == torch.float32
@@ -385,17 +404,17 @@ class FastFeatures(object):
            m.in_channels in (16, 32, 64) and m.out_channels in (16, 32):
           self._wf[m] = pack_conv3x3_weights(m.weight)
         if self.x3_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
-           m.in_channels in (16, 32) and m.out_channels in (16, 32):
+           m.in_channels in (16, 32, 64) and m.out_channels in (16, 32):
           self._wf[m] = pack_conv3x3_weights_x3(m.weight)
-        if self.mfma_conv and isinstance(m, torch.nn.ConvTranspose2d) and m.kernel_size == (2, 2) and \
+        if (self.mfma_conv or self.x3_conv) and isinstance(m, torch.nn.ConvTranspose2d) and m.kernel_size == (2, 2) and \
            (m.in_channels, m.out_channels) in ((32, 16), (64, 32)):
-          self._wf[m] = pack_convt2x2_weights(m.weight)
-        if self.mfma_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
+          self._wf[m] = pack_convt2x2_weights(m.weight) if self.mfma_conv else pack_convt2x2_weights_x3(m.weight)
+        if (self.mfma_conv or self.x3_conv) and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.in_channels in (1, 2) and m.out_channels == 16:
           self._wt[m] = m.weight.detach().float().contiguous()
     pos = getattr(self.net, 'pos', None)
     self._pos = None
-    if self.mfma_conv and pos is not None and len(pos) == 5 and pos[0] in self._wt and pos[2] in self._wf and \
+    if (self.mfma_conv or self.x3_conv) and pos is not None and len(pos) == 5 and pos[0] in self._wt and pos[2] in self._wf and \
        pos[4].kernel_size == (1, 1) and pos[4].in_channels == 16 and pos[4].out_channels == 1:
       self._pos = (pos[4].weight.detach().float().reshape(16).contiguous(), float(pos[4].bias.detach()))
     self._key = key
@@ -416,7 +435,7 @@ class FastFeatures(object):
     for blk in U.down:
       f = blk[0].out_channels
       if x is None and blk[0] in self._wt:
-        y = conv3x3_thin(obs, self._wt[blk[0]], self._w[blk[0]][1])      # /255 and the cast happen in the kernel
+        y = conv3x3_thin(obs, self._wt[blk[0]], self._w[blk[0]][1], dtype=self.dtype)   # /255 and the cast happen in the kernel
       elif x is None:
         # uint8 NHWC / 255 (models.py:144-147); the NHWC memory is exactly a channels-last NCHW tensor
         x = (obs.float() / 255.0).to(self.dtype).permute(0, 3, 1, 2)
@@ -470,8 +489,9 @@ class FastFeatures(object):
   @torch.no_grad()
   def pos(self, corr):
     """`pos_layers` (layers.py:439-472) on the correlation map [B,1,oh,ow] float32 -> advantages [B, oh*ow] float32:
-    the 1 -> 16 layer on the vector ALU into a zero-margined bf16 map padded to a multiple of 16, then the 16 -> 16
-    layer on the matrix cores with the final 1 x 1 projection fused into its epilogue (fp32 from the accumulators)."""
+    the 1 -> 16 layer on the vector ALU into a zero-margined map (of this object's dtype) padded to a multiple of 16, then
+    the 16 -> 16 layer on the matrix cores with the final 1 x 1 projection fused into its epilogue (fp32 from the
+    accumulators)."""
     self._refresh()
     if self._pos is None:
       return self.net.pos(corr).flatten(1)
@@ -481,7 +501,7 @@ class FastFeatures(object):
     key = (B, hp, wp, corr.device.index)
     buf = self._posbuf.get(key)
     if buf is None:
-      buf = torch.zeros((B, 16, hp, wp), dtype=torch.bfloat16, device=corr.device).contiguous(memory_format=_CL)
+      buf = torch.zeros((B, 16, hp, wp), dtype=self.dtype, device=corr.device).contiguous(memory_format=_CL)
       self._posbuf = {key: buf}
     conv3x3_thin(corr.reshape(B, oh, ow, 1).contiguous(), self._wt[pos[0]], self._w[pos[0]][1], out=buf)
     pw, pb = self._pos

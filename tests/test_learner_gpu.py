@@ -509,7 +509,7 @@ def test_replay_kernels_match_the_library_formulation(literal):
   np.testing.assert_allclose(wa.cpu().numpy(), wb.cpu().numpy(), rtol=2e-6)
 
 
-@pytest.mark.parametrize('cin,cout,H', [(16, 16, 32), (16, 32, 16), (32, 16, 48), (32, 32, 16)])
+@pytest.mark.parametrize('cin,cout,H', [(16, 16, 32), (16, 32, 16), (32, 16, 48), (32, 32, 16), (64, 32, 32), (64, 16, 16)])
 def test_conv3x3_bf16x3_matches_torch_fp64(cin, cout, H):
   """The fp32-class MFMA convolution (`k_conv3x3_x3`: bf16 hi/lo split, hi hi + hi lo + lo hi, fp32 accumulation) + bias +
   ReLU against float64 torch: 3e-5 of the output scale (the split's 2^-16 per product; fp32 itself sits at 1e-6 here), for
@@ -533,6 +533,69 @@ def test_conv3x3_bf16x3_matches_torch_fp64(cin, cout, H):
   assert yn.is_contiguous() and torch.equal(yn, y.contiguous())
 
 
+@pytest.mark.parametrize('cin,cout,H,W', [(32, 16, 12, 32), (64, 32, 8, 16)])
+def test_convt2x2_bf16x3_matches_torch_fp64(cin, cout, H, W):
+  """The fp32-class transposed convolution (`k_convt2x2_x3`) + bias + ReLU into a slice of the concat buffer against
+  float64 torch: 3e-5 of the output scale; the other half of the buffer untouched."""
+  from stackrl_amd import qops
+  F = torch.nn.functional
+  g = torch.Generator(device='cuda').manual_seed(cin + H)
+  B = 3
+  x = torch.randn((B, cin, H, W), generator=g, device='cuda').contiguous(memory_format=torch.channels_last)
+  w = torch.randn((cin, cout, 2, 2), generator=g, device='cuda') / cin ** 0.5
+  b = torch.randn(cout, generator=g, device='cuda') * 0.1
+  ref = F.relu(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2))
+  cat = torch.full((B, 2 * cout, 2 * H, 2 * W), 3.0, device='cuda').contiguous(memory_format=torch.channels_last)
+  qops.convt2x2_bias_relu(x, qops.pack_convt2x2_weights_x3(w), b, cout, cat, 0)
+  assert float((cat[:, :cout].double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+  assert bool((cat[:, cout:] == 3.0).all())
+
+
+def test_thin_conv_and_projection_head_fp32():
+  """float32 outputs of the thin first layers (fp32 FMAs: 1e-6 of the scale against float64) and the fp32-class
+  16 -> 16 -> 1 tail of `pos_layers` (bf16x3 products, fp32 projection: 3e-5) on a zero-margined padded buffer."""
+  from stackrl_amd import qops
+  F = torch.nn.functional
+  g = torch.Generator(device='cuda').manual_seed(21)
+  B, H, W = 3, 40, 56
+  for cin, dt in ((2, torch.uint8), (1, torch.uint8), (1, torch.float32)):
+    x = torch.randint(0, 256, (B, H, W, cin), generator=g, device='cuda', dtype=torch.uint8) if dt == torch.uint8 else \
+        torch.randn((B, H, W, cin), generator=g, device='cuda') * 30.0
+    w = (torch.rand((16, cin, 3, 3), generator=g, device='cuda') - 0.5) * 0.5
+    b = torch.rand(16, generator=g, device='cuda') - 0.5
+    xf = x.float() / 255.0 if dt == torch.uint8 else x
+    ref = F.relu(F.conv2d(xf.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1))
+    y = qops.conv3x3_thin(x, w, b, dtype=torch.float32)
+    assert y.shape == ref.shape and y.dtype == torch.float32 and y.is_contiguous(memory_format=torch.channels_last)
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+  buf = torch.zeros((B, 16, 48, 64), device='cuda').contiguous(memory_format=torch.channels_last)
+  qops.conv3x3_thin(x, w, b, out=buf)
+  assert torch.equal(buf[:, :, :H, :W], y) and float(buf[:, :, H:].abs().sum()) == 0 and float(buf[:, :, :, W:].abs().sum()) == 0
+  w2 = (torch.rand((16, 16, 3, 3), generator=g, device='cuda') - 0.5) * 0.2
+  b2 = torch.rand(16, generator=g, device='cuda') - 0.5
+  pw = torch.rand(16, generator=g, device='cuda') - 0.5
+  got = qops.conv3x3_relu_project(buf, qops.pack_conv3x3_weights_x3(w2), b2, pw, 0.25, H, W)
+  act = F.relu(F.conv2d(buf.double()[:, :, :H, :W], w2.double(), b2.double(), padding=1))
+  ref = (act * pw.double()[None, :, None, None]).sum(1) + 0.25
+  assert got.shape == (B, H, W) and got.dtype == torch.float32
+  assert float((got.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+
+
+def test_fast_position_head_fp32_tracks_the_module():
+  """`FastFeatures(dtype=float32).pos` against `net.pos` in fp32: fp32-class agreement (1e-4 of the advantage range)."""
+  from stackrl_amd import nets, qops
+  net = nets.DeepQSiamFCN(seed=9).cuda().eval()
+  g = torch.Generator(device='cuda').manual_seed(2)
+  corr = torch.randn((4, 1, 97, 97), generator=g, device='cuda') * 20.0
+  ff = qops.FastFeatures(net, dtype=torch.float32)
+  got = ff.pos(corr)
+  assert ff._pos is not None     # the hand-written head ran, not the module
+  with torch.no_grad():
+    ref = net.pos(corr).flatten(1)
+  assert got.shape == ref.shape == (4, 97 * 97) and got.dtype == torch.float32
+  assert float((got - ref).abs().max()) <= 1e-4 * float(ref.max() - ref.min())
+
+
 def test_fast_features_fp32_match_the_module():
   """The fp32 fast rollout (`FastFeatures(dtype=float32)`: bias-free library fp32 convolutions + the fused fp32 epilogues
   of csrc/epilogue.hip instead of separate bias / ReLU / max-pool / concatenate / layout kernels) against the stock fp32
@@ -551,8 +614,9 @@ def test_fast_features_fp32_match_the_module():
   for got, ref in ((fx, ex), (fw, ew)):
     assert got.shape == ref.shape and got.dtype == torch.float32 and got.is_contiguous()
     assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
-  # (b) + the 16- / 32-channel layers on the matrix cores as bf16x3 products: fp32-class, 2e-4 of the feature scale after
-  #     the whole U-Net (2^-16 per product, a dozen layers deep)
+  # (b) + the 16- / 32-output-channel layers and the two upper transposed convolutions on the matrix cores as bf16x3
+  #     products, the thin first layers on the vector ALU: fp32-class, 2e-4 of the feature scale after the whole U-Net
+  #     (2^-16 per product, a dozen layers deep)
   gx, gw = qops.FastFeatures(net, dtype=torch.float32)((xm, xo))
   for got, ref in ((gx, ex), (gw, ew)):
     assert got.dtype == torch.float32 and float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
