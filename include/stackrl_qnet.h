@@ -57,6 +57,13 @@ int srl_bias_act_f32(const float* in_dev, float* out_dev, const float* bias_dev,
                      int32_t out_stride, int32_t out_offset, int32_t nchw_hw, int32_t relu, void* stream);
 int srl_bias_act_pool_f32(const float* in_dev, float* skip_dev, float* pooled_dev, const float* bias_dev, int32_t B,
                           int32_t H, int32_t W, int32_t C, int32_t skip_stride, int32_t skip_offset, void* stream);
+/* Backward of the float32 bias + activation pass for the update path (agents/dqn.py:466-469): gx = gy * (y > 0) (relu)
+ * or gy, and gbias[c] = sum over pixels of gx[.][c], summed in a fixed order.  gy, y (the activation's output), gx:
+ * float32 channels-last [npix][C]; C a multiple of 8 that divides 2,048, at most 256; scratch:
+ * srl_bias_act_bwd_scratch_floats(npix, C) floats. */
+int64_t srl_bias_act_bwd_scratch_floats(int64_t npix, int32_t C);
+int srl_bias_act_bwd_f32(const float* gy_dev, const float* y_dev, float* gx_dev, float* gbias_dev, float* scratch_dev,
+                         int64_t npix, int32_t C, int32_t relu, void* stream);
 const char* srl_epilogue_last_error(void);
 
 /* 3 x 3 convolution (stride 1, SAME) + bias + ReLU on the matrix cores for the thin, wide layers of `layers.unet`

@@ -112,6 +112,73 @@ __global__ void __launch_bounds__(256) k_bias_act_pool(const E* __restrict__ in,
   store8(pooled + ((b * H2 + y2) * W2 + x2) * C + g * 8, m);
 }
 
+
+// Backward of y = relu(x + bias) (or y = x + bias) for the update path (`DQN.train`, agents/dqn.py:466-469): the gradient
+// with respect to x, gx = gy * (y > 0), and the per-block partial sums of the bias gradient, one pass over gy and y.
+// float32 channels-last [npix][C]; a block walks `pixb` consecutive pixels, thread = (pixel lane, 8-channel group).
+// The partials are summed in index order by k_bias_grad_finish: a fixed summation order and no cross-block
+// synchronisation inside a kernel.
+__global__ void __launch_bounds__(256) k_bias_act_bwd(const float* __restrict__ gy, const float* __restrict__ y,
+                                                      float* __restrict__ gx, float* __restrict__ partial, long long npix,
+                                                      int C, int relu, int pixb) {
+  __shared__ float sh[256 * 8];
+  const int cg = C / 8, ppi = 256 / cg;          // channel groups, pixels per iteration
+  const int g = threadIdx.x % cg, pl = threadIdx.x / cg;
+  const long long p0 = (long long)blockIdx.x * pixb;
+  long long p1 = p0 + pixb; if (p1 > npix) p1 = npix;
+  float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if (pl < ppi)
+    for (long long p = p0 + pl; p < p1; p += ppi) {
+      float a[8], b[8];
+      load8(gy + p * C + g * 8, a);
+      if (relu) {
+        load8(y + p * C + g * 8, b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = b[k] > 0.0f ? a[k] : 0.0f;
+      }
+      store8(gx + p * C + g * 8, a);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += a[k];
+    }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sh[threadIdx.x * 8 + k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < C) {   // channel c: the partial sums of its group's pixel lanes, in lane order
+    const int c = threadIdx.x, gg = c / 8, k = c % 8;
+    float s = 0.0f;
+    for (int q = 0; q < ppi; ++q) s += sh[(q * cg + gg) * 8 + k];
+    partial[(long long)blockIdx.x * C + c] = s;
+  }
+}
+
+// gb[c] = sum over blocks of partial[b][c], in a fixed order: a workgroup takes 32 channels (or all C < 32), its 256
+// threads are (row r, channel): row r adds the blocks r, r + rows, ... in turn (coalesced 128-byte reads), then the rows
+// are added in index order.
+__global__ void __launch_bounds__(256) k_bias_grad_finish(const float* __restrict__ partial, int nblk, int C,
+                                                          float* __restrict__ gb) {
+  __shared__ float sh[256];
+  const int cw = C < 32 ? C : 32, rows = 256 / cw;
+  const int c = blockIdx.x * cw + threadIdx.x % cw, r = threadIdx.x / cw;
+  float s = 0.0f;
+  if (r < rows && c < C)
+    for (int b = r; b < nblk; b += rows) s += partial[(long long)b * C + c];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < cw && c < C) {
+    float t = 0.0f;
+    for (int q = 0; q < rows; ++q) t += sh[q * cw + threadIdx.x];
+    gb[c] = t;
+  }
+}
+
+// pixels per block of k_bias_act_bwd: at most 1,024 blocks, whole iterations of the block's pixel lanes
+static int bwd_pixb(long long npix, int C) {
+  const int ppi = 256 / (C / 8);
+  long long pixb = (npix + 1023) / 1024;
+  if (pixb < 4 * ppi) pixb = 4 * ppi;
+  return (int)((pixb + ppi - 1) / ppi * ppi);
+}
+
 thread_local char e_err[256] = "";
 
 int finish(const char* what) {
@@ -176,6 +243,26 @@ int srl_bias_act_pool_f32(const float* in, float* skip, float* pooled, const flo
   hipLaunchKernelGGL(k_bias_act_pool<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, skip,
                      pooled, bias, B, H, W, C, skip_stride, skip_offset);
   return finish("srl_bias_act_pool_f32");
+}
+
+int64_t srl_bias_act_bwd_scratch_floats(int64_t npix, int32_t C) {
+  if (npix < 1 || C < 8 || C % 8 || C > 256 || 256 % (C / 8)) return -1;
+  const int pixb = bwd_pixb(npix, C);
+  return ((npix + pixb - 1) / pixb) * C;
+}
+
+int srl_bias_act_bwd_f32(const float* gy, const float* y, float* gx, float* gbias, float* scratch, int64_t npix, int32_t C,
+                         int32_t relu, void* stream) {
+  if (!gy || (relu && !y) || !gx || !gbias || !scratch || srl_bias_act_bwd_scratch_floats(npix, C) < 0) {
+    snprintf(e_err, sizeof e_err, "srl_bias_act_bwd_f32: bad arguments (C a multiple of 8 that divides 2,048, at most 256)");
+    return 1;
+  }
+  const int pixb = bwd_pixb(npix, C);
+  const int nblk = (int)((npix + pixb - 1) / pixb);
+  hipLaunchKernelGGL(k_bias_act_bwd, dim3(nblk), dim3(256), 0, (hipStream_t)stream, gy, y, gx, scratch, (long long)npix, C,
+                     relu, pixb);
+  hipLaunchKernelGGL(k_bias_grad_finish, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, scratch, nblk, C, gbias);
+  return finish("srl_bias_act_bwd_f32");
 }
 
 }  // extern "C"

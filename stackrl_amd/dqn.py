@@ -138,6 +138,10 @@ class DQN(object):
       if self.device.type == 'cuda' and hasattr(self._q_net, 'correlation'):
         from stackrl_amd import qops
         self._q_net.correlation = qops.correlation(qops.BF16X3 if xcorr == 'bf16x3' else qops.BF16)
+    # on a HIP device the bias add + ReLU of every convolution (forward, backward and the bias-gradient reduction) are
+    # the fused passes of csrc/epilogue.hip
+    if self.device.type == 'cuda' and hasattr(self._q_net, 'set_fused_epilogues'):
+      self._q_net.set_fused_epilogues(True)
     self._pg = process_group
     self._world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
     if self._world > 1:

@@ -42,6 +42,21 @@ def _init_conv(m, gen):
     nn.init.zeros_(m.bias)
 
 
+def _fused_conv(m, x, relu=True):
+  """Convolution without bias + the fused bias / ReLU pass (and its hand-written backward) of csrc/epilogue.hip."""
+  from stackrl_amd import qops
+  if isinstance(m, nn.ConvTranspose2d):
+    y = F.conv_transpose2d(x, m.weight, None, stride=m.stride)
+  else:
+    y = F.conv2d(x, m.weight, None, padding=m.padding)
+  return qops.bias_act_autograd(y, m.bias, relu)
+
+
+def _use_fused(module, x):
+  return getattr(module, 'fused_epilogues', False) and x.is_cuda and x.dtype == torch.float32 and \
+    not torch.is_autocast_enabled()
+
+
 class UNet(nn.Module):
   """`layers.unet` with `double_endpoint=True`, `out_channels=None` (layers.py:135-259)."""
 
@@ -71,6 +86,8 @@ class UNet(nn.Module):
     self.bottom_channels = filters * 2 ** depth
 
   def forward(self, x):
+    if _use_fused(self, x):
+      return self._forward_fused(x)
     levels = []
     for blk in self.down:
       x = blk(x)
@@ -83,6 +100,25 @@ class UNet(nn.Module):
       x = torch.cat([x, levels.pop()], dim=1)   # Concatenate([x, skip]), layers.py:231
       x = blk(x)
     return x, x0
+
+
+  def _forward_fused(self, x):
+    """The same graph with every bias add + ReLU (and their backward + the bias-gradient reduction) as one hand-written
+    pass each, on float32 channels-last tensors (the GPU update path of `DQN.train`)."""
+    levels = []
+    for blk in self.down:
+      x = _fused_conv(blk[2], _fused_conv(blk[0], x))
+      levels.append(x)
+      x = F.max_pool2d(x, 2)
+    x = _fused_conv(self.bottom[2], _fused_conv(self.bottom[0], x))
+    x0 = x
+    for up, blk in zip(self.up, self.upconv):
+      x = _fused_conv(up, x)
+      x = torch.cat([x, levels.pop()], dim=1)
+      x = _fused_conv(blk[2], _fused_conv(blk[0], x))
+    return x, x0
+
+  fused_epilogues = False
 
 
 def correlation_reference(x, w):
@@ -148,8 +184,27 @@ class DeepQSiamFCN(nn.Module):
     w, _ = self.right(w)
     return x, x0, w
 
+  def set_fused_epilogues(self, flag=True):
+    """GPU update path: bias add + ReLU of every convolution as one hand-written pass with its own backward
+    (csrc/epilogue.hip) instead of the library's separate kernels.  Needs the HIP extension."""
+    if flag:
+      from stackrl_amd import qops
+      qops.load()
+    self.fused_epilogues = self.left.fused_epilogues = self.right.fused_epilogues = bool(flag)
+    return self
+
+  fused_epilogues = False
+
+  def _pos(self, corr):
+    if _use_fused(self, corr) and len(self.pos) >= 3:
+      x = corr
+      for k in range(0, len(self.pos) - 1, 2):              # (conv, relu) pairs; the final 1 x 1 projection stays a module
+        x = _fused_conv(self.pos[k], x)
+      return self.pos[-1](x)
+    return self.pos(corr)
+
   def head(self, corr, x0):
-    a = self.pos(corr).flatten(1)                           # Flatten -> advantages
+    a = self._pos(corr).flatten(1)                          # Flatten -> advantages
     if not self.dueling:
       return a
     pooled = x0.mean(dim=(2, 3)) if self.dueling_avg_pool else x0.amax(dim=(2, 3))

@@ -47,6 +47,10 @@ def load():
     L.srl_convt2x2_bias_relu.argtypes = [VP] * 4 + [ctypes.c_int32] * 7 + [VP]
     L.srl_conv3x3_thin.restype = ctypes.c_int
     L.srl_conv3x3_thin.argtypes = [VP, ctypes.c_int32, VP, VP, VP] + [ctypes.c_int32] * 6 + [VP]
+    L.srl_bias_act_bwd_scratch_floats.restype = ctypes.c_int64
+    L.srl_bias_act_bwd_scratch_floats.argtypes = [ctypes.c_int64, ctypes.c_int32]
+    L.srl_bias_act_bwd_f32.restype = ctypes.c_int
+    L.srl_bias_act_bwd_f32.argtypes = [VP] * 5 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, VP]
     L.srl_conv3x3_thin_f32.restype = ctypes.c_int
     L.srl_conv3x3_thin_f32.argtypes = L.srl_conv3x3_thin.argtypes
     L.srl_convt2x2_bias_relu_f32.restype = ctypes.c_int
@@ -225,6 +229,51 @@ def bias_act(y, bias, out=None, out_offset=0, relu=True, nchw=False):
   if rc:
     raise RuntimeError(load().srl_epilogue_last_error().decode())
   return dst
+
+
+class _BiasAct(torch.autograd.Function):
+  """y <- relu(y + bias) in place on the convolution's output, with the hand-written backward (csrc/epilogue.hip
+  k_bias_act_bwd): gx = gy * (y > 0) and the bias gradient summed in a fixed order, one pass over gy and y."""
+
+  @staticmethod
+  def forward(ctx, y, bias, relu):
+    bias_act(y, bias, relu=relu)
+    ctx.mark_dirty(y)
+    ctx.relu = bool(relu)
+    ctx.save_for_backward(y)
+    return y
+
+  @staticmethod
+  def backward(ctx, gy):
+    y, = ctx.saved_tensors
+    B, C, H, W = y.shape
+    gy = gy.contiguous(memory_format=_CL)
+    gx = torch.empty_like(gy, memory_format=_CL)
+    gb = torch.empty(C, dtype=torch.float32, device=y.device)
+    L = load()
+    scratch = torch.empty(L.srl_bias_act_bwd_scratch_floats(B * H * W, C), dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+      rc = L.srl_bias_act_bwd_f32(gy.data_ptr(), y.data_ptr(), gx.data_ptr(), gb.data_ptr(), scratch.data_ptr(), B * H * W, C,
+                                  int(ctx.relu), _stream(y))
+    if rc:
+      raise RuntimeError(L.srl_epilogue_last_error().decode())
+    return gx, gb, None
+
+
+def bias_act_supported(channels):
+  return channels % 8 == 0 and channels <= 256 and 256 % (channels // 8) == 0
+
+
+def bias_act_autograd(y, bias, relu=True):
+  """relu(y + bias[c]) (or y + bias[c]) of a float32 convolution output [B,C,H,W], differentiable: in place on y (made
+  channels-last), forward and backward by the kernels of csrc/epilogue.hip.  The update path's replacement for the
+  library's separate bias add, ReLU, ReLU backward and bias-gradient reduction."""
+  if y.dtype != torch.float32 or not y.is_cuda:
+    raise RuntimeError('bias_act_autograd: float32 CUDA tensors only')
+  y = y.contiguous(memory_format=_CL)
+  if not (torch.is_grad_enabled() and (y.requires_grad or bias.requires_grad)):
+    return bias_act(y, bias.detach(), relu=relu)
+  return _BiasAct.apply(y, bias, relu)
 
 
 def bias_act_pool(y, bias, skip, skip_offset):
@@ -417,6 +466,14 @@ class FastFeatures(object):
     if (self.mfma_conv or self.x3_conv) and pos is not None and len(pos) == 5 and pos[0] in self._wt and pos[2] in self._wf and \
        pos[4].kernel_size == (1, 1) and pos[4].in_channels == 16 and pos[4].out_channels == 1:
       self._pos = (pos[4].weight.detach().float().reshape(16).contiguous(), float(pos[4].bias.detach()))
+    import os as _os
+    off = _os.environ.get('SRL_DBG_OFF', '')
+    if self.x3_conv:
+      for m in list(self._wf):
+        if 'convt' in off and isinstance(m, torch.nn.ConvTranspose2d): del self._wf[m]
+        elif 'c64' in off and isinstance(m, torch.nn.Conv2d) and m.in_channels == 64: del self._wf[m]
+      if 'thin' in off: self._wt = {}
+      if 'pos' in off or 'thin' in off: self._pos = None
     self._key = key
 
   def _mine(self, m, x):

@@ -627,3 +627,51 @@ def test_fast_features_fp32_match_the_module():
   # the same greedy actions, or actions whose Q-value is within the fp32-class tolerance of the maximum
   qa = q_ref.gather(1, a[:, None])[:, 0]
   assert bool((q_ref.amax(-1) - qa <= 2e-4 * q_ref.abs().amax(-1)).all())
+
+
+@pytest.mark.parametrize('C,shape,relu', [(16, (3, 40, 56), True), (64, (2, 8, 8), True), (256, (32, 4, 4), True), (128, (5, 7, 3), False)])
+def test_bias_act_autograd_matches_torch(C, shape, relu):
+  """The fused bias + ReLU pass of the update path (forward in place, backward = masked gradient + bias gradient in a
+  fixed summation order, csrc/epilogue.hip) against torch autograd in float64."""
+  from stackrl_amd import qops
+  g = torch.Generator(device='cuda').manual_seed(C)
+  B, H, W = shape
+  x = torch.randn((B, C, H, W), generator=g, device='cuda').contiguous(memory_format=torch.channels_last)
+  b = torch.randn(C, generator=g, device='cuda')
+  gy = torch.randn((B, C, H, W), generator=g, device='cuda').contiguous(memory_format=torch.channels_last)
+  xr, br = x.double().requires_grad_(True), b.double().requires_grad_(True)
+  yr = xr + br[None, :, None, None]
+  yr = torch.relu(yr) if relu else yr
+  yr.backward(gy.double())
+  xs = x.clone().requires_grad_(True)
+  bs = b.clone().requires_grad_(True)
+  y = qops.bias_act_autograd(xs * 1.0, bs, relu)     # `* 1.0`: a non-leaf, like a convolution's output
+  assert float((y.double() - yr).abs().max()) <= 1e-6
+  y.backward(gy)
+  assert float((xs.grad.double() - xr.grad).abs().max()) == 0.0
+  assert float((bs.grad.double() - br.grad).abs().max()) <= 2e-6 * max(1.0, float(br.grad.abs().max()))
+  # deterministic: the same bits on a second evaluation
+  xs2, bs2 = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+  qops.bias_act_autograd(xs2 * 1.0, bs2, relu).backward(gy)
+  assert torch.equal(bs2.grad, bs.grad)
+
+
+def test_fused_epilogue_net_matches_the_module_graph():
+  """`DeepQSiamFCN.set_fused_epilogues` (the GPU update path) against the plain module graph: Q-values and every
+  parameter gradient agree to float32 rounding (the fused path changes no arithmetic, only the order of the bias-gradient
+  sums)."""
+  from stackrl_amd import nets
+  net = nets.DeepQSiamFCN(seed=3).cuda()
+  g = torch.Generator(device='cuda').manual_seed(8)
+  xm = torch.randint(0, 256, (4, 128, 128, 2), generator=g, device='cuda', dtype=torch.uint8)
+  xo = torch.randint(0, 256, (4, 32, 32, 1), generator=g, device='cuda', dtype=torch.uint8)
+  gq = torch.randn((4, net.n_actions), generator=g, device='cuda')
+  q0 = net((xm, xo)); q0.backward(gq)
+  ref = {n: p.grad.clone() for n, p in net.named_parameters()}
+  net.zero_grad(set_to_none=True)
+  net.set_fused_epilogues(True)
+  q1 = net((xm, xo)); q1.backward(gq)
+  assert float((q1 - q0).abs().max()) <= 1e-5 * float(q0.abs().max())
+  for n, p in net.named_parameters():
+    scale = max(float(ref[n].abs().max()), 1e-6)
+    assert float((p.grad - ref[n]).abs().max()) <= 2e-4 * scale, n
