@@ -30,6 +30,7 @@ import json
 import os
 import socket
 import subprocess
+import threading
 import sys
 import time
 
@@ -63,12 +64,17 @@ def parse_args(argv=None):
   ap.add_argument('--rollout', default='both', choices=['f32', 'bf16', 'both'])
   ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL; gloo for rehearsals')
   ap.add_argument('--same-device', action='store_true', help='rehearsal: every rank uses device 0 (needs --backend gloo)')
+  ap.add_argument('--leg-b-timeout', type=float, default=900.0,
+                  help='N > 1: seconds leg B (DQN) may take after leg A before the launcher ends the ranks and prints leg A')
   ap.add_argument('--launch-only', action='store_true',
                   help='rehearsal without a GPU: spawn, rendezvous, barriers and aggregation only; value is null')
   return ap.parse_args(argv)
 
 
 # ----------------------------------------------------------------------------------------------- launcher
+PROVISIONAL = '#provisional '
+
+
 def free_port():
   s = socket.socket()
   s.bind(('127.0.0.1', 0))
@@ -87,8 +93,21 @@ def launch(args, argv):
                LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                SRL_BENCH_CHILD='1')
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    out = None if r == 0 else subprocess.DEVNULL
+    out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
     procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
+  got = {'final': None, 'provisional': None}
+
+  def reader():
+    for raw in procs[0].stdout:
+      text = raw.decode(errors='replace').rstrip('\n')
+      if text.startswith(PROVISIONAL):
+        got['provisional'] = text[len(PROVISIONAL):]
+        got['since'] = time.time()
+      elif text.strip():
+        got['final'] = text
+
+  th = threading.Thread(target=reader, daemon=True)
+  th.start()
   rc = 0
   deadline = None
   while any(p.poll() is None for p in procs):
@@ -96,12 +115,24 @@ def launch(args, argv):
     failed = [p for p in procs if p.poll() not in (None, 0)]
     if failed and deadline is None:
       deadline = time.time() + 20.0          # a rank died: give the others a moment, then end exactly those we started
+    if deadline is None and got.get('since') and time.time() - got['since'] > args.leg_b_timeout:
+      print('bench.py: leg B exceeded --leg-b-timeout ({} s): ending the ranks'.format(args.leg_b_timeout), file=sys.stderr)
+      deadline = time.time()
     if deadline is not None and time.time() > deadline:
       for p in procs:
         if p.poll() is None:
           p.kill()
+  th.join(timeout=5.0)
   for p in procs:
     rc = rc or (p.returncode or 0)
+  if got['final'] is not None:
+    print(got['final'], flush=True)
+  elif got['provisional'] is not None:
+    # leg A finished on every rank and was aggregated; a rank ended in leg B: the headline stands, the line says so
+    print(got['provisional'], flush=True)
+    print('bench.py: a rank ended during leg B (exit codes {}); the line above carries leg A only'.format(
+      [p.returncode for p in procs]), file=sys.stderr)
+    return 0
   return rc
 
 
@@ -281,6 +312,8 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
   from stackrl_amd import env as envs, nets, qops
   from stackrl_amd.dqn import DQN, PolynomialDecay
   from stackrl_amd.training import Trainer
+  if os.environ.get('SRL_BENCH_FAIL_LEG_B') == str(rank):     # test hook: this rank is lost in leg B
+    raise RuntimeError('injected leg-B failure on rank {}'.format(rank))
   B, L, res, name = dqn_shape(args)
   # as the headline (--config 2|3|4) the leg follows the contract's K timed / W warm-up steps; the three eager updates
   # and the graph capture of the update (DQN._GRAPH_WARMUP) then run before those, as part of the setup
@@ -378,9 +411,9 @@ def worker(args):
   json_fd = os.dup(1)
   os.dup2(2, 1)
 
-  def emit(line):
+  def emit(line, provisional=False):
     sys.stdout.flush()
-    os.write(json_fd, (json.dumps(line) + '\n').encode())
+    os.write(json_fd, ((PROVISIONAL if provisional else '') + json.dumps(line) + '\n').encode())
 
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -437,27 +470,7 @@ def worker(args):
   a = env_leg(args, rank, world, pool, barrier, solver_kw)
   dt_max, placed_all = aggregate(a['dt'], a['placed'], world, 'cuda')
 
-  dqn = None
-  if not args.no_dqn:
-    dqn = {}
-    for dtype in (['f32', 'bf16'] if args.rollout == 'both' else [args.rollout]):
-      # leg B must not take the headline down with it: an exception is recorded, not raised (with the DQN leg as the
-      # headline, --config 2|3|4, it is raised)
-      try:
-        dqn[dtype] = dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype)
-      except Exception as e:   # noqa: BLE001
-        if args.config != 1:
-          raise
-        import traceback
-        traceback.print_exc()
-        dqn[dtype] = {'error': '{}: {}'.format(type(e).__name__, e)}
-        torch.cuda.synchronize()
-
-  mse = None
-  if rank == 0 and args.gpus == 1 and not args.no_cpu:
-    mse = reward_mse(args, pool, L, solver_kw)
-
-  if rank == 0:
+  def make_line(dqn, mse):
     B, res, ms, nl, sub, sw = a['B'], a['res'], a['ms'], a['nl'], a['sub'], a['sw']
     traffic, traffic_source = traffic_record(B, a['L'], res)
     render_s = float(ms[1]) / 1e3
@@ -501,7 +514,35 @@ def worker(args):
                   dtype=d['rollout_dtype'], env_only={'value': placed_all / dt_max, 'steps': args.steps,
                                                       'warmup': args.warmup, 'ms_per_step': 1e3 * dt_max / args.steps})
       line['config'] = dict(line['config'], workload=d['workload'], note='leg A (config keys above) is reported under env_only')
-    emit(line)
+    return line
+
+  if rank == 0 and world > 1 and os.environ.get('SRL_BENCH_CHILD') == '1' and args.config == 1 and not args.no_dqn:
+    # leg A is complete on every rank: hand the headline to the launcher now, so that a rank lost in leg B (whose
+    # collectives the others would then wait in) cannot take it down; the final line below replaces it
+    emit(make_line({'error': 'a rank ended during leg B (DQN); leg A above is complete'}, None), provisional=True)
+
+  dqn = None
+  if not args.no_dqn:
+    dqn = {}
+    for dtype in (['f32', 'bf16'] if args.rollout == 'both' else [args.rollout]):
+      # leg B must not take the headline down with it: an exception is recorded, not raised (with the DQN leg as the
+      # headline, --config 2|3|4, it is raised)
+      try:
+        dqn[dtype] = dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype)
+      except Exception as e:   # noqa: BLE001
+        if args.config != 1 or world > 1:   # with other ranks waiting in this leg's collectives there is no going on
+          raise
+        import traceback
+        traceback.print_exc()
+        dqn[dtype] = {'error': '{}: {}'.format(type(e).__name__, e)}
+        torch.cuda.synchronize()
+
+  mse = None
+  if rank == 0 and args.gpus == 1 and not args.no_cpu:
+    mse = reward_mse(args, pool, L, solver_kw)
+
+  if rank == 0:
+    emit(make_line(dqn, mse))
   if use_dist:
     dist.barrier()
     dist.destroy_process_group()

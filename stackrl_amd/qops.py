@@ -466,14 +466,6 @@ class FastFeatures(object):
     if (self.mfma_conv or self.x3_conv) and pos is not None and len(pos) == 5 and pos[0] in self._wt and pos[2] in self._wf and \
        pos[4].kernel_size == (1, 1) and pos[4].in_channels == 16 and pos[4].out_channels == 1:
       self._pos = (pos[4].weight.detach().float().reshape(16).contiguous(), float(pos[4].bias.detach()))
-    import os as _os
-    off = _os.environ.get('SRL_DBG_OFF', '')
-    if self.x3_conv:
-      for m in list(self._wf):
-        if 'convt' in off and isinstance(m, torch.nn.ConvTranspose2d): del self._wf[m]
-        elif 'c64' in off and isinstance(m, torch.nn.Conv2d) and m.in_channels == 64: del self._wf[m]
-      if 'thin' in off: self._wt = {}
-      if 'pos' in off or 'thin' in off: self._pos = None
     self._key = key
 
   def _mine(self, m, x):

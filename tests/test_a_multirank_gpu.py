@@ -58,3 +58,34 @@ def test_two_rank_graphed_update_keeps_replicas_equal(tmp_path):
   mp.start_processes(_two_rank_update, args=(2, 29000 + os.getpid() % 2000, out), nprocs=2, join=True, start_method='fork')
   res = torch.load(out)
   assert res == {'replicas_equal': True, 'graphed': True, 'moved': True, 'losses_differ': True, 'finite': True}
+
+
+def _run_bench(extra_env, *flags):
+  import json, os, subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, **extra_env)
+  env.pop('RANK', None); env.pop('WORLD_SIZE', None)
+  p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--same-device', '--backend', 'gloo',
+                      '--no-cpu', '--envs', '64', '--steps', '3', '--warmup', '1', '--dqn-envs', '32', '--dqn-rocks', '4',
+                      '--dqn-iters', '3', '--dqn-warmup', '1', '--dqn-slots', '8'] + list(flags),
+                     env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+  lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+  return p.returncode, lines, p.stderr.decode()
+
+
+def test_bench_two_ranks_one_json_line_and_survives_a_lost_rank():
+  """`python bench.py --gpus 2` as the driver runs it (here: both ranks on device 0, gloo): the launcher starts the
+  ranks, exactly one JSON line comes out, leg B carries the all-reduce time; and when a rank is lost in leg B the
+  launcher still prints leg A's aggregated headline, marked as such, and ends the other rank."""
+  import json
+  if torch.cuda.is_initialized():
+    pytest.skip('this process has already initialised the GPU: it must not start (fork + exec) other programs')
+  rc, lines, err = _run_bench({})
+  assert rc == 0 and len(lines) == 1, err[-2000:]
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['parallelism'] == 'env-shard x2'
+  assert set(d['dqn']) == {'f32', 'bf16'} and all(v['allreduce_ms'] is not None and v['update_graphed'] for v in d['dqn'].values())
+  rc, lines, err = _run_bench({'SRL_BENCH_FAIL_LEG_B': '1'})
+  assert rc == 0 and len(lines) == 1, err[-2000:]
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 2 and d['value'] > 0 and 'error' in d['dqn']
