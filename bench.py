@@ -303,6 +303,20 @@ def dqn_shape(args):
   return args.dqn_envs or B, args.dqn_rocks or L, args.dqn_res or res, name
 
 
+_RCCL = {}
+
+
+def rccl_group(args, world):
+  """The process group of leg B's gradient all-reduce: RCCL (backend 'nccl') over all ranks, one per GPU; None = the
+  default (gloo) group for the one-device rehearsals (--backend gloo); at N = 1 there is no group at all."""
+  import torch.distributed as dist
+  if args.backend != 'nccl' or not (dist.is_available() and dist.is_initialized()):
+    return None
+  if 'pg' not in _RCCL:
+    _RCCL['pg'] = dist.new_group(backend='nccl')
+  return _RCCL['pg']
+
+
 def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
   """`Training.run` (training.py:338-380) for --dqn-iters iterations after --dqn-warmup: per iteration one rollout forward
   over the rank's envs (`agent.collect`), one non-blocking vectorised env step on a side stream, one minibatch-32 update
@@ -330,7 +344,7 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
               exploration=PolynomialDecay(1.0, 400000, .1), prioritization=0.6,
               priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=7 + rank,
               policy_op=qops.FusedPolicy(autocast=torch.bfloat16 if dtype == 'bf16' else None, fast=True),
-              xcorr='bf16x3', graphs=True)                     # config.gin:55-112
+              xcorr='bf16x3', graphs=True, process_group=rccl_group(args, world))   # config.gin:55-112
   tr = Trainer(env, agent)
   tr.initialize(num_steps=4)
   if pre:
@@ -368,17 +382,17 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
   if dist.is_available() and dist.is_initialized():     # (world 1 under SRL_BENCH_FORCE_DIST=1: exercises the RCCL call itself)
     g = agent._flat_grad
     for _ in range(3):
-      dist.all_reduce(g)
+      dist.all_reduce(g, group=agent._pg)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(10):
-      dist.all_reduce(g)
+      dist.all_reduce(g, group=agent._pg)
     b.record()
     torch.cuda.synchronize()
     ar_ms = a.elapsed_time(b) / 10
   macs = sum(nets.forward_macs(H=res, h=res // 4).values())
-  dt_max, steps_all = aggregate(dt, B * iters, world, 'cuda')
+  dt_max, steps_all = aggregate(dt, B * iters, world, 'cpu')
   flops_fwd = 2.0 * macs * B
   out = {
     'workload': 'Stack-v0, {} envs per GPU x {} rocks, {}x{} maps, DQN rollout + minibatch-32 update per iteration '
@@ -456,10 +470,10 @@ def worker(args):
   if use_dist:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29511')
-    if args.backend == 'nccl':
-      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev))
-    else:
-      dist.init_process_group('gloo', rank=rank, world_size=world)
+    # the env path has no data-path collective: its barriers and the two scalar reductions of `aggregate` go over gloo
+    # (host side), so leg A depends on nothing but the rendezvous; the gradient all-reduce of leg B runs over RCCL in a
+    # group of its own (`rccl_group`), created when leg B starts
+    dist.init_process_group('gloo', rank=rank, world_size=world)
 
   def barrier():
     torch.cuda.synchronize()
@@ -468,7 +482,7 @@ def worker(args):
     torch.cuda.synchronize()
 
   a = env_leg(args, rank, world, pool, barrier, solver_kw)
-  dt_max, placed_all = aggregate(a['dt'], a['placed'], world, 'cuda')
+  dt_max, placed_all = aggregate(a['dt'], a['placed'], world, 'cpu')
 
   def make_line(dqn, mse):
     B, res, ms, nl, sub, sw = a['B'], a['res'], a['ms'], a['nl'], a['sub'], a['sw']
