@@ -658,11 +658,33 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     const uint32_t todo = fmaxf(h_empty, 0.0f) == 0.0f ? (cov | goalm) : 0xffffffffu;
     const uint2* __restrict__ ctab = P.codec;
     const uint32_t gp_lo = goal_pair(colmask, gdiff), gp_hi = goal_pair(colmask >> 2, gdiff);
+    // what the four pixels of a group no rock reaches add to the two sums in a goal row (the columns are fixed per
+    // thread when `aligned`): the very terms the general path below computes from the table's empty-pixel entry
+    float cu_in[4], ci_in[4];
+    const float cu_out = fmaxf(h_empty, 0.0f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int m = __builtin_amdgcn_sbfe((int)colmask, t, 1);
+      cu_in[t] = fmaxf(h_empty, __int_as_float(__float_as_int(gz) & m));
+      ci_in[t] = __int_as_float(__float_as_int(fminf(h_empty, gz)) & m);
+    }
     int i = walk_i0, jb = walk_j0;
     for (int k = 0; k < nrounds; ++k) {
       const int g = tid + k * SRL_RENDER_THREADS;
       if (((todo >> k) & 1u) && g < ngroups4) {
         const bool covg = (cov >> k) & 1u;
+#ifndef SRL_ABL_NOCONSTROUND
+        if (aligned && __builtin_amdgcn_ballot_w64(covg) == 0ull) {
+          // no group of the wave holds a rock pixel this round (their H / observation bytes left with the early stores):
+          // the sums take per-thread constants — no table look-ups, no stores
+          const bool rowin = (unsigned)(i - g0) < (unsigned)g2;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { spu += rowin ? cu_in[t] : cu_out; spi += rowin ? ci_in[t] : 0.0f; }
+          jb += walk_dj; i += walk_di;
+          if (jb >= res) { jb -= res; ++i; }
+          continue;
+        }
+#endif
         uint4 r4 = make_uint4(0u, 0u, 0u, 0u);   // codec-table rows of the four pixels (0: no rock)
         if (covg) r4 = ((const uint4*)L.tile)[g];
         const uint32_t rw[4] = {r4.x, r4.y, r4.z, r4.w};
