@@ -675,3 +675,40 @@ def test_fused_epilogue_net_matches_the_module_graph():
   for n, p in net.named_parameters():
     scale = max(float(ref[n].abs().max()), 1e-6)
     assert float((p.grad - ref[n]).abs().max()) <= 2e-4 * scale, n
+
+
+def test_update_stays_finite_under_the_concurrent_env_step():
+  """configs[4]'s per-GPU shard (2,048 envs x 32 rocks, 64^2 maps), the loop of `Training.run`: the graph-replayed update
+  runs while the env step occupies the GPU from its side stream.  With the library's bias-gradient reductions this
+  ended in a corrupt gradient element within ten updates in 5 runs of 6 (DESIGN.md section 4, update-path kernels);
+  the fused bias / ReLU passes must keep the gradient bucket, the parameters and the Adam state finite and small."""
+  from stackrl_amd import assets, env as envs, nets, qops
+  from stackrl_amd.dqn import DQN, PolynomialDecay
+  from stackrl_amd.training import Trainer
+  B, L = 2048, 32
+  env = envs.make('Stack-v0', n_parallel=B, seed=11, pool=assets.default_pool(), episode_length=L, side_stream=True,
+                  resolution_factor=4)
+  net = nets.DeepQSiamFCN(env.observation_spec, seed=1).cuda()
+  agent = DQN(net, learning_rate=6.25e-5, adam_betas=(0.95, 0.95), minibatch_size=32, replay_memory_size=B * 16,
+              discount_factor=.966667, collect_batch_size=B, exploration=PolynomialDecay(1.0, 400000, .1), prioritization=0.6,
+              priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=7,
+              policy_op=qops.FusedPolicy(autocast=torch.bfloat16, fast=True), xcorr='bf16x3', graphs=True)
+  assert net.fused_epilogues
+  tr = Trainer(env, agent)
+  tr.initialize(num_steps=4)
+  step = env.reset()
+  agent.acknowledge_reset()
+  for it in range(16):
+    if callable(step):
+      step = step()
+    action = agent.collect(*step)
+    step = env.step(action)            # side stream: runs underneath the update
+    loss, _ = agent.train()
+    g = agent._flat_grad
+    assert bool(torch.isfinite(g).all()) and float(g.abs().max()) < 1e4, 'update {}: gradient bucket corrupt'.format(it)
+    assert math.isfinite(float(loss))
+  step() if callable(step) else None
+  opt = agent._optimizer
+  assert agent._train_graph is not None
+  assert bool(torch.isfinite(opt.flat).all()) and bool(torch.isfinite(opt.m).all()) and bool(torch.isfinite(opt.v).all())
+  env.close()
