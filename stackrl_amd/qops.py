@@ -308,13 +308,29 @@ def pool2x2(buf, C, offset=0):
   return pooled
 
 
-def pack_conv3x3_weights(w):
-  """Conv2d weight [cout, cin, 3, 3] -> bf16 A-fragment order of csrc/conv_mfma.hip (see include/stackrl_qnet.h)."""
-  cout, cin = int(w.shape[0]), int(w.shape[1])
-  n = load().srl_conv3x3_wfrag_elems(cin, cout)
-  if n < 0:
-    raise ValueError('conv3x3 MFMA kernel: unsupported channels %d -> %d' % (cin, cout))
-  dev = w.device
+_PACK_INDEX = {}
+
+
+def _pack(w, kind, build, x3=False):
+  """Gather of a weight tensor into a kernel's fragment order.  The flat gather index (and the mask of padded taps)
+  depends on the layer shape only and is built once per (kind, shape, device): re-packing after every weight update —
+  once per rollout while training — is then one gather per layer.  x3: the fragments of bf16(w), then those of
+  bf16(w - bf16(w)) (the fp32-class kernels)."""
+  key = (kind, tuple(w.shape), w.device)
+  if key not in _PACK_INDEX:
+    _PACK_INDEX[key] = build()
+  idx, mask = _PACK_INDEX[key]
+  flat = w.detach().float().reshape(-1)
+  if x3:
+    hi = flat.to(torch.bfloat16)
+    lo = (flat - hi.float()).to(torch.bfloat16)
+    out = torch.cat([hi[idx], lo[idx]])
+    return out * torch.cat([mask, mask]) if mask is not None else out
+  out = flat.to(torch.bfloat16)[idx]
+  return out * mask if mask is not None else out
+
+
+def _conv3x3_index(cout, cin, dev):
   ks = torch.arange(5 if cin == 16 else 9 * (cin // 32), device=dev)[:, None, None, None]
   mt = torch.arange(cout // 16, device=dev)[None, :, None, None]
   lane = torch.arange(64, device=dev)[None, None, :, None]
@@ -327,19 +343,26 @@ def pack_conv3x3_weights(w):
     tap, ci = ks // m + 0 * k, 32 * (ks % m) + k
   co = 16 * mt + (lane & 15)
   tapc = tap.clamp(max=8)
-  vals = w.detach().float()[co, ci, tapc // 3, tapc % 3] * (tap < 9)
-  out = vals.to(torch.bfloat16).contiguous().reshape(-1)
-  assert out.numel() == n
+  idx = ((co * cin + ci) * 9 + tapc).reshape(-1)
+  mask = (tap < 9).expand_as(idx.reshape(tapc.shape[0], co.shape[1], 64, 8)).reshape(-1).to(torch.bfloat16) if cin == 16 else None
+  return idx, mask
+
+
+def pack_conv3x3_weights(w, x3=False):
+  """Conv2d weight [cout, cin, 3, 3] -> bf16 A-fragment order of csrc/conv_mfma.hip (see include/stackrl_qnet.h)."""
+  cout, cin = int(w.shape[0]), int(w.shape[1])
+  n = load().srl_conv3x3_wfrag_elems(cin, cout)
+  if n < 0:
+    raise ValueError('conv3x3 MFMA kernel: unsupported channels %d -> %d' % (cin, cout))
+  out = _pack(w, 'conv3x3', lambda: _conv3x3_index(cout, cin, w.device), x3)
+  assert out.numel() == n * (2 if x3 else 1)
   return out
 
 
 def pack_conv3x3_weights_x3(w):
   """Conv2d weight [cout, cin, 3, 3] (cin in {16, 32, 64}, cout in {16, 32}) -> the two bf16 fragment sets of the fp32-class kernel
   (srl_conv3x3_bias_relu_f32): the fragments of bf16(w), then those of bf16(w - bf16(w))."""
-  w = w.detach().float()
-  hi = w.to(torch.bfloat16)
-  lo = (w - hi.float()).to(torch.bfloat16)
-  return torch.cat([pack_conv3x3_weights(hi.float()), pack_conv3x3_weights(lo.float())]).contiguous()
+  return pack_conv3x3_weights(w, x3=True)
 
 
 def conv3x3_bias_relu(x, wfrag, bias, cout, out=None, out_offset=0, pool=False, nchw=False):
@@ -364,22 +387,22 @@ def conv3x3_bias_relu(x, wfrag, bias, cout, out=None, out_offset=0, pool=False, 
   return (dst, pooled) if pool else dst
 
 
-def pack_conv3x3_gemm_weights(w, x3=False):
-  """Conv2d weight [cout, cin, 3, 3] -> bf16 A-fragment order of csrc/conv_gemm.hip ([cin / 32][tap][cout / 16][lane][8]);
-  x3: the fragments of bf16(w) followed by those of bf16(w - bf16(w)) (the fp32-class kernel)."""
-  w = w.detach().float()
-  if x3:
-    hi = w.to(torch.bfloat16).float()
-    return torch.cat([pack_conv3x3_gemm_weights(hi), pack_conv3x3_gemm_weights(w - hi)]).contiguous()
-  cout, cin = int(w.shape[0]), int(w.shape[1])
-  dev = w.device
+def _conv3x3_gemm_index(cout, cin, dev):
   cb = torch.arange(cin // 32, device=dev)[:, None, None, None, None]
   tap = torch.arange(9, device=dev)[None, :, None, None, None]
   mt = torch.arange(cout // 16, device=dev)[None, None, :, None, None]
   lane = torch.arange(64, device=dev)[None, None, None, :, None]
   j = torch.arange(8, device=dev)[None, None, None, None, :]
-  out = w[16 * mt + (lane & 15), 32 * cb + 8 * (lane >> 4) + j, tap // 3, tap % 3].to(torch.bfloat16).contiguous().reshape(-1)
-  assert out.numel() == load().srl_conv3x3_gemm_wfrag_elems(cin, cout)
+  co, ci = 16 * mt + (lane & 15), 32 * cb + 8 * (lane >> 4) + j
+  return ((co * cin + ci) * 9 + tap).reshape(-1), None
+
+
+def pack_conv3x3_gemm_weights(w, x3=False):
+  """Conv2d weight [cout, cin, 3, 3] -> bf16 A-fragment order of csrc/conv_gemm.hip ([cin / 32][tap][cout / 16][lane][8]);
+  x3: the fragments of bf16(w) followed by those of bf16(w - bf16(w)) (the fp32-class kernel)."""
+  cout, cin = int(w.shape[0]), int(w.shape[1])
+  out = _pack(w, 'conv3x3_gemm', lambda: _conv3x3_gemm_index(cout, cin, w.device), x3)
+  assert out.numel() == load().srl_conv3x3_gemm_wfrag_elems(cin, cout) * (2 if x3 else 1)
   return out
 
 
@@ -402,13 +425,7 @@ def conv3x3_gemm_bias_relu(x, wfrag, bias, cout, out=None, out_offset=0):
   return dst
 
 
-def pack_convt2x2_weights(w):
-  """ConvTranspose2d weight [cin, cout, 2, 2] -> bf16 A-fragment order of k_convt2x2 (include/stackrl_qnet.h)."""
-  cin, cout = int(w.shape[0]), int(w.shape[1])
-  n = load().srl_convt2x2_wfrag_elems(cin, cout)
-  if n < 0:
-    raise ValueError('convT 2x2 MFMA kernel: unsupported channels %d -> %d' % (cin, cout))
-  dev = w.device
+def _convt2x2_index(cin, cout, dev):
   ks = torch.arange(cin // 32, device=dev)[:, None, None, None]
   mt = torch.arange(4 * cout // 16, device=dev)[None, :, None, None]
   lane = torch.arange(64, device=dev)[None, None, :, None]
@@ -416,17 +433,23 @@ def pack_convt2x2_weights(w):
   ci = 32 * ks + 8 * (lane >> 4) + j
   m = 16 * mt + (lane & 15)
   q, co = m // cout, m % cout
-  out = w.detach().float()[ci, co, q >> 1, q & 1].to(torch.bfloat16).contiguous().reshape(-1)
-  assert out.numel() == n
+  return ((ci * cout + co) * 4 + q).reshape(-1), None     # w[ci][co][q >> 1][q & 1]
+
+
+def pack_convt2x2_weights(w, x3=False):
+  """ConvTranspose2d weight [cin, cout, 2, 2] -> bf16 A-fragment order of k_convt2x2 (include/stackrl_qnet.h)."""
+  cin, cout = int(w.shape[0]), int(w.shape[1])
+  n = load().srl_convt2x2_wfrag_elems(cin, cout)
+  if n < 0:
+    raise ValueError('convT 2x2 MFMA kernel: unsupported channels %d -> %d' % (cin, cout))
+  out = _pack(w, 'convt2x2', lambda: _convt2x2_index(cin, cout, w.device), x3)
+  assert out.numel() == n * (2 if x3 else 1)
   return out
 
 
 def pack_convt2x2_weights_x3(w):
   """ConvTranspose2d weight -> the hi and lo bf16 fragment sets of the fp32-class kernel (srl_convt2x2_bias_relu_f32)."""
-  w = w.detach().float()
-  hi = w.to(torch.bfloat16)
-  lo = (w - hi.float()).to(torch.bfloat16)
-  return torch.cat([pack_convt2x2_weights(hi.float()), pack_convt2x2_weights(lo.float())]).contiguous()
+  return pack_convt2x2_weights(w, x3=True)
 
 
 def convt2x2_bias_relu(x, wfrag, bias, cout, out, out_offset=0):
@@ -472,6 +495,50 @@ def conv3x3_relu_project(x, wfrag, bias, proj_w, proj_b, hv, wv):
   return out
 
 
+class _LazyPacked(object):
+  """Packed weights by module: `m in d` = the module has a hand-written kernel; `d[m]` packs on first use after a weight
+  update (a layer whose kernel is not used at the current map size is never packed)."""
+
+  def __init__(self):
+    self._make = {}
+    self._done = {}
+
+  def offer(self, m, make):
+    self._make[m] = make
+
+  def __contains__(self, m):
+    return m in self._make
+
+  def __getitem__(self, m):
+    if m not in self._done:
+      self._done[m] = self._make[m]()
+    return self._done[m]
+
+  def packed(self):
+    """(module, packed weights) of what has been packed since the last weight update."""
+    return list(self._done.items())
+
+
+class _WeightBias(object):
+  """(weight in the forward's dtype and channels-last, float32 bias) of a module; the weight copy is made on first use."""
+
+  def __init__(self, m, dtype):
+    self._m, self._dtype, self._w = m, dtype, None
+    self._b = m.bias.detach().float().contiguous()
+
+  def __getitem__(self, i):
+    if i == 1:
+      return self._b
+    if i != 0:
+      raise IndexError(i)
+    if self._w is None:
+      self._w = self._m.weight.detach().to(self._dtype).contiguous(memory_format=_CL)
+    return self._w
+
+  def __iter__(self):
+    return iter((self[0], self[1]))
+
+
 class FastFeatures(object):
   """Inference-only forward of the two U-Nets (`DeepQSiamFCN.features`, models.py:160-177; `layers.unet`,
   layers.py:135-259) in bf16 channels-last: library convolutions without bias, and the fused element-wise passes of
@@ -490,9 +557,9 @@ class FastFeatures(object):
     self.x3_conv = bool(x3_conv) and dtype == torch.float32
     self._key = None
     self._w = {}
-    self._wf = {}
+    self._wf = _LazyPacked()
     self._wt = {}
-    self._wg = {}
+    self._wg = _LazyPacked()
     self._pos = None
     self._posbuf = {}
 
@@ -503,25 +570,25 @@ class FastFeatures(object):
     if key == self._key:
       return
     self._w = {}
-    self._wf = {}
+    self._wf = _LazyPacked()
     self._wt = {}
-    self._wg = {}
+    self._wg = _LazyPacked()
     for m in self.net.modules():
       if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
-        self._w[m] = (m.weight.detach().to(self.dtype).contiguous(memory_format=_CL), m.bias.detach().float().contiguous())
+        self._w[m] = _WeightBias(m, self.dtype)
         if self.mfma_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.in_channels in (16, 32, 64) and m.out_channels in (16, 32):
-          self._wf[m] = pack_conv3x3_weights(m.weight)
+          self._wf.offer(m, lambda m=m: pack_conv3x3_weights(m.weight))
         if self.x3_conv and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.in_channels in (16, 32, 64) and m.out_channels in (16, 32):
-          self._wf[m] = pack_conv3x3_weights_x3(m.weight)
+          self._wf.offer(m, lambda m=m: pack_conv3x3_weights_x3(m.weight))
         # the deep levels (64 / 128 / 256 output channels): implicit GEMM on the matrix cores (csrc/conv_gemm.hip)
         if (self.mfma_conv or self.x3_conv) and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.out_channels in (64, 128, 256) and m.in_channels % 32 == 0:
-          self._wg[m] = pack_conv3x3_gemm_weights(m.weight, x3=self.x3_conv)
+          self._wg.offer(m, lambda m=m: pack_conv3x3_gemm_weights(m.weight, x3=self.x3_conv))
         if (self.mfma_conv or self.x3_conv) and isinstance(m, torch.nn.ConvTranspose2d) and m.kernel_size == (2, 2) and \
            (m.in_channels, m.out_channels) in ((32, 16), (64, 32)):
-          self._wf[m] = pack_convt2x2_weights(m.weight) if self.mfma_conv else pack_convt2x2_weights_x3(m.weight)
+          self._wf.offer(m, lambda m=m: pack_convt2x2_weights(m.weight, x3=not self.mfma_conv))
         if (self.mfma_conv or self.x3_conv) and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.in_channels in (1, 2) and m.out_channels == 16:
           self._wt[m] = m.weight.detach().float().contiguous()

@@ -301,9 +301,12 @@ def test_fast_rollout_follows_graph_replayed_updates(ref_pool):
     assert torch.equal(w, m.weight.detach().to(torch.bfloat16)) and torch.equal(b, m.bias.detach().float())
     n += 1
   assert n >= 20
-  for m, wf in pol._ff._wf.items():
+  assert len(pol._ff._wf.packed()) >= 15 and len(pol._ff._wg.packed()) >= 8      # packed on use, after the update
+  for m, wf in pol._ff._wf.packed():
     pack = qops.pack_conv3x3_weights if isinstance(m, torch.nn.Conv2d) else qops.pack_convt2x2_weights
     assert torch.equal(wf, pack(m.weight))
+  for m, wg in pol._ff._wg.packed():
+    assert torch.equal(wg, qops.pack_conv3x3_gemm_weights(m.weight))
   xc, wc = qops.FastFeatures(net)(obs)                          # and its features track a cache built afresh
   assert float((xb.float() - xc.float()).abs().max()) <= 0.05 * float(xc.float().abs().max())
   env.close()
