@@ -97,6 +97,7 @@ int srl_conv3x3_bias_relu_f32(const float* in_dev, const void* wfrag_dev, const 
  * [cin / 32][tap][cout / 16][lane][8], element = w[16 mt + lane % 16][32 cb + 8 (lane / 16) + j][tap / 3][tap % 3]. */
 int32_t srl_conv3x3_gemm_supported(int32_t cin, int32_t cout, int32_t W);
 int64_t srl_conv3x3_gemm_wfrag_elems(int32_t cin, int32_t cout);
+int32_t srl_conv3x3_gemm_batch_multiple(int32_t cout, int32_t W);   /* maps per workgroup: B must be a multiple of it */
 int srl_conv3x3_gemm_bias_relu(const void* in_dev, const void* wfrag_dev, const float* bias_dev, void* out_dev, int32_t B,
                                int32_t W, int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset, int32_t f32,
                                void* stream);

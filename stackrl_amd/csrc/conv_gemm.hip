@@ -176,7 +176,7 @@ template <int CIN, int COUT, int W, bool X3>
 int launch_gemm(const void* in, const void* wfrag, const float* bias, void* out, int B, int ostride, int ooff, hipStream_t st) {
   typedef GemmCfg<COUT, W> G;
   const size_t lds = sizeof(uint16_t) * G::TILE * (X3 ? 2 : 1);
-  const int nwg = G::NI > 1 ? B / G::NI : B * ((W * W) / G::PXT);
+  const int nwg = G::NI > 1 || G::PXT == W * W ? B / G::NI : B * ((W * W) / G::PXT);
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)k_conv3x3_gemm<CIN, COUT, W, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -193,9 +193,15 @@ template <bool X3>
 int dispatch(const void* in, const void* wfrag, const float* bias, void* out, int B, int W, int cin, int cout, int ostride,
              int ooff, hipStream_t st) {
 #define SRL_CASE(CI, CO, WW) if (cin == CI && cout == CO && W == WW) return launch_gemm<CI, CO, WW, X3>(in, wfrag, bias, out, B, ostride, ooff, st);
+  // 128^2 observations: the left U-Net's levels at 32^2 / 16^2 / 8^2, the right U-Net's bottom at 8^2
   SRL_CASE(32, 64, 32) SRL_CASE(64, 64, 32) SRL_CASE(128, 64, 32)
   SRL_CASE(64, 128, 16) SRL_CASE(128, 128, 16) SRL_CASE(256, 128, 16)
   SRL_CASE(128, 256, 8) SRL_CASE(256, 256, 8)
+  SRL_CASE(32, 64, 8) SRL_CASE(64, 64, 8)
+  // 64^2 observations (resolution_factor 4): one level further down
+  SRL_CASE(32, 64, 16) SRL_CASE(64, 64, 16) SRL_CASE(128, 64, 16)
+  SRL_CASE(64, 128, 8) SRL_CASE(128, 128, 8) SRL_CASE(256, 128, 8)
+  SRL_CASE(128, 256, 4) SRL_CASE(256, 256, 4)
 #undef SRL_CASE
   snprintf(gm_err, sizeof gm_err, "srl_conv3x3_gemm: unsupported layer %d -> %d at %d x %d", cin, cout, W, W);
   return 1;
@@ -208,9 +214,16 @@ extern "C" {
 const char* srl_conv_gemm_last_error(void) { return gm_err; }
 
 int32_t srl_conv3x3_gemm_supported(int32_t cin, int32_t cout, int32_t W) {
-  return (W == 32 && cout == 64 && (cin == 32 || cin == 64 || cin == 128)) ||
-         (W == 16 && cout == 128 && (cin == 64 || cin == 128 || cin == 256)) ||
-         (W == 8 && cout == 256 && (cin == 128 || cin == 256));
+  if (cout == 64) return ((W == 32 || W == 16) && (cin == 32 || cin == 64 || cin == 128)) || (W == 8 && (cin == 32 || cin == 64));
+  if (cout == 128) return (W == 16 || W == 8) && (cin == 64 || cin == 128 || cin == 256);
+  if (cout == 256) return (W == 8 || W == 4) && (cin == 128 || cin == 256);
+  return 0;
+}
+
+// maps per workgroup: the batch must be a multiple of it
+int32_t srl_conv3x3_gemm_batch_multiple(int32_t cout, int32_t W) {
+  const int pxt = 128 * (4 / (cout / 64));
+  return pxt >= W * W ? pxt / (W * W) : 1;
 }
 
 int64_t srl_conv3x3_gemm_wfrag_elems(int32_t cin, int32_t cout) {
@@ -221,9 +234,9 @@ int64_t srl_conv3x3_gemm_wfrag_elems(int32_t cin, int32_t cout) {
 int srl_conv3x3_gemm_bias_relu(const void* in, const void* wfrag, const float* bias, void* out, int32_t B, int32_t W,
                                int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset, int32_t f32, void* stream) {
   if (!in || !wfrag || !bias || !out || B < 1 || !srl_conv3x3_gemm_supported(cin, cout, W) || out_stride % 4 ||
-      out_offset % 4 || (W == 8 && B % 2)) {
-    snprintf(gm_err, sizeof gm_err, "srl_conv3x3_gemm_bias_relu: bad arguments (layers: 32|64|128 -> 64 at 32^2, 64|128|256 -> 128 "
-             "at 16^2, 128|256 -> 256 at 8^2 with an even batch)");
+      out_offset % 4 || B % srl_conv3x3_gemm_batch_multiple(cout, W)) {
+    snprintf(gm_err, sizeof gm_err, "srl_conv3x3_gemm_bias_relu: bad arguments (layers: srl_conv3x3_gemm_supported; the batch a "
+             "multiple of srl_conv3x3_gemm_batch_multiple)");
     return 1;
   }
   if (f32) return dispatch<true>(in, wfrag, bias, out, B, W, cin, cout, out_stride, out_offset, (hipStream_t)stream);

@@ -55,6 +55,8 @@ def load():
     L.srl_pool2x2.argtypes = [VP, VP] + [ctypes.c_int32] * 7 + [VP]
     L.srl_conv3x3_gemm_supported.restype = ctypes.c_int32
     L.srl_conv3x3_gemm_supported.argtypes = [ctypes.c_int32] * 3
+    L.srl_conv3x3_gemm_batch_multiple.restype = ctypes.c_int32
+    L.srl_conv3x3_gemm_batch_multiple.argtypes = [ctypes.c_int32] * 2
     L.srl_conv3x3_gemm_wfrag_elems.restype = ctypes.c_int64
     L.srl_conv3x3_gemm_wfrag_elems.argtypes = [ctypes.c_int32] * 2
     L.srl_conv3x3_gemm_bias_relu.restype = ctypes.c_int
@@ -407,7 +409,8 @@ def pack_conv3x3_gemm_weights(w, x3=False):
 
 
 def conv3x3_gemm_supported(cin, cout, W, B):
-  return bool(load().srl_conv3x3_gemm_supported(cin, cout, W)) and (W != 8 or B % 2 == 0)
+  L = load()
+  return bool(L.srl_conv3x3_gemm_supported(cin, cout, W)) and B % L.srl_conv3x3_gemm_batch_multiple(cout, W) == 0
 
 
 def conv3x3_gemm_bias_relu(x, wfrag, bias, cout, out=None, out_offset=0):

@@ -718,7 +718,8 @@ def test_update_stays_finite_under_the_concurrent_env_step():
   env.close()
 
 
-_GEMM_LAYERS = [(32, 64, 32), (64, 64, 32), (128, 64, 32), (64, 128, 16), (128, 128, 16), (256, 128, 16), (128, 256, 8), (256, 256, 8)]
+_GEMM_LAYERS = [(32, 64, 32), (64, 64, 32), (128, 64, 32), (64, 128, 16), (128, 128, 16), (256, 128, 16), (128, 256, 8), (256, 256, 8),
+                (32, 64, 8), (64, 64, 16), (128, 64, 16), (256, 128, 8), (128, 256, 4)]
 
 
 @pytest.mark.parametrize('cin,cout,W', _GEMM_LAYERS)
@@ -729,7 +730,7 @@ def test_conv3x3_gemm_matches_torch_fp64(cin, cout, W, f32):
   plain output and a channel slice of a wider buffer."""
   from stackrl_amd import qops
   g = torch.Generator(device='cuda').manual_seed(cin + cout + W)
-  B = 4
+  B = 8
   dt = torch.float32 if f32 else torch.bfloat16
   x = torch.randn(B, cin, W, W, generator=g, device='cuda').to(dt).contiguous(memory_format=torch.channels_last)
   w = torch.randn(cout, cin, 3, 3, generator=g, device='cuda') / (3 * cin ** 0.5)
