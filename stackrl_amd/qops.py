@@ -719,7 +719,9 @@ class FusedPolicy(object):
     self._ff = None
 
   @torch.no_grad()
-  def __call__(self, net, inputs, epsilon, gen):
+  def __call__(self, net, inputs, epsilon, gen, on_chunk=None):
+    """on_chunk(actions, upto): called after every chunk with the full-batch action tensor, final up to `upto` (a
+    pipelined env starts the step of the shards inside, `env.PipelinedVecStackEnv.actions_ready`)."""
     xm, xo = inputs
     B = xm.shape[0]
     u = torch.rand(B, generator=gen, device=xm.device)
@@ -739,6 +741,8 @@ class FusedPolicy(object):
       corr = xcorr_forward(x, w)
       adv = self._ff.pos(corr) if self.fast else net.pos(corr).flatten(1)
       out[s:e] = policy_head(adv, u[s:e], rnd[s:e], epsilon)
+      if on_chunk is not None:
+        on_chunk(out, e)
     return out
 
 

@@ -760,3 +760,34 @@ def test_pool2x2_of_a_channel_slice(dt):
   got = qops.pool2x2(buf, 32, 16)
   assert got.is_contiguous(memory_format=torch.channels_last)
   assert torch.equal(got, torch.nn.functional.max_pool2d(buf[:, 16:].float(), 2).to(dt))
+
+
+def test_pipelined_env_equals_the_monolithic_env_and_overlaps_the_policy(ref_pool):
+  """`PipelinedVecStackEnv`: the same seeds and actions give bit-identical observations, rewards and done flags as the
+  one-shard env, through the plain `step` and through `step_begin` / `actions_ready` / `step_end` driven by the fused
+  policy's chunk callback (the `Trainer` path), over an episode and its auto-reset."""
+  from stackrl_amd import env as envs, nets, qops
+  from stackrl_amd.dqn import DQN
+  B, L = 64, 3
+  a = envs.make('Stack-v0', n_parallel=B, seed=5, pool=ref_pool, episode_length=L)
+  b = envs.make('Stack-v0', n_parallel=B, seed=5, pool=ref_pool, episode_length=L, groups=4)
+  assert isinstance(b, envs.PipelinedVecStackEnv) and b.batch_size == B and b.n_actions == a.n_actions
+  assert a.seed(5) == b.seed(5)
+  sa, sb = a.reset()(), b.reset()()
+  net = nets.DeepQSiamFCN(a.observation_spec, seed=2).cuda()
+  agent = DQN(net, collect_batch_size=B, replay_memory_size=B * 8, exploration=0.3, seed=1,
+              policy_op=qops.FusedPolicy(chunk=16, autocast=torch.bfloat16, fast=True))
+  calls = []
+  for t in range(L + 2):
+    assert torch.equal(sa[0][0], sb[0][0]) and torch.equal(sa[0][1], sb[0][1]) and torch.equal(sa[1], sb[1]) and torch.equal(sa[2], sb[2])
+    if t % 2 == 0:
+      act = a.sample()
+      sa, sb = a.step(act)(), b.step(act)()
+    else:
+      b.step_begin()
+      launched = []
+      act = agent.collect(*sb, on_chunk=lambda out, upto: (b.actions_ready(out, upto), launched.append(b._pending['launched'])))
+      calls.append(launched)
+      sa, sb = a.step(act)(), b.step_end(act)()
+  assert calls and calls[0] == [1, 2, 3, 4]          # one shard started after each policy chunk of 16 envs
+  a.close(); b.close()
