@@ -1,7 +1,8 @@
 // settle.hip — K1 (place / smooth placing / settle) + K4 (Observer.pose) + the episode machine.
 //
 // One workgroup per env: 128 threads (2 waves) for L <= 8 bodies, 256 threads with one contact point per thread up to
-// 16, 256 threads with two above (srl_k_step / _pp1 / _pp2).  The env's whole persistent state ("blob": poses,
+// 16 (128 threads with two points per thread in batches of >= 3,072 envs), 256 threads with two above
+// (srl_k_step / _pp1 / _t128 / _pp2).  The env's whole persistent state ("blob": poses,
 // velocities, ground and body-body manifolds with their warm-start impulses, slot tables) is loaded into
 // LDS once, every sub-step runs out of LDS, and the blob is written back once — HBM traffic per env step
 // is 2 x BLOB words regardless of how many sub-steps the stop criterion takes.
@@ -1119,6 +1120,13 @@ extern "C" __global__ void __launch_bounds__(256, 3) srl_k_step_pp1(const DevPar
 extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp2(const DevParams* __restrict__ Pp,
     const int64_t* __restrict__ action, int force_reset) {
   step_body<256, 2>(Pp, action, force_reset);
+}
+
+// 9 - 16 rocks, large batches: two waves per env with two points per thread and no LDS copy of the local vertices —
+// 35 KB per env, four workgroups per CU instead of three (the shapes with >= 2,048 envs are throughput-bound)
+extern "C" __global__ void __launch_bounds__(128, 2) srl_k_step_t128(const DevParams* __restrict__ Pp,
+    const int64_t* __restrict__ action, int force_reset) {
+  step_body<128, 2>(Pp, action, force_reset);
 }
 
 // ------------------------------------------------------------------ ParallelEnv.sample (utils.py:534-538)

@@ -112,6 +112,19 @@ int derive(DevParams& P) {
   return SRL_OK;
 }
 
+// 9 - 16 rocks in batches of 3,072 envs or more run two waves per env with two contact points per thread and without
+// the LDS copy of the local vertices: 35 KB per env, so four workgroups share a CU instead of three — these batches are
+// throughput-bound (+6 % at 4,096 envs: 47.5 against 50.6 ms per launch; -1 % at 2,048, -6 % at 1,024, where the launch
+// lasts as long as its slowest env).  SRL_STEP_VARIANT=two_wave | four_wave overrides the choice (parity tests).
+bool two_wave_variant(const DevParams& P) {
+  const int L = P.c.episode_length;
+  if (L <= 8 || L > 16) return false;
+  const char* v = getenv("SRL_STEP_VARIANT");
+  if (v && !strcmp(v, "two_wave")) return true;
+  if (v && !strcmp(v, "four_wave")) return false;
+  return P.c.n_envs >= 3072;
+}
+
 void layout(DevParams& P) {
   int L = P.c.episode_length;
   P.NS = nslots(L);
@@ -140,7 +153,7 @@ void layout(DevParams& P) {
   P.S_WV = s; s += 3 * P.VS * L;
   // above 16 rocks the local vertices are read from the (L2-resident) mesh table instead of an LDS copy: 70 instead of
   // 97 KB per env, so that two workgroups share a CU
-  if (L > 16) P.S_LV = -1; else { P.S_LV = s; s += 3 * P.VS * L; }
+  if (L > 16 || two_wave_variant(P)) P.S_LV = -1; else { P.S_LV = s; s += 3 * P.VS * L; }
   s = (s + 1) & ~1;
   P.S_USED = s; s += 2 * SRL_MAX_BODIES;   // colouring scratch (uint64 per body); BLOB is a multiple of 4 words
   P.S_MISC = s; s += M_WORDS;
@@ -182,6 +195,7 @@ int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void*
   const DevParams* dP = env->d_P;
   if (env->step_pp == 0) SRL_LAUNCH(env, 0, srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
   else if (env->step_pp == 2) SRL_LAUNCH(env, 0, srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
+  else if (env->step_pp == 3) SRL_LAUNCH(env, 0, srl_k_step_t128, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
   else SRL_LAUNCH(env, 0, srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
   if (force_reset < 0) {   // srl_step_simulation: sub-steps only
     HIP_TRY(hipGetLastError());
@@ -393,6 +407,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   // 128 threads up to 8 rocks, 256 up to 16 (one contact point per thread), 256 with two points per thread above
   // (settle.hip "Variants")
   if (4 * P.NS <= 128 && SRL_GMAXP * P.c.episode_length <= 128) { env->step_threads = 128; env->step_pp = 0; }
+  else if (two_wave_variant(P)) { env->step_threads = 128; env->step_pp = 3; }
   else if (4 * P.NS <= 256) { env->step_threads = 256; env->step_pp = 1; }
   else { env->step_threads = 256; env->step_pp = 2; }
   const int res = P.c.overhead_res;
@@ -401,6 +416,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_t128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->render_lds));
   // K3: object maps of the whole pool, once
   hipLaunchKernelGGL(srl_k_objmap, dim3(n_mesh, P.n_orient), dim3(256), env->objmap_lds, 0, P, env->d_objmap, env->d_objmap_u8);

@@ -157,6 +157,22 @@ def test_large_configs(ref_pool, oracle_mod, L, n, kw):
   assert g.n_actions == {4: 2401, 3: 4225}.get(kw.get('resolution_factor', kw.get('observable_size_ratio')), 9409)
 
 
+def test_two_wave_settle_variant_matches_the_oracle(ref_pool, oracle_mod, monkeypatch):
+  """9 - 16 rocks in batches of >= 3,072 envs run `srl_k_step_t128` (two waves per env, two contact points per thread, no
+  LDS vertex copy); forced here on a small batch (SRL_STEP_VARIANT, read at srl_create) and held bit-exact against the
+  oracle over a 14-rock episode and its auto-reset.  (`test_full_size_dqn_config_properties` compares it at 4,096 envs with
+  the four-wave variant of a 64-env batch.)"""
+  monkeypatch.setenv('SRL_STEP_VARIANT', 'two_wave')
+  L, n = 14, 5
+  g, o = _mk(ref_pool, oracle_mod, n, L, seed=17)
+  gout, oout = g.reset(), o.reset()
+  assert np.array_equal(gout[0][0].cpu().numpy(), oout[0][0])
+  for k in range(L + 1):
+    ga, oa = g.sample(), o.sample()
+    assert np.array_equal(ga.cpu().numpy(), oa)
+    _cmp_step(g, o, g.step(ga), o.step(oa), 'step {}'.format(k))
+
+
 def test_full_size_batch_properties(ref_pool):
   """BASELINE configs[1] size (1,024 envs x 8 rocks): size-independent properties instead of the oracle —
   every env places exactly L rocks, done on the L-th step, rocks at rest above the ground inside the time cap,
