@@ -38,7 +38,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E (MI355X_MICROARCH.md)
-PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}   # dense MFMA peaks, same guide (fp32 matrix = fp32 vector rate)
+# dense MFMA peaks, same guide.  The fp32-class rollout computes every product as three bf16 MFMAs (hi hi + hi lo + lo hi,
+# csrc/conv_mfma.hip, conv_gemm.hip, xcorr_mfma.hip): its ceiling is a third of the bf16 peak, not the fp32 MFMA peak (157.3)
+PEAK_TFLOPS = {'f32': 2500.0 / 3.0, 'bf16': 2500.0}
 
 
 def parse_args(argv=None):
@@ -417,7 +419,9 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
       'frac': flops_fwd / (fwd_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 'traffic': None,
       'alg_flops_per_launch': flops_fwd, 'avg_launch_ms': fwd_ms,
       'note': 'model-level: 2 x {:.1f} M MAC per sample (SURVEY.md N1) x samples / HIP-event time of agent.collect in '
-              'the timed region; peak = dense {} MFMA'.format(macs / 1e6, dtype),
+              'the timed region; peak = {}'.format(macs / 1e6, 'dense bf16 MFMA' if dtype == 'bf16' else
+                                                   'dense bf16 MFMA / 3 (fp32-class products = three bf16 MFMAs; the fp32 MFMA peak '
+                                                   'would be 157.3)'),
     },
   }
   env.close()
