@@ -318,7 +318,12 @@ def rccl_group(args, world):
   if args.backend != 'nccl' or not (dist.is_available() and dist.is_initialized()):
     return None
   if 'pg' not in _RCCL:
+    import torch
     _RCCL['pg'] = dist.new_group(backend='nccl')
+    # the communicator is built by the first collective: here, not inside the timed region (and from here on RCCL's
+    # watchdog thread is alive while the update is captured into hipGraphs)
+    dist.all_reduce(torch.zeros(1, device='cuda'), group=_RCCL['pg'])
+    torch.cuda.synchronize()
   return _RCCL['pg']
 
 

@@ -17,6 +17,11 @@ import torch.distributed as dist
 from stackrl_amd.memory import ReplayMemory
 
 
+# Stream captures run in thread-local error mode: with a process group alive (RCCL's watchdog thread polls its events)
+# another thread's HIP calls must not invalidate a capture in progress on this one
+CAPTURE_MODE = 'thread_local'
+
+
 class PolynomialDecay(object):
   """keras.optimizers.schedules.PolynomialDecay (config.gin:73-81), cycle=False."""
 
@@ -104,7 +109,7 @@ class GraphedEval(object):
         self.net(self.static_in)
     torch.cuda.current_stream().wait_stream(side)
     self.graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(self.graph), torch.no_grad():
+    with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE), torch.no_grad():
       self.static_out = self.net(self.static_in)
 
   def __call__(self, inputs):
@@ -422,14 +427,14 @@ class DQN(object):
       self._graphs = False                 # the target evaluations are part of this graph, not graphs of their own
       try:
         if self._world == 1:
-          with torch.cuda.graph(g):
+          with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
             self._graph_out = self._update()
         else:
-          with torch.cuda.graph(g):
+          with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
             loss, mtd, indexes, td_abs, new_logits = self._forward_backward()
           self._graph_out = (loss, mtd)
           g2 = torch.cuda.CUDAGraph()
-          with torch.cuda.graph(g2, pool=g.pool()):
+          with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode=CAPTURE_MODE):
             self._apply(indexes, td_abs, new_logits)
           self._apply_graph = g2
       finally:
