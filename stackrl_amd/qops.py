@@ -711,8 +711,10 @@ class FusedPolicy(object):
   library convs for the two U-Nets and the position convs, HIP cross-correlation, HIP arg-max + epsilon-greedy.
   Draws the same random numbers in the same order as `DQN.policy`, so both paths give identical actions."""
 
-  def __init__(self, chunk=512, autocast=None, fast=None):
-    self.chunk = int(chunk)      # rollout batches are processed in chunks to bound activation memory
+  def __init__(self, chunk=2048, autocast=None, fast=None):
+    # rollout batches are processed in chunks to bound activation memory: 2,048 samples hold ~10 GB of fp32 activations
+    # (of 288 GB) and run 4 % faster per sample than 512 (more workgroups per launch: 24.9 against 26.1 ms per 4,096, bf16)
+    self.chunk = int(chunk)
     self.autocast = autocast     # None = fp32 like the reference; torch.bfloat16 runs the library convs on MFMA
     # fused epilogues around bias-free library convolutions (bf16: + the MFMA convolution kernels; fp32: epilogues only)
     self.fast = (autocast == torch.bfloat16) if fast is None else bool(fast)
