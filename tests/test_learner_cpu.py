@@ -554,3 +554,51 @@ def test_bench_spawns_its_own_ranks_world_size_2_gloo():
   d = json.loads(lines[0])
   assert d['n_gpus'] == 2 and d['steps'] == 7 and d['warmup'] == 2 and d['value'] is None and d['launch_only']
   assert d['aggregate_check'] == {'max_dt': 1.5, 'sum_placed': 300.0}
+
+
+def test_weight_packers_match_the_fragment_layouts_written_out():
+  """`qops._pack` (cached flat gather index per layer shape) against the fragment layouts of include/stackrl_qnet.h
+  written out with advanced indexing: 3 x 3 convolution (k = tap pairs at 16 input channels, tap x 32-channel blocks
+  above), the implicit-GEMM order [cin / 32][tap][cout / 16][lane][8], the transposed convolution, and the hi / lo sets of
+  the fp32-class kernels."""
+  from stackrl_amd import qops
+  lane = torch.arange(64)
+  def conv(w):
+    cout, cin = w.shape[:2]
+    ks = torch.arange(5 if cin == 16 else 9 * (cin // 32))[:, None, None, None]
+    mt = torch.arange(cout // 16)[None, :, None, None]; l = lane[None, None, :, None]; j = torch.arange(8)[None, None, None, :]
+    k = 8 * (l >> 4) + j
+    if cin == 16:
+      tap, ci = 2 * ks + (k >> 4), k & 15
+    else:
+      m = cin // 32; tap, ci = ks // m + 0 * k, 32 * (ks % m) + k
+    tc = tap.clamp(max=8)
+    return (w.float()[16 * mt + (l & 15), ci, tc // 3, tc % 3] * (tap < 9)).to(torch.bfloat16).reshape(-1)
+  def gemm(w):
+    cout, cin = w.shape[:2]
+    cb = torch.arange(cin // 32)[:, None, None, None, None]; tap = torch.arange(9)[None, :, None, None, None]
+    mt = torch.arange(cout // 16)[None, None, :, None, None]; l = lane[None, None, None, :, None]; j = torch.arange(8)[None, None, None, None, :]
+    return w.float()[16 * mt + (l & 15), 32 * cb + 8 * (l >> 4) + j, tap // 3, tap % 3].to(torch.bfloat16).reshape(-1)
+  def convt(w):
+    cin, cout = w.shape[:2]
+    ks = torch.arange(cin // 32)[:, None, None, None]; mt = torch.arange(4 * cout // 16)[None, :, None, None]
+    l = lane[None, None, :, None]; j = torch.arange(8)[None, None, None, :]
+    m = 16 * mt + (l & 15); q, co = m // cout, m % cout
+    return w.float()[32 * ks + 8 * (l >> 4) + j, co, q >> 1, q & 1].to(torch.bfloat16).reshape(-1)
+  g = torch.Generator().manual_seed(0)
+  split = lambda w: (w.to(torch.bfloat16).float(), w - w.to(torch.bfloat16).float())
+  for cin, cout in ((16, 16), (16, 32), (32, 16), (64, 32)):
+    w = torch.randn(cout, cin, 3, 3, generator=g)
+    hi, lo = split(w)
+    assert torch.equal(qops.pack_conv3x3_weights(w), conv(w))
+    assert torch.equal(qops.pack_conv3x3_weights_x3(w), torch.cat([conv(hi), conv(lo)]))
+  for cin, cout in ((32, 64), (256, 128)):
+    w = torch.randn(cout, cin, 3, 3, generator=g)
+    hi, lo = split(w)
+    assert torch.equal(qops.pack_conv3x3_gemm_weights(w), gemm(w))
+    assert torch.equal(qops.pack_conv3x3_gemm_weights(w, x3=True), torch.cat([gemm(hi), gemm(lo)]))
+  for cin, cout in ((32, 16), (64, 32)):
+    w = torch.randn(cin, cout, 2, 2, generator=g)
+    hi, lo = split(w)
+    assert torch.equal(qops.pack_convt2x2_weights(w), convt(w))
+    assert torch.equal(qops.pack_convt2x2_weights_x3(w), torch.cat([convt(hi), convt(lo)]))
