@@ -62,9 +62,6 @@ def parse_args(argv=None):
   ap.add_argument('--dqn-envs', type=int, default=None, help='leg B: envs per GPU (default by --gpus, see above)')
   ap.add_argument('--dqn-rocks', type=int, default=None)
   ap.add_argument('--dqn-res', type=int, default=None, choices=[64, 128])
-  ap.add_argument('--dqn-groups', type=int, default=1,
-                  help='leg B: env shards that step as soon as the policy has their actions (env.PipelinedVecStackEnv); 1 = one '
-                       'vectorised step after the forward, the default: measured slower, DESIGN.md section 6')
   ap.add_argument('--dqn-slots', type=int, default=16, help='replay capacity in transitions per env')
   ap.add_argument('--rollout', default='both', choices=['f32', 'bf16', 'both'])
   ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL; gloo for rehearsals')
@@ -346,10 +343,8 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
   kw = dict(solver_kw)
   if res == 64:
     kw['resolution_factor'] = 4
-  # the env as shards that start their step as their actions arrive (env.PipelinedVecStackEnv: same trajectories)
-  groups = args.dqn_groups if B % max(args.dqn_groups, 1) == 0 else 1
   env = envs.make('Stack-v0', n_parallel=B, seed=args.seed, pool=pool, episode_length=L, side_stream=True,
-                  env_index_offset=rank * B, groups=groups, **kw)
+                  env_index_offset=rank * B, **kw)
   net = nets.DeepQSiamFCN(env.observation_spec, seed=1).cuda()
   agent = DQN(net, learning_rate=6.25e-5, adam_betas=(0.95, 0.95), minibatch_size=32,
               replay_memory_size=B * args.dqn_slots, discount_factor=.966667, collect_batch_size=B,
@@ -375,14 +370,10 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
       step = step()
     if k >= 0:
       ev[k][0].record()
-    if groups > 1:
-      env.step_begin()
-      action = agent.collect(*step, on_chunk=env.actions_ready)   # shards start stepping under the rest of the forward
-    else:
-      action = agent.collect(*step)
+    action = agent.collect(*step)
     if k >= 0:
       ev[k][1].record()
-    step = env.step_end(action) if groups > 1 else env.step(action)   # side stream(s): overlaps the update below
+    step = env.step(action)                # side stream: overlaps the update below
     if k >= 0:
       ev[k][2].record()
     agent.train()
@@ -416,7 +407,7 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
     'rollout_dtype': dtype, 'update_dtype': 'f32 (cross-correlation as bf16x3 split on MFMA)',
     'iterations': iters, 'warmup': warm,
     'env_steps_per_s': steps_all / dt_max, 'iters_per_s': iters / dt_max, 'ms_per_iter': 1e3 * dt_max / iters,
-    'rollout_forward_ms': fwd_ms, 'update_ms': upd_ms, 'allreduce_ms': ar_ms, 'env_groups': groups,
+    'rollout_forward_ms': fwd_ms, 'update_ms': upd_ms, 'allreduce_ms': ar_ms,
     'grad_bucket_bytes': int(agent._flat_grad.numel() * 4), 'update_graphed': agent._train_graph is not None,
     'roofline': {
       'kernel': 'Q-net rollout forward (DeepQSiamFCN, {} samples)'.format(B), 'bound': 'mfma',

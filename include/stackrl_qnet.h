@@ -102,6 +102,14 @@ int srl_conv3x3_gemm_bias_relu(const void* in_dev, const void* wfrag_dev, const 
                                int32_t W, int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset, int32_t f32,
                                void* stream);
 const char* srl_conv_gemm_last_error(void);
+/* The transposed convolutions of the deep levels (128 -> 64, 256 -> 128; any map size) as a GEMM on the matrix cores
+ * (csrc/conv_gemm.hip): in channels-last [B][H][W][cin] -> the channel slice [out_offset, out_offset + cout) of a
+ * channels-last buffer [B][2H][2W][out_stride]; f32 = 0 bfloat16, 1 float32 (fp32-class, wfrag = hi set then lo set).
+ * wfrag: the order of srl_convt2x2_wfrag_elems. */
+int32_t srl_convt2x2_gemm_supported(int32_t cin, int32_t cout);
+int srl_convt2x2_gemm_bias_relu(const void* in_dev, const void* wfrag_dev, const float* bias_dev, void* out_dev, int32_t B,
+                                int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset,
+                                int32_t f32, void* stream);
 /* The thin first layers (1 or 2 input channels -> 16) on the vector ALU: in uint8 (in_dtype 0: the env's observation
  * bytes, scaled by 1/255 as in models.py:144-147) or float32 (in_dtype 1) channels-last [B][H][W][cin]; w float32
  * [16][cin][3][3], bias float32 [16]; out bfloat16 channels-last [B][Hp][Wp][16] with Hp >= H, Wp >= W (only the H x W

@@ -54,8 +54,7 @@ k_conv3x3_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag,
                void* __restrict__ out_, int ostride, int ooff) {
   typedef GemmCfg<COUT, W> G;
   constexpr int NCB = CIN / 32, MT = COUT / 16;
-  constexpr int NPL = X3 ? 2 : 1;                  // LDS planes (hi, lo)
-  extern __shared__ uint16_t tile[];               // [NPL][NI][TH][TWD][PS]
+  extern __shared__ uint16_t tile[];               // [1 or (X3) 2 planes: hi, lo][NI][TH][TWD][PS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % G::WM, wn = wave / G::WM;
   const int n = lane & 15, g = lane >> 4;
@@ -170,6 +169,86 @@ k_conv3x3_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag,
   }
 }
 
+// Transposed convolution 2 x 2, stride 2 (`up{i}` of layers.unet, layers.py:222-229) + bias + ReLU of the deep levels
+// (64 / 128 output channels) as a GEMM: every input pixel produces its 2 x 2 block of output pixels,
+// D[(dy, dx, co)][pixel] = sum_ci W[ci][co][dy][dx] X[pixel][ci] — M = 4 COUT rows, K = CIN, no halo, any map size.
+// A wave owns 64 rows x 128 consecutive input pixels (of the flattened [B][H][W] order); the four waves of a workgroup
+// take four row blocks (COUT = 128: two workgroups per pixel tile).  K has only CIN / 32 = 2 .. 8 steps, so nothing is
+// staged: the A fragments (pre-packed, L2-resident) and the B fragments (16 or, fp32-class, 32 bytes of one pixel's
+// channels, shared by the workgroup's waves through L1) come straight from global memory.  Output: the channel slice of
+// the concat buffer, 4 consecutive channels of one output pixel per lane and tile.
+template <int CIN, int COUT, bool X3>
+__global__ void __launch_bounds__(256, 2)
+k_convt2x2_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag, const float* __restrict__ bias,
+                void* __restrict__ out_, int H, int W, int ostride, int ooff, long long npix) {
+  constexpr int KS = CIN / 32, MT = 4 * COUT / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+  const int mb = blockIdx.y * 4 + wave;                 // 64-row block of the 4 COUT rows
+  const long long p0 = (long long)blockIdx.x * 128;
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[mt][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  const bf16x8* wf = (const bf16x8*)wfrag + (4 * mb) * 64 + lane;
+  constexpr size_t LO = (size_t)KS * MT * 64;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    bf16x8 ah[4], al[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      ah[mt] = wf[((size_t)ks * MT + mt) * 64];
+      if (X3) al[mt] = wf[LO + ((size_t)ks * MT + mt) * 64];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      long long p = p0 + 16 * t + n;
+      if (p >= npix) p = npix - 1;                      // (a partial last tile: clamped loads, stores skipped)
+      bf16x8 xh, xl;
+      if (X3) {
+        const float* s = (const float*)in_ + p * CIN + 32 * ks + 8 * g;
+        const float4 a = *(const float4*)s, c = *(const float4*)(s + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t h = g_bf16_rne(v[j]);
+          xh[j] = (short)h;
+          xl[j] = (short)g_bf16_rne(v[j] - __uint_as_float(h << 16));
+        }
+      } else {
+        xh = *(const bf16x8*)((const uint16_t*)in_ + p * CIN + 32 * ks + 8 * g);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        if (X3) {
+          acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], xh, acc[mt][t], 0, 0, 0);
+          acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], xl, acc[mt][t], 0, 0, 0);
+        }
+        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], xh, acc[mt][t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const long long p = p0 + 16 * t + n;
+    if (p >= npix) continue;
+    const int x = (int)(p % W);
+    const long long by = p / W;                         // b * H + y
+    const long long b = by / H; const int y = (int)(by - b * H);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = 64 * mb + 16 * mt + 4 * g;          // row of the GEMM = (dy, dx, co)
+      const int q = m / COUT, co = m - q * COUT, dy = q >> 1, dx = q & 1;
+      const float4 bz = *(const float4*)(bias + co);
+      const float v0 = fmaxf(acc[mt][t][0] + bz.x, 0.0f), v1 = fmaxf(acc[mt][t][1] + bz.y, 0.0f);
+      const float v2 = fmaxf(acc[mt][t][2] + bz.z, 0.0f), v3 = fmaxf(acc[mt][t][3] + bz.w, 0.0f);
+      const size_t o = (((size_t)b * 2 * H + 2 * y + dy) * 2 * W + 2 * x + dx) * ostride + ooff + co;
+      if (X3) *(float4*)((float*)out_ + o) = make_float4(v0, v1, v2, v3);
+      else *(uint2*)((uint16_t*)out_ + o) = make_uint2(g_bf16_rne(v0) | (g_bf16_rne(v1) << 16), g_bf16_rne(v2) | (g_bf16_rne(v3) << 16));
+    }
+  }
+}
+
 thread_local char gm_err[256] = "";
 
 template <int CIN, int COUT, int W, bool X3>
@@ -241,6 +320,32 @@ int srl_conv3x3_gemm_bias_relu(const void* in, const void* wfrag, const float* b
   }
   if (f32) return dispatch<true>(in, wfrag, bias, out, B, W, cin, cout, out_stride, out_offset, (hipStream_t)stream);
   return dispatch<false>(in, wfrag, bias, out, B, W, cin, cout, out_stride, out_offset, (hipStream_t)stream);
+}
+
+int32_t srl_convt2x2_gemm_supported(int32_t cin, int32_t cout) {
+  return (cin == 128 && cout == 64) || (cin == 256 && cout == 128);
+}
+
+int srl_convt2x2_gemm_bias_relu(const void* in, const void* wfrag, const float* bias, void* out, int32_t B, int32_t H, int32_t W,
+                                int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset, int32_t f32, void* stream) {
+  if (!in || !wfrag || !bias || !out || B < 1 || H < 1 || W < 1 || !srl_convt2x2_gemm_supported(cin, cout) || out_stride % 4 ||
+      out_offset % 4) {
+    snprintf(gm_err, sizeof gm_err, "srl_convt2x2_gemm_bias_relu: bad arguments (128 -> 64 or 256 -> 128 channels)");
+    return 1;
+  }
+  const long long npix = (long long)B * H * W;
+  const dim3 grid((unsigned)((npix + 127) / 128), (unsigned)(4 * cout / 256)), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+#define SRL_CT(CI, CO) \
+  if (cin == CI && cout == CO) { \
+    if (f32) hipLaunchKernelGGL((k_convt2x2_gemm<CI, CO, true>), grid, blk, 0, st, in, (const uint16_t*)wfrag, bias, out, H, W, out_stride, out_offset, npix); \
+    else hipLaunchKernelGGL((k_convt2x2_gemm<CI, CO, false>), grid, blk, 0, st, in, (const uint16_t*)wfrag, bias, out, H, W, out_stride, out_offset, npix); \
+  }
+  SRL_CT(128, 64) SRL_CT(256, 128)
+#undef SRL_CT
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(gm_err, sizeof gm_err, "srl_convt2x2_gemm_bias_relu: %s", hipGetErrorString(e)); return 2; }
+  return 0;
 }
 
 }  // extern "C"

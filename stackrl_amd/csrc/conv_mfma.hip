@@ -630,14 +630,15 @@ int srl_conv3x3_thin_f32(const void* in, int32_t in_dtype, const float* w, const
 }
 
 int32_t srl_convt2x2_wfrag_elems(int32_t cin, int32_t cout) {
-  if (!((cin == 32 && cout == 16) || (cin == 64 && cout == 32))) return -1;
+  // (128 -> 64 and 256 -> 128: the same fragment order, consumed by srl_convt2x2_gemm_bias_relu, csrc/conv_gemm.hip)
+  if (!((cin == 32 && cout == 16) || (cin == 64 && cout == 32) || (cin == 128 && cout == 64) || (cin == 256 && cout == 128))) return -1;
   return (cin / 32) * (4 * cout / 16) * 64 * 8;
 }
 
 int srl_convt2x2_bias_relu(const void* in, const void* wfrag, const float* bias, void* out, int32_t B, int32_t H, int32_t W,
                            int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset, void* stream) {
   if (!in || !wfrag || !bias || !out || B < 1 || H < 1 || W < 16 || W % 16 || out_stride % 4 || out_offset % 4 ||
-      srl_convt2x2_wfrag_elems(cin, cout) < 0) {
+      !((cin == 32 && cout == 16) || (cin == 64 && cout == 32))) {
     snprintf(c_err, sizeof c_err, "srl_convt2x2_bias_relu: bad arguments (W a multiple of 16; 32 -> 16 or 64 -> 32 channels)");
     return 1;
   }
@@ -654,7 +655,7 @@ int srl_convt2x2_bias_relu(const void* in, const void* wfrag, const float* bias,
 int srl_convt2x2_bias_relu_f32(const float* in, const void* wfrag, const float* bias, float* out, int32_t B, int32_t H, int32_t W,
                                int32_t cin, int32_t cout, int32_t out_stride, int32_t out_offset, void* stream) {
   if (!in || !wfrag || !bias || !out || B < 1 || H < 1 || W < 16 || W % 16 || out_stride % 4 || out_offset % 4 ||
-      srl_convt2x2_wfrag_elems(cin, cout) < 0) {
+      !((cin == 32 && cout == 16) || (cin == 64 && cout == 32))) {
     snprintf(c_err, sizeof c_err, "srl_convt2x2_bias_relu_f32: bad arguments (W a multiple of 16; 32 -> 16 or 64 -> 32 channels)");
     return 1;
   }

@@ -264,10 +264,8 @@ class DQN(object):
 
   # ------------------------------------------------------------------ policy (dqn.py:330-375)
   @torch.no_grad()
-  def policy(self, inputs, exploration=False, values=False, on_chunk=None):
+  def policy(self, inputs, exploration=False, values=False):
     if self._policy_op is not None and exploration and not values and self._exploration_mode == 'epsilon-greedy':
-      if on_chunk is not None:
-        return self._policy_op(self._q_net, inputs, self.exploration, self._gen, on_chunk=on_chunk)
       return self._policy_op(self._q_net, inputs, self.exploration, self._gen)
     with torch.no_grad():
       q = self._q_net(inputs)
@@ -292,9 +290,8 @@ class DQN(object):
   def observe(self, state, reward, terminal, action):
     self._replay_memory.add(state, reward, terminal, action)
 
-  def collect(self, state, reward, terminal, on_chunk=None):
-    """on_chunk: see `qops.FusedPolicy` — lets a pipelined env start stepping while the rest of the batch is evaluated."""
-    action = self.policy(state, exploration=True, on_chunk=on_chunk)
+  def collect(self, state, reward, terminal):
+    action = self.policy(state, exploration=True)
     self._replay_memory.add(state, reward, terminal, action)
     return action
 

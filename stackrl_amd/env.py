@@ -298,144 +298,6 @@ class VecStackEnv(object):
     return ms, n
 
 
-class PipelinedVecStackEnv(object):
-  """The same B envs as `VecStackEnv(n_parallel=B)` — same seeds, same trajectories, bit for bit — held as `groups`
-  independent shards of B / groups envs, each with its own HIP stream, so that a shard can start its step as soon as
-  ITS actions exist: while the policy is still evaluating the later envs of the batch (`step_begin` /
-  `actions_ready` / `step_end`), the settle kernels of the earlier ones already run.  The reference's `ParallelEnv`
-  steps its worker processes as their actions arrive in the same way (utils.py:468-486 sends per worker).  Outputs are
-  written straight into the shards' slices of full-batch tensors (no copies).  `step(action)` keeps the plain interface.
-  Measured on MI355X: NOT a gain — the resident settle workgroups hold 144 of a CU's 160 KB of
-  LDS for tens of milliseconds, so the convolution kernels of the remaining forward wait for CUs (forward 27 -> 85 ms at
-  4,096 envs) and the iteration gets longer; `bench.py` and `Trainer` use it only when asked (`groups=`)."""
-
-  def __init__(self, n_parallel=None, groups=4, block=None, seed=None, pool=None, device=None, env_index_offset=0,
-               **kwargs):
-    B, K = int(n_parallel or 1), int(groups)
-    if K < 1 or B % K:
-      raise ValueError('n_parallel must be a multiple of groups')
-    kwargs.pop('side_stream', None)
-    self._block = block
-    self._B, self._K, self._G = B, K, B // K
-    self.pool = pool if pool is not None else _assets.default_pool()
-    self._envs = [VecStackEnv(n_parallel=self._G, block=False, seed=seed, pool=self.pool, device=device,
-                              env_index_offset=int(env_index_offset) + k * self._G, side_stream=True, **kwargs)
-                  for k in range(K)]
-    e0 = self._envs[0]
-    self.config = e0.config
-    self._device = e0._device
-    self._pending = None
-
-  # ---- the ParallelEnv surface
-  multiprocessing = False
-
-  @property
-  def batch_size(self):
-    return self._B
-
-  @property
-  def groups(self):
-    return self._K
-
-  @property
-  def observation_spec(self):
-    return self._envs[0].observation_spec
-
-  @property
-  def action_spec(self):
-    return self._envs[0].action_spec
-
-  @property
-  def n_actions(self):
-    return self._envs[0].n_actions
-
-  @property
-  def num_maps_on_show(self):
-    return self._envs[0].num_maps_on_show
-
-  def __call__(self, *args, **kwargs):
-    return self.step(*args, **kwargs)
-
-  def seed(self, seed):
-    out = []
-    for e in self._envs:
-      out += e.seed(seed)
-    return out
-
-  def close(self):
-    for e in self._envs:
-      e.close()
-
-  terminate = close
-
-  def sample(self):
-    return torch.cat([e.sample() for e in self._envs])
-
-  def sweeps(self):
-    return np.concatenate([e.sweeps() for e in self._envs])
-
-  def _outputs(self):
-    e0 = self._envs[0]
-    keys = self.config.reward_keys
-    om = torch.empty((self._B,) + tuple(e0._observation_spec[0].shape), dtype=torch.uint8, device=self._device)
-    oo = torch.empty((self._B,) + tuple(e0._observation_spec[1].shape), dtype=torch.uint8, device=self._device)
-    reward = torch.empty(self._B if keys is None else (self._B, len(keys)), dtype=torch.float32, device=self._device)
-    done = torch.empty(self._B, dtype=torch.uint8, device=self._device)
-    return om, oo, reward, done
-
-  def _slices(self, tensors, k):
-    s, e = k * self._G, (k + 1) * self._G
-    return tuple(t[s:e] for t in tensors)
-
-  def _waiter(self, waits, out):
-    def wait():
-      for w in waits:
-        w()
-      return out
-    return wait
-
-  def reset(self, block=None):
-    om, oo, _, _ = self._outputs()
-    waits = [e.reset(block=False, out=self._slices((om, oo), k)) for k, e in enumerate(self._envs)]
-    keys = self.config.reward_keys
-    out = ((om, oo), torch.zeros(self._B if keys is None else (self._B, len(keys)), dtype=torch.float32, device=self._device),
-           torch.zeros(self._B, dtype=torch.bool, device=self._device))
-    wait = self._waiter(waits, out)
-    block = self._block if block is None else block
-    return wait() if block else wait
-
-  # ---- pipelined step: step_begin(); [actions_ready(action, upto) ...]; step_end(action)
-  def step_begin(self):
-    self._pending = dict(out=self._outputs(), waits=[], launched=0)
-
-  def actions_ready(self, action, upto):
-    """`action[:upto]` (int64, the full-batch action tensor) is final: every shard that lies inside starts its step."""
-    p = self._pending
-    while p['launched'] < self._K and (p['launched'] + 1) * self._G <= upto:
-      k = p['launched']
-      p['waits'].append(self._envs[k].step(action[k * self._G:(k + 1) * self._G], block=False, out=self._slices(p['out'], k)))
-      p['launched'] += 1
-
-  def step_end(self, action, block=None):
-    if self._pending is None:
-      self.step_begin()
-    if not torch.is_tensor(action):
-      action = torch.as_tensor(action)
-    action = action.to(device=self._device, dtype=torch.int64).contiguous()
-    if action.shape != (self._B,):
-      raise ValueError('action must have shape [{}]'.format(self._B))
-    self.actions_ready(action, self._B)
-    p, self._pending = self._pending, None
-    om, oo, reward, done = p['out']
-    wait = self._waiter(p['waits'], ((om, oo), reward, done.view(torch.bool)))
-    block = self._block if block is None else block
-    return wait() if block else wait
-
-  def step(self, action, block=None):
-    self.step_begin()
-    return self.step_end(action, block=block)
-
-
 class StartedVecStackEnv(VecStackEnv):
   """`StartedStackEnv` (Stack-v1, env.py:348-441): an episode uses `n_objects` rocks, the first `n_objects -
   episode_length` of which are placed by `start_policy` inside `reset`, so the agent sees only the last
@@ -574,9 +436,6 @@ def make(env='Stack-v0', n_parallel=None, block=None, seed=None, as_path=False, 
     return StartedVecStackEnv(n_parallel=n_parallel or 1, block=block, seed=seed, **kwargs)
   elif env != 'Stack-v0':
     raise ValueError("Invalid env {}: 'Stack-v0', 'Stack-v1' and 'Stack-v2' are implemented.".format(env))
-  groups = kwargs.pop('groups', None)                    # build option: shards that step as their actions arrive
-  if groups and int(groups) > 1:
-    return PipelinedVecStackEnv(n_parallel=n_parallel or 1, groups=groups, block=block, seed=seed, **kwargs)
   return VecStackEnv(n_parallel=n_parallel or 1, block=block, seed=seed, **kwargs)
 
 

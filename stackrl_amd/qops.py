@@ -53,6 +53,10 @@ def load():
     L.srl_bias_act_bwd_f32.argtypes = [VP] * 5 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, VP]
     L.srl_pool2x2.restype = ctypes.c_int
     L.srl_pool2x2.argtypes = [VP, VP] + [ctypes.c_int32] * 7 + [VP]
+    L.srl_convt2x2_gemm_supported.restype = ctypes.c_int32
+    L.srl_convt2x2_gemm_supported.argtypes = [ctypes.c_int32] * 2
+    L.srl_convt2x2_gemm_bias_relu.restype = ctypes.c_int
+    L.srl_convt2x2_gemm_bias_relu.argtypes = [VP] * 4 + [ctypes.c_int32] * 8 + [VP]
     L.srl_conv3x3_gemm_supported.restype = ctypes.c_int32
     L.srl_conv3x3_gemm_supported.argtypes = [ctypes.c_int32] * 3
     L.srl_conv3x3_gemm_batch_multiple.restype = ctypes.c_int32
@@ -455,6 +459,18 @@ def pack_convt2x2_weights_x3(w):
   return pack_convt2x2_weights(w, x3=True)
 
 
+def convt2x2_gemm_bias_relu(x, wfrag, bias, cout, out, out_offset=0):
+  """relu(conv_transpose2d(x, k=2, s=2) + bias) of the deep levels (128 -> 64, 256 -> 128; any map size) into the channel
+  slice of `out`, csrc/conv_gemm.hip k_convt2x2_gemm; bf16 or float32 (wfrag from pack_convt2x2_weights(w, x3=True))."""
+  B, cin, H, W = x.shape
+  with torch.cuda.device(x.device):
+    rc = load().srl_convt2x2_gemm_bias_relu(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, cin, cout,
+                                            out.shape[1], out_offset, int(x.dtype == torch.float32), _stream(x))
+  if rc:
+    raise RuntimeError(load().srl_conv_gemm_last_error().decode())
+  return out
+
+
 def convt2x2_bias_relu(x, wfrag, bias, cout, out, out_offset=0):
   """relu(conv_transpose2d(x, k=2, s=2) + bias) into the channel slice [out_offset, out_offset + cout) of `out`
   (channels-last, twice the spatial size of x), csrc/conv_mfma.hip.  bf16 tensors: bf16 MFMA; float32 tensors: the
@@ -592,6 +608,9 @@ class FastFeatures(object):
         if (self.mfma_conv or self.x3_conv) and isinstance(m, torch.nn.ConvTranspose2d) and m.kernel_size == (2, 2) and \
            (m.in_channels, m.out_channels) in ((32, 16), (64, 32)):
           self._wf.offer(m, lambda m=m: pack_convt2x2_weights(m.weight, x3=not self.mfma_conv))
+        if (self.mfma_conv or self.x3_conv) and isinstance(m, torch.nn.ConvTranspose2d) and m.kernel_size == (2, 2) and \
+           (m.in_channels, m.out_channels) in ((128, 64), (256, 128)):
+          self._wg.offer(m, lambda m=m: pack_convt2x2_weights(m.weight, x3=not self.mfma_conv))
         if (self.mfma_conv or self.x3_conv) and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.in_channels in (1, 2) and m.out_channels == 16:
           self._wt[m] = m.weight.detach().float().contiguous()
@@ -655,11 +674,13 @@ class FastFeatures(object):
     for k, (up, blk) in enumerate(zip(U.up, U.upconv)):
       cat = cats.pop()
       f = up.out_channels
-      w, b = self._w[up]
+      b = self._w[up][1]
       if up in self._wf and x.shape[3] % 16 == 0 and x.is_contiguous(memory_format=_CL):
         convt2x2_bias_relu(x, self._wf[up], b, f, cat, 0)
+      elif up in self._wg and x.is_contiguous(memory_format=_CL):
+        convt2x2_gemm_bias_relu(x, self._wg[up], b, f, cat, 0)
       else:
-        y = _cl(F.conv_transpose2d(x, w, None, stride=up.stride))
+        y = _cl(F.conv_transpose2d(x, self._w[up][0], None, stride=up.stride))
         bias_act(y, b, out=cat, out_offset=0)       # Concatenate([up, skip]) without a copy
       if self._mine(blk[0], cat):
         y = conv3x3_bias_relu(cat, self._wf[blk[0]], self._w[blk[0]][1], f)
@@ -721,9 +742,7 @@ class FusedPolicy(object):
     self._ff = None
 
   @torch.no_grad()
-  def __call__(self, net, inputs, epsilon, gen, on_chunk=None):
-    """on_chunk(actions, upto): called after every chunk with the full-batch action tensor, final up to `upto` (a
-    pipelined env starts the step of the shards inside, `env.PipelinedVecStackEnv.actions_ready`)."""
+  def __call__(self, net, inputs, epsilon, gen):
     xm, xo = inputs
     B = xm.shape[0]
     u = torch.rand(B, generator=gen, device=xm.device)
@@ -743,8 +762,6 @@ class FusedPolicy(object):
       corr = xcorr_forward(x, w)
       adv = self._ff.pos(corr) if self.fast else net.pos(corr).flatten(1)
       out[s:e] = policy_head(adv, u[s:e], rnd[s:e], epsilon)
-      if on_chunk is not None:
-        on_chunk(out, e)
     return out
 
 

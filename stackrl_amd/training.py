@@ -177,14 +177,8 @@ class Trainer(object):
           if callable(step):
             step = step()
           self._reward += step
-          if hasattr(env, 'actions_ready'):
-            # sharded env: a shard starts its step as soon as the policy has produced its actions
-            env.step_begin()
-            action = agent.collect(*step, on_chunk=env.actions_ready)
-            step = env.step_end(action)
-          else:
-            action = agent.collect(*step)
-            step = env.step(action)          # non-blocking: the settle/render kernels overlap the update below
+          action = agent.collect(*step)
+          step = env.step(action)          # non-blocking: the settle/render kernels overlap the update below
         t1 = time.perf_counter()
         with self._train_timer:
           loss, merr = agent.train()

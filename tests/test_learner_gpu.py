@@ -306,7 +306,8 @@ def test_fast_rollout_follows_graph_replayed_updates(ref_pool):
     pack = qops.pack_conv3x3_weights if isinstance(m, torch.nn.Conv2d) else qops.pack_convt2x2_weights
     assert torch.equal(wf, pack(m.weight))
   for m, wg in pol._ff._wg.packed():
-    assert torch.equal(wg, qops.pack_conv3x3_gemm_weights(m.weight))
+    pack = qops.pack_conv3x3_gemm_weights if isinstance(m, torch.nn.Conv2d) else qops.pack_convt2x2_weights
+    assert torch.equal(wg, pack(m.weight))
   xc, wc = qops.FastFeatures(net)(obs)                          # and its features track a cache built afresh
   assert float((xb.float() - xc.float()).abs().max()) <= 0.05 * float(xc.float().abs().max())
   env.close()
@@ -762,32 +763,26 @@ def test_pool2x2_of_a_channel_slice(dt):
   assert torch.equal(got, torch.nn.functional.max_pool2d(buf[:, 16:].float(), 2).to(dt))
 
 
-def test_pipelined_env_equals_the_monolithic_env_and_overlaps_the_policy(ref_pool):
-  """`PipelinedVecStackEnv`: the same seeds and actions give bit-identical observations, rewards and done flags as the
-  one-shard env, through the plain `step` and through `step_begin` / `actions_ready` / `step_end` driven by the fused
-  policy's chunk callback (the `Trainer` path), over an episode and its auto-reset."""
-  from stackrl_amd import env as envs, nets, qops
-  from stackrl_amd.dqn import DQN
-  B, L = 64, 3
-  a = envs.make('Stack-v0', n_parallel=B, seed=5, pool=ref_pool, episode_length=L)
-  b = envs.make('Stack-v0', n_parallel=B, seed=5, pool=ref_pool, episode_length=L, groups=4)
-  assert isinstance(b, envs.PipelinedVecStackEnv) and b.batch_size == B and b.n_actions == a.n_actions
-  assert a.seed(5) == b.seed(5)
-  sa, sb = a.reset()(), b.reset()()
-  net = nets.DeepQSiamFCN(a.observation_spec, seed=2).cuda()
-  agent = DQN(net, collect_batch_size=B, replay_memory_size=B * 8, exploration=0.3, seed=1,
-              policy_op=qops.FusedPolicy(chunk=16, autocast=torch.bfloat16, fast=True))
-  calls = []
-  for t in range(L + 2):
-    assert torch.equal(sa[0][0], sb[0][0]) and torch.equal(sa[0][1], sb[0][1]) and torch.equal(sa[1], sb[1]) and torch.equal(sa[2], sb[2])
-    if t % 2 == 0:
-      act = a.sample()
-      sa, sb = a.step(act)(), b.step(act)()
-    else:
-      b.step_begin()
-      launched = []
-      act = agent.collect(*sb, on_chunk=lambda out, upto: (b.actions_ready(out, upto), launched.append(b._pending['launched'])))
-      calls.append(launched)
-      sa, sb = a.step(act)(), b.step_end(act)()
-  assert calls and calls[0] == [1, 2, 3, 4]          # one shard started after each policy chunk of 16 envs
-  a.close(); b.close()
+@pytest.mark.parametrize('cin,cout,H,W', [(128, 64, 16, 16), (256, 128, 8, 8), (128, 64, 5, 7)])
+@pytest.mark.parametrize('f32', [False, True])
+def test_convt2x2_gemm_matches_torch_fp64(cin, cout, H, W, f32):
+  """The transposed convolutions of the deep levels as a GEMM (`k_convt2x2_gemm`) + bias + ReLU into a slice of the concat
+  buffer against float64 torch, both precisions; an odd map size exercises the partial last pixel tile."""
+  from stackrl_amd import qops
+  F = torch.nn.functional
+  g = torch.Generator(device='cuda').manual_seed(cin + H)
+  B = 3
+  dt = torch.float32 if f32 else torch.bfloat16
+  x = torch.randn((B, cin, H, W), generator=g, device='cuda').to(dt).contiguous(memory_format=torch.channels_last)
+  w = torch.randn((cin, cout, 2, 2), generator=g, device='cuda') / cin ** 0.5
+  b = torch.randn(cout, generator=g, device='cuda') * 0.1
+  wr = w if f32 else w.to(torch.bfloat16).float()
+  ref = F.relu(F.conv_transpose2d(x.double(), wr.double(), b.double(), stride=2))
+  cat = torch.full((B, 2 * cout, 2 * H, 2 * W), 3.0, device='cuda', dtype=dt).contiguous(memory_format=torch.channels_last)
+  qops.convt2x2_gemm_bias_relu(x, qops.pack_convt2x2_weights(w, x3=f32), b, cout, cat, 0)
+  err = (cat[:, :cout].double() - ref).abs()
+  if f32:
+    assert float(err.max()) <= 3e-5 * float(ref.abs().max())
+  else:
+    assert bool((err <= 2.0 ** -8 * ref.abs().clamp(min=1e-2 * float(ref.abs().max()))).all())
+  assert bool((cat[:, cout:] == 3.0).all())
