@@ -15,8 +15,13 @@
  *  - every function returns an SRL_* code (include/srl_types.h); `srl_last_error()` gives the
  *    message of the calling thread's last failure.
  *  - `srl_reset/srl_step/srl_sample` only enqueue work on `stream` and return; the caller's
- *    buffers are valid when the stream reaches that point.  No allocation happens in them.
- *  - a handle is not thread-safe; distinct handles are independent.
+ *    buffers are valid when the stream reaches that point.  No device allocation, free or blocking
+ *    copy happens in them in steady state (the first launch after srl_create / srl_load_meshes /
+ *    srl_seed uploads the parameter block with one blocking copy; with srl_set_profiling on, HIP
+ *    events are created on demand).
+ *  - a handle is not thread-safe; distinct handles are independent: they share no device or host
+ *    state (no process-wide tables, no common scratch buffers), so handles on different streams may
+ *    step concurrently (`tests/test_parity_gpu.py::test_two_handles_on_two_streams_*`).
  */
 #ifndef STACKRL_HIP_H_
 #define STACKRL_HIP_H_

@@ -184,3 +184,42 @@ def goal_from_rng(cfg, key, episode):
   r = np.zeros(4, np.int32)
   lib().srlo_goal_from_rng(ctypes.byref(c), ctypes.c_uint32(key), ctypes.c_uint32(episode), _p(r))
   return r
+
+
+def goal_from_draws(cfg, x24, ru, rv):
+  """`Rewarder._reset_goal` (rewarder.py:225-259) on an explicit draw list (tests/golden/rewarder_golden.npz)."""
+  c = cfg.to_c()
+  r = np.zeros(4, np.int32)
+  lib().srlo_goal_from_draws(ctypes.byref(c), ctypes.c_uint32(int(x24)), ctypes.c_uint32(int(ru)), ctypes.c_uint32(int(rv)), _p(r))
+  return r
+
+
+def rewarder_call(cfg, H, rect, positions, distances, memory):
+  """`Rewarder.__call__` (rewarder.py:144-179) on an explicit state; `memory` float32[4] is updated in place."""
+  c = cfg.to_c()
+  H = np.ascontiguousarray(H, np.float32)
+  rect = np.ascontiguousarray(rect, np.int32)
+  positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+  distances = np.ascontiguousarray(distances, np.float32).reshape(-1, 2)
+  assert memory.dtype == np.float32 and memory.shape == (4,) and len(positions) == len(distances)
+  keys = cfg.reward_keys
+  out = np.zeros(1 if keys is None else len(keys), np.float32)
+  rc = lib().srlo_rewarder_call(ctypes.byref(c), _p(H), _p(rect), ctypes.c_int32(len(positions)), _p(positions), _p(distances),
+                                _p(memory), _p(out))
+  if rc:
+    raise ValueError(lib().srlo_last_error().decode())
+  return out
+
+
+def pack_observation(cfg, H, rect, O):
+  """`StackEnv.observation` (env.py:225-231, :171-172) of an explicit (H, goal rectangle, O)."""
+  c = cfg.to_c()
+  H = np.ascontiguousarray(H, np.float32)
+  O = np.ascontiguousarray(O, np.float32)
+  rect = np.ascontiguousarray(rect, np.int32)
+  om = np.zeros(H.shape + (2,), np.uint8)
+  oo = np.zeros(O.shape + (1,), np.uint8)
+  rc = lib().srlo_pack_observation(ctypes.byref(c), _p(H), _p(rect), _p(O), _p(om), _p(oo))
+  if rc:
+    raise ValueError(lib().srlo_last_error().decode())
+  return om, oo

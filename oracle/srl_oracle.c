@@ -132,6 +132,7 @@ uint32_t srlo_rng(uint32_t key, uint32_t episode, uint32_t stream, uint32_t draw
 static inline uint32_t rng_below(uint32_t r, uint32_t n) {
   return (uint32_t)(((uint64_t)r * (uint64_t)n) >> 32);
 }
+uint32_t srlo_rng_below(uint32_t r, uint32_t n) { return rng_below(r, n); }
 enum { STREAM_MESH = 0, STREAM_GOAL = 1, STREAM_ACTION = 2 };
 
 /* ------------------------------------------------------------------ data */
@@ -383,12 +384,29 @@ int srlo_set_script(srlo_env* e, const int32_t* mesh_ids, const int32_t* goal_re
 }
 
 /* ------------------------------------------------------------------ goal (rewarder.py:211-259) */
-void srlo_goal_from_rng(const srl_config* cfg, uint32_t key, uint32_t episode, int32_t* rect) {
+/* `Rewarder._reset_goal`, scalar-area branch (rewarder.py:225-259), on an explicit draw list — what the reference's RNG
+ * stream is asked for, in its order: x24 = the value of `beta(b, 4 - b)` as a 24-bit fraction (the swap bit `randint(2)`
+ * only selects which Beta it is drawn from), ru / rv = 32-bit words behind `randint(lo, hi)` of the two offsets (reduced
+ * to the range by rng_below).  Pinned by the reference's own rewarder.py (tests/golden/rewarder_golden.npz). */
+void srlo_goal_from_draws(const srl_config* cfg, uint32_t x24, uint32_t ru, uint32_t rv, int32_t* rect) {
   struct srlo_env tmp;
   memset(&tmp, 0, sizeof tmp);
   tmp.c = *cfg;
   derive(&tmp);
   int H = cfg->overhead_res;
+  int h = tmp.goal_min_h + (int)(((uint64_t)x24 * (uint64_t)(tmp.goal_max_h - tmp.goal_min_h)) >> 24);   /* int(min + beta (max - min)) */
+  int w = tmp.goal_size / h;
+  if (w < tmp.goal_min_w) w = tmp.goal_min_w;
+  if (w > tmp.goal_max_w) w = tmp.goal_max_w;
+  int umax = H - h, vmax = H - w;
+  int ulo = umax / 8, uhi = 7 * umax / 8 + 1;   /* margin_factor = 8, rewarder.py:16 */
+  int vlo = vmax / 8, vhi = 7 * vmax / 8 + 1;
+  int u = ulo + (int)rng_below(ru, (uint32_t)(uhi - ulo));
+  int v = vlo + (int)rng_below(rv, (uint32_t)(vhi - vlo));
+  rect[0] = u; rect[1] = v; rect[2] = h; rect[3] = w;
+}
+
+void srlo_goal_from_rng(const srl_config* cfg, uint32_t key, uint32_t episode, int32_t* rect) {
   /* b = 1 + 2*randint(2); beta(b, 4-b): Beta(1,3) = min of 3 uniforms, Beta(3,1) = max of 3 */
   uint32_t bbit = srlo_rng(key, episode, STREAM_GOAL, 0) >> 31;
   uint32_t u0 = srlo_rng(key, episode, STREAM_GOAL, 1) >> 8;
@@ -397,16 +415,7 @@ void srlo_goal_from_rng(const srl_config* cfg, uint32_t key, uint32_t episode, i
   uint32_t lo = u0 < u1 ? u0 : u1; lo = lo < u2 ? lo : u2;
   uint32_t hi = u0 > u1 ? u0 : u1; hi = hi > u2 ? hi : u2;
   uint32_t X = bbit ? hi : lo; /* 24-bit fixed point in [0,1) */
-  int h = tmp.goal_min_h + (int)(((uint64_t)X * (uint64_t)(tmp.goal_max_h - tmp.goal_min_h)) >> 24);
-  int w = tmp.goal_size / h;
-  if (w < tmp.goal_min_w) w = tmp.goal_min_w;
-  if (w > tmp.goal_max_w) w = tmp.goal_max_w;
-  int umax = H - h, vmax = H - w;
-  int ulo = umax / 8, uhi = 7 * umax / 8 + 1;   /* margin_factor = 8, rewarder.py:16 */
-  int vlo = vmax / 8, vhi = 7 * vmax / 8 + 1;
-  int u = ulo + (int)rng_below(srlo_rng(key, episode, STREAM_GOAL, 4), (uint32_t)(uhi - ulo));
-  int v = vlo + (int)rng_below(srlo_rng(key, episode, STREAM_GOAL, 5), (uint32_t)(vhi - vlo));
-  rect[0] = u; rect[1] = v; rect[2] = h; rect[3] = w;
+  srlo_goal_from_draws(cfg, X, srlo_rng(key, episode, STREAM_GOAL, 4), srlo_rng(key, episode, STREAM_GOAL, 5), rect);
 }
 
 /* ------------------------------------------------------------------ depth codec */
@@ -1312,16 +1321,11 @@ static void sim_step(const struct srlo_env* e, env_t* s, v3 pos, int oi) {
 }
 
 /* ------------------------------------------------------------------ reward (rewarder.py:162-179, :261-295) */
-/* discount of one body (rewarder.py:261-269) */
-static float body_discount(const struct srlo_env* e, const env_t* s, int b) {
+/* `Rewarder._discount` (rewarder.py:261-269) of a translation / rotation error */
+static float discount_of(const struct srlo_env* e, float perr, float oerr) {
   const srl_config* c = &e->c;
   float pmax = (float)c->object_res * e->px;     /* rewarder.py:126 */
   float omax = 3.14159265358979f;
-  v3 dp = vsub(s->place_x[b], s->x[b]);
-  float perr = sqrtf(vdot(dp, dp));
-  q4 a = s->place_q[b], q = s->q[b];
-  float dw = fabsf((a.x * q.x + a.y * q.y) + (a.z * q.z + a.w * q.w));
-  float oerr = 2.0f * srlo_acosf(fminf(dw, 1.0f));
   float disc = 1.0f;
   if (c->reward_pexp >= 0) {
     float t = perr / pmax, pw = 1.0f;
@@ -1336,8 +1340,16 @@ static float body_discount(const struct srlo_env* e, const env_t* s, int b) {
   return disc;
 }
 
+/* What `Rewarder` reads of the world: the overhead map, the goal rectangle, and per rock its position and its
+ * (translation, rotation) distance from the pose it was placed at (`Simulator.positions`, `.distances_from_place`). */
+typedef struct {
+  const float* H; const int32_t* goal; int nb;
+  const float* pos;      /* [nb][3] */
+  const float* dist;     /* [nb][2] = perr, oerr */
+} rew_in_t;
+
 /* the current value of one metric (rewarder.py:162-175) */
-static float metric_value(const struct srlo_env* e, env_t* s, int metric) {
+static float metric_value(const struct srlo_env* e, const rew_in_t* s, int metric) {
   const srl_config* c = &e->c;
   if (metric == SRL_METRIC_IOU || metric == SRL_METRIC_OR) {
     float inter, uni;
@@ -1347,59 +1359,109 @@ static float metric_value(const struct srlo_env* e, env_t* s, int metric) {
   }
   float r = 0.0f; int nout = 0;
   for (int b = 0; b < s->nb; ++b) {
-    float fu = floorf(s->x[b].x / e->px), fv = floorf(s->x[b].y / e->px); /* xy_to_pixel: // */
+    float fu = floorf(s->pos[3 * b] / e->px), fv = floorf(s->pos[3 * b + 1] / e->px); /* xy_to_pixel: // */
     int in = fu >= (float)s->goal[0] && fv >= (float)s->goal[1] &&
              fu < (float)(s->goal[0] + s->goal[2]) && fv < (float)(s->goal[1] + s->goal[3]);
     if (!in) { nout++; continue; }
-    r = r + body_discount(e, s, b);
+    r = r + discount_of(e, s->dist[2 * b], s->dist[2 * b + 1]);
   }
   if (metric == SRL_METRIC_DOR) return r / (float)c->episode_length;
   return r / (float)(c->episode_length + nout);
 }
 
 /* average discount of all rocks, inside the goal or not (`_discounted(intersection=False)`, rewarder.py:149-151) */
-static float average_discount(const struct srlo_env* e, env_t* s) {
+static float average_discount(const struct srlo_env* e, const rew_in_t* s) {
   float d = 0.0f;
-  for (int b = 0; b < s->nb; ++b) d = d + body_discount(e, s, b);
+  for (int b = 0; b < s->nb; ++b) d = d + discount_of(e, s->dist[2 * b], s->dist[2 * b + 1]);
   return d / (float)s->nb;
 }
 
-/* Rewarder.__call__ (rewarder.py:144-160): the step's reward(s) into out[0 .. n_rewards) */
-static void step_rewards(const struct srlo_env* e, env_t* s, float* out) {
+/* Rewarder.__call__ (rewarder.py:144-160): the step's reward(s) into out[0 .. n_rewards); memory = Rewarder._memory */
+static void rewarder_call(const struct srlo_env* e, const rew_in_t* s, float* memory, float* out) {
   const srl_config* c = &e->c;
   if (c->metric == SRL_METRIC_ALL) {
     for (int m = 0; m < 4; ++m) {
       float mv = metric_value(e, s, m);
-      out[m] = (mv - s->prev_metric[m]) * e->scale;      /* rewarder.py:176-179 */
-      s->prev_metric[m] = mv;
+      out[m] = (mv - memory[m]) * e->scale;              /* rewarder.py:176-179 */
+      memory[m] = mv;
     }
   } else if (c->metric == SRL_METRIC_EVAL) {
     float mv = metric_value(e, s, SRL_METRIC_IOU);
-    out[0] = (mv - s->prev_metric[0]) * e->scale;
-    s->prev_metric[0] = mv;
+    out[0] = (mv - memory[0]) * e->scale;
+    memory[0] = mv;
     float ad = average_discount(e, s);
-    out[1] = ad - s->prev_metric[3];                     /* memory[-1] of a 4-entry array, not scaled */
-    s->prev_metric[3] = ad;
+    out[1] = ad - memory[3];                             /* memory[-1] of a 4-entry array, not scaled */
+    memory[3] = ad;
   } else {
     float mv = metric_value(e, s, c->metric);
-    out[0] = (mv - s->prev_metric[c->metric]) * e->scale;
-    s->prev_metric[c->metric] = mv;
+    out[0] = (mv - memory[c->metric]) * e->scale;
+    memory[c->metric] = mv;
   }
 }
 
+/* `Simulator.distances_from_place` (simulator.py:113-128) of every rock, then the rewarder on that state */
+static void step_rewards(const struct srlo_env* e, env_t* s, float* out) {
+  float pos[3 * MAXB], dist[2 * MAXB];
+  for (int b = 0; b < s->nb; ++b) {
+    v3 dp = vsub(s->place_x[b], s->x[b]);
+    q4 a = s->place_q[b], q = s->q[b];
+    float dw = fabsf((a.x * q.x + a.y * q.y) + (a.z * q.z + a.w * q.w));
+    pos[3 * b] = s->x[b].x; pos[3 * b + 1] = s->x[b].y; pos[3 * b + 2] = s->x[b].z;
+    dist[2 * b] = sqrtf(vdot(dp, dp));
+    dist[2 * b + 1] = 2.0f * srlo_acosf(fminf(dw, 1.0f));
+  }
+  int32_t goal[4] = {s->goal[0], s->goal[1], s->goal[2], s->goal[3]};
+  rew_in_t in = {s->H, goal, s->nb, pos, dist};
+  rewarder_call(e, &in, s->prev_metric, out);
+}
+
+/* `Rewarder.__call__` on an explicit state (the fixture entry point: tests/golden/rewarder_golden.npz) */
+int srlo_rewarder_call(const srl_config* cfg, const float* H, const int32_t* goal_rect, int32_t n_bodies,
+                       const float* positions, const float* distances, float* memory, float* out) {
+  struct srlo_env tmp;
+  memset(&tmp, 0, sizeof tmp);
+  tmp.c = *cfg;
+  int rc = derive(&tmp);
+  if (rc) return rc;
+  rew_in_t in = {H, goal_rect, n_bodies, positions, distances};
+  rewarder_call(&tmp, &in, memory, out);
+  return SRL_OK;
+}
+
 /* ------------------------------------------------------------------ episode machine */
-static void pack_obs(const struct srlo_env* e, const env_t* s, uint8_t* om, uint8_t* oo) {
+/* `StackEnv.observation` + `_return` (env.py:225-231, :171-172): stack [H, G], cast uint8(x 255 / max(max_z, omd)) in float32
+ * (truncating); n_obj = number of float32 object-map pixels */
+static void pack_obs_raw(const struct srlo_env* e, const float* H, const int32_t* goal, const float* O, int n_obj,
+                         uint8_t* om, uint8_t* oo) {
   const srl_config* c = &e->c;
-  int res = c->overhead_res, r = c->object_res;
+  int res = c->overhead_res;
   float den = fmaxf(c->max_z, c->object_max_dimension);            /* env.py:171-172 */
   for (int i = 0; i < res; ++i)
     for (int j = 0; j < res; ++j) {
-      int in = (i >= s->goal[0] && i < s->goal[0] + s->goal[2] && j >= s->goal[1] && j < s->goal[1] + s->goal[3]);
+      int in = (i >= goal[0] && i < goal[0] + goal[2] && j >= goal[1] && j < goal[1] + goal[3]);
       float g = in ? e->goal_z : 0.0f;
-      om[(i * res + j) * 2 + 0] = (uint8_t)((s->H[i * res + j] * 255.0f) / den);
+      om[(i * res + j) * 2 + 0] = (uint8_t)((H[i * res + j] * 255.0f) / den);
       om[(i * res + j) * 2 + 1] = (uint8_t)((g * 255.0f) / den);
     }
-  for (int k = 0; k < r * r * e->n_slots; ++k) oo[k] = (uint8_t)((s->O[k] * 255.0f) / den);
+  for (int k = 0; k < n_obj; ++k) oo[k] = (uint8_t)((O[k] * 255.0f) / den);
+}
+
+static void pack_obs(const struct srlo_env* e, const env_t* s, uint8_t* om, uint8_t* oo) {
+  const int32_t goal[4] = {s->goal[0], s->goal[1], s->goal[2], s->goal[3]};
+  pack_obs_raw(e, s->H, goal, s->O, e->c.object_res * e->c.object_res * e->n_slots, om, oo);
+}
+
+/* fixture entry points (tests/golden/rewarder_golden.npz): observation packing of an explicit (H, goal, O) and the
+ * action unflatten of env.py:240-241 */
+int srlo_pack_observation(const srl_config* cfg, const float* H, const int32_t* goal_rect, const float* O,
+                          uint8_t* obs_map, uint8_t* obs_obj) {
+  struct srlo_env tmp;
+  memset(&tmp, 0, sizeof tmp);
+  tmp.c = *cfg;
+  int rc = derive(&tmp);
+  if (rc) return rc;
+  pack_obs_raw(&tmp, H, goal_rect, O, cfg->object_res * cfg->object_res, obs_map, obs_obj);
+  return SRL_OK;
 }
 
 /* Observer.__call__ object branch for the env's state: the pending rock (observer.py:262-277), or with ordering freedom

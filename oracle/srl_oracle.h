@@ -13,9 +13,14 @@
  *
  * PARITY PINNING: the observer arithmetic (depth->elevation, flip, pose, pixel<->xy) is
  * pinned against golden vectors produced by the reference's own observer.py
- * (tests/golden/observer_golden.npz).  The physics/rasteriser live in the unpinned
- * third-party `pybullet` wheel with no reference tests: for those rows the oracle is
- * "parity unpinned" and is the build's own definition.
+ * (tests/golden/observer_golden.npz); the rewarder (goal rectangle from an explicit draw
+ * list, the four metrics, 'all' / 'eval', reward = scale x change) and the observation
+ * packing / action unflatten of env.py against golden vectors produced by the reference's
+ * own rewarder.py and the expressions of env.py:171-172, :225-231, :240-241
+ * (tests/golden/rewarder_golden.npz, made by tests/golden/make_rewarder_golden.py).
+ * The physics/rasteriser live in the unpinned third-party `pybullet` wheel with no
+ * reference tests: for those rows the oracle is "parity unpinned" and is the build's
+ * own definition.
  */
 #ifndef SRL_ORACLE_H_
 #define SRL_ORACLE_H_
@@ -78,6 +83,21 @@ void srlo_pose(const srl_config* cfg, const float* height, const float* object_m
 /* Rewarder sums (rewarder.py:297-307) in the oracle's fixed summation order */
 void srlo_iou_sums(const srl_config* cfg, const float* height, const int32_t* goal_rect,
                    float* inter, float* uni);
+/* `Rewarder.__call__` (rewarder.py:144-179) on an explicit state: H float[res*res], goal_rect (u, v, h, w), positions
+ * float[n_bodies][3] (`Simulator.positions`), distances float[n_bodies][2] = (translation, rotation) error of each rock
+ * from its placing pose (`Simulator.distances_from_place`); memory float[4] = `Rewarder._memory` (in / out);
+ * out = 1, 4 ('all') or 2 ('eval') rewards.  The same code path the env step runs (step_rewards). */
+int srlo_rewarder_call(const srl_config* cfg, const float* H, const int32_t* goal_rect, int32_t n_bodies,
+                       const float* positions, const float* distances, float* memory, float* out);
+/* `StackEnv.observation` / `_return` (env.py:225-231, :171-172) of an explicit (H, goal, O): obs_map u8[res*res*2],
+ * obs_obj u8[ores*ores] */
+int srlo_pack_observation(const srl_config* cfg, const float* H, const int32_t* goal_rect, const float* O,
+                          uint8_t* obs_map, uint8_t* obs_obj);
+/* `Rewarder._reset_goal` (rewarder.py:225-259) on an explicit draw list: x24 = the Beta draw as a 24-bit fraction,
+ * ru / rv = the 32-bit words behind the two `randint(lo, hi)` offsets */
+void srlo_goal_from_draws(const srl_config* cfg, uint32_t x24, uint32_t ru, uint32_t rv, int32_t* rect);
+/* the reduction of a 32-bit word to [0, n) that the offsets use (exposed so that a fixture can state the draw it wants) */
+uint32_t srlo_rng_below(uint32_t r, uint32_t n);
 /* counter RNG draw (key, episode, stream, draw) -> u32 */
 uint32_t srlo_rng(uint32_t key, uint32_t episode, uint32_t stream, uint32_t draw);
 /* goal rectangle from the counter RNG (rewarder.py:225-259 restated on integer order statistics) */

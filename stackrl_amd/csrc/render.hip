@@ -368,7 +368,8 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   const int walk_i0 = (int)__umulhi((uint32_t)(4 * tid), P.res_magic), walk_j0 = 4 * tid - walk_i0 * res;
   // res divides 4 * 512 (64, 128, 256 ...): the walk never changes columns, so the column part of the goal test is
   // a per-thread constant: bit t of colmask = column walk_j0 + t lies in the goal rectangle's column range
-  const bool aligned = walk_dj == 0;
+  // (maps of fewer than 4 x 512 pixels take the general walk: its rounds test the group index against the map size)
+  const bool aligned = walk_dj == 0 && ngroups4 >= SRL_RENDER_THREADS;
   uint32_t colmask = 0u;
   const uint32_t gdiff = (gbyte ^ zbyte) << 8, zpair = (zbyte << 8) | (zbyte << 24);
   {

@@ -31,8 +31,14 @@
 
 #define SRL_GJK_GROUP 32
 
-__constant__ uint8_t c_pair_i[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
-__constant__ uint8_t c_pair_j[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
+// Bodies (i < j) of pair id p = j (j - 1) / 2 + i, computed when the kernel fills its LDS table.  (Until round 3 this
+// was a pair of process-wide __constant__ tables that every srl_create rewrote: device state shared by all handles.)
+__device__ __forceinline__ int pair_word(int p) {
+  int j = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+  while (j * (j - 1) / 2 > p) --j;
+  while ((j + 1) * j / 2 <= p) ++j;
+  return (p - j * (j - 1) / 2) | (j << 16);
+}
 
 // misc words in LDS
 enum { M_MODE = 0, M_U, M_V, M_NEXT, M_ZMAX, M_FLAGS, M_NCOL, M_CNT, M_NB, M_PENDING, M_STATUS, M_DONE, M_ORIENT, M_MOVING, M_RES0, M_RES1, M_SOLO, M_WORDS = 20 };
@@ -79,8 +85,7 @@ struct Lds {
   __device__ __forceinline__ float* WV(int b) const { return sm + oWV + vs3 * b; }
   __device__ __forceinline__ float* LV(int b) const { return sm + oLV + vs3 * b; }
   __device__ __forceinline__ int* MISC() const { return (int*)(sm + oMISC); }
-  // bodies (i < j) of pair id p: an LDS copy of the constant tables (a global load inside the sub-step loop would cost a
-  // lone wave a memory round trip)
+  // bodies (i < j) of pair id p: an LDS table filled once per launch (pair_word)
   __device__ __forceinline__ int* PAIR() const { return (int*)(sm + oPAIR); }
   __device__ __forceinline__ void pair(int p, int& i, int& j) const { const int w = PAIR()[p]; i = w & 0xffff; j = w >> 16; }
 };
@@ -975,7 +980,7 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
 
   // ---- load the persistent blob into LDS
   for (int k = tid; k < P.BLOB; k += T) sm[k] = gblob[k];
-  for (int k = tid; k < P.NP; k += T) L.PAIR()[k] = (int)c_pair_i[k] | ((int)c_pair_j[k] << 16);
+  for (int k = tid; k < P.NP; k += T) L.PAIR()[k] = pair_word(k);
   __syncthreads();
 
   // ---- K4: Observer.pose (observer.py:392-421): z = max(H[window] + O | O > 1e-4) - oz/2

@@ -48,6 +48,10 @@ struct srl_env {
   uint8_t* d_objmap_u8 = nullptr;
   uchar4* d_me = nullptr;
   uint2* d_codec = nullptr;       // overhead depth codec tabulated over the lattice of fl(FAR - z) (DevParams::codec)
+  // where srl_reset sends the reward / done of a reset (zeros nobody reads, utils.py:545-552): owned by the handle and
+  // allocated in srl_create, so that srl_reset allocates nothing and handles share no buffer
+  float* d_reset_r = nullptr;
+  uint8_t* d_reset_d = nullptr;
   int step_threads = 256;
   int step_pp = 1;
   size_t step_lds = 0, render_lds = 0, objmap_lds = 0;
@@ -157,7 +161,7 @@ void layout(DevParams& P) {
   s = (s + 1) & ~1;
   P.S_USED = s; s += 2 * SRL_MAX_BODIES;   // colouring scratch (uint64 per body); BLOB is a multiple of 4 words
   P.S_MISC = s; s += M_WORDS;
-  P.S_PAIR = s; s += P.NP;                 // pair id -> (i | j << 16), copied from the constant tables once per launch
+  P.S_PAIR = s; s += P.NP;                 // pair id -> (i | j << 16), filled once per launch (settle.hip pair_word)
   P.LDS_WORDS = P.BLOB + s;
 }
 
@@ -188,8 +192,9 @@ int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void*
   if (!env->d_mh) return fail(SRL_ENOMESH, "srl_load_meshes must be called first");
   const DevParams& P = env->P;
   const int n = P.c.n_envs;
-  if (env->P_dirty) {   // only after create / load_meshes / seed, never in steady state
-    HIP_TRY(hipMemcpyAsync(env->d_P, &env->P, sizeof(DevParams), hipMemcpyHostToDevice, st));
+  if (env->P_dirty) {   // only after create / load_meshes / seed (all of which leave the device idle), never in steady state:
+    // a blocking copy, so that the kernels below read the parameters whatever stream they run on
+    HIP_TRY(hipMemcpy(env->d_P, &env->P, sizeof(DevParams), hipMemcpyHostToDevice));
     env->P_dirty = false;
   }
   const DevParams* dP = env->d_P;
@@ -244,19 +249,13 @@ int srl_create(const srl_config* cfg, srl_env** out) {
   layout(env->P);
   DevParams& P = env->P;
   const int n = P.c.n_envs, res = P.c.overhead_res;
-  // pair tables
-  {
-    uint8_t pi[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2], pj[SRL_MAX_BODIES * (SRL_MAX_BODIES - 1) / 2];
-    for (int j = 1; j < SRL_MAX_BODIES; ++j)
-      for (int i = 0; i < j; ++i) { pi[j * (j - 1) / 2 + i] = (uint8_t)i; pj[j * (j - 1) / 2 + i] = (uint8_t)j; }
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_i), pi, sizeof pi));
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pair_j), pj, sizeof pj));
-  }
   HIP_TRY(hipMalloc((void**)&P.hdr, sizeof(EnvHdr) * (size_t)n));
   HIP_TRY(hipMalloc((void**)&P.blob, sizeof(float) * (size_t)n * P.BLOB));
   HIP_TRY(hipMalloc((void**)&P.H, sizeof(float) * (size_t)n * res * res));
   HIP_TRY(hipMalloc((void**)&P.flags, sizeof(int32_t)));
   HIP_TRY(hipMalloc((void**)&env->d_P, sizeof(DevParams)));
+  HIP_TRY(hipMalloc((void**)&env->d_reset_r, sizeof(float) * 4 * (size_t)n));   // up to 4 rewards per env (metric 'all')
+  HIP_TRY(hipMalloc((void**)&env->d_reset_d, (size_t)n));
   HIP_TRY(hipMemset(P.blob, 0, sizeof(float) * (size_t)n * P.BLOB));
   HIP_TRY(hipMemset(P.H, 0, sizeof(float) * (size_t)n * res * res));
   HIP_TRY(hipMemset(P.flags, 0, sizeof(int32_t)));
@@ -299,6 +298,7 @@ void srl_destroy(srl_env* env) {
   (void)hipFree(env->P.hdr); (void)hipFree(env->P.blob); (void)hipFree(env->P.H); (void)hipFree(env->P.flags); (void)hipFree(env->d_P);
   (void)hipFree(env->d_mh); (void)hipFree(env->d_mv); (void)hipFree(env->d_mt); (void)hipFree(env->d_mp); (void)hipFree(env->d_objmap); (void)hipFree(env->d_objmap_u8);
   (void)hipFree(env->d_codec); (void)hipFree(env->d_me);
+  (void)hipFree(env->d_reset_r); (void)hipFree(env->d_reset_d);
   delete env;
 }
 
@@ -412,6 +412,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   else { env->step_threads = 256; env->step_pp = 2; }
   const int res = P.c.overhead_res;
   env->render_lds = render_lds_bytes(res);
+  if (env->render_lds > 160 * 1024) return fail(SRL_EINVAL, "overhead_res exceeds the 160 KB LDS budget of the render tile (at most 176)");
   env->objmap_lds = 0;
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)srl_k_step_pp1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env->step_lds));
@@ -431,11 +432,15 @@ int srl_seed(srl_env* env, uint32_t seed) {
   env->P.seed = seed;
   env->P.sample_counter = 0;
   env->P_dirty = true;
+  // episode counters restart: the header array makes a round trip through the host as one contiguous blocking copy each
+  // way (a strided 2-D copy of one word per env was used here until round 3)
   HIP_TRY(hipDeviceSynchronize());
   const int n = env->P.c.n_envs;
-  std::vector<uint32_t> z((size_t)n, 0u);
-  HIP_TRY(hipMemcpy2D(&env->P.hdr[0].episode, sizeof(EnvHdr), z.data(), sizeof(uint32_t), sizeof(uint32_t), (size_t)n,
-                      hipMemcpyHostToDevice));
+  std::vector<EnvHdr> h((size_t)n);
+  HIP_TRY(hipMemcpy(h.data(), env->P.hdr, sizeof(EnvHdr) * (size_t)n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i) h[i].episode = 0u;
+  HIP_TRY(hipMemcpy(env->P.hdr, h.data(), sizeof(EnvHdr) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());
   return SRL_OK;
 }
 
@@ -446,30 +451,23 @@ int srl_set_script(srl_env* env, const int32_t* mesh_ids, const int32_t* goal_re
   for (size_t k = 0; k < (size_t)n * L; ++k)
     if (mesh_ids[k] < 0 || mesh_ids[k] >= P.n_mesh) return fail(SRL_EINVAL, "script mesh id out of range");
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy2D(&P.hdr[0].script_ids[0], sizeof(EnvHdr), mesh_ids, sizeof(int32_t) * L, sizeof(int32_t) * L,
-                      (size_t)n, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy2D(&P.hdr[0].script_goal[0], sizeof(EnvHdr), goal_rect, sizeof(int32_t) * 4, sizeof(int32_t) * 4,
-                      (size_t)n, hipMemcpyHostToDevice));
-  std::vector<int32_t> ones((size_t)n, 1);
-  HIP_TRY(hipMemcpy2D(&P.hdr[0].has_script, sizeof(EnvHdr), ones.data(), sizeof(int32_t), sizeof(int32_t), (size_t)n,
-                      hipMemcpyHostToDevice));
+  std::vector<EnvHdr> h((size_t)n);
+  HIP_TRY(hipMemcpy(h.data(), P.hdr, sizeof(EnvHdr) * (size_t)n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < L; ++k) h[i].script_ids[k] = mesh_ids[(size_t)i * L + k];
+    for (int k = 0; k < 4; ++k) h[i].script_goal[k] = goal_rect[(size_t)i * 4 + k];
+    h[i].has_script = 1;
+  }
+  HIP_TRY(hipMemcpy(P.hdr, h.data(), sizeof(EnvHdr) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());
   return SRL_OK;
 }
 
 int srl_reset(srl_env* env, void* obs_map, void* obs_obj, void* stream) {
   if (!env || !obs_map || !obs_obj) return fail(SRL_EINVAL, "null argument");
-  // reward/done of a reset are zeros (utils.py:545-552); the kernels still need somewhere to write them
-  static thread_local float* scratch_r = nullptr;
-  static thread_local uint8_t* scratch_d = nullptr;
-  static thread_local int scratch_n = 0;
-  const int n = env->P.c.n_envs;
-  if (scratch_n < n) {
-    (void)hipFree(scratch_r); (void)hipFree(scratch_d);
-    HIP_TRY(hipMalloc((void**)&scratch_r, sizeof(float) * 4 * (size_t)n));   // up to 4 rewards per env (metric 'all')
-    HIP_TRY(hipMalloc((void**)&scratch_d, (size_t)n));
-    scratch_n = n;
-  }
-  return launch_step_render(env, nullptr, obs_map, obs_obj, scratch_r, scratch_d, (hipStream_t)stream, 1);
+  // reward/done of a reset are zeros (utils.py:545-552); the kernels still need somewhere to write them: the handle's own
+  // buffers (srl_create)
+  return launch_step_render(env, nullptr, obs_map, obs_obj, env->d_reset_r, env->d_reset_d, (hipStream_t)stream, 1);
 }
 
 int srl_step(srl_env* env, const int64_t* action, void* obs_map, void* obs_obj, float* reward, uint8_t* done,
@@ -524,7 +522,7 @@ int srl_sync_status(srl_env* env, void* stream) {
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   int32_t f = 0;
   HIP_TRY(hipMemcpy(&f, env->P.flags, sizeof f, hipMemcpyDeviceToHost));
-  if (f) HIP_TRY(hipMemset(env->P.flags, 0, sizeof f));
+  if (f) { const int32_t zero = 0; HIP_TRY(hipMemcpy(env->P.flags, &zero, sizeof zero, hipMemcpyHostToDevice)); }
   if (f & 1) return fail(SRL_EINVAL_ACTION, "Invalid action.");
   if (f & 2) return fail(SRL_ESIM_DIVERGED, "Maximum number of simulator steps reached. This may be caused by incorrect behaviour due to a large time step value");
   if (f & 4) return fail(SRL_ESIM_DIVERGED, "More close rock pairs than manifold slots in some env (SRL_ST_PAIR_OVERFLOW): the step is not valid");

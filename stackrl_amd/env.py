@@ -180,6 +180,9 @@ class VecStackEnv(object):
     with torch.cuda.device(self._device):
       _check(self._lib.srl_reset(self._h, om.data_ptr(), oo.data_ptr(), self._stream()))
     self._left = self.config.episode_length
+    if self._side is not None:      # the caching allocator must not hand these blocks out again while the side stream writes them
+      for t in (om, oo):
+        t.record_stream(self._side)
     keys = self.config.reward_keys
     out = ((om, oo), torch.zeros(self._B if keys is None else (self._B, len(keys)), dtype=torch.float32, device=self._device),
            torch.zeros(self._B, dtype=torch.bool, device=self._device))     # utils.py:545-552
@@ -221,6 +224,8 @@ class VecStackEnv(object):
     self._fork()
     with torch.cuda.device(self._device):
       _check(self._lib.srl_sample(self._h, a.data_ptr(), self._stream()))
+    if self._side is not None:
+      a.record_stream(self._side)
     self._join()
     return a
 

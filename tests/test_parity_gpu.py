@@ -257,3 +257,79 @@ def test_input_constraints_are_reported(ref_pool):
   bad.tris[int(ref_pool.tri_off[0])] = bad.tris[int(ref_pool.tri_off[0]) + 1]      # a face listed twice: an edge with 3 faces
   with pytest.raises(ValueError):
     envs.VecStackEnv(n_parallel=2, seed=0, pool=bad, episode_length=2)
+
+
+def _banded(shape, dtype, band=4096):
+  """A caller buffer with canary bands on both sides: (view to hand to the env, the whole allocation, pattern)."""
+  n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+  pat = 0xA5
+  raw = torch.full((band + n + band,), pat, dtype=torch.uint8, device='cuda')
+  return raw[band:band + n].view(dtype).view(shape), raw, band, n
+
+
+def _bands_intact(raw, band, n):
+  return bool((raw[:band] == 0xA5).all()) and bool((raw[band + n:] == 0xA5).all())
+
+
+def test_two_handles_on_two_streams_equal_one_handle_and_the_oracle(ref_pool, oracle_mod):
+  """include/stackrl_hip.h: "distinct handles are independent" (the reference's workers are separate processes,
+  utils.py:424-448).  Two handles of 24 envs, each on its own stream, step CONCURRENTLY (both launched before either is
+  waited for) over RNG-driven episodes and their auto-reset, next to a one-handle env of the same 48 envs and the oracle:
+  observations, rewards, done flags bit-identical three ways, states equal; the caller buffers of the two handles are
+  slices of one allocation with canary bands around it, which stay untouched (no env kernel writes outside what it was
+  given).  Round 2 had one failing record of a four-handle run against the one-handle env (gpurun_out/t_learner.log); the
+  handles then shared process-wide `__constant__` pair tables rewritten by every srl_create and a thread-local reset
+  scratch that was freed and re-allocated on growth — both gone."""
+  from stackrl_amd import env as envs
+  from stackrl_amd.config import StackConfig
+  B, G, L, seed = 48, 24, 6, 77
+  a = envs.VecStackEnv(n_parallel=B, seed=seed, pool=ref_pool, episode_length=L)
+  o = oracle_mod.OracleEnv(StackConfig(n_envs=B, episode_length=L), ref_pool, seed=seed)
+  shards = [envs.VecStackEnv(n_parallel=G, seed=seed, pool=ref_pool, episode_length=L, env_index_offset=k * G,
+                             side_stream=True) for k in range(2)]
+  assert a.seed(seed) == shards[0].seed(seed) + shards[1].seed(seed)
+  spec = a.observation_spec
+
+  def buffers():
+    return [_banded((B,) + tuple(spec[0].shape), torch.uint8), _banded((B,) + tuple(spec[1].shape), torch.uint8),
+            _banded((B,), torch.float32), _banded((B,), torch.uint8)]
+
+  bufs = buffers()
+  om, oo = bufs[0][0], bufs[1][0]
+  waits = [s.reset(block=False, out=(om[k * G:(k + 1) * G], oo[k * G:(k + 1) * G])) for k, s in enumerate(shards)]
+  sa = a.reset()()
+  so = o.reset()
+  for w in waits:
+    w()
+  assert torch.equal(sa[0][0], om) and torch.equal(sa[0][1], oo)
+  assert np.array_equal(om.cpu().numpy(), so[0][0]) and np.array_equal(oo.cpu().numpy(), so[0][1])
+  assert all(_bands_intact(*b[1:]) for b in bufs[:2])
+  filler = torch.randn(1024, 1024, device='cuda')
+  for t in range(2 * (L + 1)):
+    act = a.sample()
+    assert np.array_equal(act.cpu().numpy(), o.sample())
+    assert torch.equal(act, torch.cat([s.sample() for s in shards]))
+    bufs = buffers()
+    om, oo, r, d = (b[0] for b in bufs)
+    waits = []
+    for k, s in enumerate(shards):        # both shards in flight, with current-stream work in between, before anything is waited for
+      waits.append(s.step(act[k * G:(k + 1) * G], block=False,
+                          out=(om[k * G:(k + 1) * G], oo[k * G:(k + 1) * G], r[k * G:(k + 1) * G], d[k * G:(k + 1) * G])))
+      filler = (filler @ filler) * 1e-3
+    sa = a.step(act)()
+    for w in waits:
+      w()
+    tag = 'call {}'.format(t)
+    for nm, x, y in (('obs_map', sa[0][0], om), ('obs_obj', sa[0][1], oo), ('reward', sa[1], r), ('done', sa[2], d.view(torch.bool))):
+      if not torch.equal(x, y):
+        bad = (x != y).reshape(B, -1).any(1).nonzero()[:, 0].tolist()
+        raise AssertionError('{}: {} of the two-handle run differs from the one-handle env in envs {}'.format(tag, nm, bad[:16]))
+    assert all(_bands_intact(*b[1:]) for b in bufs), tag + ': an env kernel wrote outside its caller buffer'
+    _cmp_step(a, o, sa, o.step(act.cpu().numpy()), tag)
+    ps = [s.state() for s in shards]
+    pa = a.state()
+    for i in range(4):
+      assert np.array_equal(pa[i], np.concatenate([p[i] for p in ps])), tag + ': state {}'.format(i)
+  a.close()
+  for s in shards:
+    s.close()
