@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E (MI355X_MICROARCH.md)
 # dense MFMA peaks, same guide.  The fp32-class rollout computes every product as three bf16 MFMAs (hi hi + hi lo + lo hi,
 # csrc/conv_mfma.hip, conv_gemm.hip, xcorr_mfma.hip): its ceiling is a third of the bf16 peak, not the fp32 MFMA peak (157.3)
-PEAK_TFLOPS = {'f32': 2500.0 / 3.0, 'bf16': 2500.0}
+PEAK_TFLOPS = {'bf16x3': 2500.0 / 3.0, 'bf16': 2500.0}
 
 
 def parse_args(argv=None):
@@ -63,7 +63,8 @@ def parse_args(argv=None):
   ap.add_argument('--dqn-rocks', type=int, default=None)
   ap.add_argument('--dqn-res', type=int, default=None, choices=[64, 128])
   ap.add_argument('--dqn-slots', type=int, default=16, help='replay capacity in transitions per env')
-  ap.add_argument('--rollout', default='both', choices=['f32', 'bf16', 'both'])
+  ap.add_argument('--rollout', default='both', choices=['bf16x3', 'f32', 'bf16', 'both'],
+                  help="rollout precision: 'bf16x3' = fp32-class (every product as three bf16 MFMAs; 'f32' is an alias), 'bf16'")
   ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL; gloo for rehearsals')
   ap.add_argument('--same-device', action='store_true', help='rehearsal: every rank uses device 0 (needs --backend gloo)')
   ap.add_argument('--leg-b-timeout', type=float, default=900.0,
@@ -134,7 +135,7 @@ def launch(args, argv):
     print(got['provisional'], flush=True)
     print('bench.py: a rank ended during leg B (exit codes {}); the line above carries leg A only'.format(
       [p.returncode for p in procs]), file=sys.stderr)
-    return 0
+    return rc or 1        # the provisional line is printed, but a lost rank is not a success
   return rc
 
 
@@ -192,25 +193,51 @@ def aggregate(dt, placed, world, device):
   return float(t.item()), float(tot.item())
 
 
-def traffic_record(B, L, res):
-  """HBM bytes per render launch from the PMC counters.  They come from separate `rocprofv3 --pmc` passes of this very
-  command (counter collection cannot run inside the timed process), summarised by tools/pmc_summary.py into
-  profiles/rNN_render_pmc.json; the line names the file and the commit that last touched it."""
+def _latest_profile(pattern):
+  """(relative path, parsed JSON) of the newest profiles/rNN_<pattern>, or (None, None).  Counter collection cannot run
+  inside the timed process: these files come from separate `rocprofv3 --pmc` passes (tools/refresh_profiles_r03.sh),
+  each records the commit it was taken at (`commit`, written by the tool that made it — this process starts no child
+  process: it has initialised the GPU by the time the line is assembled, and the GPU box has no .git anyway)."""
   import glob
+  files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_' + pattern)))
+  if not files:
+    return None, None
+  try:
+    with open(files[-1]) as f:
+      return os.path.relpath(files[-1], ROOT), json.load(f)
+  except Exception:   # noqa: BLE001
+    return None, None
+
+
+def traffic_record(B, L, res):
+  """HBM bytes per render launch from the PMC counters (profiles/rNN_render_pmc.json, tools/pmc_summary.py)."""
   if not (B == 1024 and L == 8 and res == 128):
     return None, None
-  pmcs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_render_pmc.json')))
-  if not pmcs:
+  rel, d = _latest_profile('render_pmc.json')
+  if d is None:
     return None, None
-  with open(pmcs[-1]) as f:
-    traffic = json.load(f).get('traffic_bytes_per_launch')
-  rel = os.path.relpath(pmcs[-1], ROOT)
-  try:
-    commit = subprocess.check_output(['git', '-C', ROOT, 'log', '-1', '--format=%h', '--', rel],
-                                     stderr=subprocess.DEVNULL).decode().strip() or None
-  except Exception:
-    commit = None
-  return traffic, {'file': rel, 'commit': commit, 'how': 'separate rocprofv3 --pmc passes of bench.py (FETCH_SIZE, WRITE_SIZE)'}
+  return d.get('traffic_bytes_per_launch'), {'file': rel, 'commit': d.get('commit'),
+                                              'how': 'separate rocprofv3 --pmc passes of bench.py (FETCH_SIZE, WRITE_SIZE)'}
+
+
+def settle_counters(B, L, res):
+  """VALU utilisation and waiting share of srl_k_step from its PMC passes (profiles/rNN_settle_pmc.json, tools/pmc_insts.py)."""
+  if not (B == 1024 and L == 8 and res == 128):
+    return {}
+  rel, d = _latest_profile('settle_pmc.json')
+  if d is None:
+    return {}
+  return {'valu_util': d.get('valu_util'), 'wait_frac': d.get('wait_frac'),
+          'counters_source': {'file': rel, 'commit': d.get('commit'), 'how': d.get('how')}}
+
+
+def mfma_counters(dtype):
+  """MFMA-pipe busy fraction of the rollout forward from its PMC pass (profiles/rNN_qnet_mfma_pmc_<dtype>.json, tools/pmc_mfma.py)."""
+  rel, d = _latest_profile('qnet_mfma_pmc_{}.json'.format(dtype))
+  if d is None:
+    return {}
+  return {'mfma_busy_frac': d.get('mfma_busy_frac'),
+          'mfma_busy_source': {'file': rel, 'commit': d.get('commit'), 'how': d.get('how')}}
 
 
 # ----------------------------------------------------------------------------------------------- leg A
@@ -360,7 +387,10 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
   step = env.reset()
   agent.acknowledge_reset()
   t0 = None
+  placed_calls = 0        # timed calls that are placements: call c after reset() is the auto-reset when c % (L + 1) == L (env.py:235-236)
   for it in range(warm + iters):
+    if it >= warm and it % (L + 1) != L:
+      placed_calls += 1
     if it == warm:
       step = step() if callable(step) else step
       barrier()
@@ -399,20 +429,26 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
     torch.cuda.synchronize()
     ar_ms = a.elapsed_time(b) / 10
   macs = sum(nets.forward_macs(H=res, h=res // 4).values())
-  dt_max, steps_all = aggregate(dt, B * iters, world, 'cpu')
+  dt_max, steps_all = aggregate(dt, B * placed_calls, world, 'cpu')
   flops_fwd = 2.0 * macs * B
   out = {
     'workload': 'Stack-v0, {} envs per GPU x {} rocks, {}x{} maps, DQN rollout + minibatch-32 update per iteration '
                 '(BASELINE {} per-GPU shard)'.format(B, L, res, res, name),
-    'rollout_dtype': dtype, 'update_dtype': 'f32 (cross-correlation as bf16x3 split on MFMA)',
+    'rollout_dtype': dtype,
+    'rollout_dtype_note': ('fp32-class: every product as three bf16 MFMAs (hi*hi + hi*lo + lo*hi), ~16 mantissa bits, held to 2e-5 ... 3e-5 of fp64 per layer in tests — tighter than bf16, looser than fp32' if dtype == 'bf16x3' else 'operands rounded to bf16: narrower than the reference\'s fp32'),
+    'update_dtype': 'f32 (cross-correlation as bf16x3 split on MFMA)',
+    'replay_next_index': 'reference (memory.py:239-242, literal)',
     'iterations': iters, 'warmup': warm,
-    'env_steps_per_s': steps_all / dt_max, 'iters_per_s': iters / dt_max, 'ms_per_iter': 1e3 * dt_max / iters,
+    # placements per second, as leg A counts them (the auto-reset call of every episode is stepped and timed but places
+    # nothing); step_calls_per_s counts every vectorised step() call
+    'env_steps_per_s': steps_all / dt_max, 'step_calls_per_s': steps_all / dt_max * iters / max(placed_calls, 1),
+    'placement_calls': placed_calls, 'iters_per_s': iters / dt_max, 'ms_per_iter': 1e3 * dt_max / iters,
     'rollout_forward_ms': fwd_ms, 'update_ms': upd_ms, 'allreduce_ms': ar_ms,
     'grad_bucket_bytes': int(agent._flat_grad.numel() * 4), 'update_graphed': agent._train_graph is not None,
     'roofline': {
       'kernel': 'Q-net rollout forward (DeepQSiamFCN, {} samples)'.format(B), 'bound': 'mfma',
       'achieved': flops_fwd / (fwd_ms * 1e-3) / 1e12, 'peak': PEAK_TFLOPS[dtype], 'unit': 'TFLOP/s',
-      'frac': flops_fwd / (fwd_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 'traffic': None,
+      'frac': flops_fwd / (fwd_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 'traffic': None, **mfma_counters(dtype),
       'alg_flops_per_launch': flops_fwd, 'avg_launch_ms': fwd_ms,
       'note': 'model-level: 2 x {:.1f} M MAC per sample (SURVEY.md N1) x samples / HIP-event time of agent.collect in '
               'the timed region; peak = {}'.format(macs / 1e6, 'dense bf16 MFMA' if dtype == 'bf16' else
@@ -501,7 +537,7 @@ def worker(args):
     line = {
       'metric': 'env steps/sec (batched Stack-v0)', 'value': placed_all / dt_max, 'unit': 'env_steps/s',
       'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt_max / args.steps,
-      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',   # leg A computes in float32
       'config': {
         'workload': 'Stack-v0, {} vectorised envs per GPU, {} rocks, random policy on device, physics+render '
                     'kernels only (BASELINE configs[1])'.format(B, a['L']),
@@ -527,12 +563,13 @@ def worker(args):
         'sweeps_per_substep_mean': float(sw.sum() / max(sub.sum(), 1)),
         'sweeps_mean': float(sw.mean()), 'sweeps_mean_of_per_step_max': float(sw.max(1).mean()),
         'note': 'latency-bound: one launch lasts as long as its slowest env (stop criterion simulator.py:322-335)',
+        **settle_counters(B, a['L'], res),
       },
       'cpu_baseline': cpu, 'reward_mse_vs_cpu': mse, 'dqn': dqn,
     }
     if args.config != 1 and dqn:
-      # the DQN leg as the headline: fp32 rollout (the reference's dtype) when it was run
-      d = dqn.get('f32') or next(iter(dqn.values()))
+      # the DQN leg as the headline: the fp32-class rollout (bf16x3 products; the reference computes in fp32) when it was run
+      d = dqn.get('bf16x3') or next(iter(dqn.values()))
       line.update(value=d['env_steps_per_s'], steps=d['iterations'], warmup=d['warmup'], ms_per_step=d['ms_per_iter'],
                   dtype=d['rollout_dtype'], env_only={'value': placed_all / dt_max, 'steps': args.steps,
                                                       'warmup': args.warmup, 'ms_per_step': 1e3 * dt_max / args.steps})
@@ -547,7 +584,7 @@ def worker(args):
   dqn = None
   if not args.no_dqn:
     dqn = {}
-    for dtype in (['f32', 'bf16'] if args.rollout == 'both' else [args.rollout]):
+    for dtype in (['bf16x3', 'bf16'] if args.rollout == 'both' else ['bf16x3' if args.rollout == 'f32' else args.rollout]):
       # leg B must not take the headline down with it: an exception is recorded, not raised (with the DQN leg as the
       # headline, --config 2|3|4, it is raised)
       try:

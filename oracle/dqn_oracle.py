@@ -15,7 +15,7 @@ NEG_INF = -math.inf
 
 
 class RefMemory(object):
-  def __init__(self, n_parts, max_length, n_steps=1, epsilon=1e-3, literal_next_index=False):
+  def __init__(self, n_parts, max_length, n_steps=1, epsilon=1e-3, literal_next_index=True):   # memory.py:239-242 as written
     max_length -= max_length % n_parts                  # memory.py:54
     self.P, self.L, self.n = n_parts, max_length // n_parts, n_steps
     N = max_length

@@ -128,7 +128,7 @@ class DQN(object):
                replay_memory_size=100000, prefetch=None, target_update_period=10000, reward_scale=None,
                discount_factor=.99, collect_batch_size=None, exploration_mode=None, exploration=None,
                prioritization=None, priority_bias_compensation=None, double=False, n_step=None, seed=None,
-               device=None, process_group=None, policy_op=None, reference_next_index=False,
+               device=None, process_group=None, policy_op=None, reference_next_index=True,
                adam_betas=(0.9, 0.999), xcorr=None, graphs=False):
     if not isinstance(q_net, torch.nn.Module):
       raise TypeError('Invalid type {} for argument q_net. Must be a torch Module.'.format(type(q_net)))   # dqn.py:122-125
@@ -395,7 +395,7 @@ class DQN(object):
     self._iterations += 1
     # consumers that cache re-packed weights (qops.FastFeatures) key on this: a graph replay changes the parameters
     # without bumping any tensor version
-    self._q_net._weights_epoch = self._iterations
+    self._q_net._weights_epoch = getattr(self._q_net, '_weights_epoch', 0) + 1   # monotonic: bumped by every update and every restore
     if self._iterations % self._target_update_period == 0:           # dqn.py:478-484
       self._target_q_net.load_state_dict(self._target_sync_source())
     return loss, mtd
@@ -460,11 +460,20 @@ class DQN(object):
     return d
 
   def load_state_dict(self, d):
-    self._q_net.load_state_dict(d['q_net'])
-    self._target_q_net.load_state_dict(d['target_q_net'])
-    self._optimizer.load_state_dict(d['optimizer'])
-    self._iterations = int(d['iterations'])
-    self._q_net._weights_epoch = -self._iterations - 1               # restored weights: never equal to a cached epoch
-    self._gen.set_state(d['gen'].cpu())
+    """Accepts the whole dict of `state_dict` or a part of it (the Trainer keeps what the replicas share and what belongs
+    to one rank in separate files)."""
+    if 'q_net' in d:
+      self._q_net.load_state_dict(d['q_net'])
+      self._target_q_net.load_state_dict(d['target_q_net'])
+      self._optimizer.load_state_dict(d['optimizer'])
+      self._iterations = int(d['iterations'])
+      self._q_net._weights_epoch = getattr(self._q_net, '_weights_epoch', 0) + 1   # restored weights: a new epoch, never an earlier one's
+    if 'gen' in d:
+      self._gen.set_state(d['gen'].cpu())
     if 'replay_memory' in d:
       self._replay_memory.load_state_dict(d['replay_memory'])
+
+  def reseed(self, seed):
+    """New streams for exploration and minibatch sampling (a rank that resumes without state of its own)."""
+    self._gen.manual_seed(int(seed) % (2 ** 63) + 1)
+    self._replay_memory._gen.manual_seed(int(seed) % (2 ** 63))

@@ -7,9 +7,9 @@ ships every minibatch to the GPU; here everything stays in HBM (a B = 4,096, 64-
 
 Reference quirks, restated deliberately:
   * memory.py:239-242 computes the next index as `(i + n) % L + i // L` — for partition p > 0 that is
-    `(k + n) % L + p`, a slot of partition 0, not of p (correct only for a single env).  The intended
-    "stay inside the partition" arithmetic `(k + n) % L + p * L` is the default here;
-    `reference_next_index=True` reproduces the literal formula (tests pin both).
+    `(k + n) % L + p`, a slot of partition 0, not of p (correct only for a single env).  The literal formula is the
+    DEFAULT (results identical to the reference's come first); `reference_next_index=False` selects the intended
+    "stay inside the partition" arithmetic `(k + n) % L + p * L` (tests pin both).
   * memory.py:169-172 / :306-309 mask with `logits * float(!isinf)`, i.e. -inf * 0 = NaN; the intent (minimum over
     the finite logits) is what is implemented.
   * `alpha * logits` with alpha = 0 gives NaN for unsampleable slots (memory.py:223); they are kept at -inf.
@@ -21,7 +21,7 @@ import torch
 
 class ReplayMemory(object):
   def __init__(self, state_spec, max_length, alpha=None, beta=None, iters_counter=None, n_steps=None,
-               epsilon=1e-3, seed=None, device=None, reference_next_index=False):
+               epsilon=1e-3, seed=None, device=None, reference_next_index=True):
     """state_spec: sequence of (shape-with-batch, dtype), e.g. (((B,128,128,2), uint8), ((B,32,32,1), uint8)).
     alpha / beta: scalars or callables of the iteration count (memory.py:64-78)."""
     self.device = torch.device(device) if device is not None else torch.device('cpu')

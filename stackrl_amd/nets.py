@@ -45,6 +45,11 @@ def _init_conv(m, gen):
 def _fused_conv(m, x, relu=True):
   """Convolution without bias + the fused bias / ReLU pass (and its hand-written backward) of csrc/epilogue.hip."""
   from stackrl_amd import qops
+  if not qops.bias_act_supported(m.out_channels):
+    # channel counts the fused pass is not built for (above 256, or C / 8 not dividing 256 — e.g. a 512-channel bottom
+    # with left_filters=32): the module path, as before the fused passes existed
+    y = m(x)
+    return F.relu(y) if relu else y
   if isinstance(m, nn.ConvTranspose2d):
     y = F.conv_transpose2d(x, m.weight, None, stride=m.stride)
   else:

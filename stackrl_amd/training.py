@@ -305,20 +305,59 @@ class Trainer(object):
       self._last_save_iter = iters
       self.log('Done.')
 
+  # Checkpoint files (training.py:467-485 keeps one `tf.train.Checkpoint`; there is one process per GPU here):
+  #   checkpoint/ckpt.pt            what every replica shares — both nets, the optimiser slots, the iteration counter —
+  #                                 written by rank 0 only (max_to_keep=1, never a half-written file)
+  #   checkpoint/ckpt.rank<r>.pt    what belongs to rank r alone — its replay shard, the generators of its exploration
+  #                                 and of its minibatch sampling, its training-return metric — written by rank r
+  # so that after a resume the ranks do not hold copies of rank 0's replay memory and draw the same minibatch indices
+  # and exploration numbers.  A barrier separates the writers from any reader.
+  _SHARED_KEYS = ('q_net', 'target_q_net', 'optimizer', 'iterations')
+
+  def _rank_file(self):
+    return os.path.join(os.path.dirname(self._ckpt_file), 'ckpt.rank{}.pt'.format(self._rank))
+
+  def _barrier(self):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+      dist.barrier()
+
   def checkpoint(self):
     """training.py:467-485: agent (nets, optimiser, counters, replay memory) + the training-return metric."""
     iters = self.iterations
-    if iters != self._last_checkpoint_iter and self._ckpt_file is not None and self._rank == 0:
+    if iters != self._last_checkpoint_iter and self._ckpt_file is not None:
       self.log('Saving checkpoint...')
       os.makedirs(os.path.dirname(self._ckpt_file), exist_ok=True)
-      tmp = self._ckpt_file + '.tmp'
-      torch.save({'agent': self._agent.state_dict(memory=self._checkpoint_memory), 'reward': self._reward.state_dict()}, tmp)
-      os.replace(tmp, self._ckpt_file)                             # max_to_keep=1, never a half-written file
+      d = self._agent.state_dict(memory=self._checkpoint_memory)
+      local = {'agent': {k: v for k, v in d.items() if k not in self._SHARED_KEYS}, 'reward': self._reward.state_dict(),
+               'iterations': iters}
+      tmp = self._rank_file() + '.tmp'
+      torch.save(local, tmp)
+      os.replace(tmp, self._rank_file())
+      if self._rank == 0:
+        tmp = self._ckpt_file + '.tmp'
+        torch.save({'agent': {k: d[k] for k in self._SHARED_KEYS}}, tmp)
+        os.replace(tmp, self._ckpt_file)                           # max_to_keep=1, never a half-written file
+      self._barrier()
       self._last_checkpoint_iter = iters
       self.log('Done.')
 
   def restore(self):
+    self._barrier()
     d = torch.load(self._ckpt_file, map_location=self._agent.device, weights_only=False)
     self._agent.load_state_dict(d['agent'])
-    self._reward.load_state_dict(d['reward'])
+    mine = None
+    if os.path.isfile(self._rank_file()):
+      mine = torch.load(self._rank_file(), map_location=self._agent.device, weights_only=False)
+      if mine.get('iterations') != self.iterations:                # a rank file of another checkpoint: not this run's state
+        mine = None
+    if mine is not None:
+      self._agent.load_state_dict(mine['agent'])
+      self._reward.load_state_dict(mine['reward'])
+    else:
+      # no state of this rank's own (e.g. resumed on more GPUs than the run was saved on): its generators restart from
+      # rank-specific seeds and `initialize` collects its replay shard afresh
+      self._agent.reseed(self.iterations * 1000003 + self._rank)
+      if 'reward' in d:                                            # files written before the per-rank split
+        self._reward.load_state_dict(d['reward'])
     self._last_checkpoint_iter = self.iterations

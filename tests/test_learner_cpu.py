@@ -151,7 +151,8 @@ def test_literal_next_index_leaves_partition():
   mem = ReplayMemory((((4, 1, 1, 1), torch.uint8),), 40, reference_next_index=True)
   i = torch.tensor([3, 13, 29])
   assert mem.next_indexes(i, 1).tolist() == [4, 5, 2]          # (i+1)%10 + i//10
-  mem2 = ReplayMemory((((4, 1, 1, 1), torch.uint8),), 40)
+  assert ReplayMemory((((4, 1, 1, 1), torch.uint8),), 40).next_indexes(i, 1).tolist() == [4, 5, 2]   # and it is the default
+  mem2 = ReplayMemory((((4, 1, 1, 1), torch.uint8),), 40, reference_next_index=False)       # the in-partition option
   assert mem2.next_indexes(i, 1).tolist() == [4, 14, 20]
 
 
@@ -425,6 +426,60 @@ def test_training_loop_writes_the_reference_file_formats_and_resumes(tmp_path):
   # and continues: the next update draws the same minibatch and lands on the same weights in both
   la, _ = agent.train(); lb, _ = agent2.train()
   assert float(la) == float(lb)
+
+
+def _ckpt_rank(rank, world, port, d, out):
+  import torch.distributed as dist
+  from stackrl_amd.training import Trainer
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  spec = ((16, 16, 2), (4, 4, 1))
+  B, L = 3, 4
+
+  def make():
+    agent = _toy_agent(spec, B, seed=3 + rank)                  # rank-local exploration / sampling streams
+    return agent, Trainer(_ToyEnv(B, L, spec, seed=10 + rank), agent, directory=d, log_interval=2, checkpoint_interval=4,
+                          train_reward_buffer_length=2)
+  agent, tr = make()
+  tr.initialize(num_steps=6)
+  tr.run(4)                                                      # ends with a checkpoint at iteration 4
+  agent2, tr2 = make()
+  tr2.initialize()                                               # restores: shared file + this rank's own file
+  same_mem = torch.equal(agent._replay_memory._actions, agent2._replay_memory._actions) and \
+    all(torch.equal(a, b) for a, b in zip(agent._replay_memory._states, agent2._replay_memory._states))
+  same_gen = torch.equal(agent._gen.get_state(), agent2._gen.get_state()) and \
+    torch.equal(agent._replay_memory._gen.get_state(), agent2._replay_memory._gen.get_state())
+  flat = torch.cat([p.detach().flatten() for p in agent2._params])
+  allp = [torch.zeros_like(flat) for _ in range(world)]
+  dist.all_gather(allp, flat)
+  mem = agent2._replay_memory._states[0].flatten().float()
+  allm = [torch.zeros_like(mem) for _ in range(world)]
+  dist.all_gather(allm, mem)
+  gen = agent2._replay_memory._gen.get_state().float()
+  allg = [torch.zeros_like(gen) for _ in range(world)]
+  dist.all_gather(allg, gen)
+  torch.save({'iterations': agent2.iterations, 'own_memory_restored': bool(same_mem), 'own_generators_restored': bool(same_gen)}, out + str(rank))
+  if rank == 0:
+    torch.save({'weights_equal_across_ranks': bool(torch.equal(allp[0], allp[1])),
+                'memories_differ_across_ranks': bool(not torch.equal(allm[0], allm[1])),
+                'sampling_streams_differ_across_ranks': bool(not torch.equal(allg[0], allg[1])),
+                'files': sorted(os.listdir(os.path.join(d, 'checkpoint')))}, out)
+  dist.destroy_process_group()
+
+
+def test_checkpoint_keeps_rank_local_state_per_rank_world_size_2_gloo(tmp_path):
+  """One process per GPU: nets / optimiser / iteration counter are shared (rank 0 writes ckpt.pt), the replay shard, the
+  exploration and sampling generators and the return metric are each rank's own (ckpt.rank<r>.pt).  After a resume every
+  rank holds ITS memory and streams again — not copies of rank 0's, which would make the all-reduced gradient N copies of
+  the same minibatch — and the replicas' weights are equal."""
+  import torch.multiprocessing as mp
+  d, out = str(tmp_path / 'run'), str(tmp_path / 'res.pt')
+  mp.spawn(_ckpt_rank, args=(2, 27000 + os.getpid() % 2000, d, out), nprocs=2, join=True)
+  res = torch.load(out)
+  assert res == {'weights_equal_across_ranks': True, 'memories_differ_across_ranks': True,
+                 'sampling_streams_differ_across_ranks': True, 'files': ['ckpt.pt', 'ckpt.rank0.pt', 'ckpt.rank1.pt']}
+  for r in range(2):
+    assert torch.load(out + str(r)) == {'iterations': 4, 'own_memory_restored': True, 'own_generators_restored': True}
 
 
 def test_curriculum_moves_on_when_the_goal_return_is_reached(tmp_path):
