@@ -217,6 +217,43 @@ int srl_replay_gather(const int64_t* idx_dev, int32_t mb, int64_t part_len, int6
                       float* weight_dev, void* stream);
 const char* srl_learner_last_error(void);
 
+/* ---- update-path convolutions (csrc/train_conv.hip): the forward (with saved activations), data-gradient and
+ * weight-gradient convolutions of `DQN.train` (stackrl/agents/dqn.py:466-473 differentiates `DeepQSiamFCN`,
+ * stackrl/nets/models.py:106-201 / layers.py:135-259) in true float32 on the matrix cores (v_mfma_f32_16x16x4_f32).
+ * Tensors are float32, channels-last: pixel p of [B][H][W] holds its channels at p * stride + offset (a channel slice of a
+ * wider buffer, e.g. the decoder's concatenation buffer).  Nothing is allocated; results are bit-identical on repetition
+ * (no atomics: fixed-order partial sums).
+ *
+ * srl_tconv: y[p][co] = act(bias[co] + sum_{t, ci} x[p + d(t)][ci] wp[t][ci][co]); taps = 9: 3 x 3, stride 1, SAME;
+ * taps = 1: 1 x 1.  wp = packed weights [taps][cin_p][cout], cin_p = cin rounded up to 4 (srl_trepack); cout a multiple of
+ * 16; bias may be NULL.  The data gradient of a 3 x 3 layer is the same call on the flipped / transposed packing (kind 1).
+ * d2s > 0 (taps = 1, cout = 4 d2s): the 2 x 2 stride-2 transposed convolution — output channel q d2s + co is stored at
+ * pixel (2 y + q / 2, 2 x + q % 2), channel co of y [B][2H][2W], bias indexed by co. */
+int srl_tconv(const float* x_dev, int32_t x_stride, int32_t x_off, const float* wp_dev, const float* bias_dev, float* y_dev,
+              int32_t y_stride, int32_t y_off, int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps,
+              int32_t relu, int32_t d2s, void* stream);
+/* srl_twrw: gw = sum_p x[p + d(t)][ci] gz[p][co] in the framework's parameter layout — Conv2d [cout][cin][3][3] (or 1 x 1),
+ * or (convt = 1, taps = 1, cout = 4 cout_t, gz stored space-to-depth) ConvTranspose2d [cin][cout_t][2][2].  gz contiguous
+ * [B][H][W][cout]; scratch: srl_twrw_scratch_floats(...) floats. */
+int64_t srl_twrw_scratch_floats(int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps);
+int srl_twrw(const float* x_dev, int32_t x_stride, int32_t x_off, const float* gz_dev, float* gw_dev, float* scratch_dev,
+             int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, int32_t convt, void* stream);
+/* srl_tact_bwd: gz[p][c] = (g[p][c] + the gradient gpool[B][H/2][W/2][C] routed back through the 2 x 2 max-pool of y to the
+ * first maximal element of each window, if gpool != NULL) * [y[p][c] > 0] (relu), contiguous [B][H][W][C] or (s2d = 1)
+ * space-to-depth [B][H/2][W/2][4 C] with channel (2 (y % 2) + x % 2) C + c; gbias (may be NULL) = sum over pixels of gz in
+ * a fixed order.  C a multiple of 4 with C / 4 dividing 256, C <= 256; scratch: srl_tact_bwd_scratch_floats(B H W, C). */
+int64_t srl_tact_bwd_scratch_floats(int64_t npix, int32_t C);
+int srl_tact_bwd(const float* g_dev, int32_t g_stride, int32_t g_off, const float* y_dev, int32_t y_stride, int32_t y_off,
+                 const float* gpool_dev, float* gz_dev, float* gbias_dev, float* scratch_dev, int32_t B, int32_t H, int32_t W,
+                 int32_t C, int32_t relu, int32_t s2d, void* stream);
+/* srl_trepack: every packed weight layout of every layer from the flat parameter bucket in one launch.  desc: int64
+ * [nlayers][8] = {src_off, dst_off, cin, cout, taps, kind, cin_pad, 0}, destination ranges consecutive from 0 to `total`;
+ * kind 0 conv forward [t][cin_p][cout]; 1 conv data gradient [t][cout][cin_pad] (taps flipped; cin_pad = cin, or cin rounded
+ * up to 16 with zero columns so that a thin layer's data gradient has a supported channel count); 2 transposed conv forward
+ * [cin][4 cout] (k = q cout + co); 3 transposed conv data gradient [4 cout][cin]. */
+int srl_trepack(const float* flat_dev, float* packed_dev, const int64_t* desc_dev, int32_t nlayers, int64_t total, void* stream);
+const char* srl_train_conv_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,8 @@ def stale():
 
 
 QLIB = os.path.join(HERE, 'libstackrl_qnet.so')
-QSRC = ['qnet.hip', 'heuristics.hip', 'xcorr_mfma.hip', 'epilogue.hip', 'conv_mfma.hip', 'conv_gemm.hip', 'learner.hip']
+QSRC = ['qnet.hip', 'heuristics.hip', 'xcorr_mfma.hip', 'epilogue.hip', 'conv_mfma.hip', 'conv_gemm.hip', 'learner.hip',
+        'train_conv.hip']
 QDEPS = QSRC + [ os.path.join('..', '..', 'include', 'stackrl_qnet.h')]
 # the Q-net ops are ordinary fp32 kernels compared against a torch fp32 reference with a stated tolerance
 QFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wall', '-Wno-unused-function',

@@ -1,0 +1,167 @@
+"""GPU tests of the update path's hand-written convolutions (csrc/train_conv.hip, stackrl_amd/qtrain.py) against float64
+torch: forward, data gradient and weight gradient of the 3 x 3 layers, the 2 x 2 transposed layers, the activation-gradient
+pass with the max-pool routing, and the whole `DeepQSiamFCN` forward / backward against the module graph's autograd.
+
+The kernels multiply and accumulate in float32 (v_mfma_f32_16x16x4_f32): the stated tolerance against float64 is 2e-5 of
+each tensor's scale (accumulation order over up to 2,304 x pixels terms); the whole net goes through the bf16x3
+cross-correlation (2e-5 per application, stated in tests/test_learner_gpu.py), so its tolerance is 2e-4."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def _rel(got, want):
+  got, want = got.detach(), want.detach().double()
+  return float((got.double() - want).abs().max()) / max(float(want.abs().max()), 1e-30)
+
+
+def _packed(mods):
+  from stackrl_amd import qtrain
+  net = torch.nn.Sequential(*mods).cuda()
+  P = qtrain.Packed(net)
+  P.refresh()
+  return net, P
+
+
+@pytest.mark.parametrize('cin,cout,B,H,W', [(2, 16, 2, 32, 48), (1, 16, 3, 97, 97), (16, 16, 2, 48, 32), (32, 64, 5, 16, 16),
+                                            (64, 32, 6, 8, 8), (128, 64, 3, 4, 4), (256, 256, 4, 8, 8), (48, 16, 1, 20, 17)])
+def test_conv3x3_forward_data_and_weight_gradients_match_torch_fp64(cin, cout, B, H, W):
+  from stackrl_amd import qtrain
+  F = torch.nn.functional
+  g = torch.Generator(device='cuda').manual_seed(cin * 7 + cout + H)
+  (conv,), P = _packed([torch.nn.Conv2d(cin, cout, 3, padding=1)])
+  with torch.no_grad():
+    conv.bias.copy_(torch.randn(cout, generator=g, device='cuda') * 0.1)
+  # the input as a channel slice of a wider buffer, the output into a channel slice of another
+  xbuf = torch.randn((B, H, W, cin + 4), generator=g, device='cuda')
+  x = qtrain.Act(xbuf, cin, 4 if cin % 4 == 0 else 0) if cin % 4 == 0 else qtrain.Act(xbuf[..., :cin].contiguous())
+  xd = x.dense().permute(0, 3, 1, 2).double().requires_grad_()
+  ybuf = torch.full((B, H, W, cout + 8), 7.0, device='cuda')
+  y = qtrain.tconv(x, P.w(conv, 0), conv.bias, cout, relu=True, out=(ybuf, 8))
+  ref = F.relu(F.conv2d(xd, conv.weight.double(), conv.bias.double(), padding=1))
+  assert _rel(y.dense().permute(0, 3, 1, 2), ref) <= TOL
+  assert bool((ybuf[..., :8] == 7.0).all())
+  # backward: activation gradient (ReLU mask + bias gradient), weight gradient, data gradient
+  gy = torch.randn((B, H, W, cout), generator=g, device='cuda')
+  sc = qtrain._Scratch()
+  gb = torch.zeros(cout, device='cuda')
+  gz = qtrain.tact_bwd(qtrain.Act(gy), y, sc, gbias=gb, relu=True)
+  assert torch.equal(gz, gy * (y.dense() > 0))
+  gw = torch.zeros_like(conv.weight)
+  qtrain.twrw(x, gz, gw, sc)
+  # reference gradients
+  wd = conv.weight.detach().double().requires_grad_(); bd = conv.bias.detach().double().requires_grad_()
+  xd2 = x.dense().permute(0, 3, 1, 2).double().requires_grad_()
+  out = F.relu(F.conv2d(xd2, wd, bd, padding=1))
+  out.backward(gy.permute(0, 3, 1, 2).double())
+  assert _rel(gw, wd.grad) <= TOL, 'weight gradient'
+  assert _rel(gb, bd.grad) <= TOL, 'bias gradient'
+  cpad = (cin + 15) // 16 * 16
+  gx = qtrain.tconv(qtrain.Act(gz), P.w(conv, 1), None, cpad, relu=False)
+  assert _rel(gx.t[..., :cin].permute(0, 3, 1, 2), xd2.grad) <= TOL, 'data gradient'
+  if cpad != cin:
+    assert float(gx.t[..., cin:].abs().max()) == 0.0
+  # bit-identical on repetition (fixed-order reductions, no atomics)
+  gw2 = torch.zeros_like(gw); qtrain.twrw(x, gz, gw2, sc)
+  assert torch.equal(gw, gw2)
+
+
+@pytest.mark.parametrize('cin,cout,B,H,W', [(32, 16, 2, 24, 16), (64, 32, 3, 8, 8), (256, 128, 4, 8, 8), (128, 64, 2, 5, 7)])
+def test_transposed_conv_forward_and_gradients_match_torch_fp64(cin, cout, B, H, W):
+  """`up{i}` (layers.py:222-229) as a 1 x 1 convolution to 4 cout channels + depth-to-space, into the first half of a
+  concatenation buffer; its gradients from the space-to-depth activation gradient."""
+  from stackrl_amd import qtrain
+  F = torch.nn.functional
+  g = torch.Generator(device='cuda').manual_seed(cin + cout + H)
+  (up,), P = _packed([torch.nn.ConvTranspose2d(cin, cout, 2, stride=2)])
+  with torch.no_grad():
+    up.bias.copy_(torch.randn(cout, generator=g, device='cuda') * 0.1)
+  x = qtrain.Act(torch.randn((B, H, W, cin), generator=g, device='cuda'))
+  cat = torch.full((B, 2 * H, 2 * W, 2 * cout), 3.0, device='cuda')
+  y = qtrain.tconv(x, P.w(up, 2), up.bias, 4 * cout, taps=1, relu=True, out=(cat, 0), d2s=cout)
+  xd = x.t.permute(0, 3, 1, 2).double().requires_grad_()
+  wd = up.weight.detach().double().requires_grad_(); bd = up.bias.detach().double().requires_grad_()
+  ref = F.relu(F.conv_transpose2d(xd, wd, bd, stride=2))
+  assert _rel(y.dense().permute(0, 3, 1, 2), ref) <= TOL
+  assert bool((cat[..., cout:] == 3.0).all())
+  gcat = torch.randn((B, 2 * H, 2 * W, 2 * cout), generator=g, device='cuda')
+  ref.backward(gcat[..., :cout].permute(0, 3, 1, 2).double())
+  sc = qtrain._Scratch()
+  gb = torch.zeros(cout, device='cuda')
+  gz = qtrain.tact_bwd(qtrain.Act(gcat, cout, 0), y, sc, gbias=gb, relu=True, s2d=True)
+  assert tuple(gz.shape) == (B, H, W, 4 * cout)
+  gw = torch.zeros_like(up.weight)
+  qtrain.twrw(x, gz, gw, sc, taps=1, convt=True)
+  gx = qtrain.tconv(qtrain.Act(gz), P.w(up, 3), None, cin, taps=1, relu=False)
+  assert _rel(gb, bd.grad) <= TOL and _rel(gw, wd.grad) <= TOL and _rel(gx.t.permute(0, 3, 1, 2), xd.grad) <= TOL
+
+
+@pytest.mark.parametrize('C,B,H,W', [(16, 2, 16, 24), (64, 3, 8, 8), (256, 2, 4, 4)])
+def test_activation_gradient_routes_the_max_pool_like_the_library(C, B, H, W):
+  """gz = (g + pool gradient to the first maximum of each 2 x 2 window) * [y > 0] against autograd of
+  relu -> (identity, max_pool2d); y holds ties (zeros after the ReLU and equal positive values)."""
+  from stackrl_amd import qtrain
+  F = torch.nn.functional
+  gen = torch.Generator(device='cuda').manual_seed(C + H)
+  pre = torch.randn((B, H, W, C), generator=gen, device='cuda').round(decimals=0)      # integers: many exact ties
+  ybuf = torch.zeros((B, H, W, 2 * C), device='cuda')
+  ybuf[..., C:] = F.relu(pre)
+  y = qtrain.Act(ybuf, C, C)
+  g = torch.randn((B, H, W, 2 * C), generator=gen, device='cuda')
+  gp = torch.randn((B, H // 2, W // 2, C), generator=gen, device='cuda')
+  pd = pre.permute(0, 3, 1, 2).double().requires_grad_()
+  yd = F.relu(pd)
+  (yd * g[..., C:].permute(0, 3, 1, 2).double()).sum().backward(retain_graph=True)
+  (F.max_pool2d(yd, 2) * gp.permute(0, 3, 1, 2).double()).sum().backward()
+  sc = qtrain._Scratch()
+  gb = torch.zeros(C, device='cuda')
+  gz = qtrain.tact_bwd(qtrain.Act(g, C, C), y, sc, gbias=gb, gpool=gp, relu=True)
+  want = pd.grad.permute(0, 2, 3, 1)
+  assert float((gz.double() - want).abs().max()) <= 1e-6
+  assert _rel(gb, want.sum(dim=(0, 1, 2))) <= 1e-5
+
+
+@pytest.mark.parametrize('rf', [5, 4])
+def test_hand_net_forward_and_backward_match_the_module_autograd(rf):
+  """`HandNet` against `DeepQSiamFCN`'s own graph in float64 (Stack-v0 shapes and the 64 x 64 configuration): Q values and
+  every parameter's gradient for a random upstream gradient, the backward restricted to the first samples of a larger
+  saved forward (the update evaluates Q(s, .) and Q(s', .) in one pass)."""
+  import copy
+  from stackrl_amd import nets, qtrain
+  h = 2 ** rf
+  spec = ((4 * h, 4 * h, 2), (h, h, 1))
+  net = nets.DeepQSiamFCN(spec, seed=3).cuda()
+  gen = torch.Generator(device='cuda').manual_seed(rf)
+  B, n = 5, 3
+  xm = torch.randint(0, 256, (B, 4 * h, 4 * h, 2), generator=gen, device='cuda', dtype=torch.uint8)
+  xm[..., 1] = (xm[..., 1] > 128).to(torch.uint8) * 170
+  xo = torch.randint(0, 120, (B, h, h, 1), generator=gen, device='cuda', dtype=torch.uint8)
+  ref = copy.deepcopy(net).double()
+  fx, fx0 = ref.left(xm.permute(0, 3, 1, 2).double() / 255.0)          # models.py:144-147 in float64
+  fw, _ = ref.right(xo.permute(0, 3, 1, 2).double() / 255.0)
+  qd = ref.head(ref.correlation(fx, fw), fx0)
+  gq = torch.randn((n, qd.shape[1]), generator=gen, device='cuda') / qd.shape[1] ** 0.5
+  qd[:n].backward(gq.double())
+  for p in net.parameters():
+    p.grad = torch.zeros_like(p)
+  hn = qtrain.HandNet(net)
+  hn.refresh()
+  q = hn.forward((xm, xo), save=True)
+  assert _rel(q.detach(), qd.detach()) <= 2e-4
+  q0 = hn.forward((xm, xo))                                  # the no-grad evaluation is the same arithmetic
+  assert torch.equal(q0, q.detach())
+  hn.backward(gq)
+  worst = 0.0
+  for (name, p), pr in zip(net.named_parameters(), ref.parameters()):
+    if float(pr.grad.abs().max()) < 1e-12:          # the projection's bias cancels in A - mean(A): its gradient is zero
+      assert float(p.grad.abs().max()) <= 1e-5, name          # float32 cancellation of 9,409 terms
+      continue
+    e = _rel(p.grad, pr.grad)
+    worst = max(worst, e)
+    assert e <= 2e-3, (name, e)
+  print('resolution factor', rf, 'worst relative parameter-gradient error', worst)
