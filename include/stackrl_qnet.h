@@ -234,15 +234,21 @@ int srl_tconv(const float* x_dev, int32_t x_stride, int32_t x_off, const float* 
               int32_t relu, int32_t d2s, void* stream);
 /* srl_twrw: gw = sum_p x[p + d(t)][ci] gz[p][co] in the framework's parameter layout — Conv2d [cout][cin][3][3] (or 1 x 1),
  * or (convt = 1, taps = 1, cout = 4 cout_t, gz stored space-to-depth) ConvTranspose2d [cin][cout_t][2][2].  gz contiguous
- * [B][H][W][cout]; scratch: srl_twrw_scratch_floats(...) floats. */
+ * [B][H][W][cout]; scratch: srl_twrw_scratch_floats(...) floats.  bias_partial (may be NULL): the bias-gradient partials
+ * srl_tact_bwd left in ITS scratch (bias_nblk = srl_tact_bwd_blocks(...) rows of bias_C floats); the finishing launch then
+ * also writes gbias[bias_C] — one launch per layer for both gradients. */
 int64_t srl_twrw_scratch_floats(int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps);
 int srl_twrw(const float* x_dev, int32_t x_stride, int32_t x_off, const float* gz_dev, float* gw_dev, float* scratch_dev,
-             int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, int32_t convt, void* stream);
+             int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, int32_t convt,
+             const float* bias_partial_dev, int32_t bias_nblk, int32_t bias_C, float* gbias_dev, void* stream);
 /* srl_tact_bwd: gz[p][c] = (g[p][c] + the gradient gpool[B][H/2][W/2][C] routed back through the 2 x 2 max-pool of y to the
  * first maximal element of each window, if gpool != NULL) * [y[p][c] > 0] (relu), contiguous [B][H][W][C] or (s2d = 1)
  * space-to-depth [B][H/2][W/2][4 C] with channel (2 (y % 2) + x % 2) C + c; gbias (may be NULL) = sum over pixels of gz in
- * a fixed order.  C a multiple of 4 with C / 4 dividing 256, C <= 256; scratch: srl_tact_bwd_scratch_floats(B H W, C). */
+ * a fixed order.  C a multiple of 4 with C / 4 dividing 256, C <= 256; scratch (may be NULL: no bias gradient):
+ * srl_tact_bwd_scratch_floats(B H W, C) floats = srl_tact_bwd_blocks(B H W, C) rows of per-block partial sums, always
+ * written when given; gbias NULL leaves finishing them to srl_twrw. */
 int64_t srl_tact_bwd_scratch_floats(int64_t npix, int32_t C);
+int32_t srl_tact_bwd_blocks(int64_t npix, int32_t C);
 int srl_tact_bwd(const float* g_dev, int32_t g_stride, int32_t g_off, const float* y_dev, int32_t y_stride, int32_t y_off,
                  const float* gpool_dev, float* gz_dev, float* gbias_dev, float* scratch_dev, int32_t B, int32_t H, int32_t W,
                  int32_t C, int32_t relu, int32_t s2d, void* stream);

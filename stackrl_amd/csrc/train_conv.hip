@@ -102,6 +102,53 @@ __device__ __forceinline__ void stage_x(float* lds, const Tile<TAPS, TW>& T, con
   }
 }
 
+// The same in two halves for tensors whose channel slices are 16-byte aligned (every layer but the thin first ones):
+// stage_fetch reads the chunk's 16 channels as float4s into registers — issued BEFORE the matrix products of the chunk in
+// flight, so that the global-memory latency hides under them — and stage_put writes them to LDS after the barrier.
+template <int TAPS, int TW>
+struct StageRegs {
+  static constexpr int NV = (Tile<TAPS, TW>::LPIX * (CK / 4) + 255) / 256;
+  float4 v[NV];
+};
+
+template <int TAPS, int TW>
+__device__ __forceinline__ void stage_fetch(StageRegs<TAPS, TW>& R, const Tile<TAPS, TW>& T, const float* __restrict__ x, int xs,
+                                            int xo, int B, int H, int W, int cin, int c0) {
+  typedef Tile<TAPS, TW> TT;
+#pragma unroll
+  for (int i = 0; i < StageRegs<TAPS, TW>::NV; ++i) {
+    const int idx = threadIdx.x + 256 * i;
+    const int lp = idx >> 2, c = (idx & 3) * 4;
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (lp < TT::LPIX && c0 + c < cin) {
+      if (TAPS == 1) {
+        const long long p = T.p0 + lp;
+        if (p < (long long)B * H * W) v = *(const float4*)(x + p * xs + xo + c0 + c);
+      } else {
+        const int s = lp / (TT::PW * TT::PW), r = lp - s * TT::PW * TT::PW;
+        const int yy = T.y0 - 1 + r / TT::PW, xx = T.x0 - 1 + r % TT::PW, b = T.b0 + s;
+        if (b < B && yy >= 0 && yy < H && xx >= 0 && xx < W)
+          v = *(const float4*)(x + (((long long)b * H + yy) * W + xx) * xs + xo + c0 + c);
+      }
+    }
+    R.v[i] = v;
+  }
+}
+
+template <int TAPS, int TW>
+__device__ __forceinline__ void stage_put(float* lds, const StageRegs<TAPS, TW>& R) {
+  typedef Tile<TAPS, TW> TT;
+#pragma unroll
+  for (int i = 0; i < StageRegs<TAPS, TW>::NV; ++i) {
+    const int idx = threadIdx.x + 256 * i;
+    const int lp = idx >> 2, c = (idx & 3) * 4;
+    if (lp < TT::LPIX) {
+      float* d = lds + lp * CKP + c;
+      d[0] = R.v[i].x; d[1] = R.v[i].y; d[2] = R.v[i].z; d[3] = R.v[i].w;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- conv
 // grid.x = tiles, grid.y = chunks of COT * 16 output channels.  wp: [TAPS][cin_p][cout], cin_p = cin rounded up to 4.
 // d2s > 0: output channel k = q * d2s + co is stored at pixel (2 y + q / 2, 2 x + q % 2), channel co of a map twice the
@@ -126,24 +173,49 @@ __global__ void __launch_bounds__(256) k_tconv(const float* __restrict__ x, int 
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) lp[nt][t] = T.lds_pixel((4 * wv + nt) * 16 + (l & 15), t) * CKP + (l >> 4);
+  // aligned: every channel slice starts on a 16-byte boundary and cin is a multiple of 16 -> float4 staging, the next
+  // chunk's global loads issued before the current chunk's matrix products
+  const bool aligned = (xs & 3) == 0 && (xo & 3) == 0 && (cin & 15) == 0;
+  StageRegs<TAPS, TW> R;
+  if (aligned) stage_fetch<TAPS, TW>(R, T, x, xs, xo, B, H, W, cin, 0);
   for (int c0 = 0; c0 < cin_p; c0 += CK) {
     const int ck = cin_p - c0 < CK ? cin_p - c0 : CK;
     __syncthreads();
-    stage_x<TAPS, TW>(lds, T, x, xs, xo, B, H, W, cin, c0, ck);
+    if (aligned) stage_put<TAPS, TW>(lds, R);
+    else stage_x<TAPS, TW>(lds, T, x, xs, xo, B, H, W, cin, c0, ck);
     __syncthreads();
+    if (aligned && c0 + CK < cin_p) stage_fetch<TAPS, TW>(R, T, x, xs, xo, B, H, W, cin, c0 + CK);
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
-      for (int k4 = 0; k4 < ck; k4 += 4) {
-        float a[COT], b[4];
-        const float* wr = wp + ((long long)t * cin_p + c0 + k4 + (l >> 4)) * cout + co0 + (l & 15);
+      const float* wt = wp + ((long long)t * cin_p + c0 + (l >> 4)) * cout + co0 + (l & 15);
+      if (ck == CK) {
+        float a[4][COT];
 #pragma unroll
-        for (int ct = 0; ct < COT; ++ct) a[ct] = co0 + ct * 16 < cout ? wr[ct * 16] : 0.0f;
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) b[nt] = lds[lp[nt][t] + k4];
+          for (int ct = 0; ct < COT; ++ct) a[kk][ct] = co0 + ct * 16 < cout ? wt[(long long)kk * 4 * cout + ct * 16] : 0.0f;
 #pragma unroll
-        for (int ct = 0; ct < COT; ++ct)
+        for (int kk = 0; kk < 4; ++kk) {
+          float b[4];
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], b[nt], acc[ct][nt], 0, 0, 0);
+          for (int nt = 0; nt < 4; ++nt) b[nt] = lds[lp[nt][t] + 4 * kk];
+#pragma unroll
+          for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][ct], b[nt], acc[ct][nt], 0, 0, 0);
+        }
+      } else {
+        for (int k4 = 0; k4 < ck; k4 += 4) {
+          float a[COT], b[4];
+#pragma unroll
+          for (int ct = 0; ct < COT; ++ct) a[ct] = co0 + ct * 16 < cout ? wt[(long long)k4 * cout + ct * 16] : 0.0f;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) b[nt] = lds[lp[nt][t] + k4];
+#pragma unroll
+          for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], b[nt], acc[ct][nt], 0, 0, 0);
+        }
       }
     }
   }
@@ -251,17 +323,45 @@ __global__ void __launch_bounds__(256) k_twrw(const float* __restrict__ x, int x
 
 // gw (torch layout) = sum over the G partials in index order.  kind 0: Conv2d weight [cout][cin][3][3] (or 1 x 1);
 // kind 1: ConvTranspose2d weight [cin][cout_t][2][2] from the 1 x 1 form with cout = 4 cout_t channels k = q cout_t + co.
+// A workgroup takes 32 consecutive elements; its 256 threads are (row r of 8, element): row r adds the partials
+// r, r + 8, ... in turn (128-byte reads), then the rows are added in index order — a fixed summation order.
+// Blocks past the weight elements (nwb of them) finish the layer's bias gradient from the partials k_tact_bwd left
+// (bpart [bnblk][bC], 32 channels per block): one launch per layer instead of two.
 __global__ void __launch_bounds__(256) k_twrw_finish(const float* __restrict__ partial, int G, int taps, int cin, int cout,
-                                                     int kind, float* __restrict__ gw) {
+                                                     int kind, float* __restrict__ gw, int nwb, const float* __restrict__ bpart,
+                                                     int bnblk, int bC, float* __restrict__ gb) {
+  __shared__ float sh[256];
+  if ((int)blockIdx.x >= nwb) {
+    const int c = ((int)blockIdx.x - nwb) * 32 + (threadIdx.x & 31), r = threadIdx.x >> 5;
+    float s = 0.0f;
+    if (c < bC)
+      for (int b = r; b < bnblk; b += 8) s += bpart[(long long)b * bC + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < bC) {
+      float t8 = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t8 += sh[q * 32 + threadIdx.x];
+      gb[c] = t8;
+    }
+    return;
+  }
   const int cin16 = (cin + 15) & ~15;
-  const long long n = (long long)taps * cin16 * cout, e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
+  const long long n = (long long)taps * cin16 * cout, e = (long long)blockIdx.x * 32 + (threadIdx.x & 31);
+  const int r = threadIdx.x >> 5;
+  float s = 0.0f;
+  if (e < n)
+    for (int g = r; g < G; g += 8) s += partial[(long long)g * n + e];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x >= 32 || e >= n) return;
+  float t8 = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) t8 += sh[q * 32 + threadIdx.x];
   const int co = (int)(e % cout), ci = (int)((e / cout) % cin16), t = (int)(e / ((long long)cout * cin16));
   if (ci >= cin) return;
-  float s = 0.0f;
-  for (int g = 0; g < G; ++g) s += partial[(long long)g * n + e];
-  if (kind == 0) gw[((long long)co * cin + ci) * taps + t] = s;
-  else { const int ct = cout / 4, q = co / ct, c = co - q * ct; gw[((long long)ci * ct + c) * 4 + q] = s; }
+  if (kind == 0) gw[((long long)co * cin + ci) * taps + t] = t8;
+  else { const int ct = cout / 4, q = co / ct, c = co - q * ct; gw[((long long)ci * ct + c) * 4 + q] = t8; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- act bwd
@@ -387,9 +487,11 @@ int launch_conv(const float* x, int xs, int xo, const float* wp, const float* bi
   if (TAPS == 1) tiles = ((long long)B * H * W + 255) / 256;
   else if (TW == 16) tiles = (long long)B * ((H + 15) / 16) * ((W + 15) / 16);
   else tiles = (long long)((B + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8);
-  if (cout % 64 == 0)
+  // output channels per workgroup: 64 when that still gives the chip >= 512 workgroups, else 32, else 16 (the deep levels
+  // have few pixel tiles: a 256 -> 256 layer at 8 x 8 x 64 samples is 16 tiles)
+  if (cout % 64 == 0 && tiles * (cout / 64) >= 512)
     hipLaunchKernelGGL((k_tconv<TAPS, TW, 4>), dim3((unsigned)tiles, cout / 64), dim3(256), 0, st, x, xs, xo, wp, bias, y, ys, yo, B, H, W, cin, cout, relu, d2s);
-  else if (cout % 32 == 0)
+  else if (cout % 32 == 0 && tiles * (cout / 32) >= 512)
     hipLaunchKernelGGL((k_tconv<TAPS, TW, 2>), dim3((unsigned)tiles, cout / 32), dim3(256), 0, st, x, xs, xo, wp, bias, y, ys, yo, B, H, W, cin, cout, relu, d2s);
   else
     hipLaunchKernelGGL((k_tconv<TAPS, TW, 1>), dim3((unsigned)tiles, cout / 16), dim3(256), 0, st, x, xs, xo, wp, bias, y, ys, yo, B, H, W, cin, cout, relu, d2s);
@@ -452,7 +554,8 @@ int64_t srl_twrw_scratch_floats(int32_t B, int32_t H, int32_t W, int32_t cin, in
 }
 
 int srl_twrw(const float* x, int32_t x_stride, int32_t x_off, const float* gz, float* gw, float* scratch, int32_t B,
-             int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, int32_t convt, void* stream) {
+             int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t taps, int32_t convt, const float* bias_partial,
+             int32_t bias_nblk, int32_t bias_C, float* gbias, void* stream) {
   if (!x || !gz || !gw || !scratch || srl_twrw_scratch_floats(B, H, W, cin, cout, taps) < 0 || (convt && (taps != 1 || cout % 4)))
     return t_bad("srl_twrw: bad arguments");
   hipStream_t st = (hipStream_t)stream;
@@ -463,7 +566,9 @@ int srl_twrw(const float* x, int32_t x_stride, int32_t x_off, const float* gz, f
   else rc = launch_wrw<9, 8>(x, x_stride, x_off, gz, scratch, G, B, H, W, cin, cout, st);
   if (rc) return rc;
   const long long n = (long long)taps * ((cin + 15) & ~15) * cout;
-  hipLaunchKernelGGL(k_twrw_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, G, taps, cin, cout, convt ? 1 : 0, gw);
+  const int nwb = (int)((n + 31) / 32), nbb = (bias_partial && gbias) ? (bias_C + 31) / 32 : 0;
+  hipLaunchKernelGGL(k_twrw_finish, dim3(nwb + nbb), dim3(256), 0, st, scratch, G, taps, cin, cout, convt ? 1 : 0, gw, nwb,
+                     bias_partial, bias_nblk, bias_C, gbias);
   return t_finish("srl_twrw finish");
 }
 
@@ -473,18 +578,24 @@ int64_t srl_tact_bwd_scratch_floats(int64_t npix, int32_t C) {
   return ((npix + pixb - 1) / pixb) * C;
 }
 
+int32_t srl_tact_bwd_blocks(int64_t npix, int32_t C) {
+  if (srl_tact_bwd_scratch_floats(npix, C) < 0) return -1;
+  const int pixb = act_pixb(npix, C);
+  return (int32_t)((npix + pixb - 1) / pixb);
+}
+
 int srl_tact_bwd(const float* g, int32_t g_stride, int32_t g_off, const float* y, int32_t y_stride, int32_t y_off,
                  const float* gpool, float* gz, float* gbias, float* scratch, int32_t B, int32_t H, int32_t W, int32_t C,
                  int32_t relu, int32_t s2d, void* stream) {
   const long long npix = (long long)B * H * W;
   if (!g || !gz || (!y && (relu || gpool)) || srl_tact_bwd_scratch_floats(npix, C) < 0 || g_stride % 4 || g_off % 4 ||
-      y_stride % 4 || y_off % 4 || ((gpool || s2d) && ((H | W) & 1)) || (gbias && !scratch))
+      y_stride % 4 || y_off % 4 || ((gpool || s2d) && ((H | W) & 1)))
     return t_bad("srl_tact_bwd: bad arguments (C a multiple of 4 with C / 4 dividing 256, strides / offsets multiples of 4)");
   const int pixb = act_pixb(npix, C);
   const int nblk = (int)((npix + pixb - 1) / pixb);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_tact_bwd, dim3(nblk), dim3(256), 0, st, g, g_stride, g_off, y, y_stride, y_off, gpool, gz,
-                     gbias ? scratch : (float*)nullptr, B, H, W, C, relu, s2d, pixb);
+                     scratch, B, H, W, C, relu, s2d, pixb);
   if (gbias) hipLaunchKernelGGL(k_tbias_finish, dim3((C + 31) / 32), dim3(256), 0, st, scratch, nblk, C, gbias);
   return t_finish("srl_tact_bwd");
 }

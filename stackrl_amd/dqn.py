@@ -129,7 +129,7 @@ class DQN(object):
                discount_factor=.99, collect_batch_size=None, exploration_mode=None, exploration=None,
                prioritization=None, priority_bias_compensation=None, double=False, n_step=None, seed=None,
                device=None, process_group=None, policy_op=None, reference_next_index=True,
-               adam_betas=(0.9, 0.999), xcorr=None, graphs=False):
+               adam_betas=(0.9, 0.999), xcorr=None, graphs=False, hand_convs=None):
     if not isinstance(q_net, torch.nn.Module):
       raise TypeError('Invalid type {} for argument q_net. Must be a torch Module.'.format(type(q_net)))   # dqn.py:122-125
     self.device = torch.device(device) if device is not None else next(q_net.parameters()).device
@@ -235,6 +235,28 @@ class DQN(object):
     # the loss and its gradient as one hand-written kernel (csrc/learner.hip) on a HIP device
     self._fused = self.device.type == 'cuda'
     self._ws = {}
+    # hand_convs: every convolution of the update (forward with saved activations, data gradient, weight gradient) on the
+    # kernels of csrc/train_conv.hip instead of the library's (stackrl_amd/qtrain.py; None = on a HIP device whenever the
+    # net and the optimiser allow it: the config.gin network over the flat Keras-Adam bucket)
+    self._hand = self._hand_t = None
+    if hand_convs is None:
+      hand_convs = self._fused and isinstance(self._optimizer, KerasAdam) and self._hand_supported()
+    if hand_convs:
+      from stackrl_amd import qtrain
+      self._hand = qtrain.HandNet(self._q_net, flat=self._optimizer.flat)
+      self._hand_t = qtrain.HandNet(self._target_q_net)
+      self._hand_t.refresh()
+
+  def _hand_supported(self):
+    """`qtrain.HandNet` covers the config.gin network: a `DeepQSiamFCN` with the dueling head on average-pooled features,
+    two position layers, and the observation sizes the cross-correlation kernels are built for."""
+    from stackrl_amd import nets, qops
+    n = self._q_net
+    if not isinstance(n, nets.DeepQSiamFCN) or not n.dueling or not n.dueling_avg_pool or len(n.pos) != 5:
+      return False
+    (H, W), (h, w) = n.in_hw
+    chans = [m.out_channels for m in n.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)) and m.out_channels > 1]
+    return H == W and h == w and (H, h) in qops.MFMA_SHAPES and all(c % 16 == 0 and c <= 256 for c in chans)
 
   def __call__(self, state, reward, terminal, action=None):
     return self.collect(state, reward, terminal) if action is None else self.observe(state, reward, terminal, action)
@@ -339,6 +361,27 @@ class DQN(object):
     if self._fused and not (self._gamma == 0 and not self._n_step):
       # target evaluations, then loss, mean TD, |TD|, new priorities and d loss / d Q(s, .) in one kernel (dqn.py:408-469)
       from stackrl_amd import qops
+      if self._hand is not None:
+        # hand-written convolutions: Q_target(s', .), then Q(s, .) and Q(s', .) of the online net in ONE pass over the 2 mb
+        # samples (activations saved; the backward runs over the first mb)
+        mb = int(actions.shape[0])
+        self._hand.refresh()
+        with torch.no_grad():
+          tq = self._hand_t.forward(next_states)
+          if self._n_step:
+            rewards = (self._gamma_r * rewards).sum(dim=-1)
+        if self._double:
+          both = tuple(torch.cat([a, b]) for a, b in zip(states, next_states))
+          q2 = self._hand.forward(both, save=True)
+          q_all, qo = q2[:mb], q2[mb:].detach()
+        else:
+          q_all, qo = self._hand.forward(states, save=True), None
+        loss, mtd, td_abs, new_logits, grad_q = qops.td_epilogue(
+          q_all.detach(), qo, tq, actions, rewards, terminal, weights, self._gamma, self._huber_delta, self._reward_scale,
+          self._double, self._replay_memory.epsilon, self._ws)
+        self._flat_grad.zero_()
+        self._hand.backward(grad_q)
+        return loss, mtd, indexes, td_abs, new_logits
       with torch.no_grad():
         tq = self._g_target(next_states) if self._graphs else self._target_q_net(next_states)
         qo = (self._g_online(next_states) if self._graphs else self._q_net(next_states)) if self._double else None
@@ -388,6 +431,8 @@ class DQN(object):
   _GRAPH_WARMUP = 3   # eager updates before the capture (library solver search, optimiser state, lazy initialisations)
 
   def train(self):
+    if self._hand_t is not None:
+      self._hand_t.refresh_if_stale()        # eagerly, outside any graph: the target net changes only through framework ops
     if self._graphs:
       loss, mtd = self._train_graphed()
     else:
@@ -398,6 +443,8 @@ class DQN(object):
     self._q_net._weights_epoch = getattr(self._q_net, '_weights_epoch', 0) + 1   # monotonic: bumped by every update and every restore
     if self._iterations % self._target_update_period == 0:           # dqn.py:478-484
       self._target_q_net.load_state_dict(self._target_sync_source())
+      if self._hand_t is not None:
+        self._hand_t.refresh()                                       # eagerly: the target's packed weights are read by the graph
     return loss, mtd
 
   def _target_sync_source(self):
@@ -468,6 +515,8 @@ class DQN(object):
       self._optimizer.load_state_dict(d['optimizer'])
       self._iterations = int(d['iterations'])
       self._q_net._weights_epoch = getattr(self._q_net, '_weights_epoch', 0) + 1   # restored weights: a new epoch, never an earlier one's
+      if self._hand_t is not None:
+        self._hand_t.refresh()
     if 'gen' in d:
       self._gen.set_state(d['gen'].cpu())
     if 'replay_memory' in d:

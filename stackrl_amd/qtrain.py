@@ -31,7 +31,9 @@ def _lib():
     L.srl_twrw_scratch_floats.restype = I64
     L.srl_twrw_scratch_floats.argtypes = [I32] * 6
     L.srl_twrw.restype = ctypes.c_int
-    L.srl_twrw.argtypes = [VP, I32, I32, VP, VP, VP] + [I32] * 7 + [VP]
+    L.srl_twrw.argtypes = [VP, I32, I32, VP, VP, VP] + [I32] * 7 + [VP, I32, I32, VP, VP]
+    L.srl_tact_bwd_blocks.restype = I32
+    L.srl_tact_bwd_blocks.argtypes = [I64, I32]
     L.srl_tact_bwd_scratch_floats.restype = I64
     L.srl_tact_bwd_scratch_floats.argtypes = [I64, I32]
     L.srl_tact_bwd.restype = ctypes.c_int
@@ -98,20 +100,24 @@ class _Scratch(object):
     return t
 
 
-def twrw(x, gz, gw, scratch, taps=9, convt=False):
+def twrw(x, gz, gw, scratch, taps=9, convt=False, bias=None):
   """`srl_twrw`: weight gradient of a layer with input `Act` x and activation gradient gz (contiguous [B, H, W, cout] tensor)
-  into gw (the parameter's gradient tensor, framework layout)."""
+  into gw (the parameter's gradient tensor, framework layout).  bias = (partials, blocks, C, gbias) left by
+  `tact_bwd(..., defer_bias=True)`: the same finishing launch writes the bias gradient."""
   B, H, W = x.B, x.H, x.W
   cout = int(gz.shape[-1])
   n = _lib().srl_twrw_scratch_floats(B, H, W, x.C, cout, taps)
   sc = scratch.get('wrw', n, gz.device)
+  bp, bn, bc, gb = bias if bias is not None else (None, 0, 0, None)
   with torch.cuda.device(gz.device):
     _chk(_lib().srl_twrw(x.ptr(), x.stride, x.off, gz.data_ptr(), gw.data_ptr(), sc.data_ptr(), B, H, W, x.C, cout, taps,
-                         int(bool(convt)), qops._stream(gz)))
+                         int(bool(convt)), None if bp is None else bp.data_ptr(), int(bn), int(bc),
+                         None if gb is None else gb.data_ptr(), qops._stream(gz)))
 
 
-def tact_bwd(g, y, scratch, gbias=None, gpool=None, relu=True, s2d=False):
-  """`srl_tact_bwd`: g, y `Act`s of the same shape -> gz tensor ([B, H, W, C], or space-to-depth [B, H/2, W/2, 4C])."""
+def tact_bwd(g, y, scratch, gbias=None, gpool=None, relu=True, s2d=False, defer_bias=False):
+  """`srl_tact_bwd`: g, y `Act`s of the same shape -> gz tensor ([B, H, W, C], or space-to-depth [B, H/2, W/2, 4C]).
+  defer_bias: leave the bias gradient as per-block partials and return (gz, (partials, blocks, C, gbias)) for `twrw`."""
   B, H, W, C = g.B, g.H, g.W, g.C
   dev = g.t.device
   gz = torch.empty((B, H // 2, W // 2, 4 * C) if s2d else (B, H, W, C), dtype=torch.float32, device=dev)
@@ -119,8 +125,10 @@ def tact_bwd(g, y, scratch, gbias=None, gpool=None, relu=True, s2d=False):
   with torch.cuda.device(dev):
     _chk(_lib().srl_tact_bwd(g.ptr(), g.stride, g.off, None if y is None else y.ptr(), 0 if y is None else y.stride,
                              0 if y is None else y.off, None if gpool is None else gpool.data_ptr(), gz.data_ptr(),
-                             None if gbias is None else gbias.data_ptr(), None if sc is None else sc.data_ptr(), B, H, W, C,
-                             int(bool(relu)), int(bool(s2d)), qops._stream(g.t)))
+                             None if (gbias is None or defer_bias) else gbias.data_ptr(), None if sc is None else sc.data_ptr(),
+                             B, H, W, C, int(bool(relu)), int(bool(s2d)), qops._stream(g.t)))
+  if defer_bias:
+    return gz, (sc, _lib().srl_tact_bwd_blocks(B * H * W, C), C, gbias)
   return gz
 
 
@@ -219,6 +227,16 @@ class HandNet(object):
   def refresh(self):
     """Re-pack the weights (call after every optimiser step / target sync)."""
     self.packed.refresh()
+    self._versions = self._param_versions()
+
+  def _param_versions(self):
+    return tuple(p._version for p in self.net.parameters())
+
+  def refresh_if_stale(self):
+    """Re-pack when a parameter has been written since the last packing (in-place writes seen by the framework — a target
+    sync, a restore; not the hipGraph replay of the optimiser step, after which the caller re-packs itself)."""
+    if getattr(self, '_versions', None) != self._param_versions():
+      self.refresh()
 
   # ---------------------------------------------------------------------------------------------- U-Net (layers.py:135-259)
   def _conv(self, m, x, out=None, relu=True):
@@ -252,15 +270,15 @@ class HandNet(object):
   def _layer_bwd(self, m, x_in, y, g, n, gpool=None, need_dx=True, s2d=False):
     """One convolution backwards: g = gradient wrt the layer's output `y` (an `Act`), for the first n samples.  Writes the
     bias and weight gradients, returns the gradient wrt the input (an `Act`) or None."""
-    gz = tact_bwd(g, y.first(n), self.scratch, gbias=m.bias.grad, gpool=gpool, relu=True, s2d=s2d)
+    gz, bias = tact_bwd(g, y.first(n), self.scratch, gbias=m.bias.grad, gpool=gpool, relu=True, s2d=s2d, defer_bias=True)
     if isinstance(m, torch.nn.ConvTranspose2d):
       xin = x_in.first(n)
-      twrw(xin, gz, m.weight.grad, self.scratch, taps=1, convt=True)
+      twrw(xin, gz, m.weight.grad, self.scratch, taps=1, convt=True, bias=bias)
       if not need_dx:
         return None
       return tconv(Act(gz), self.packed.w(m, 3), None, m.in_channels, taps=1, relu=False)
     taps = m.kernel_size[0] * m.kernel_size[1]
-    twrw(x_in.first(n), gz, m.weight.grad, self.scratch, taps=taps)
+    twrw(x_in.first(n), gz, m.weight.grad, self.scratch, taps=taps, bias=bias)
     if not need_dx:
       return None
     cpad = (m.in_channels + 15) // 16 * 16
