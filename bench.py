@@ -17,7 +17,7 @@ Workloads (BASELINE.json `configs`):
   leg B  the DQN configs — rollout (Q-net forward on every env) + one minibatch-32 update per iteration
          (training.py:338-380), reported under "dqn": configs[2] (4,096 envs x 16 rocks) at N = 1, configs[3]'s per-GPU
          shard (2,048 x 16) at N = 2 / 4, configs[4]'s (2,048 x 32 rocks, 64 x 64 maps) at N = 8; the one collective is
-         the RCCL all-reduce of the flat gradient bucket.  Rollout in fp32 (the reference's dtype) and, as a second
+         the RCCL all-reduce of the flat gradient bucket.  Rollout in fp32-class precision (bf16x3 products) and, as a second
          labelled entry, bf16.  `--config 2|3|4` makes that leg the headline `value` instead.
 
 Extra objects on the JSON line: `roofline` (render kernel K2, HBM-bound: algorithmic bytes / HIP-event time measured in
@@ -233,7 +233,7 @@ def settle_counters(B, L, res):
 
 def mfma_counters(dtype):
   """MFMA-pipe busy fraction of the rollout forward from its PMC pass (profiles/rNN_qnet_mfma_pmc_<dtype>.json, tools/pmc_mfma.py)."""
-  rel, d = _latest_profile('qnet_mfma_pmc_{}.json'.format(dtype))
+  rel, d = _latest_profile('qnet_mfma_pmc_{}.json'.format({'bf16x3': 'fp32'}.get(dtype, dtype)))   # tools/profile_qnet.py's names
   if d is None:
     return {}
   return {'mfma_busy_frac': d.get('mfma_busy_frac'),
@@ -436,7 +436,8 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
                 '(BASELINE {} per-GPU shard)'.format(B, L, res, res, name),
     'rollout_dtype': dtype,
     'rollout_dtype_note': ('fp32-class: every product as three bf16 MFMAs (hi*hi + hi*lo + lo*hi), ~16 mantissa bits, held to 2e-5 ... 3e-5 of fp64 per layer in tests — tighter than bf16, looser than fp32' if dtype == 'bf16x3' else 'operands rounded to bf16: narrower than the reference\'s fp32'),
-    'update_dtype': 'f32 (cross-correlation as bf16x3 split on MFMA)',
+    'update_dtype': 'f32 (hand-written convolutions in true float32 on the matrix cores, csrc/train_conv.hip; cross-correlation as bf16x3 split)',
+    'update_hand_convs': agent._hand is not None,
     'replay_next_index': 'reference (memory.py:239-242, literal)',
     'iterations': iters, 'warmup': warm,
     # placements per second, as leg A counts them (the auto-reset call of every episode is stepped and timed but places

@@ -1,10 +1,27 @@
 #!/usr/bin/env python3
 """Mean per-launch SQ instruction counters of one kernel from rocprofv3 --pmc passes (one directory per pass).
-usage: pmc_insts.py <kernel> <dir> [<dir> ...]"""
+usage: pmc_insts.py <kernel> <dir> [<dir> ...] [--json out.json]
+
+With --json: a summary for bench.py's line (`settle.valu_util`, `settle.wait_frac`): VALU utilisation = SQ_INSTS_VALU x 4
+cycles (one 64-lane instruction occupies a 16-lane SIMD for four cycles) / (1,024 SIMDs x the launch's duration from the same
+passes' kernel trace x 2.4 GHz); waiting share = SQ_WAIT_ANY / SQ_WAVE_CYCLES (both in quad-cycles, summed over the waves).
+The commit the passes were taken at comes from SRL_COMMIT (set by the refresh script from `git rev-parse` before the box is
+asked for: the GPU box has no .git)."""
 import sys, glob, csv, os, collections
-kernel = sys.argv[1]
+import json
+args = sys.argv[1:]
+js = None
+if '--json' in args:
+  i = args.index('--json'); js = args[i + 1]; args = args[:i] + args[i + 2:]
+kernel = args[0]
 acc = collections.defaultdict(list)
-for d in sys.argv[2:]:
+dur = []
+for d in args[1:]:
+  for f in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
+    for row in csv.DictReader(open(f)):
+      if row['Kernel_Name'].startswith(kernel):
+        dur.append((int(row['End_Timestamp']) - int(row['Start_Timestamp'])) * 1e-9)
+for d in args[1:]:
   for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
     for row in csv.DictReader(open(f)):
       if row['Kernel_Name'].startswith(kernel):
@@ -17,3 +34,17 @@ if 'SQ_WAVES' in acc:
   for k in sorted(acc):
     if k.startswith('SQ_INSTS'):
       print('%-28s per wave %10.1f' % (k, sum(acc[k]) / len(acc[k]) / w))
+
+if js:
+  mean = lambda k: (sum(acc[k]) / len(acc[k])) if acc.get(k) else None
+  d = sum(dur) / len(dur) if dur else None
+  valu = mean('SQ_INSTS_VALU')
+  out = {'kernel': kernel, 'launches': len(dur), 'avg_launch_ms': None if d is None else 1e3 * d,
+         'valu_insts_per_launch': valu,
+         'valu_util': None if (valu is None or d is None) else valu * 4.0 / (1024 * d * 2.4e9),
+         'wait_frac': None if (mean('SQ_WAIT_ANY') is None or not mean('SQ_WAVE_CYCLES')) else mean('SQ_WAIT_ANY') / mean('SQ_WAVE_CYCLES'),
+         'lds_insts_per_launch': mean('SQ_INSTS_LDS'), 'salu_insts_per_launch': mean('SQ_INSTS_SALU'), 'waves': mean('SQ_WAVES'),
+         'how': 'separate rocprofv3 --kernel-trace --pmc passes of bench.py (tools/refresh_profiles_r03.sh): valu_util = SQ_INSTS_VALU x 4 '
+                '/ (1,024 SIMDs x launch duration x 2.4 GHz); wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES',
+         'commit': os.environ.get('SRL_COMMIT')}
+  json.dump(out, open(js, 'w'), indent=2)

@@ -11,6 +11,7 @@ cycles = the dispatch durations of the same run's kernel trace x 2.4 GHz (the MI
 this pass also collects, is reported summed over the 8 XCDs and agrees with that within a few per cent once divided by 8)."""
 import sys, glob, csv, os, collections
 d = sys.argv[1]
+js = sys.argv[sys.argv.index('--json') + 1] if '--json' in sys.argv else None
 CLOCK = 2.4e9
 tr = glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)[0]
 dur = {int(r['Dispatch_Id']): (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-9 * CLOCK for r in csv.DictReader(open(tr))}
@@ -38,3 +39,13 @@ print('timed region (3 forwards of 512 samples): MFMA busy cycles %.3g summed ov
 for n, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]:
   m, g, c = v[0], v[1], v[2]
   print('  %5.1f %% of its own time  %5.1f %% of all MFMA cycles  %4d launches  %s' % (100 * m / (1024 * g) if g else 0, 100 * m / tm if tm else 0, c, n))
+
+if js:
+  import json
+  json.dump({'mfma_busy_frac': tm / (1024 * tg) if tg else None, 'mfma_busy_cycles': tm, 'kernel_ms': tg / CLOCK * 1e3,
+             'top_kernels': [{'kernel': n, 'mfma_busy_frac_of_own_time': (v[0] / (1024 * v[1]) if v[1] else None),
+                              'share_of_mfma_cycles': v[0] / tm if tm else None, 'launches': v[2]}
+                             for n, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]],
+             'how': 'rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/profile_qnet.py run 512 <dtype>: '
+                    'busy cycles summed over the SIMDs / (1,024 SIMDs x kernel time x 2.4 GHz), three forwards of 512 samples',
+             'commit': os.environ.get('SRL_COMMIT')}, open(js, 'w'), indent=2)

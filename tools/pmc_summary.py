@@ -28,5 +28,6 @@ out = {
   'traffic_bytes_per_launch': int((mean(w) + 2 * mean(f)) * 1024),
   'traffic_formula': '(WRITE_SIZE + 2 * FETCH_SIZE) * 1024',
   'algorithmic_bytes_per_launch': int(alg),
+  'commit': os.environ.get('SRL_COMMIT'),
 }
 print(json.dumps(out, indent=2))
