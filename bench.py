@@ -159,12 +159,14 @@ def _cpu_worker(a):
   return n * L * episodes, time.perf_counter() - t0
 
 
-def cpu_baseline(L, seed, kw, budget_envs=48, episodes=2):
+def cpu_baseline(L, seed, kw, budget_envs=48, episodes=20):
   """The oracle (oracle/srl_oracle.c, built -O3 at the x86-64-v3 level, oracle/Makefile) on this host's cores: `cores` processes x `budget_envs`
   envs x `episodes` episodes of the same workload, forked before this process touches the GPU."""
   import multiprocessing as mp
+  # sample: about 10 s of work per core (the contract asks for 10 - 30 s of CPU work): 48 envs x 20 episodes per process at
+  # ~1 k placements/s per core; the one-thread figure on a tenth of it
   cores = min(os.cpu_count() or 1, 16)
-  n1, t1 = _cpu_worker((budget_envs, L, seed, 0, episodes, kw))     # one-thread figure first
+  n1, t1 = _cpu_worker((budget_envs, L, seed, 0, max(1, episodes // 10), kw))     # one-thread figure first
   ctx = mp.get_context('fork')
   t0 = time.perf_counter()
   with ctx.Pool(cores) as pool:
