@@ -380,7 +380,7 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
               exploration=PolynomialDecay(1.0, 400000, .1), prioritization=0.6,
               priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=7 + rank,
               policy_op=qops.FusedPolicy(autocast=torch.bfloat16 if dtype == 'bf16' else None, fast=True),
-              xcorr='bf16x3', graphs=True, process_group=rccl_group(args, world))   # config.gin:55-112
+              xcorr='bf16x3', graphs=True, process_group=rccl_group(args, world), prefetch=3)   # config.gin:55-112 (prefetch :104)
   tr = Trainer(env, agent)
   tr.initialize(num_steps=4)
   if pre:
@@ -440,7 +440,7 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
     'rollout_dtype_note': ('fp32-class: every product as three bf16 MFMAs (hi*hi + hi*lo + lo*hi), ~16 mantissa bits, held to 2e-5 ... 3e-5 of fp64 per layer in tests — tighter than bf16, looser than fp32' if dtype == 'bf16x3' else 'operands rounded to bf16: narrower than the reference\'s fp32'),
     'update_dtype': 'f32 (hand-written convolutions in true float32 on the matrix cores, csrc/train_conv.hip; cross-correlation as bf16x3 split)',
     'update_hand_convs': agent._hand is not None,
-    'replay_next_index': 'reference (memory.py:239-242, literal)',
+    'replay_next_index': 'reference (memory.py:239-242, literal)', 'prefetch': 3,
     'iterations': iters, 'warmup': warm,
     # placements per second, as leg A counts them (the auto-reset call of every episode is stepped and timed but places
     # nothing); step_calls_per_s counts every vectorised step() call

@@ -222,6 +222,10 @@ class DQN(object):
                                        n_steps=n_step, seed=seed, device=self.device,
                                        reference_next_index=reference_next_index)
     self._double = double
+    # prefetch: how many minibatches are sampled ahead of the update that uses them (dqn.py:247-252; None / 0 = none)
+    self._prefetch = int(prefetch or 0)
+    self._fifo = None
+    self._last_sample_indexes = None
     self._gen = torch.Generator(device=self.device)
     if seed is not None:
       self._gen.manual_seed(int(seed) + 1)
@@ -346,17 +350,52 @@ class DQN(object):
       loss = loss * weights
     return loss.mean()
 
-  def _forward_backward(self):
-    """First half of one minibatch update (dqn.py:397-469): sample, target evaluations, forward, loss, backward into the
-    flat gradient bucket.  Returns (loss, mean TD error, indexes, |TD|, new priorities or None)."""
-    weights = indexes = None
+  def _draw(self):
+    """One minibatch from the replay memory as a flat tuple of tensors:
+    (indexes | None, weights | None, states..., actions, rewards, next_states..., terminal)."""
     if self._prioritized:
       indexes, weights, (states, actions, rewards, next_states, terminal) = \
         self._replay_memory.sample(self._minibatch_size, get_weights=True)
-      if not self._bias_compensation:
-        weights = None
     else:
+      indexes = weights = None
       states, actions, rewards, next_states, terminal = self._replay_memory.sample(self._minibatch_size)
+    return (indexes, weights) + tuple(states) + (actions, rewards) + tuple(next_states) + (terminal,)
+
+  def _next_minibatch(self):
+    """`next(self._replay_memory_iter)` (dqn.py:399-405).  The reference reads its minibatches through
+    `dataset.prefetch(prefetch)` (dqn.py:247-252; config.gin:104 sets 3): a background thread keeps `prefetch` minibatches
+    sampled AHEAD of the update that consumes them, so a minibatch was drawn — with the priorities, the importance-weight
+    schedule and the transitions of that moment — about `prefetch` updates before it is used.  Restated deterministically:
+    a FIFO of `prefetch` minibatches, filled on the first call; every update takes the oldest and a new one is drawn in its
+    place before the update's own priorities are written (the producer thread refills as soon as a slot is free).  The slots
+    live at fixed addresses (shift copies), so the whole thing replays from the update's hipGraph."""
+    k = self._prefetch
+    if not k:
+      flat = self._draw()
+    else:
+      if self._fifo is None:
+        self._fifo = [tuple(None if t is None else t.clone() for t in self._draw()) for _ in range(k)]
+      flat = tuple(None if t is None else t.clone() for t in self._fifo[0])
+      for i in range(k - 1):
+        for dst, src in zip(self._fifo[i], self._fifo[i + 1]):
+          if dst is not None:
+            dst.copy_(src)
+      for dst, src in zip(self._fifo[k - 1], self._draw()):
+        if dst is not None:
+          dst.copy_(src)
+    indexes, weights = flat[0], flat[1]
+    ns = (len(flat) - 5) // 2
+    states, actions, rewards = flat[2:2 + ns], flat[2 + ns], flat[3 + ns]
+    next_states, terminal = flat[4 + ns:4 + 2 * ns], flat[4 + 2 * ns]
+    return indexes, weights, (states, actions, rewards, next_states, terminal)
+
+  def _forward_backward(self):
+    """First half of one minibatch update (dqn.py:397-469): sample, target evaluations, forward, loss, backward into the
+    flat gradient bucket.  Returns (loss, mean TD error, indexes, |TD|, new priorities or None)."""
+    indexes, weights, (states, actions, rewards, next_states, terminal) = self._next_minibatch()
+    if not self._bias_compensation:
+      weights = None
+    self._last_sample_indexes = indexes
     new_logits = None
     if self._fused and not (self._gamma == 0 and not self._n_step):
       # target evaluations, then loss, mean TD, |TD|, new priorities and d loss / d Q(s, .) in one kernel (dqn.py:408-469)
@@ -521,6 +560,13 @@ class DQN(object):
       self._gen.set_state(d['gen'].cpu())
     if 'replay_memory' in d:
       self._replay_memory.load_state_dict(d['replay_memory'])
+      if self._fifo is not None and self._train_graph is None:
+        self._fifo = None                      # minibatches drawn from the memory that was just replaced
+      elif self._fifo is not None:             # (a captured update reads the slots at their addresses: refill in place)
+        for slot in self._fifo:
+          for dst, src in zip(slot, self._draw()):
+            if dst is not None:
+              dst.copy_(src)
 
   def reseed(self, seed):
     """New streams for exploration and minibatch sampling (a rank that resumes without state of its own)."""

@@ -428,6 +428,42 @@ def test_training_loop_writes_the_reference_file_formats_and_resumes(tmp_path):
   assert float(la) == float(lb)
 
 
+def test_prefetch_restates_the_staleness_of_the_reference_pipeline():
+  """`agents.DQN.prefetch = 3` (config.gin:104; dqn.py:247-252): minibatches are sampled `prefetch` updates before they are
+  used.  (i) On a memory that does not change, the FIFO hands out the generator's minibatches in order, none lost or
+  repeated.  (ii) Transitions that become sampleable after update 0 cannot be in the minibatches of updates 1 .. prefetch
+  (those were drawn before), and turn up afterwards; without prefetch they can be drawn at once."""
+  def agent(prefetch):
+    a = DQN(_small_net(seed=2), learning_rate=1e-3, minibatch_size=3, replay_memory_size=8, discount_factor=.9,
+            collect_batch_size=1, exploration=0.5, prioritization=None, double=True, seed=9, prefetch=prefetch)
+    rng = np.random.RandomState(0)
+    obs = lambda: (torch.from_numpy(rng.randint(0, 256, (1, 16, 16, 2)).astype(np.uint8)),
+                   torch.from_numpy(rng.randint(0, 256, (1, 4, 4, 1)).astype(np.uint8)))
+    for t in range(4):                     # actions 0, 1, 2 are sampleable (the newest transition has no successor yet)
+      a.observe(obs(), torch.tensor([0.0]), torch.zeros(1, dtype=torch.bool), torch.tensor([t]))
+    return a, obs
+  seqs = {}
+  for k in (None, 3):                      # (i)
+    a, _ = agent(k)
+    seqs[k] = [sorted(a._next_minibatch()[2][1].tolist()) for _ in range(6)]
+  assert seqs[None] == seqs[3] == [[0, 1, 2]] * 6
+  for k in (None, 2):                      # (ii)
+    a, obs = agent(k)
+    used = []
+    for u in range(8):
+      if u == 1:                           # three more transitions: actions 3, 4, 5 become sampleable
+        for t in (4, 5, 6, 7):
+          a.observe(obs(), torch.tensor([0.0]), torch.zeros(1, dtype=torch.bool), torch.tensor([t]))
+      used.append(set(a._next_minibatch()[2][1].tolist()))
+    old = {0, 1, 2}
+    assert used[0] <= old
+    if k:
+      assert all(used[u] <= old for u in range(1, 1 + k)), used       # drawn before the new transitions existed
+      assert any(not (used[u] <= old) for u in range(1 + k, 8)), used
+    else:
+      assert any(not (used[u] <= old) for u in range(1, 8)), used
+
+
 def _ckpt_rank(rank, world, port, d, out):
   import torch.distributed as dist
   from stackrl_amd.training import Trainer
