@@ -20,6 +20,17 @@ def _rel(got, want):
   return float((got.double() - want).abs().max()) / max(float(want.abs().max()), 1e-30)
 
 
+def _where(got, want):
+  """Where a tensor leaves its reference (for the assertion message: a fault that shows once is localised by its record)."""
+  got, want = got.detach().double(), want.detach().double()
+  bad = ((got - want).abs() > 1e-3 * want.abs().max()).nonzero()
+  if bad.numel() == 0:
+    return 'no element off by more than 1e-3 of the scale'
+  rng = [(int(bad[:, d].min()), int(bad[:, d].max())) for d in range(bad.shape[1])]
+  return '{} elements off; index ranges per dim {}; first {}; got {} want {}'.format(
+    bad.shape[0], rng, bad[0].tolist(), float(got[tuple(bad[0])]), float(want[tuple(bad[0])]))
+
+
 def _packed(mods):
   from stackrl_amd import qtrain
   net = torch.nn.Sequential(*mods).cuda()
@@ -59,11 +70,11 @@ def test_conv3x3_forward_data_and_weight_gradients_match_torch_fp64(cin, cout, B
   xd2 = x.dense().permute(0, 3, 1, 2).double().requires_grad_()
   out = F.relu(F.conv2d(xd2, wd, bd, padding=1))
   out.backward(gy.permute(0, 3, 1, 2).double())
-  assert _rel(gw, wd.grad) <= TOL, 'weight gradient'
-  assert _rel(gb, bd.grad) <= TOL, 'bias gradient'
+  assert _rel(gw, wd.grad) <= TOL, 'weight gradient: ' + _where(gw, wd.grad)
+  assert _rel(gb, bd.grad) <= TOL, 'bias gradient: ' + _where(gb, bd.grad)
   cpad = (cin + 15) // 16 * 16
   gx = qtrain.tconv(qtrain.Act(gz), P.w(conv, 1), None, cpad, relu=False)
-  assert _rel(gx.t[..., :cin].permute(0, 3, 1, 2), xd2.grad) <= TOL, 'data gradient'
+  assert _rel(gx.t[..., :cin].permute(0, 3, 1, 2), xd2.grad) <= TOL, 'data gradient: ' + _where(gx.t[..., :cin].permute(0, 3, 1, 2), xd2.grad)
   if cpad != cin:
     assert float(gx.t[..., cin:].abs().max()) == 0.0
   # bit-identical on repetition (fixed-order reductions, no atomics)
