@@ -145,6 +145,8 @@ def test_nonblocking_step_returns_callable(ref_pool, oracle_mod):
   (12, 6, dict(resolution_factor=4)),            # 64 x 64 height map, 16 x 16 object map, 2,401 actions (config 5)
   (32, 3, dict(resolution_factor=4)),            # configs[4]'s per-GPU workload together: 32 rocks (`_t512`) WITH 64 x 64 maps
   (6, 5, dict(observable_size_ratio=3)),         # 96 x 96 height map: 4.5 epilogue rounds whose groups change columns
+  (5, 7, dict(resolution_factor=3)),             # 32 x 32 height map (1,024 pixels < 4 x 512 threads): the general walk with its bound on
+                                                 # the group index (round 3: the aligned walk wrote past such a map), 8 x 8 object map, 625 actions
 ])
 def test_large_configs(ref_pool, oracle_mod, L, n, kw):
   g, o = _mk(ref_pool, oracle_mod, n, L, seed=31, **kw)
@@ -154,7 +156,7 @@ def test_large_configs(ref_pool, oracle_mod, L, n, kw):
     ga, oa = g.sample(), o.sample()
     assert np.array_equal(ga.cpu().numpy(), oa)
     _cmp_step(g, o, g.step(ga), o.step(oa), 'step {}'.format(k))
-  assert g.n_actions == {4: 2401, 3: 4225}.get(kw.get('resolution_factor', kw.get('observable_size_ratio')), 9409)
+  assert g.n_actions == {('resolution_factor', 4): 2401, ('observable_size_ratio', 3): 4225, ('resolution_factor', 3): 625}.get(next(iter(kw.items()), None), 9409)
 
 
 def test_two_wave_settle_variant_matches_the_oracle(ref_pool, oracle_mod, monkeypatch):
