@@ -33,7 +33,9 @@ int srl_xcorr_forward(const float* x_dev, const float* w_dev, float* out_dev, in
  *                     [B][C][kh][kh]                                                 -> out [B][C][H][H]
  *   mode 2  d/dw    : in x [B][C][H][H],            kern dOut [B][O][O]              -> out [B][C][kh][kh]
  * precision 0: operands rounded to bf16; 1 ("bf16x3", float32 operands only): hi/lo bf16 split, hi*hi + hi*lo + lo*hi.
- * `scratch` is caller-owned device memory of at least srl_xcorr_mfma_scratch_bytes(...) bytes (Toeplitz fragments). */
+ * `scratch` is caller-owned device memory of at least srl_xcorr_mfma_scratch_bytes(...) bytes: the per-workgroup partial
+ * outputs of a small-batch forward whose channels are spread over workgroups (0 bytes otherwise: scratch may then be NULL).
+ * (Until round 3 it also held the materialised Toeplitz fragments; they are now built in the kernel from LDS.) */
 int64_t srl_xcorr_mfma_scratch_bytes(int32_t mode, int32_t precision, int32_t B, int32_t C, int32_t H, int32_t kh);
 int srl_xcorr_mfma(int32_t mode, int32_t precision, const void* in_dev, int32_t in_f32, const void* kern_dev,
                    int32_t kern_f32, float* out_dev, void* scratch_dev, int64_t scratch_bytes, int32_t B, int32_t C,

@@ -15,13 +15,17 @@
 //   out[y, x] += sum_k A[y, k] * T[k, x],     A[y, k] = map[y + i, x0 + k],     T[k, x] = kern[i, k - x]  (0 <= k - x < KH)
 //
 // For a 16 x 16 output tile at (y0, x0) only k in [0, 16 + KH - 1) matters: KB = 1 + ceil((KH - 1) / 16) k-blocks of 16
-// (v_mfma_f32_16x16x16_bf16, fp32 accumulation).  T does not depend on the tile (shift invariance), so its MFMA
-// fragments are built once per kernel row by a small prep kernel (k_toeplitz) and then feed every tile.
+// (v_mfma_f32_16x16x16_bf16, fp32 accumulation).  T does not depend on the tile (shift invariance): lane l of a
+// Toeplitz fragment holds kern[i][t0 .. t0 + 3], t0 = 16 j + 4 (l / 16) - l % 16 — four CONSECUTIVE elements of the
+// kernel row.  So the fragments are not materialised (rounds 1-2 had a prep kernel write them to global memory: 805 MB
+// written and read again per 512 samples of the rollout): the kernel rows of the current (sample, channel) sit in LDS,
+// zero-padded on both sides, and a fragment is three aligned 32-bit LDS reads + two v_alignbyte_b32.
 //
 // Main kernel: one workgroup per sample, one wave per row of output tiles.  One channel of the map is staged in LDS at
-// a time (bf16, zero-padded); per kernel row a wave reads its A fragments (8 bytes per lane, shared by its tiles: tile
-// t uses k-blocks t .. t + KB - 1), the KB Toeplitz fragments (global, L2-resident: all waves of the sample read the
-// same ones) and issues T * KB MFMAs.  Accumulators stay in registers over all kernel rows (and channels, when summed).
+// a time (bf16, zero-padded) together with that channel's kernel rows; per kernel row a wave reads its A fragments
+// (8 bytes per lane, shared by its tiles: tile t uses k-blocks t .. t + KB - 1), builds the KB Toeplitz fragments of the
+// NEXT row from LDS and issues T * KB MFMAs.  Accumulators stay in registers over all kernel rows (and channels, when
+// summed).
 //
 // Precision: 0 = operands rounded to bf16 (products exact in fp32, fp32 accumulation) — the rollout path under bf16
 // autocast; 1 = "bf16x3": every fp32 operand is split into hi + lo bf16 parts and hi*hi + hi*lo + lo*hi is
@@ -46,6 +50,8 @@ struct XcorrCfg {
   static constexpr int NKB = T + KB - 1;             // k-blocks a row of tiles touches
   static constexpr int ROWS = 16 * T + KH - 1;       // staged rows; rows >= HIN stay zero
   static constexpr int RS = 16 * NKB + 4;            // row stride in elements: rows stay 8-byte aligned
+  // kernel rows in LDS: 16 zeros, the KH elements, zeros up to what the last fragment's three-word read touches
+  static constexpr int KR = 16 + 16 * KB + 8;        // elements per row (even: rows are 4-byte aligned)
 };
 
 __device__ __forceinline__ uint32_t bf16_rne(float f) {   // round to nearest even (finite inputs)
@@ -60,47 +66,41 @@ __device__ __forceinline__ float load_elem(const void* p, size_t k) {
   return bf16_to_f32(((const uint16_t*)p)[k]);
 }
 
-// Toeplitz fragments of kernel row `row` (B operand of v_mfma_f32_16x16x16_bf16: lane l holds column l % 16, rows
-// 4 (l / 16) .. + 3 of the k-block): frag[row][j][lane][r] = kern[row][t], t = 16 j + 4 (lane / 16) + r - lane % 16,
-// zero outside [0, KH).  SPLIT: a second array of the same size holds the lo parts.
-template <int KH, bool F32, bool SPLIT>
-__global__ void __launch_bounds__(64) k_toeplitz(const void* __restrict__ kern, uint16_t* __restrict__ frag, size_t nrows) {
-  constexpr int KB = 1 + (KH - 1 + 15) / 16;
-  const size_t row = blockIdx.x;
-  const int j = blockIdx.y, lane = threadIdx.x;
-  uint32_t hi[4], lo[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int t = 16 * j + 4 * (lane >> 4) + r - (lane & 15);
-    const float v = (t >= 0 && t < KH) ? load_elem<F32>(kern, row * KH + t) : 0.0f;
-    hi[r] = bf16_rne(v);
-    lo[r] = SPLIT ? bf16_rne(v - bf16_to_f32(hi[r])) : 0u;
-  }
-  const size_t at = (row * KB + j) * 64 + lane;
-  ((uint2*)frag)[at] = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-  if (SPLIT) ((uint2*)frag)[nrows * KB * 64 + at] = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+// Toeplitz fragment (B operand of v_mfma_f32_16x16x16_bf16: lane l holds column l % 16, rows 4 (l / 16) .. + 3 of
+// k-block j) of a kernel row held in LDS with 16 leading zeros: elements 16 + t0 .. 16 + t0 + 3, t0 = 16 j + 4 (l / 16) -
+// l % 16 — from the three aligned words that hold them, shifted by one element when the start is odd.
+__device__ __forceinline__ bf16x4 toeplitz_frag(const uint16_t* krow, int j, int lane) {
+  const int base = 16 + 16 * j + 4 * (lane >> 4) - (lane & 15);
+  const uint32_t* w = (const uint32_t*)krow + (base >> 1);
+  const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+  const uint32_t sh = (uint32_t)(base & 1) * 2u;
+  const uint32_t a = __builtin_amdgcn_alignbyte(w1, w0, sh), b = __builtin_amdgcn_alignbyte(w2, w1, sh);
+  union { uint32_t u[2]; bf16x4 v; } r;
+  r.u[0] = a; r.u[1] = b;
+  return r.v;
 }
 
 // IN_PER_C: the map is per channel ([B][C][HIN][HIN]) or shared by the channels ([B][HIN][HIN]);
 // K_PER_C: likewise for the kernel rows; SUM: one output per sample (channels summed) or one per (sample, channel).
-template <int HIN, int KH, bool IN_PER_C, bool K_PER_C, bool SUM, bool F32, bool SPLIT>
+template <int HIN, int KH, bool IN_PER_C, bool K_PER_C, bool SUM, bool F32, bool KF32, bool SPLIT>
 __global__ void __launch_bounds__((64 * XcorrCfg<HIN, KH>::T))
-k_xcorr_mfma(const void* __restrict__ in, const uint16_t* __restrict__ frag, float* __restrict__ out, int C, int cper,
-             size_t nrows) {
+k_xcorr_mfma(const void* __restrict__ in, const void* __restrict__ kern, float* __restrict__ out, int C, int cper) {
   typedef XcorrCfg<HIN, KH> G;
-  extern __shared__ uint16_t xs[];   // [ROWS][RS] bf16 hi parts (+ the same again for the lo parts)
+  extern __shared__ uint16_t xs[];   // [ROWS][RS] bf16 hi parts (+ the same again for the lo parts), then the kernel rows
   constexpr int TILE = G::ROWS * G::RS;
+  constexpr int KTILE = KH * G::KR;
+  static_assert(TILE % 4 == 0 && KTILE % 2 == 0, "LDS regions are zeroed in 8-byte words and stay 4-byte aligned");
+  uint16_t* ks = xs + (SPLIT ? 2 : 1) * TILE;   // [KH][KR] hi (+ [KH][KR] lo)
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, yt = tid >> 6;
   constexpr int NT = 64 * G::T;
-  {   // zero the tile(s) once: the padding rows / columns are never written again
-    uint2* z = (uint2*)xs;
-    for (int k = tid; k < (SPLIT ? 2 : 1) * TILE / 4; k += NT) z[k] = make_uint2(0u, 0u);
+  {   // zero the tile(s) and the kernel rows once: the padding is never written again
+    uint32_t* z = (uint32_t*)xs;
+    for (int k = tid; k < (SPLIT ? 2 : 1) * (TILE + KTILE) / 2; k += NT) z[k] = 0u;
   }
   f32x4 acc[G::T];
 #pragma unroll
   for (int t = 0; t < G::T; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   const int arow = 16 * yt + (lane & 15), acol = 4 * (lane >> 4);
-  const size_t lo_off = nrows * G::KB * 64;   // in fragments (8 bytes)
   // blockIdx.y takes channels [c0, c1): with few samples the channels are spread over workgroups (summed outputs
   // then land in per-workgroup partials, reduced by k_sum_partials in a fixed order)
   const int c0 = blockIdx.y * cper, c1 = min(C, c0 + cper);
@@ -140,14 +140,25 @@ k_xcorr_mfma(const void* __restrict__ in, const uint16_t* __restrict__ frag, flo
       }
       __syncthreads();
     }
-    const bf16x4* tw = (const bf16x4*)frag + ((K_PER_C ? (size_t)b * C + c : (size_t)b) * KH) * G::KB * 64 + lane;
-    // kernel-row loop, software-pipelined: the Toeplitz fragments of row i + 1 are requested (global, L2) before the
-    // MFMAs of row i are issued, so their latency is covered by the 21 MFMAs instead of being waited for
+    if (K_PER_C || c == c0) {   // this channel's (or the sample's) kernel rows into LDS, behind 16 zeros each
+      if (IN_PER_C || c == c0) {} else __syncthreads();   // (the previous channel's fragment reads are done)
+      const size_t kbase = (K_PER_C ? (size_t)b * C + c : (size_t)b) * KH * KH;
+      for (int k = tid; k < KH * KH; k += NT) {
+        const int r = k / KH, t = k - r * KH;
+        const float v = load_elem<KF32>(kern, kbase + k);
+        const uint32_t hi = bf16_rne(v);
+        ks[r * G::KR + 16 + t] = (uint16_t)hi;
+        if (SPLIT) ks[KTILE + r * G::KR + 16 + t] = (uint16_t)bf16_rne(v - bf16_to_f32(hi));
+      }
+      __syncthreads();
+    }
+    // kernel-row loop, software-pipelined: the Toeplitz fragments of row i + 1 are built (LDS) before the MFMAs of row i
+    // are issued, so their latency is covered by the 21 MFMAs instead of being waited for
     bf16x4 tf[G::KB], tl[SPLIT ? G::KB : 1];
 #pragma unroll
     for (int j = 0; j < G::KB; ++j) {
-      tf[j] = tw[(size_t)j * 64];
-      if (SPLIT) tl[j] = tw[lo_off + (size_t)j * 64];
+      tf[j] = toeplitz_frag(ks, j, lane);
+      if (SPLIT) tl[j] = toeplitz_frag(ks + KTILE, j, lane);
     }
 #pragma unroll 2
     for (int i = 0; i < KH; ++i) {
@@ -155,8 +166,8 @@ k_xcorr_mfma(const void* __restrict__ in, const uint16_t* __restrict__ frag, flo
       bf16x4 nf[G::KB], nl[SPLIT ? G::KB : 1];
 #pragma unroll
       for (int j = 0; j < G::KB; ++j) {
-        nf[j] = tw[((size_t)in * G::KB + j) * 64];
-        if (SPLIT) nl[j] = tw[lo_off + ((size_t)in * G::KB + j) * 64];
+        nf[j] = toeplitz_frag(ks + in * G::KR, j, lane);
+        if (SPLIT) nl[j] = toeplitz_frag(ks + KTILE + in * G::KR, j, lane);
       }
       bf16x4 af[G::NKB], al[SPLIT ? G::NKB : 1];
       const uint16_t* ar = xs + (arow + i) * G::RS + acol;
@@ -223,10 +234,8 @@ thread_local char x_err[256] = "";
 template <int HIN, int KH, bool IN_PER_C, bool K_PER_C, bool SUM, bool IF32, bool KF32, bool SPLIT>
 int launch2(const void* in, const void* kern, float* out, void* scratch, int B, int C, hipStream_t st) {
   typedef XcorrCfg<HIN, KH> G;
-  const size_t nrows = (size_t)(K_PER_C ? B * C : B) * KH;
-  hipLaunchKernelGGL((k_toeplitz<KH, KF32, SPLIT>), dim3((unsigned)nrows, G::KB), dim3(64), 0, st, kern, (uint16_t*)scratch, nrows);
-  const size_t lds = sizeof(uint16_t) * G::ROWS * G::RS * (SPLIT ? 2 : 1);
-  auto fn = k_xcorr_mfma<HIN, KH, IN_PER_C, K_PER_C, SUM, IF32, SPLIT>;
+  const size_t lds = sizeof(uint16_t) * (G::ROWS * G::RS + KH * G::KR) * (SPLIT ? 2 : 1);
+  auto fn = k_xcorr_mfma<HIN, KH, IN_PER_C, K_PER_C, SUM, IF32, KF32, SPLIT>;
   static bool lds_opted_in = false;   // per instantiation; set once, outside any later stream capture
   if (lds > 65536 && !lds_opted_in) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -238,11 +247,9 @@ int launch2(const void* in, const void* kern, float* out, void* scratch, int B, 
   }
   int cper, csplit;
   channel_split(B, C, &cper, &csplit);
-  const size_t frag_bytes = nrows * G::KB * 64 * 4 * sizeof(uint16_t) * (SPLIT ? 2 : 1);
-  float* partial = (float*)((char*)scratch + frag_bytes);
+  float* partial = (float*)scratch;
   const bool two_pass = SUM && csplit > 1;
-  hipLaunchKernelGGL(fn, dim3(B, csplit), dim3(64 * G::T), lds, st, in, (const uint16_t*)scratch, two_pass ? partial : out, C,
-                     cper, nrows);
+  hipLaunchKernelGGL(fn, dim3(B, csplit), dim3(64 * G::T), lds, st, in, kern, two_pass ? partial : out, C, cper);
   if (two_pass)
     hipLaunchKernelGGL(k_sum_partials, dim3((G::O * G::O + 255) / 256, B), dim3(256), 0, st, partial, out, csplit, G::O * G::O);
   hipError_t e = hipGetLastError();
@@ -287,20 +294,20 @@ const char* srl_xcorr_mfma_last_error(void) { return x_err; }
 int64_t srl_xcorr_mfma_scratch_bytes(int32_t mode, int32_t precision, int32_t B, int32_t C, int32_t H, int32_t kh) {
   int hin, ks;
   if (B < 1 || C < 1 || !shapes(mode, H, kh, &hin, &ks)) return -1;
-  const int64_t KB = 1 + (ks - 1 + 15) / 16;
-  const int64_t nrows = (int64_t)(mode == 2 ? B : B * C) * ks;
   int cper, csplit;
   channel_split(B, C, &cper, &csplit);
   const int64_t O = hin - ks + 1;
-  const int64_t partials = (mode == 0 && csplit > 1) ? (int64_t)B * csplit * O * O * (int64_t)sizeof(float) : 0;
-  return nrows * KB * 64 * 4 * (int64_t)sizeof(uint16_t) * (precision ? 2 : 1) + partials;
+  // the per-workgroup partial outputs of the forward when the channels are spread over workgroups (small batches); the
+  // Toeplitz fragments are no longer materialised
+  return (mode == 0 && csplit > 1) ? (int64_t)B * csplit * O * O * (int64_t)sizeof(float) : 0;
 }
 
 int srl_xcorr_mfma(int32_t mode, int32_t precision, const void* in, int32_t in_f32, const void* kern, int32_t kern_f32,
                    float* out, void* scratch, int64_t scratch_bytes, int32_t B, int32_t C, int32_t H, int32_t kh,
                    void* stream) {
   int hin, ks;
-  if (!in || !kern || !out || !scratch || B < 1 || C < 1 || precision < 0 || precision > 1) {
+  if (!in || !kern || !out || B < 1 || C < 1 || precision < 0 || precision > 1 ||
+      (!scratch && srl_xcorr_mfma_scratch_bytes(mode, precision, B, C, H, kh) > 0)) {
     snprintf(x_err, sizeof x_err, "srl_xcorr_mfma: bad arguments");
     return 1;
   }
