@@ -15,11 +15,11 @@
 //   out[y, x] += sum_k A[y, k] * T[k, x],     A[y, k] = map[y + i, x0 + k],     T[k, x] = kern[i, k - x]  (0 <= k - x < KH)
 //
 // For a 16 x 16 output tile at (y0, x0) only k in [0, 16 + KH - 1) matters: KB = 1 + ceil((KH - 1) / 16) k-blocks of 16
-// (v_mfma_f32_16x16x16_bf16, fp32 accumulation).  T does not depend on the tile (shift invariance): lane l of a
-// Toeplitz fragment holds kern[i][t0 .. t0 + 3], t0 = 16 j + 4 (l / 16) - l % 16 — four CONSECUTIVE elements of the
-// kernel row.  So the fragments are not materialised (rounds 1-2 had a prep kernel write them to global memory: 805 MB
+// (round 3: 2 k-blocks of 32 for KH = 32, v_mfma_f32_16x16x32_bf16 at full rate; fp32 accumulation).  T does not depend
+// on the tile (shift invariance): lane l of a Toeplitz fragment holds kern[i][t0 .. t0 + 7], t0 = 32 j + 8 (l / 16) - l % 16
+// — eight CONSECUTIVE elements of the kernel row.  So the fragments are not materialised (rounds 1-2 had a prep kernel write them to global memory: 805 MB
 // written and read again per 512 samples of the rollout): the kernel rows of the current (sample, channel) sit in LDS,
-// zero-padded on both sides, and a fragment is three aligned 32-bit LDS reads + two v_alignbyte_b32.
+// zero-padded on both sides, and a fragment is five aligned 32-bit LDS reads + four v_alignbyte_b32.
 //
 // Main kernel: one workgroup per sample, one wave per row of output tiles.  One channel of the map is staged in LDS at
 // a time (bf16, zero-padded) together with that channel's kernel rows; per kernel row a wave reads its A fragments
@@ -40,18 +40,22 @@
 namespace {
 
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int HIN, int KH>
 struct XcorrCfg {
   static constexpr int O = HIN - KH + 1;             // outputs per side
   static constexpr int T = (O + 15) / 16;            // 16 x 16 output tiles per side = waves per workgroup
-  static constexpr int KB = 1 + (KH - 1 + 15) / 16;  // k-blocks per tile and kernel row
-  static constexpr int NKB = T + KB - 1;             // k-blocks a row of tiles touches
+  // a tile needs k in [0, 16 + KH - 1): KB blocks of 32 (v_mfma_f32_16x16x32_bf16: the K = 16 form runs at half rate on
+  // gfx950).  Tile t's block j starts at element 16 (t + 2 j): the A fragments of a row of tiles are the 32-wide windows
+  // at 16 u, u = 0 .. NA - 1 (neighbouring windows overlap by half; tile t + 2 reuses tile t's second window).
+  static constexpr int KB = (16 + KH - 1 + 31) / 32;
+  static constexpr int NA = T + 2 * KB - 2;          // A windows a row of tiles touches
   static constexpr int ROWS = 16 * T + KH - 1;       // staged rows; rows >= HIN stay zero
-  static constexpr int RS = 16 * NKB + 4;            // row stride in elements: rows stay 8-byte aligned
-  // kernel rows in LDS: 16 zeros, the KH elements, zeros up to what the last fragment's three-word read touches
-  static constexpr int KR = 16 + 16 * KB + 8;        // elements per row (even: rows are 4-byte aligned)
+  static constexpr int RS = 16 * (NA + 1) + 8;       // row stride in elements: windows stay 16-byte aligned
+  // kernel rows in LDS: 16 zeros, the KH elements, zeros up to what the last fragment's five-word read touches
+  static constexpr int KR = 16 + 32 * KB + 16;       // elements per row (even: rows are 4-byte aligned)
 };
 
 __device__ __forceinline__ uint32_t bf16_rne(float f) {   // round to nearest even (finite inputs)
@@ -66,17 +70,18 @@ __device__ __forceinline__ float load_elem(const void* p, size_t k) {
   return bf16_to_f32(((const uint16_t*)p)[k]);
 }
 
-// Toeplitz fragment (B operand of v_mfma_f32_16x16x16_bf16: lane l holds column l % 16, rows 4 (l / 16) .. + 3 of
-// k-block j) of a kernel row held in LDS with 16 leading zeros: elements 16 + t0 .. 16 + t0 + 3, t0 = 16 j + 4 (l / 16) -
-// l % 16 — from the three aligned words that hold them, shifted by one element when the start is odd.
-__device__ __forceinline__ bf16x4 toeplitz_frag(const uint16_t* krow, int j, int lane) {
-  const int base = 16 + 16 * j + 4 * (lane >> 4) - (lane & 15);
+// Toeplitz fragment (B operand of v_mfma_f32_16x16x32_bf16: lane l holds column l % 16, rows 8 (l / 16) .. + 7 of
+// k-block j) of a kernel row held in LDS with 16 leading zeros: T[k][x] = kern[k - x], i.e. the eight consecutive
+// elements 16 + t0 .. 16 + t0 + 7, t0 = 32 j + 8 (l / 16) - l % 16 — from the five aligned words that hold them, shifted
+// by one element when the start is odd.
+__device__ __forceinline__ bf16x8 toeplitz_frag(const uint16_t* krow, int j, int lane) {
+  const int base = 16 + 32 * j + 8 * (lane >> 4) - (lane & 15);
   const uint32_t* w = (const uint32_t*)krow + (base >> 1);
-  const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+  const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
   const uint32_t sh = (uint32_t)(base & 1) * 2u;
-  const uint32_t a = __builtin_amdgcn_alignbyte(w1, w0, sh), b = __builtin_amdgcn_alignbyte(w2, w1, sh);
-  union { uint32_t u[2]; bf16x4 v; } r;
-  r.u[0] = a; r.u[1] = b;
+  union { uint32_t u[4]; bf16x8 v; } r;
+  r.u[0] = __builtin_amdgcn_alignbyte(w1, w0, sh); r.u[1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+  r.u[2] = __builtin_amdgcn_alignbyte(w3, w2, sh); r.u[3] = __builtin_amdgcn_alignbyte(w4, w3, sh);
   return r.v;
 }
 
@@ -89,7 +94,7 @@ k_xcorr_mfma(const void* __restrict__ in, const void* __restrict__ kern, float* 
   extern __shared__ uint16_t xs[];   // [ROWS][RS] bf16 hi parts (+ the same again for the lo parts), then the kernel rows
   constexpr int TILE = G::ROWS * G::RS;
   constexpr int KTILE = KH * G::KR;
-  static_assert(TILE % 4 == 0 && KTILE % 2 == 0, "LDS regions are zeroed in 8-byte words and stay 4-byte aligned");
+  static_assert(TILE % 8 == 0 && KTILE % 2 == 0 && G::RS % 8 == 0, "A windows are 16-byte LDS reads; kernel rows stay 4-byte aligned");
   uint16_t* ks = xs + (SPLIT ? 2 : 1) * TILE;   // [KH][KR] hi (+ [KH][KR] lo)
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, yt = tid >> 6;
   constexpr int NT = 64 * G::T;
@@ -100,7 +105,7 @@ k_xcorr_mfma(const void* __restrict__ in, const void* __restrict__ kern, float* 
   f32x4 acc[G::T];
 #pragma unroll
   for (int t = 0; t < G::T; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-  const int arow = 16 * yt + (lane & 15), acol = 4 * (lane >> 4);
+  const int arow = 16 * yt + (lane & 15), acol = 8 * (lane >> 4);
   // blockIdx.y takes channels [c0, c1): with few samples the channels are spread over workgroups (summed outputs
   // then land in per-workgroup partials, reduced by k_sum_partials in a fixed order)
   const int c0 = blockIdx.y * cper, c1 = min(C, c0 + cper);
@@ -154,7 +159,7 @@ k_xcorr_mfma(const void* __restrict__ in, const void* __restrict__ kern, float* 
     }
     // kernel-row loop, software-pipelined: the Toeplitz fragments of row i + 1 are built (LDS) before the MFMAs of row i
     // are issued, so their latency is covered by the 21 MFMAs instead of being waited for
-    bf16x4 tf[G::KB], tl[SPLIT ? G::KB : 1];
+    bf16x8 tf[G::KB], tl[SPLIT ? G::KB : 1];
 #pragma unroll
     for (int j = 0; j < G::KB; ++j) {
       tf[j] = toeplitz_frag(ks, j, lane);
@@ -163,27 +168,27 @@ k_xcorr_mfma(const void* __restrict__ in, const void* __restrict__ kern, float* 
 #pragma unroll 2
     for (int i = 0; i < KH; ++i) {
       const int in = i + 1 < KH ? i + 1 : i;
-      bf16x4 nf[G::KB], nl[SPLIT ? G::KB : 1];
+      bf16x8 nf[G::KB], nl[SPLIT ? G::KB : 1];
 #pragma unroll
       for (int j = 0; j < G::KB; ++j) {
         nf[j] = toeplitz_frag(ks + in * G::KR, j, lane);
         if (SPLIT) nl[j] = toeplitz_frag(ks + KTILE + in * G::KR, j, lane);
       }
-      bf16x4 af[G::NKB], al[SPLIT ? G::NKB : 1];
+      bf16x8 af[G::NA], al[SPLIT ? G::NA : 1];
       const uint16_t* ar = xs + (arow + i) * G::RS + acol;
 #pragma unroll
-      for (int kb = 0; kb < G::NKB; ++kb) {
-        af[kb] = *(const bf16x4*)(ar + 16 * kb);
-        if (SPLIT) al[kb] = *(const bf16x4*)(ar + TILE + 16 * kb);
+      for (int u = 0; u < G::NA; ++u) {
+        af[u] = *(const bf16x8*)(ar + 16 * u);
+        if (SPLIT) al[u] = *(const bf16x8*)(ar + TILE + 16 * u);
       }
 #pragma unroll
       for (int t = 0; t < G::T; ++t)
 #pragma unroll
         for (int j = 0; j < G::KB; ++j) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af[t + j], tf[j], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t + 2 * j], tf[j], acc[t], 0, 0, 0);
           if (SPLIT) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af[t + j], tl[j], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[t + j], tf[j], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t + 2 * j], tl[j], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t + 2 * j], tf[j], acc[t], 0, 0, 0);
           }
         }
 #pragma unroll
