@@ -87,17 +87,24 @@ __device__ __forceinline__ bf16x8 toeplitz_frag(const uint16_t* krow, int j, int
 
 // IN_PER_C: the map is per channel ([B][C][HIN][HIN]) or shared by the channels ([B][HIN][HIN]);
 // K_PER_C: likewise for the kernel rows; SUM: one output per sample (channels summed) or one per (sample, channel).
-template <int HIN, int KH, bool IN_PER_C, bool K_PER_C, bool SUM, bool F32, bool KF32, bool SPLIT>
-__global__ void __launch_bounds__((64 * XcorrCfg<HIN, KH>::T))
+// TH: rows of output tiles per workgroup (= waves per workgroup).  A sample's T tile rows are spread over ceil(T / TH)
+// workgroups (blockIdx.z), each staging only the 16 TH + KH - 1 map rows it needs: with TH = 4 the forward's workgroup
+// holds 76 KB of LDS instead of 108, two fit a CU, and one's staging (global loads, conversion, barriers) runs under the
+// other's matrix products — with one workgroup per CU nothing covered it (MFMA pipes busy 58 % of the kernel's time).
+template <int HIN, int KH, int TH, bool IN_PER_C, bool K_PER_C, bool SUM, bool F32, bool KF32, bool SPLIT>
+__global__ void __launch_bounds__((64 * TH))
 k_xcorr_mfma(const void* __restrict__ in, const void* __restrict__ kern, float* __restrict__ out, int C, int cper) {
   typedef XcorrCfg<HIN, KH> G;
-  extern __shared__ uint16_t xs[];   // [ROWS][RS] bf16 hi parts (+ the same again for the lo parts), then the kernel rows
-  constexpr int TILE = G::ROWS * G::RS;
+  extern __shared__ uint16_t xs[];   // [ROWS_L][RS] bf16 hi parts (+ the same again for the lo parts), then the kernel rows
+  constexpr int ROWS_L = 16 * TH + KH - 1;   // staged map rows: local row r = map row 16 TH blockIdx.z + r
+  constexpr int TILE = ROWS_L * G::RS;
   constexpr int KTILE = KH * G::KR;
   static_assert(TILE % 8 == 0 && KTILE % 2 == 0 && G::RS % 8 == 0, "A windows are 16-byte LDS reads; kernel rows stay 4-byte aligned");
   uint16_t* ks = xs + (SPLIT ? 2 : 1) * TILE;   // [KH][KR] hi (+ [KH][KR] lo)
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, yt = tid >> 6;
-  constexpr int NT = 64 * G::T;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int row0 = 16 * TH * blockIdx.z;                 // first map row of this workgroup's tile rows
+  const int yt = (tid >> 6) + TH * blockIdx.z;           // this wave's row of output tiles (may lie past the last one)
+  constexpr int NT = 64 * TH;
   {   // zero the tile(s) and the kernel rows once: the padding is never written again
     uint32_t* z = (uint32_t*)xs;
     for (int k = tid; k < (SPLIT ? 2 : 1) * (TILE + KTILE) / 2; k += NT) z[k] = 0u;
@@ -105,7 +112,7 @@ k_xcorr_mfma(const void* __restrict__ in, const void* __restrict__ kern, float* 
   f32x4 acc[G::T];
 #pragma unroll
   for (int t = 0; t < G::T; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-  const int arow = 16 * yt + (lane & 15), acol = 8 * (lane >> 4);
+  const int arow = 16 * (tid >> 6) + (lane & 15), acol = 8 * (lane >> 4);
   // blockIdx.y takes channels [c0, c1): with few samples the channels are spread over workgroups (summed outputs
   // then land in per-workgroup partials, reduced by k_sum_partials in a fixed order)
   const int c0 = blockIdx.y * cper, c1 = min(C, c0 + cper);
@@ -114,14 +121,16 @@ k_xcorr_mfma(const void* __restrict__ in, const void* __restrict__ kern, float* 
       __syncthreads();   // the previous channel's reads are done (first trip: the zero fill is complete)
       const size_t base = (IN_PER_C ? (size_t)b * C + c : (size_t)b) * HIN * HIN;
       if (HIN % 4 == 0) {   // 4 elements per thread and step
-        for (int k = tid; k < HIN * HIN / 4; k += NT) {
+        const int nrow = min(ROWS_L, HIN - row0);       // map rows of this workgroup that exist (the others stay zero)
+        for (int k = tid; k < nrow * (HIN / 4); k += NT) {
           const int r = k / (HIN / 4), cc = (k - r * (HIN / 4)) * 4;
+          const int kg = k + row0 * (HIN / 4);
           float v[4];
           if (F32) {
-            const float4 q = ((const float4*)((const float*)in + base))[k];
+            const float4 q = ((const float4*)((const float*)in + base))[kg];
             v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
           } else {
-            const uint2 q = ((const uint2*)((const uint16_t*)in + base))[k];
+            const uint2 q = ((const uint2*)((const uint16_t*)in + base))[kg];
             v[0] = bf16_to_f32(q.x & 0xffffu); v[1] = bf16_to_f32(q.x >> 16);
             v[2] = bf16_to_f32(q.y & 0xffffu); v[3] = bf16_to_f32(q.y >> 16);
           }
@@ -135,9 +144,10 @@ k_xcorr_mfma(const void* __restrict__ in, const void* __restrict__ kern, float* 
           if (SPLIT) *(uint2*)(xs + TILE + r * G::RS + cc) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
         }
       } else {   // odd sides (the padded gradient map): element by element
-        for (int k = tid; k < HIN * HIN; k += NT) {
+        const int nrow = min(ROWS_L, HIN - row0);
+        for (int k = tid; k < nrow * HIN; k += NT) {
           const int r = k / HIN, cc = k - r * HIN;
-          const float v = load_elem<F32>(in, base + k);
+          const float v = load_elem<F32>(in, base + (size_t)row0 * HIN + k);
           const uint32_t hi = bf16_rne(v);
           xs[r * G::RS + cc] = (uint16_t)hi;
           if (SPLIT) xs[TILE + r * G::RS + cc] = (uint16_t)bf16_rne(v - bf16_to_f32(hi));
@@ -236,11 +246,11 @@ inline void channel_split(int B, int C, int* cper, int* csplit) {
 
 thread_local char x_err[256] = "";
 
-template <int HIN, int KH, bool IN_PER_C, bool K_PER_C, bool SUM, bool IF32, bool KF32, bool SPLIT>
+template <int HIN, int KH, int TH, bool IN_PER_C, bool K_PER_C, bool SUM, bool IF32, bool KF32, bool SPLIT>
 int launch2(const void* in, const void* kern, float* out, void* scratch, int B, int C, hipStream_t st) {
   typedef XcorrCfg<HIN, KH> G;
-  const size_t lds = sizeof(uint16_t) * (G::ROWS * G::RS + KH * G::KR) * (SPLIT ? 2 : 1);
-  auto fn = k_xcorr_mfma<HIN, KH, IN_PER_C, K_PER_C, SUM, IF32, KF32, SPLIT>;
+  const size_t lds = sizeof(uint16_t) * ((16 * TH + KH - 1) * G::RS + KH * G::KR) * (SPLIT ? 2 : 1);
+  auto fn = k_xcorr_mfma<HIN, KH, TH, IN_PER_C, K_PER_C, SUM, IF32, KF32, SPLIT>;
   static bool lds_opted_in = false;   // per instantiation; set once, outside any later stream capture
   if (lds > 65536 && !lds_opted_in) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -254,7 +264,7 @@ int launch2(const void* in, const void* kern, float* out, void* scratch, int B, 
   channel_split(B, C, &cper, &csplit);
   float* partial = (float*)scratch;
   const bool two_pass = SUM && csplit > 1;
-  hipLaunchKernelGGL(fn, dim3(B, csplit), dim3(64 * G::T), lds, st, in, kern, two_pass ? partial : out, C, cper);
+  hipLaunchKernelGGL(fn, dim3(B, csplit, (G::T + TH - 1) / TH), dim3(64 * TH), lds, st, in, kern, two_pass ? partial : out, C, cper);
   if (two_pass)
     hipLaunchKernelGGL(k_sum_partials, dim3((G::O * G::O + 255) / 256, B), dim3(256), 0, st, partial, out, csplit, G::O * G::O);
   hipError_t e = hipGetLastError();
@@ -265,10 +275,11 @@ int launch2(const void* in, const void* kern, float* out, void* scratch, int B, 
   return 0;
 }
 
-template <int HIN, int KH, bool IN_PER_C, bool K_PER_C, bool SUM>
+// THS / THN: tile rows per workgroup with / without the bf16x3 split (without it a whole sample fits twice per CU anyway)
+template <int HIN, int KH, int THS, int THN, bool IN_PER_C, bool K_PER_C, bool SUM>
 int launch(const void* in, int in_f32, const void* kern, int kern_f32, int split, float* out, void* scratch, int B, int C,
            hipStream_t st) {
-#define SRL_X(IF, KF, SP) return launch2<HIN, KH, IN_PER_C, K_PER_C, SUM, IF, KF, SP>(in, kern, out, scratch, B, C, st)
+#define SRL_X(IF, KF, SP) return launch2<HIN, KH, (SP ? THS : THN), IN_PER_C, K_PER_C, SUM, IF, KF, SP>(in, kern, out, scratch, B, C, st)
   if (split) {
     if (in_f32 && kern_f32) SRL_X(true, true, true);
     snprintf(x_err, sizeof x_err, "srl_xcorr_mfma: precision 1 (bf16x3) takes float32 operands");
@@ -326,13 +337,15 @@ int srl_xcorr_mfma(int32_t mode, int32_t precision, const void* in, int32_t in_f
   }
   hipStream_t st = (hipStream_t)stream;
   if (H == 128) {
-    if (mode == 0) return launch<128, 32, true, true, true>(in, in_f32, kern, kern_f32, precision, out, scratch, B, C, st);
-    if (mode == 1) return launch<159, 32, false, true, false>(in, in_f32, kern, kern_f32, precision, out, scratch, B, C, st);
-    return launch<128, 97, true, false, false>(in, in_f32, kern, kern_f32, precision, out, scratch, B, C, st);
+    // tile rows per workgroup: 4 of 7 (forward: 76 KB of LDS with the bf16x3 split, two workgroups per CU), 3 of 8 (d/dx:
+    // 70 KB), both rows of the d/dw's 2 (its 97 kernel rows are the larger part of the 140 KB)
+    if (mode == 0) return launch<128, 32, 4, 7, true, true, true>(in, in_f32, kern, kern_f32, precision, out, scratch, B, C, st);
+    if (mode == 1) return launch<159, 32, 3, 4, false, true, false>(in, in_f32, kern, kern_f32, precision, out, scratch, B, C, st);
+    return launch<128, 97, 2, 2, true, false, false>(in, in_f32, kern, kern_f32, precision, out, scratch, B, C, st);
   }
-  if (mode == 0) return launch<64, 16, true, true, true>(in, in_f32, kern, kern_f32, precision, out, scratch, B, C, st);
-  if (mode == 1) return launch<79, 16, false, true, false>(in, in_f32, kern, kern_f32, precision, out, scratch, B, C, st);
-  return launch<64, 49, true, false, false>(in, in_f32, kern, kern_f32, precision, out, scratch, B, C, st);
+  if (mode == 0) return launch<64, 16, 4, 4, true, true, true>(in, in_f32, kern, kern_f32, precision, out, scratch, B, C, st);
+  if (mode == 1) return launch<79, 16, 4, 4, false, true, false>(in, in_f32, kern, kern_f32, precision, out, scratch, B, C, st);
+  return launch<64, 49, 1, 1, true, false, false>(in, in_f32, kern, kern_f32, precision, out, scratch, B, C, st);
 }
 
 }  // extern "C"
