@@ -786,3 +786,42 @@ def test_convt2x2_gemm_matches_torch_fp64(cin, cout, H, W, f32):
   else:
     assert bool((err <= 2.0 ** -8 * ref.abs().clamp(min=1e-2 * float(ref.abs().max()))).all())
   assert bool((cat[:, cout:] == 3.0).all())
+
+
+def test_prefetch_fifo_replays_from_the_update_graph(ref_pool):
+  """`DQN(prefetch=2)` (the reference's `dataset.prefetch`, dqn.py:247-252): the FIFO of minibatches lives at fixed
+  addresses, so the hipGraph-replayed update must use, update for update, the same minibatches as the eager one and land on
+  the same weights (the update's kernels are deterministic); and the hand-written update (`HandNet`) against the module
+  graph through the library within the float32-class tolerance of the cross-correlation."""
+  from stackrl_amd import env as envs, nets, qops
+  from stackrl_amd.dqn import DQN, PolynomialDecay
+  from stackrl_amd.training import Trainer
+  B, L = 8, 4
+  runs = []
+  for kw in (dict(graphs=False), dict(graphs=True), dict(graphs=False, hand_convs=False)):
+    env = envs.make('Stack-v0', n_parallel=B, seed=5, pool=ref_pool, episode_length=L)
+    net = nets.DeepQSiamFCN(env.observation_spec, seed=2).cuda()
+    agent = DQN(net, learning_rate=6.25e-5, adam_betas=(0.95, 0.95), minibatch_size=8, replay_memory_size=B * 16,
+                discount_factor=.966667, collect_batch_size=B, exploration=1.0, prioritization=0.6,
+                priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=9,
+                policy_op=qops.FusedPolicy(), xcorr='bf16x3', prefetch=2, **kw)
+    assert (agent._hand is not None) == kw.get('hand_convs', True)
+    tr = Trainer(env, agent)
+    tr.initialize(num_steps=10)
+    used, losses = [], []
+    for _ in range(7):                     # 3 eager warm-up updates, the capture, 3 replays (graphs=True)
+      loss, _ = agent.train()
+      used.append(agent._last_sample_indexes.clone()); losses.append(float(loss))
+    runs.append((used, losses, [p.detach().clone() for p in net.parameters()], agent._train_graph is not None))
+    env.close()
+  (ua, la, wa, ga), (ub, lb, wb, gb), (uc, lc, wc, gc) = runs
+  assert not ga and gb and not gc
+  # the graph's own `indexes` tensor is static: what it held after each replay is what that update used
+  for x, y in zip(ua, ub):
+    assert torch.equal(x, y)
+  assert la == lb
+  for p, q in zip(wa, wb):
+    assert torch.equal(p, q)
+  for x, y in zip(ua[:1], uc[:1]):         # the library path draws the same first minibatch; later priorities differ in the last bits
+    assert torch.equal(x, y)
+  assert abs(la[0] - lc[0]) <= 1e-3 * max(1e-6, abs(lc[0]))
