@@ -11,6 +11,8 @@ written (`baselines_golden.npz`) holds inputs and expected outputs only.
 import importlib.util
 import os
 import sys
+
+sys.dont_write_bytecode = True   # the reference tree is read-only: no __pycache__ beside its files
 import types
 
 import numpy as np

@@ -17,6 +17,8 @@ import importlib.util
 import os
 import sys
 
+sys.dont_write_bytecode = True   # the reference tree is read-only: no __pycache__ beside its files
+
 import numpy as np
 
 REF = '/root/reference/stackrl/envs/stack/observer.py'

@@ -27,6 +27,8 @@ oracle's restatement of the same functions.
 import importlib.util
 import os
 import sys
+
+sys.dont_write_bytecode = True   # the reference tree is read-only: no __pycache__ beside its files
 import types
 
 import numpy as np
