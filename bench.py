@@ -63,6 +63,9 @@ def parse_args(argv=None):
   ap.add_argument('--dqn-rocks', type=int, default=None)
   ap.add_argument('--dqn-res', type=int, default=None, choices=[64, 128])
   ap.add_argument('--dqn-slots', type=int, default=16, help='replay capacity in transitions per env')
+  ap.add_argument('--dqn-groups', type=int, default=None,
+                  help='leg B: the rank\'s envs as this many handles that step as their actions arrive (PipelinedVecStackEnv); '
+                       'default 2, 1 = one handle')
   ap.add_argument('--rollout', default='both', choices=['bf16x3', 'f32', 'bf16', 'both'],
                   help="rollout precision: 'bf16x3' = fp32-class (every product as three bf16 MFMAs; 'f32' is an alias), 'bf16'")
   ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL; gloo for rehearsals')
@@ -372,6 +375,9 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
   kw = dict(solver_kw)
   if res == 64:
     kw['resolution_factor'] = 4
+  groups = args.dqn_groups if args.dqn_groups else 2
+  if groups > 1:
+    kw['groups'] = groups
   env = envs.make('Stack-v0', n_parallel=B, seed=args.seed, pool=pool, episode_length=L, side_stream=True,
                   env_index_offset=rank * B, **kw)
   net = nets.DeepQSiamFCN(env.observation_spec, seed=1).cuda()
@@ -385,7 +391,21 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
   tr.initialize(num_steps=4)
   if pre:
     tr.run(pre)
-  ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(iters)]
+  ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(iters)]
+
+  class PolicyTimer(object):
+    """HIP-event pairs around every policy evaluation of the timed region (one per iteration, or one per group)"""
+    def __init__(self):
+      self.on, self.pairs = False, []
+    def start(self):
+      if self.on:
+        self.pairs.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+        self.pairs[-1][0].record()
+    def stop(self):
+      if self.on:
+        self.pairs[-1][1].record()
+
+  agent.policy_timer = ptimer = PolicyTimer()
   step = env.reset()
   agent.acknowledge_reset()
   t0 = None
@@ -395,27 +415,23 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
       placed_calls += 1
     if it == warm:
       step = step() if callable(step) else step
+      getattr(env, 'drain', lambda: None)()
       barrier()
       t0 = time.perf_counter()
     k = it - warm
-    if callable(step):
-      step = step()
+    ptimer.on = k >= 0
+    step = tr.collect_step(env, step)      # policy forward(s), replay add, env step(s) on the side stream(s): they overlap the update below
     if k >= 0:
       ev[k][0].record()
-    action = agent.collect(*step)
-    if k >= 0:
-      ev[k][1].record()
-    step = env.step(action)                # side stream: overlaps the update below
-    if k >= 0:
-      ev[k][2].record()
     agent.train()
     if k >= 0:
-      ev[k][3].record()
-  step = step() if callable(step) else step
+      ev[k][1].record()
+  tr._drain(env, step)
   barrier()
   dt = time.perf_counter() - t0
-  fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev)
-  upd_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / len(ev)
+  agent.policy_timer = None
+  fwd_ms = sum(a.elapsed_time(b) for a, b in ptimer.pairs) / len(ev)
+  upd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / len(ev)
   # all-reduce of the gradient bucket, timed on its own after the loop (inside the update it hides in upd_ms)
   ar_ms = None
   if dist.is_available() and dist.is_initialized():     # (world 1 under SRL_BENCH_FORCE_DIST=1: exercises the RCCL call itself)
@@ -441,6 +457,7 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
     'update_dtype': 'f32 (hand-written convolutions in true float32 on the matrix cores, csrc/train_conv.hip; cross-correlation as bf16x3 split)',
     'update_hand_convs': agent._hand is not None,
     'replay_next_index': 'reference (memory.py:239-242, literal)', 'prefetch': 3,
+    'env_groups': groups,   # handles the rank's envs are held as (PipelinedVecStackEnv: a group's forward runs under the other's straggler tail)
     'iterations': iters, 'warmup': warm,
     # placements per second, as leg A counts them (the auto-reset call of every episode is stepped and timed but places
     # nothing); step_calls_per_s counts every vectorised step() call
@@ -453,8 +470,8 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
       'achieved': flops_fwd / (fwd_ms * 1e-3) / 1e12, 'peak': PEAK_TFLOPS[dtype], 'unit': 'TFLOP/s',
       'frac': flops_fwd / (fwd_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 'traffic': None, **mfma_counters(dtype),
       'alg_flops_per_launch': flops_fwd, 'avg_launch_ms': fwd_ms,
-      'note': 'model-level: 2 x {:.1f} M MAC per sample (SURVEY.md N1) x samples / HIP-event time of agent.collect in '
-              'the timed region; peak = {}'.format(macs / 1e6, 'dense bf16 MFMA' if dtype == 'bf16' else
+      'note': 'model-level: 2 x {:.1f} M MAC per sample (SURVEY.md N1) x samples / HIP-event time of the policy evaluations of an '
+              'iteration in the timed region (with env_groups > 1 they run beside the other group\'s settle kernel); peak = {}'.format(macs / 1e6, 'dense bf16 MFMA' if dtype == 'bf16' else
                                                    'dense bf16 MFMA / 3 (fp32-class products = three bf16 MFMAs; the fp32 MFMA peak '
                                                    'would be 157.3)'),
     },

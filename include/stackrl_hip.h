@@ -122,6 +122,13 @@ int srl_get_object_map(srl_env* env, int32_t mesh_id, float* object_map);
  * accumulated milliseconds and launch counts since the last call: index 0 = settle (K1+K4),
  * 1 = render (K2+K5+obs pack), 2 = reserved. */
 int srl_set_profiling(srl_env* env, int32_t enable);
+
+/* Tuning hint, between srl_create and srl_load_meshes: the number of envs that step on this device at the same time over
+ * ALL handles of the caller (0 = this handle alone).  The reference's `ParallelEnv` has one process per env and a caller
+ * is free to hold its batch as several handles (independent shards that step as their actions arrive, utils.py:468-486);
+ * the settle kernel comes in a latency-oriented and a throughput-oriented build (9 - 16 rocks) and this number, not the
+ * handle's own n_envs, says which one fits.  Results do not depend on it (the parity tests run both builds). */
+int srl_set_concurrent_envs(srl_env* env, int32_t n_envs_on_device);
 int srl_get_kernel_times(srl_env* env, float* ms3, int32_t* launches3);
 
 #ifdef __cplusplus

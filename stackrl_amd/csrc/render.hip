@@ -270,7 +270,7 @@ __device__ __forceinline__ float wave_minmax(float v) {
 }
 
 // poses_ext != nullptr: test/profiling hook rendering explicit poses (srl_render_heightmap)
-extern "C" __global__ void __launch_bounds__(SRL_RENDER_THREADS)
+extern "C" __global__ void __launch_bounds__(SRL_RENDER_THREADS, 4)
 srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ obs_obj, float* __restrict__ reward,
              uint8_t* __restrict__ done, const float* __restrict__ poses_ext, const int32_t* __restrict__ mesh_ext,
              const int32_t* __restrict__ nb_ext, float* __restrict__ height_ext) {

@@ -29,6 +29,25 @@
 #include "srl_device.h"
 #include "srl_kernels.h"
 
+#ifdef SRL_DIAG_JITTER
+// Diagnostic build (tools/diag_conc.py): every block barrier is preceded by a pseudo-random, wave-uniform delay, so that the
+// waves of an env arrive at it — and leave the code before it — in an order that changes from barrier to barrier.  A missing
+// barrier between a write of one wave and a read of another would then show as a result that differs from the oracle's.
+__device__ __forceinline__ void srl_jitter_sync() {
+  unsigned t = (unsigned)__builtin_readcyclecounter() * 2654435761u + (threadIdx.x >> 6) * 40503u;
+  t = __builtin_amdgcn_readfirstlane(t);
+  const int n = (t >> 13) & 15;
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  t = t * 1664525u + 1013904223u;
+  const int m = (t >> 13) & 15;
+  for (int i = 0; i < m; ++i) __builtin_amdgcn_s_sleep(16);
+}
+#define __syncthreads() srl_jitter_sync()
+#endif
+
 #define SRL_GJK_GROUP 32
 
 // Bodies (i < j) of pair id p = j (j - 1) / 2 + i, computed when the kernel fills its LDS table.  (Until round 3 this
@@ -791,7 +810,11 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
     }
     __syncthreads();   // every lane has read the pre-solve velocities' companions (R, Iw, manifolds)
     STAMP(5);
+#ifdef SRL_DIAG_NOSOLO
+    const bool solo = false;                           // diagnostic build: every sweep through the block-wide path
+#else
     const bool solo = PP == 1 && misc[M_SOLO] != 0;   // (the variants with two points per thread are out of registers as it is)
+#endif
     int gturns = 0, pturns = 0;   // wave-uniform
 #pragma unroll
     for (int i = 0; i < SRL_GMAXP; ++i) if (__ballot(gp.valid && gp.idx == i)) gturns = i + 1;

@@ -54,6 +54,7 @@ struct srl_env {
   uint8_t* d_reset_d = nullptr;
   int step_threads = 256;
   int step_pp = 1;
+  int concurrent_envs = 0;   // srl_set_concurrent_envs: envs stepping on the device at the same time, over all handles
   size_t step_lds = 0, render_lds = 0, objmap_lds = 0;
   bool profiling = false;
   std::vector<EventPair> pending;
@@ -119,17 +120,19 @@ int derive(DevParams& P) {
 // 9 - 16 rocks in batches of 3,072 envs or more run two waves per env with two contact points per thread and without
 // the LDS copy of the local vertices: 35 KB per env, so four workgroups share a CU instead of three — these batches are
 // throughput-bound (+6 % at 4,096 envs: 47.5 against 50.6 ms per launch; -1 % at 2,048, -6 % at 1,024, where the launch
-// lasts as long as its slowest env).  SRL_STEP_VARIANT=two_wave | four_wave overrides the choice (parity tests).
-bool two_wave_variant(const DevParams& P) {
+// lasts as long as its slowest env).  What counts is the number of envs that step on the device at the same time: a
+// caller that splits its batch over several handles says so with srl_set_concurrent_envs (`concurrent`, 0 = this handle
+// alone).  SRL_STEP_VARIANT=two_wave | four_wave overrides the choice (parity tests).
+bool two_wave_variant(const DevParams& P, int concurrent) {
   const int L = P.c.episode_length;
   if (L <= 8 || L > 16) return false;
   const char* v = getenv("SRL_STEP_VARIANT");
   if (v && !strcmp(v, "two_wave")) return true;
   if (v && !strcmp(v, "four_wave")) return false;
-  return P.c.n_envs >= 3072;
+  return (concurrent > P.c.n_envs ? concurrent : P.c.n_envs) >= 3072;
 }
 
-void layout(DevParams& P) {
+void layout(DevParams& P, int concurrent) {
   int L = P.c.episode_length;
   P.NS = nslots(L);
   P.NP = L * (L - 1) / 2 > 0 ? L * (L - 1) / 2 : 1;
@@ -157,7 +160,7 @@ void layout(DevParams& P) {
   P.S_WV = s; s += 3 * P.VS * L;
   // above 16 rocks the local vertices are read from the (L2-resident) mesh table instead of an LDS copy: 70 instead of
   // 97 KB per env, so that two workgroups share a CU
-  if (L > 16 || two_wave_variant(P)) P.S_LV = -1; else { P.S_LV = s; s += 3 * P.VS * L; }
+  if (L > 16 || two_wave_variant(P, concurrent)) P.S_LV = -1; else { P.S_LV = s; s += 3 * P.VS * L; }
   s = (s + 1) & ~1;
   P.S_USED = s; s += 2 * SRL_MAX_BODIES;   // colouring scratch (uint64 per body); BLOB is a multiple of 4 words
   P.S_MISC = s; s += M_WORDS;
@@ -246,7 +249,7 @@ int srl_create(const srl_config* cfg, srl_env** out) {
   int rc = derive(env->P);
   if (rc) { delete env; return rc; }
   env->P.VS = 4;
-  layout(env->P);
+  layout(env->P, 0);
   DevParams& P = env->P;
   const int n = P.c.n_envs, res = P.c.overhead_res;
   HIP_TRY(hipMalloc((void**)&P.hdr, sizeof(EnvHdr) * (size_t)n));
@@ -399,7 +402,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   P.VS = vs;
   env->P_dirty = true;
   int old_blob = P.BLOB;
-  layout(P);
+  layout(P, env->concurrent_envs);
   if (P.BLOB != old_blob) return fail(SRL_EINVAL, "internal: blob layout changed");
   env->step_lds = sizeof(float) * (size_t)P.LDS_WORDS;
   if (env->step_lds > 160 * 1024) return fail(SRL_EINVAL, "episode_length x mesh size exceeds the 160 KB LDS budget");
@@ -407,7 +410,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   // 128 threads up to 8 rocks, 256 up to 16 (one contact point per thread), 256 with two points per thread above
   // (settle.hip "Variants")
   if (4 * P.NS <= 128 && SRL_GMAXP * P.c.episode_length <= 128) { env->step_threads = 128; env->step_pp = 0; }
-  else if (two_wave_variant(P)) { env->step_threads = 128; env->step_pp = 3; }
+  else if (two_wave_variant(P, env->concurrent_envs)) { env->step_threads = 128; env->step_pp = 3; }
   else if (4 * P.NS <= 256) { env->step_threads = 256; env->step_pp = 1; }
   else { env->step_threads = 256; env->step_pp = 2; }
   const int res = P.c.overhead_res;
@@ -424,6 +427,14 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   if (n_mesh < P.c.episode_length) { /* sampled with replacement, env.py:104-106 */ }
+  return SRL_OK;
+}
+
+int srl_set_concurrent_envs(srl_env* env, int32_t n_envs_on_device) {
+  if (!env) return fail(SRL_EINVAL, "null env");
+  if (n_envs_on_device < 0) return fail(SRL_EINVAL, "n_envs_on_device must be >= 0");
+  if (env->d_mh) return fail(SRL_EINVAL, "srl_set_concurrent_envs must precede srl_load_meshes");
+  env->concurrent_envs = n_envs_on_device;
   return SRL_OK;
 }
 

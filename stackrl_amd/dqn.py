@@ -230,6 +230,7 @@ class DQN(object):
     if seed is not None:
       self._gen.manual_seed(int(seed) + 1)
     self._policy_op = policy_op     # optional fused rollout head (stackrl_amd.qops.FusedPolicy)
+    self.policy_timer = None        # optional object with start() / stop() called around every policy evaluation (bench.py)
     # graphs: replay the no-grad target evaluations of the update from hipGraphs (HIP device only)
     self._graphs = bool(graphs) and self.device.type == 'cuda'
     self._g_target = GraphedEval(self._target_q_net) if self._graphs else None
@@ -289,19 +290,39 @@ class DQN(object):
     return self._q_net
 
   # ------------------------------------------------------------------ policy (dqn.py:330-375)
+  def policy_draws(self, batch_size):
+    """The random numbers one exploring `policy` call over `batch_size` samples consumes, drawn as that call draws them.
+    A policy evaluated group by group (`PipelinedVecStackEnv.collect_step`) hands each group its slice (`draws=`) and
+    takes the actions one call over the whole batch would take."""
+    if self._exploration_mode != 'epsilon-greedy':
+      raise NotImplementedError('group-wise collection is implemented for epsilon-greedy exploration')
+    dev = next(self._q_net.parameters()).device
+    u = torch.rand(batch_size, generator=self._gen, device=dev)
+    return u, torch.randint(self._n_actions, (batch_size,), generator=self._gen, device=dev)
+
   @torch.no_grad()
-  def policy(self, inputs, exploration=False, values=False):
+  def policy(self, inputs, exploration=False, values=False, draws=None):
+    timer = self.policy_timer
+    if timer is not None:
+      timer.start()
+    try:
+      return self._policy(inputs, exploration, values, draws)
+    finally:
+      if timer is not None:
+        timer.stop()
+
+  def _policy(self, inputs, exploration, values, draws):
     if self._policy_op is not None and exploration and not values and self._exploration_mode == 'epsilon-greedy':
-      return self._policy_op(self._q_net, inputs, self.exploration, self._gen)
+      if draws is None:
+        return self._policy_op(self._q_net, inputs, self.exploration, self._gen)
+      return self._policy_op(self._q_net, inputs, self.exploration, self._gen, draws=draws)
     with torch.no_grad():
       q = self._q_net(inputs)
     greedy = torch.argmax(q, dim=-1)                 # ties -> lowest index
     if exploration:
       e = self.exploration
       if self._exploration_mode == 'epsilon-greedy':
-        B = q.shape[0]
-        u = torch.rand(B, generator=self._gen, device=q.device)
-        rnd = torch.randint(self._n_actions, (B,), generator=self._gen, device=q.device)
+        u, rnd = draws if draws is not None else self.policy_draws(q.shape[0])
         actions = torch.where(u > e, greedy, rnd)
       else:
         z = -torch.log(-torch.log(torch.rand(q.shape, generator=self._gen, device=q.device)))

@@ -45,7 +45,7 @@ class VecStackEnv(object):
   """B independent Stack-v0 envs on one GPU (drop-in for `ParallelEnv`, utils.py:302)."""
 
   def __init__(self, n_parallel=None, block=None, seed=None, pool=None, device=None,
-               env_index_offset=0, side_stream=False, **kwargs):
+               env_index_offset=0, side_stream=False, concurrent_envs=None, **kwargs):
     """
     Args:
       n_parallel: number of environments B (utils.py:324).
@@ -57,6 +57,8 @@ class VecStackEnv(object):
       side_stream: run the env kernels on their own HIP stream so that a non-blocking `step` overlaps the
         caller's work on the current stream (the reference overlaps env processes with `agent.train()`,
         training.py:359-368); the returned callable joins the streams.
+      concurrent_envs: envs that step on the device at the same time over all handles of the caller (a tuning hint for
+        the settle kernel's build, `srl_set_concurrent_envs`; results do not depend on it).  None -> this handle alone.
       kwargs: StackEnv arguments (env.py:28-51), e.g. episode_length, sim_time_step, rewarder.
     """
     if not torch.cuda.is_available():
@@ -69,6 +71,8 @@ class VecStackEnv(object):
     self._h = ctypes.c_void_p()
     with torch.cuda.device(self._device):
       _check(self._lib.srl_create(ctypes.byref(self._c), ctypes.byref(self._h)))
+      if concurrent_envs:
+        _check(self._lib.srl_set_concurrent_envs(self._h, int(concurrent_envs)))
       self.pool = pool if pool is not None else _assets.default_pool()
       p = self.pool
       _check(self._lib.srl_load_meshes(self._h, _np_ptr(p.verts), _np_ptr(p.vert_off), _np_ptr(p.tris),
@@ -303,6 +307,188 @@ class VecStackEnv(object):
     return ms, n
 
 
+class PipelinedVecStackEnv(object):
+  """The same B envs as `VecStackEnv(n_parallel=B)` — same seeds, same trajectories, bit for bit — held as `groups`
+  handles of B / groups envs, each on its own HIP stream, so that the training loop can treat the groups the way the
+  reference's `ParallelEnv` treats its worker processes (utils.py:468-486: every worker is sent its action and answers
+  when it is done): `collect_step` evaluates the policy on group k as soon as group k's step has finished and starts
+  group k's next step as soon as its actions exist, while the other groups are still settling.
+
+  Why it pays on MI355X: a settle launch lasts as long as its slowest env and for most of
+  that time most of its workgroups have finished — at 4,096 envs x 16 rocks about half of the launch's slot-time is
+  idle — but the Q-net forward of the NEXT step cannot use those CUs because it needs the observations of every env.
+  With two groups the forward of one group runs under the straggler tail of the other.  (More than two groups lose
+  again: concurrent settle launches share the CUs round robin, so they all finish late, and HIP multiplexes streams
+  over four hardware queues.)
+
+  The plain `ParallelEnv` surface (`reset`, `step`, `sample`, `seed`, ...) is here too; outputs are full-batch tensors
+  the groups write their slices of (no copies)."""
+
+  def __init__(self, n_parallel=None, groups=2, block=None, seed=None, pool=None, device=None, env_index_offset=0,
+               **kwargs):
+    B, K = int(n_parallel or 1), int(groups)
+    if K < 1 or B % K:
+      raise ValueError('n_parallel must be a multiple of groups')
+    kwargs.pop('side_stream', None)
+    kwargs.setdefault('concurrent_envs', B)
+    self._block = block
+    self._B, self._K, self._G = B, K, B // K
+    self.pool = pool if pool is not None else _assets.default_pool()
+    self._envs = [VecStackEnv(n_parallel=self._G, block=False, seed=seed, pool=self.pool, device=device,
+                              env_index_offset=int(env_index_offset) + k * self._G, side_stream=True, **kwargs)
+                  for k in range(K)]
+    e0 = self._envs[0]
+    self.config = e0.config
+    self._device = e0._device
+    self._cur = None        # the latest step: full-batch tensors + the per-group waits not yet taken
+
+  # ---- the ParallelEnv surface (utils.py:270-281, :417-422)
+  multiprocessing = False
+
+  @property
+  def batch_size(self):
+    return self._B
+
+  @property
+  def groups(self):
+    return self._K
+
+  @property
+  def observation_spec(self):
+    return self._envs[0].observation_spec
+
+  @property
+  def action_spec(self):
+    return self._envs[0].action_spec
+
+  @property
+  def n_actions(self):
+    return self._envs[0].n_actions
+
+  @property
+  def num_maps_on_show(self):
+    return self._envs[0].num_maps_on_show
+
+  def __call__(self, *args, **kwargs):
+    return self.step(*args, **kwargs)
+
+  def seed(self, seed):
+    out = []
+    for e in self._envs:
+      out += e.seed(seed)
+    return out
+
+  def set_script(self, mesh_ids, goal_rect):
+    for k, e in enumerate(self._envs):
+      e.set_script(mesh_ids[k * self._G:(k + 1) * self._G], goal_rect[k * self._G:(k + 1) * self._G])
+
+  def close(self):
+    for e in self._envs:
+      e.close()
+
+  terminate = close
+
+  def sample(self):
+    return torch.cat([e.sample() for e in self._envs])
+
+  def sweeps(self):
+    return np.concatenate([e.sweeps() for e in self._envs])
+
+  def state(self):
+    return tuple(np.concatenate(x) for x in zip(*[e.state() for e in self._envs]))
+
+  def maps(self):
+    return tuple(np.concatenate(x) for x in zip(*[e.maps() for e in self._envs]))
+
+  def set_profiling(self, enable=True):
+    for e in self._envs:
+      e.set_profiling(enable)
+
+  def kernel_times(self):
+    ms, n = zip(*[e.kernel_times() for e in self._envs])
+    return np.sum(ms, 0), np.sum(n, 0)
+
+  def _outputs(self):
+    e0 = self._envs[0]
+    keys = self.config.reward_keys
+    return dict(
+      om=torch.empty((self._B,) + tuple(e0._observation_spec[0].shape), dtype=torch.uint8, device=self._device),
+      oo=torch.empty((self._B,) + tuple(e0._observation_spec[1].shape), dtype=torch.uint8, device=self._device),
+      reward=torch.empty(self._B if keys is None else (self._B, len(keys)), dtype=torch.float32, device=self._device),
+      done=torch.empty(self._B, dtype=torch.uint8, device=self._device), waits=[None] * self._K)
+
+  def _slice(self, k):
+    return slice(k * self._G, (k + 1) * self._G)
+
+  def _step_tuple(self, o, s=slice(None)):
+    return (o['om'][s], o['oo'][s]), o['reward'][s], o['done'][s].view(torch.bool)
+
+  def _wait_group(self, o, k):
+    w, o['waits'][k] = o['waits'][k], None
+    if w is not None:
+      w()                     # srl_sync_status of the group's handle + the current stream waits for the group's stream
+
+  def drain(self):
+    """Wait for every step still in flight (before a reset, a checkpoint, the end of a run)."""
+    if self._cur is not None:
+      for k in range(self._K):
+        self._wait_group(self._cur, k)
+
+  def _waiter(self, o):
+    def wait():
+      for k in range(self._K):
+        self._wait_group(o, k)
+      return self._step_tuple(o)
+    return wait
+
+  def reset(self, block=None):
+    self.drain()
+    o = self._outputs()
+    o['reward'].zero_(); o['done'].zero_()                                # utils.py:545-552
+    for k, e in enumerate(self._envs):
+      s = self._slice(k)
+      o['waits'][k] = e.reset(block=False, out=(o['om'][s], o['oo'][s]))
+    self._cur = o
+    wait = self._waiter(o)
+    block = self._block if block is None else block
+    return wait() if block else wait
+
+  def step(self, action, block=None):
+    if not torch.is_tensor(action):
+      action = torch.as_tensor(action)
+    action = action.to(device=self._device, dtype=torch.int64).contiguous()
+    if action.shape != (self._B,):
+      raise ValueError('action must have shape [{}]'.format(self._B))
+    self.drain()
+    o = self._outputs()
+    for k, e in enumerate(self._envs):
+      s = self._slice(k)
+      o['waits'][k] = e.step(action[s], block=False, out=(o['om'][s], o['oo'][s], o['reward'][s], o['done'][s]))
+    self._cur = o
+    wait = self._waiter(o)
+    block = self._block if block is None else block
+    return wait() if block else wait
+
+  def collect_step(self, policy):
+    """`action = policy(step); env.step(action)` of the training loop (training.py:352-357), group by group: the policy
+    call on group k waits for group k's latest step only, and group k's next step starts as soon as its actions exist.
+      policy(k, index_slice, (state_k, reward_k, terminal_k)) -> int64 actions [B / groups] of group k
+    Returns `(step, action)` of the whole batch: the step the policy has just acted on (complete: every group has been
+    waited for) and the actions now being carried out.  Nothing is returned to wait on — the next `collect_step`,
+    `step`, `reset` or `drain` takes the waits."""
+    if self._cur is None:
+      raise RuntimeError('collect_step needs a reset first')
+    cur, nxt = self._cur, self._outputs()
+    action = torch.empty(self._B, dtype=torch.int64, device=self._device)
+    for k, e in enumerate(self._envs):
+      s = self._slice(k)
+      self._wait_group(cur, k)
+      action[s] = policy(k, s, self._step_tuple(cur, s))
+      nxt['waits'][k] = e.step(action[s], block=False, out=(nxt['om'][s], nxt['oo'][s], nxt['reward'][s], nxt['done'][s]))
+    self._cur = nxt
+    return self._step_tuple(cur), action
+
+
 class StartedVecStackEnv(VecStackEnv):
   """`StartedStackEnv` (Stack-v1, env.py:348-441): an episode uses `n_objects` rocks, the first `n_objects -
   episode_length` of which are placed by `start_policy` inside `reset`, so the agent sees only the last
@@ -441,6 +627,9 @@ def make(env='Stack-v0', n_parallel=None, block=None, seed=None, as_path=False, 
     return StartedVecStackEnv(n_parallel=n_parallel or 1, block=block, seed=seed, **kwargs)
   elif env != 'Stack-v0':
     raise ValueError("Invalid env {}: 'Stack-v0', 'Stack-v1' and 'Stack-v2' are implemented.".format(env))
+  groups = kwargs.pop('groups', None)                    # build option: the batch as several handles (PipelinedVecStackEnv)
+  if groups and int(groups) > 1:
+    return PipelinedVecStackEnv(n_parallel=n_parallel or 1, groups=groups, block=block, seed=seed, **kwargs)
   return VecStackEnv(n_parallel=n_parallel or 1, block=block, seed=seed, **kwargs)
 
 

@@ -741,12 +741,18 @@ class FusedPolicy(object):
     self.fast = (autocast == torch.bfloat16) if fast is None else bool(fast)
     self._ff = None
 
+  @staticmethod
+  def draws(net, B, gen, device):
+    """The random numbers one call over B samples consumes, drawn as that call draws them (`draws=` of `__call__`: a
+    policy evaluated group by group passes each group its slice and takes the actions of one call over the batch)."""
+    u = torch.rand(B, generator=gen, device=device)
+    return u, torch.randint(net.n_actions, (B,), generator=gen, device=device)
+
   @torch.no_grad()
-  def __call__(self, net, inputs, epsilon, gen):
+  def __call__(self, net, inputs, epsilon, gen, draws=None):
     xm, xo = inputs
     B = xm.shape[0]
-    u = torch.rand(B, generator=gen, device=xm.device)
-    rnd = torch.randint(net.n_actions, (B,), generator=gen, device=xm.device)
+    u, rnd = draws if draws is not None else self.draws(net, B, gen, xm.device)
     out = torch.empty(B, dtype=torch.int64, device=xm.device)
     for s in range(0, B, self.chunk):
       e = min(B, s + self.chunk)

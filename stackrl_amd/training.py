@@ -174,11 +174,7 @@ class Trainer(object):
       for _ in range(max_num_iters):
         t0 = time.perf_counter()
         with self._collect_timer:
-          if callable(step):
-            step = step()
-          self._reward += step
-          action = agent.collect(*step)
-          step = env.step(action)          # non-blocking: the settle/render kernels overlap the update below
+          step = self.collect_step(env, step)   # non-blocking: the settle/render kernels overlap the update below
         t1 = time.perf_counter()
         with self._train_timer:
           loss, merr = agent.train()
@@ -202,8 +198,7 @@ class Trainer(object):
           self.check_goal()
         if self._reset_env:
           self._reset_env = False
-          if callable(step):
-            step()
+          self._drain(env, step)
           env = self._env                 # the curriculum may have moved on
           step = env.reset()
           agent.acknowledge_reset()
@@ -213,11 +208,36 @@ class Trainer(object):
       self.log_exception()
       raise
     finally:
-      if callable(step):
-        step()
+      self._drain(env, step)
       if self._directory is not None:
         self.checkpoint()
     return torch.stack(list(losses)) if losses else torch.zeros(0)
+
+  def collect_step(self, env, step):
+    """The collect half of an iteration (training.py:352-357): the agent acts on the latest env step and stores it, the
+    env starts carrying the actions out.  `step`: what the previous call (or `env.reset()`) returned; returns its
+    successor.  An env held as groups of handles (`PipelinedVecStackEnv`) is served group by group — the policy call on
+    a group waits for that group's step only, and the group's next step starts at once — with the random numbers of the
+    whole batch drawn up front, so that the actions are those of one `agent.collect` over the batch."""
+    agent = self._agent
+    if getattr(env, 'groups', 1) > 1:
+      draws = agent.policy_draws(env.batch_size)
+      step, action = env.collect_step(
+        lambda k, s, st: agent.policy(st[0], exploration=True, draws=tuple(d[s] for d in draws)))
+      self._reward += step
+      agent.observe(*step, action)
+      return None                          # the env keeps the waits; `_drain` / the next call take them
+    if callable(step):
+      step = step()
+    self._reward += step
+    action = agent.collect(*step)
+    return env.step(action)
+
+  @staticmethod
+  def _drain(env, step):
+    if callable(step):
+      step()
+    getattr(env, 'drain', lambda: None)()
 
   # ------------------------------------------------------------------ eval (training.py:398-452)
   def eval(self):

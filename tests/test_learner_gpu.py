@@ -825,3 +825,38 @@ def test_prefetch_fifo_replays_from_the_update_graph(ref_pool):
   for x, y in zip(ua[:1], uc[:1]):         # the library path draws the same first minibatch; later priorities differ in the last bits
     assert torch.equal(x, y)
   assert abs(la[0] - lc[0]) <= 1e-3 * max(1e-6, abs(lc[0]))
+
+
+def test_groupwise_collection_equals_one_collect(ref_pool):
+  """`PipelinedVecStackEnv` + `Trainer.collect_step`: the batch as two handles that step as their actions arrive, the policy
+  evaluated group by group with the random numbers of one `collect` over the batch.  Same seeds -> the same trajectories,
+  replay contents and weights as the one-handle loop, bit for bit (every kernel of the rollout works sample by sample once
+  a group holds >= 256 samples; the update's kernels are deterministic)."""
+  from stackrl_amd import env as envs, nets, qops
+  from stackrl_amd.dqn import DQN, PolynomialDecay
+  from stackrl_amd.training import Trainer
+  B, L = 512, 3
+  runs = []
+  for groups in (None, 2):
+    env = envs.make('Stack-v0', n_parallel=B, seed=5, pool=ref_pool, episode_length=L, side_stream=True,
+                    **({} if groups is None else dict(groups=groups)))
+    assert getattr(env, 'groups', 1) == (groups or 1)
+    net = nets.DeepQSiamFCN(env.observation_spec, seed=2).cuda()
+    agent = DQN(net, learning_rate=6.25e-5, adam_betas=(0.95, 0.95), minibatch_size=8, replay_memory_size=B * 8,
+                discount_factor=.966667, collect_batch_size=B, exploration=0.5, prioritization=0.6,
+                priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=9,
+                policy_op=qops.FusedPolicy(chunk=256, fast=True), xcorr='bf16x3', prefetch=3)
+    tr = Trainer(env, agent)
+    tr.initialize(num_steps=2)
+    losses = tr.run(2 * (L + 1) + 1)       # two episodes and a step: through the auto-reset call of every group
+    mem = agent._replay_memory
+    runs.append((losses.clone(), [p.detach().clone() for p in net.parameters()], mem._actions.clone(), mem._rewards.clone(),
+                 mem._states[0].clone(), mem._states[1].clone(), float(tr.returns) if tr.returns is not None else None))
+    env.close()
+  a, b = runs
+  assert torch.equal(a[2], b[2]), 'actions'
+  assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and torch.equal(a[5], b[5]), 'stored transitions'
+  assert torch.equal(a[0], b[0]), 'losses'
+  for p, q in zip(a[1], b[1]):
+    assert torch.equal(p, q)
+  assert a[6] == b[6]

@@ -335,3 +335,92 @@ def test_two_handles_on_two_streams_equal_one_handle_and_the_oracle(ref_pool, or
   a.close()
   for s in shards:
     s.close()
+
+
+def test_pipelined_env_equals_one_handle_and_the_oracle(ref_pool, oracle_mod):
+  """`PipelinedVecStackEnv` (the batch as groups of handles that step as their actions arrive): through its plain `step` and
+  through `collect_step` the 12 envs x 12 rocks follow the one-handle env and the oracle bit for bit over two episodes and
+  their auto-reset; the groups run the throughput-oriented settle build (`concurrent_envs` says 4,096 envs share the
+  device) while the one-handle env of 12 runs the latency-oriented one — results do not depend on the build."""
+  from stackrl_amd import env as envs
+  from stackrl_amd.config import StackConfig
+  B, L, seed = 12, 12, 31
+  a = envs.make('Stack-v0', n_parallel=B, seed=seed, pool=ref_pool, episode_length=L)
+  p = envs.make('Stack-v0', n_parallel=B, seed=seed, pool=ref_pool, episode_length=L, groups=3, concurrent_envs=4096)
+  q = envs.make('Stack-v0', n_parallel=B, seed=seed, pool=ref_pool, episode_length=L, groups=2)
+  o = oracle_mod.OracleEnv(StackConfig(n_envs=B, episode_length=L), ref_pool, seed=seed)
+  assert p.groups == 3 and p.batch_size == B and p.n_actions == a.n_actions
+  assert p._envs[0]._lib is not None and a.seed(seed) == p.seed(seed) == q.seed(seed)
+  sa, sp = a.reset()(), p.reset()()
+  q.reset()                                    # not waited for: collect_step takes the waits group by group
+  so = o.reset()
+  assert torch.equal(sa[0][0], sp[0][0]) and torch.equal(sa[0][1], sp[0][1])
+  assert np.array_equal(sp[0][0].cpu().numpy(), so[0][0])
+  prev = sa
+  for t in range(2 * (L + 1)):
+    act = a.sample()
+    assert torch.equal(act, p.sample()) and torch.equal(act, q.sample())
+    assert np.array_equal(act.cpu().numpy(), o.sample())
+    seen = []
+    step_q, act_q = q.collect_step(lambda k, s, st: (seen.append((k, s, st)), act[s])[1])
+    assert torch.equal(act_q, act) and [k for k, _, _ in seen] == [0, 1]
+    tag = 'call {}'.format(t)
+    for x, y in zip((prev[0][0], prev[0][1], prev[1], prev[2]), (step_q[0][0], step_q[0][1], step_q[1], step_q[2])):
+      assert torch.equal(x, y), tag + ': the step collect_step hands the policy is the one-handle env\'s latest step'
+    for k, s, st in seen:                      # and every group saw its own slice of it
+      assert torch.equal(st[0][0], prev[0][0][s]) and torch.equal(st[1], prev[1][s]) and torch.equal(st[2], prev[2][s])
+    sa, sp = a.step(act)(), p.step(act)()
+    for nm, x, y in (('obs_map', sa[0][0], sp[0][0]), ('obs_obj', sa[0][1], sp[0][1]), ('reward', sa[1], sp[1]), ('done', sa[2], sp[2])):
+      assert torch.equal(x, y), '{}: {} of the pipelined env differs from the one-handle env'.format(tag, nm)
+    _cmp_step(a, o, sa, o.step(act.cpu().numpy()), tag)
+    for i, (u, v) in enumerate(zip(a.state(), p.state())):
+      assert np.array_equal(u, v), tag + ': state {}'.format(i)
+    prev = sa
+  q.drain()
+  for i, (u, v) in enumerate(zip(a.state(), q.state())):
+    assert np.array_equal(u, v), 'final state {} after collect_step'.format(i)
+  for e in (a, p, q):
+    e.close()
+
+
+def test_env_step_under_the_concurrent_rollout_forward_equals_the_oracle(oracle_mod):
+  """The training loop steps the envs on a side stream while the Q-net's kernels run on the current one; the env's results
+  must not depend on that.  512 envs x 3 rocks over two episodes, every step in flight while the rollout forward (the
+  hand-written convolutions, the cross-correlation, the policy head) runs beside it, against the oracle in lock step: bytes,
+  rewards, poses, sub-step counts and height maps bit for bit.
+  This is the reproduction of round 2's "concurrency anomalies" (DESIGN.md section 6a): built with clang's SLP vectoriser
+  (packed-fp32 code in the settle kernel) the env returned results that differ from the oracle's in 20 - 50 env steps of
+  these 4,096 — only under this concurrency, never alone; csrc is built with -fno-slp-vectorize since (stackrl_amd/build.py)."""
+  from stackrl_amd import assets, env as envs, nets, qops
+  from stackrl_amd.config import StackConfig
+  B, L, seed = 512, 3, 5
+  pool = assets.default_pool()
+  e = envs.make('Stack-v0', n_parallel=B, seed=seed, pool=pool, episode_length=L, side_stream=True)
+  o = oracle_mod.OracleEnv(StackConfig(n_envs=B, episode_length=L), pool, seed=seed)
+  net = nets.DeepQSiamFCN(e.observation_spec, seed=2).cuda()
+  pol = qops.FusedPolicy(chunk=256, fast=True)
+  gen = torch.Generator(device='cuda').manual_seed(1)
+  step = e.reset()()
+  o.reset()
+  bad = []
+  for t in range(2 * (L + 1)):
+    a = e.sample()
+    ao = o.sample()
+    assert np.array_equal(a.cpu().numpy(), ao)
+    w = e.step(a, block=False)
+    pol(net, step[0], 1.0, gen)             # the forward on the previous observation, while the step is in flight
+    step = w()
+    (om, oo), r, d = step
+    (omo, ooo), ro, do = o.step(ao)
+    gs, os_ = e.state(), o.state()
+    gH, oH = e.maps()[0], o.maps()[0]
+    same = (np.array_equal(om.cpu().numpy(), omo) and np.array_equal(oo.cpu().numpy(), ooo)
+            and np.array_equal(r.cpu().numpy().view(np.uint32), ro.view(np.uint32)) and np.array_equal(d.cpu().numpy(), do)
+            and all(np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+                    for x, y in zip(gs, os_))
+            and np.array_equal(gH.view(np.uint32), oH.view(np.uint32)))
+    if not same:
+      envs_bad = np.nonzero((gs[0].view(np.uint32) != os_[0].view(np.uint32)).reshape(B, -1).any(1))[0]
+      bad.append((t, envs_bad[:8].tolist()))
+  e.close()
+  assert not bad, 'env results under the concurrent forward differ from the oracle (call, envs): {}'.format(bad)
