@@ -45,7 +45,7 @@ class VecStackEnv(object):
   """B independent Stack-v0 envs on one GPU (drop-in for `ParallelEnv`, utils.py:302)."""
 
   def __init__(self, n_parallel=None, block=None, seed=None, pool=None, device=None,
-               env_index_offset=0, side_stream=False, concurrent_envs=None, **kwargs):
+               env_index_offset=0, side_stream=False, concurrent_envs=None, stream_priority=None, **kwargs):
     """
     Args:
       n_parallel: number of environments B (utils.py:324).
@@ -57,6 +57,8 @@ class VecStackEnv(object):
       side_stream: run the env kernels on their own HIP stream so that a non-blocking `step` overlaps the
         caller's work on the current stream (the reference overlaps env processes with `agent.train()`,
         training.py:359-368); the returned callable joins the streams.
+      stream_priority: priority of the side stream (-1 = high: the dispatcher serves the env's long-running workgroups
+        before the kernels of the current stream; None / 0 = default).
       concurrent_envs: envs that step on the device at the same time over all handles of the caller (a tuning hint for
         the settle kernel's build, `srl_set_concurrent_envs`; results do not depend on it).  None -> this handle alone.
       kwargs: StackEnv arguments (env.py:28-51), e.g. episode_length, sim_time_step, rewarder.
@@ -86,7 +88,7 @@ class VecStackEnv(object):
     self._B, self._H, self._hh = B, H, h
     self._closed = False
     self._left = 0          # rocks of the running episode not yet placed (host mirror of the lock-step episode machine)
-    self._side = torch.cuda.Stream(device=self._device) if side_stream else None
+    self._side = torch.cuda.Stream(device=self._device, priority=int(stream_priority or 0)) if side_stream else None
     self.seed(seed if seed is not None else 0)
 
   # ---- properties (utils.py:270-281, :417-422)

@@ -30,7 +30,7 @@ torch.cuda.synchronize()
 ref = ref.clone()
 outs = [torch.empty_like(ref) for _ in range(8)]
 for load in ('none', 'pos', 'ff', 'none'):
-  bad = 0
+  bad = 0; shown = 0
   for k in range(0, N, 8):
     with torch.no_grad():
       if load == 'pos':
@@ -46,5 +46,14 @@ for load in ('none', 'pos', 'ff', 'none'):
     torch.cuda.synchronize()
     for o in outs:
       if not torch.equal(o.view(torch.int32), ref.view(torch.int32)):
-        bad += int((o.view(torch.int32) != ref.view(torch.int32)).reshape(B, -1).any(1).sum())
+        dm = (o.view(torch.int32) != ref.view(torch.int32)).reshape(B, -1)
+        bad += int(dm.any(1).sum())
+        if shown < 6:
+          for ei in dm.any(1).nonzero()[:2, 0].tolist():
+            px = dm[ei].nonzero()[:, 0]
+            a, b_ = o[ei].reshape(-1)[px], ref[ei].reshape(-1)[px]
+            rows, cols = (px // 128), (px % 128)
+            print('   env', ei, 'nb', int(nb[ei]), 'pixels', int(px.numel()), 'rows', int(rows.min()), int(rows.max()), 'cols', int(cols.min()), int(cols.max()),
+                  'max |dH|', float((a - b_).abs().max()), 'got', a[:4].tolist(), 'ref', b_[:4].tolist(), flush=True)
+            shown += 1
   print('load', load, ':', N, 'launches x', B, 'envs; env-renders that differ from the first launch:', bad, flush=True)
