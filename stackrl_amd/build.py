@@ -13,7 +13,7 @@ DEPS = ['stackrl_hip.hip', 'settle.hip', 'render.hip', 'srl_device.h', 'srl_kern
 # -fno-slp-vectorize: with the SLP vectoriser's packed-fp32 code (v_pk_fma / v_pk_mul / v_pk_add_f32, v_mov_b64) the settle
 #   kernel returned, in a few envs per thousand, results that differ from the oracle's — but only while convolution kernels of
 #   the Q-net ran on another stream; alone it was bit-exact.  Without it no difference was ever seen (DESIGN.md section 6a,
-#   tools/diag_conc.py, tests/test_parity_gpu.py::test_env_step_under_the_concurrent_rollout_forward...); speed is the same.
+#   tests/diag/diag_conc.py, tests/test_parity_gpu.py::test_env_step_under_the_concurrent_rollout_forward...); speed is the same.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-fno-slp-vectorize',
          '-fno-fast-math', '-Wall', '-Wno-unused-function', '-Wno-unused-value', '-Wno-unused-result']
 

@@ -30,7 +30,7 @@
 #include "srl_kernels.h"
 
 #ifdef SRL_DIAG_JITTER
-// Diagnostic build (tools/diag_conc.py): every block barrier is preceded by a pseudo-random, wave-uniform delay, so that the
+// Diagnostic build (tests/diag/diag_conc.py): every block barrier is preceded by a pseudo-random, wave-uniform delay, so that the
 // waves of an env arrive at it — and leave the code before it — in an order that changes from barrier to barrier.  A missing
 // barrier between a write of one wave and a read of another would then show as a result that differs from the oracle's.
 __device__ __forceinline__ void srl_jitter_sync() {

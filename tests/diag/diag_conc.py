@@ -2,7 +2,7 @@
 """Which concurrency makes an env step differ from the oracle?  B envs as `groups` handles on side streams, stepped in lock
 step with the oracle; while the step is in flight the current stream runs `load`: none | matmul | qnet."""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 if os.environ.get('SRL_DIAG_LIB'):      # run against another build of libstackrl_hip.so (diagnostic variants)
   from stackrl_amd import build as _b
@@ -44,7 +44,7 @@ for t in range(episodes * (L + 1)):
   if load in ('ldsbusy', 'vgprbusy'):
     import ctypes
     kind = 'lds' if load == 'ldsbusy' else 'vgpr'
-    Pz = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'experiments', kind + '_poison.so'))
+    Pz = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tools', 'experiments', kind + '_poison.so'))
     fn = getattr(Pz, kind + '_poison'); fn.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     for _ in range(10):
       fn(0xdeadbeef, 20000, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), None)

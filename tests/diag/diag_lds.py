@@ -2,14 +2,14 @@
 """Does an env step depend on what other kernels left in a CU's LDS?  One handle of B envs stepped in lock step with the
 oracle; before every step an LDS poisoner (tools/experiments/lds_poison.hip) fills all 160 KB of every CU with a pattern."""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from stackrl_amd import assets, env as envs
 from stackrl_amd.config import StackConfig
 from oracle import oracle
 B, L = int(sys.argv[1]), int(sys.argv[2])
 patterns = [None if x == 'none' else int(x, 0) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [None]
-here = os.path.dirname(os.path.abspath(__file__))
+here = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tools')
 KIND = os.environ.get('POISON', 'lds')      # lds | vgpr (tools/experiments/vgpr_poison.hip: every vector register of every SIMD)
 P = ctypes.CDLL(os.path.join(here, 'experiments', KIND + '_poison.so'))
 poison = getattr(P, KIND + '_poison')
