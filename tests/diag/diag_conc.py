@@ -53,7 +53,7 @@ for t in range(episodes * (L + 1)):
       filler = (filler @ filler) * 1e-3
   elif load == 'qnet':
     pol(net, step[0], 1.0, gen)
-  elif load in ('ff', 'xcorr', 'pos', 'head'):
+  elif load in ('ff', 'xcorr', 'pos', 'head', 'thin', 'proj'):
     if pol._ff is None:
       pol._ff = qops.FastFeatures(net, dtype=torch.float32)
       with torch.no_grad():
@@ -69,6 +69,16 @@ for t in range(episodes * (L + 1)):
           for _ in range(4): qops.xcorr_forward(X, W)
         elif load == 'pos':
           for _ in range(20): pol._ff.pos(C)
+        elif load in ('thin', 'proj'):       # the two kernels of the position head, one at a time
+          ff_ = pol._ff; posn = net.pos
+          if not hasattr(ff_, '_dbuf'):
+            ff_._dbuf = torch.zeros((256, 16, 112, 112), dtype=torch.float32, device='cuda').contiguous(memory_format=torch.channels_last)
+            ff_._dcorr = C.reshape(256, 97, 97, 1).contiguous()
+          for _ in range(20):
+            if load == 'thin':
+              qops.conv3x3_thin(ff_._dcorr, ff_._wt[posn[0]], ff_._w[posn[0]][1], out=ff_._dbuf)
+            else:
+              qops.conv3x3_relu_project(ff_._dbuf, ff_._wf[posn[2]], ff_._w[posn[2]][1], ff_._pos[0], ff_._pos[1], 97, 97)
         else:
           for _ in range(50): qops.policy_head(A, U, R, 0.5)
   step = w()
