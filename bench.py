@@ -388,7 +388,8 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
               exploration=PolynomialDecay(1.0, 400000, .1), prioritization=0.6,
               priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=7 + rank,
               policy_op=qops.FusedPolicy(autocast=torch.bfloat16 if dtype == 'bf16' else None, fast=True),
-              xcorr='bf16x3', graphs=True, process_group=rccl_group(args, world), prefetch=3)   # config.gin:55-112 (prefetch :104)
+              xcorr='bf16x3', graphs=True, process_group=rccl_group(args, world), prefetch=3,   # config.gin:55-112 (prefetch :104)
+              early_gradient=not os.environ.get('SRL_NO_EARLY_GRADIENT'))
   tr = Trainer(env, agent)
   tr.initialize(num_steps=4)
   if pre:
@@ -422,6 +423,7 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
       t0 = time.perf_counter()
     k = it - warm
     ptimer.on = k >= 0
+    agent.train_begin()                    # the gradient half of the update, on its own stream beside the collect step (early_gradient)
     step = tr.collect_step(env, step)      # policy forward(s), replay add, env step(s) on the side stream(s): they overlap the update below
     if k >= 0:
       ev[k][0].record()
@@ -459,6 +461,7 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
     'update_dtype': 'f32 (hand-written convolutions in true float32 on the matrix cores, csrc/train_conv.hip; cross-correlation as bf16x3 split)',
     'update_hand_convs': agent._hand is not None,
     'replay_next_index': 'reference (memory.py:239-242, literal)', 'prefetch': 3,
+    'update_early_gradient': agent._early,   # the update's gradient half runs beside the collect step (same results: the minibatch was drawn `prefetch` updates ago)
     'env_groups': groups,   # handles the rank's envs are held as (PipelinedVecStackEnv: a group's forward runs under the other's straggler tail)
     'iterations': iters, 'warmup': warm,
     # placements per second, as leg A counts them (the auto-reset call of every episode is stepped and timed but places
@@ -466,7 +469,7 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
     'env_steps_per_s': steps_all / dt_max, 'step_calls_per_s': steps_all / dt_max * iters / max(placed_calls, 1),
     'placement_calls': placed_calls, 'iters_per_s': iters / dt_max, 'ms_per_iter': 1e3 * dt_max / iters,
     'rollout_forward_ms': fwd_ms, 'update_ms': upd_ms, 'allreduce_ms': ar_ms,
-    'grad_bucket_bytes': int(agent._flat_grad.numel() * 4), 'update_graphed': agent._train_graph is not None,
+    'grad_bucket_bytes': int(agent._flat_grad.numel() * 4), 'update_graphed': agent._train_graph is not None or agent._grad_graph is not None,
     'roofline': {
       'kernel': 'Q-net rollout forward (DeepQSiamFCN, {} samples)'.format(B), 'bound': 'mfma',
       'achieved': flops_fwd / (fwd_ms * 1e-3) / 1e12, 'peak': PEAK_TFLOPS[dtype], 'unit': 'TFLOP/s',

@@ -217,6 +217,11 @@ int srl_replay_gather(const int64_t* idx_dev, int32_t mb, int64_t part_len, int6
                       const float* min_logit_dev, uint8_t* state0_dev, uint8_t* state1_dev, uint8_t* next0_dev,
                       uint8_t* next1_dev, int64_t* action_dev, float* reward_dev, uint8_t* terminal_dev,
                       float* weight_dev, void* stream);
+/* Priority trackers of `ReplayMemory` (memory.py:164-177, :282-316): out_v2 = {max logit, min finite logit (+inf if none)},
+ * out_i2 = {lowest index of the max, lowest index of the min (0 if none)} over logits[n].  Two launches with per-block
+ * partials in `scratch` (srl_logit_extrema_scratch_bytes): no cross-workgroup reduction inside a kernel. */
+int64_t srl_logit_extrema_scratch_bytes(void);
+int srl_logit_extrema(const float* logits_dev, int64_t n, float* out_v2_dev, int64_t* out_i2_dev, void* scratch_dev, void* stream);
 const char* srl_learner_last_error(void);
 
 /* ---- update-path convolutions (csrc/train_conv.hip): the forward (with saved activations), data-gradient and
@@ -260,6 +265,17 @@ int srl_tact_bwd(const float* g_dev, int32_t g_stride, int32_t g_off, const floa
  * up to 16 with zero columns so that a thin layer's data gradient has a supported channel count); 2 transposed conv forward
  * [cin][4 cout] (k = q cout + co); 3 transposed conv data gradient [4 cout][cin]. */
 int srl_trepack(const float* flat_dev, float* packed_dev, const int64_t* desc_dev, int32_t nlayers, int64_t total, void* stream);
+/* The dueling head of `DeepQSiamFCN` in the update (models.py:179-192; `tf.GradientTape` through it, agents/dqn.py:466-469):
+ * z [B][A][16] the last position map (channels last, A = O x O), pw[16] / pb[1] the 1 x 1 projection, v[B] the state value:
+ *   srl_thead_fwd:  q[b][p] = (z[b][p][:] . pw + pb) - mean_p(...) + v[b]
+ *   srl_thead_bwd:  for the first n samples, from gq[n][A]: gv[b] = sum_p gq, ga = gq - mean_p gq, gz[b][p][c] = ga pw[c],
+ *                   gpw[c] = sum z ga, gpb = sum ga; scratch: 17 n floats.
+ * One workgroup per sample and fixed-order sums: no cross-workgroup reduction inside a kernel, no atomics (the framework's
+ * multi-block reductions returned garbage under the concurrent env step). */
+int srl_thead_fwd(const float* z_dev, const float* pw_dev, const float* pb_dev, const float* v_dev, float* q_dev, int32_t B,
+                  int32_t A, void* stream);
+int srl_thead_bwd(const float* z_dev, const float* pw_dev, const float* gq_dev, float* gz_dev, float* gv_dev, float* gpw_dev,
+                  float* gpb_dev, float* scratch_dev, int32_t n, int32_t A, void* stream);
 const char* srl_train_conv_last_error(void);
 
 #ifdef __cplusplus

@@ -277,6 +277,46 @@ __global__ void __launch_bounds__(256) k_replay_gather(const int64_t* __restrict
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ priority trackers
+// (max logit, its lowest index) over all rows and (min finite logit, its lowest index; +inf, 0 when there is none) — the two
+// scans `ReplayMemory` needs when a tracked slot was overwritten (memory.py:164-177, :282-316).  Two launches: per-block
+// partials, then one block over them — the sums of the framework's single-launch multi-block reductions are what returned
+// garbage under the concurrent env step; ties go to the lower index.
+struct Ext { float mx; long long imx; float mn; long long imn; };
+__device__ __forceinline__ void ext_take(Ext& a, const Ext& b) {
+  if (b.mx > a.mx || (b.mx == a.mx && b.imx < a.imx)) { a.mx = b.mx; a.imx = b.imx; }
+  if (b.mn < a.mn || (b.mn == a.mn && b.imn < a.imn)) { a.mn = b.mn; a.imn = b.imn; }
+}
+__device__ __forceinline__ Ext ext_block(Ext e, Ext* sh) {
+  sh[threadIdx.x] = e;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) { Ext a = sh[threadIdx.x]; ext_take(a, sh[threadIdx.x + s]); sh[threadIdx.x] = a; }
+    __syncthreads();
+  }
+  return sh[0];
+}
+__global__ void __launch_bounds__(256) k_logit_extrema(const float* __restrict__ logits, long long n, Ext* __restrict__ part) {
+  __shared__ Ext sh[256];
+  Ext e; e.mx = -INFINITY; e.imx = 0x7fffffffffffffffLL; e.mn = INFINITY; e.imn = 0x7fffffffffffffffLL;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = logits[i];
+    Ext o; o.mx = v; o.imx = i; o.mn = (v - v == 0.0f) ? v : INFINITY; o.imn = i;    // finite <=> v - v == 0
+    ext_take(e, o);
+  }
+  const Ext r = ext_block(e, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+__global__ void __launch_bounds__(256) k_logit_extrema_finish(const Ext* __restrict__ part, int nblk, float* __restrict__ out_v,
+                                                              long long* __restrict__ out_i) {
+  __shared__ Ext sh[256];
+  Ext e; e.mx = -INFINITY; e.imx = 0x7fffffffffffffffLL; e.mn = INFINITY; e.imn = 0x7fffffffffffffffLL;
+  if ((int)threadIdx.x < nblk) e = part[threadIdx.x];
+  const Ext r = ext_block(e, sh);
+  if (threadIdx.x == 0) { out_v[0] = r.mx; out_i[0] = r.imx; out_v[1] = r.mn; out_i[1] = r.imn; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -360,6 +400,18 @@ int srl_replay_gather(const int64_t* idx, int32_t mb, int64_t part_len, int64_t 
   hipLaunchKernelGGL(k_replay_gather, dim3(gx, mb), dim3(256), 0, (hipStream_t)stream, idx, part_len, n_steps, (int)literal_next, o_next, m0, m1, bytes0, bytes1, m_reward,
                      m_terminal, m_action, m_logits, alpha, beta, min_logit, o_s0, o_s1, o_n0, o_n1, o_action, o_reward, o_terminal,
                      o_weight);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int64_t srl_logit_extrema_scratch_bytes(void) { return 256 * (int64_t)sizeof(Ext); }
+
+int srl_logit_extrema(const float* logits, int64_t n, float* out_v2, int64_t* out_i2, void* scratch, void* stream) {
+  if (!logits || n < 1 || !out_v2 || !out_i2 || !scratch) return fail("srl_logit_extrema: bad argument");
+  const int nblk = (int)((n + 1023) / 1024 > 256 ? 256 : (n + 1023) / 1024);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_logit_extrema, dim3(nblk), dim3(256), 0, st, logits, (long long)n, (Ext*)scratch);
+  hipLaunchKernelGGL(k_logit_extrema_finish, dim3(1), dim3(256), 0, st, (const Ext*)scratch, nblk, out_v2, (long long*)out_i2);
   HIPCHK(hipGetLastError());
   return 0;
 }

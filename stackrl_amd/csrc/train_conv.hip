@@ -530,6 +530,103 @@ int launch_wrw(const float* x, int xs, int xo, const float* gz, float* partial, 
   return t_finish("srl_twrw");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- dueling head
+// Q(s, .) of `DeepQSiamFCN` from the last position map z [B][A][16] (channels last, A = O x O pixels), the 1 x 1 projection
+// (weight pw[16], bias pb) and the state value v[B] (models.py:179-192): a[b][p] = z[b][p][:] . pw + pb,
+// q[b][p] = a[b][p] - mean_p a[b][.] + v[b].  One workgroup per sample, every sum in a fixed order (per-thread strided
+// partial sums, then a halving tree over the 256 partials): no cross-workgroup reduction, no atomics — the framework's
+// multi-block reductions are what returned garbage under the concurrent env step.
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+#pragma unroll
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  const float r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(256) k_thead_fwd(const float* __restrict__ z, const float* __restrict__ pw,
+                                                   const float* __restrict__ pb, const float* __restrict__ v,
+                                                   float* __restrict__ q, int A) {
+  __shared__ float sh[256];
+  const int b = blockIdx.x;
+  const float4* zb = (const float4*)(z + (long long)b * A * 16);
+  float* qb = q + (long long)b * A;
+  float w[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) w[c] = pw[c];
+  const float bias = pb[0];
+  float s = 0.0f;
+  for (int p = threadIdx.x; p < A; p += 256) {
+    float a = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 t = zb[4 * p + k];
+      a = fmaf(t.x, w[4 * k], a); a = fmaf(t.y, w[4 * k + 1], a); a = fmaf(t.z, w[4 * k + 2], a); a = fmaf(t.w, w[4 * k + 3], a);
+    }
+    a += bias;
+    qb[p] = a;
+    s += a;
+  }
+  const float mean = block_sum_256(s, sh) / (float)A;
+  const float add = v[b] - mean;
+  for (int p = threadIdx.x; p < A; p += 256) qb[p] += add;
+}
+
+// backward of the above for the first n samples: gq[n][A] -> gv[b] = sum_p gq[b][p], ga = gq - mean_p gq,
+// gz[b][p][c] = ga pw[c], and per-sample partials part[b][0..15] = sum_p z[b][p][c] ga, part[b][16] = sum_p ga
+__global__ void __launch_bounds__(256) k_thead_bwd(const float* __restrict__ z, const float* __restrict__ pw,
+                                                   const float* __restrict__ gq, float* __restrict__ gz,
+                                                   float* __restrict__ gv, float* __restrict__ part, int A) {
+  __shared__ float sh[256];
+  const int b = blockIdx.x;
+  const float4* zb = (const float4*)(z + (long long)b * A * 16);
+  float4* gzb = (float4*)(gz + (long long)b * A * 16);
+  const float* gb = gq + (long long)b * A;
+  float w[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) w[c] = pw[c];
+  float s = 0.0f;
+  for (int p = threadIdx.x; p < A; p += 256) s += gb[p];
+  const float tot = block_sum_256(s, sh);
+  if (threadIdx.x == 0) gv[b] = tot;
+  const float mean = tot / (float)A;
+  float acc[17];
+#pragma unroll
+  for (int c = 0; c < 17; ++c) acc[c] = 0.0f;
+  for (int p = threadIdx.x; p < A; p += 256) {
+    const float ga = gb[p] - mean;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 t = zb[4 * p + k];
+      acc[4 * k] = fmaf(t.x, ga, acc[4 * k]); acc[4 * k + 1] = fmaf(t.y, ga, acc[4 * k + 1]);
+      acc[4 * k + 2] = fmaf(t.z, ga, acc[4 * k + 2]); acc[4 * k + 3] = fmaf(t.w, ga, acc[4 * k + 3]);
+      gzb[4 * p + k] = make_float4(ga * w[4 * k], ga * w[4 * k + 1], ga * w[4 * k + 2], ga * w[4 * k + 3]);
+    }
+    acc[16] += ga;
+  }
+#pragma unroll
+  for (int c = 0; c < 17; ++c) {
+    const float r = block_sum_256(acc[c], sh);
+    if (threadIdx.x == 0) part[b * 17 + c] = r;
+  }
+}
+
+// gpw[c] = sum_b part[b][c], gpb = sum_b part[b][16], samples in index order
+__global__ void __launch_bounds__(64) k_thead_finish(const float* __restrict__ part, int n, float* __restrict__ gpw,
+                                                     float* __restrict__ gpb) {
+  const int c = threadIdx.x;
+  if (c > 16) return;
+  float s = 0.0f;
+  for (int b = 0; b < n; ++b) s += part[b * 17 + c];
+  if (c < 16) gpw[c] = s; else gpb[0] = s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -605,6 +702,21 @@ int srl_trepack(const float* flat, float* packed, const int64_t* desc_dev, int32
   hipLaunchKernelGGL(k_trepack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat, packed,
                      (const long long*)desc_dev, nlayers, (long long)total);
   return t_finish("srl_trepack");
+}
+
+int srl_thead_fwd(const float* z, const float* pw, const float* pb, const float* v, float* q, int32_t B, int32_t A, void* stream) {
+  if (!z || !pw || !pb || !v || !q || B < 1 || A < 1) return t_bad("srl_thead_fwd: bad arguments");
+  hipLaunchKernelGGL(k_thead_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, z, pw, pb, v, q, A);
+  return t_finish("srl_thead_fwd");
+}
+
+int srl_thead_bwd(const float* z, const float* pw, const float* gq, float* gz, float* gv, float* gpw, float* gpb,
+                  float* scratch, int32_t n, int32_t A, void* stream) {
+  if (!z || !pw || !gq || !gz || !gv || !gpw || !gpb || !scratch || n < 1 || A < 1) return t_bad("srl_thead_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_thead_bwd, dim3(n), dim3(256), 0, st, z, pw, gq, gz, gv, scratch, A);
+  hipLaunchKernelGGL(k_thead_finish, dim3(1), dim3(64), 0, st, scratch, n, gpw, gpb);
+  return t_finish("srl_thead_bwd");
 }
 
 }  // extern "C"

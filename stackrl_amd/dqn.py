@@ -129,7 +129,7 @@ class DQN(object):
                discount_factor=.99, collect_batch_size=None, exploration_mode=None, exploration=None,
                prioritization=None, priority_bias_compensation=None, double=False, n_step=None, seed=None,
                device=None, process_group=None, policy_op=None, reference_next_index=True,
-               adam_betas=(0.9, 0.999), xcorr=None, graphs=False, hand_convs=None):
+               adam_betas=(0.9, 0.999), xcorr=None, graphs=False, hand_convs=None, early_gradient=False):
     if not isinstance(q_net, torch.nn.Module):
       raise TypeError('Invalid type {} for argument q_net. Must be a torch Module.'.format(type(q_net)))   # dqn.py:122-125
     self.device = torch.device(device) if device is not None else next(q_net.parameters()).device
@@ -237,6 +237,15 @@ class DQN(object):
     self._g_online = GraphedEval(self._q_net) if self._graphs else None
     self._train_graph = None
     self._graph_calls = 0
+    # early_gradient: `train_begin()` starts the gradient half of the next update — target evaluation, forward, loss,
+    # backward, on the minibatch at the head of the prefetch FIFO, which was drawn `prefetch` updates ago and does not depend
+    # on the collect step of this iteration — on a stream of its own, beside the collect step; `train()` then completes the
+    # update (new minibatch into the FIFO, all-reduce, optimiser step, priorities).  Same operations on the same operands in
+    # the same order per tensor as the serial update: identical results (tests/test_learner_gpu.py).  Needs prefetch >= 1.
+    self._early = bool(early_gradient) and self.device.type == 'cuda' and self._prefetch >= 1
+    self._upd_stream = torch.cuda.Stream(device=self.device) if self._early else None
+    self._pending = None                    # outputs of a gradient half started by train_begin()
+    self._grad_graph = self._tail_graph = None
     # the loss and its gradient as one hand-written kernel (csrc/learner.hip) on a HIP device
     self._fused = self.device.type == 'cuda'
     self._ws = {}
@@ -394,26 +403,41 @@ class DQN(object):
     if not k:
       flat = self._draw()
     else:
-      if self._fifo is None:
-        self._fifo = [tuple(None if t is None else t.clone() for t in self._draw()) for _ in range(k)]
-      flat = tuple(None if t is None else t.clone() for t in self._fifo[0])
-      for i in range(k - 1):
-        for dst, src in zip(self._fifo[i], self._fifo[i + 1]):
-          if dst is not None:
-            dst.copy_(src)
-      for dst, src in zip(self._fifo[k - 1], self._draw()):
+      flat = self._peek_minibatch()
+      self._advance_fifo()
+    return self._split_minibatch(flat)
+
+  def _peek_minibatch(self):
+    """A copy of the minibatch at the head of the FIFO (filled with `prefetch` draws on the first call)."""
+    if self._fifo is None:
+      self._fifo = [tuple(None if t is None else t.clone() for t in self._draw()) for _ in range(self._prefetch)]
+    return tuple(None if t is None else t.clone() for t in self._fifo[0])
+
+  def _advance_fifo(self):
+    """The head leaves, a new minibatch is drawn into the tail (slots at fixed addresses: shift copies)."""
+    k = self._prefetch
+    for i in range(k - 1):
+      for dst, src in zip(self._fifo[i], self._fifo[i + 1]):
         if dst is not None:
           dst.copy_(src)
+    for dst, src in zip(self._fifo[k - 1], self._draw()):
+      if dst is not None:
+        dst.copy_(src)
+
+  @staticmethod
+  def _split_minibatch(flat):
     indexes, weights = flat[0], flat[1]
     ns = (len(flat) - 5) // 2
     states, actions, rewards = flat[2:2 + ns], flat[2 + ns], flat[3 + ns]
     next_states, terminal = flat[4 + ns:4 + 2 * ns], flat[4 + 2 * ns]
     return indexes, weights, (states, actions, rewards, next_states, terminal)
 
-  def _forward_backward(self):
+  def _forward_backward(self, peek=False):
     """First half of one minibatch update (dqn.py:397-469): sample, target evaluations, forward, loss, backward into the
-    flat gradient bucket.  Returns (loss, mean TD error, indexes, |TD|, new priorities or None)."""
-    indexes, weights, (states, actions, rewards, next_states, terminal) = self._next_minibatch()
+    flat gradient bucket.  Returns (loss, mean TD error, indexes, |TD|, new priorities or None).
+    peek: take the head of the FIFO and leave the FIFO as it is (`train_begin`; `_advance_fifo` follows in `train`)."""
+    indexes, weights, (states, actions, rewards, next_states, terminal) = \
+      self._split_minibatch(self._peek_minibatch()) if peek else self._next_minibatch()
     if not self._bias_compensation:
       weights = None
     self._last_sample_indexes = indexes
@@ -490,13 +514,87 @@ class DQN(object):
 
   _GRAPH_WARMUP = 3   # eager updates before the capture (library solver search, optimiser state, lazy initialisations)
 
-  def train(self):
+  def train_begin(self):
+    """Start the gradient half of the next update beside the collect step (see `early_gradient`).  Call it before
+    `collect` / `Trainer.collect_step`; `train()` completes the update.  Returns whether anything was started."""
+    if not self._early or self._pending is not None or self._fifo is None:
+      return False                           # (the first update fills the FIFO from the replay memory: serial)
+    if self._graphs and self._grad_graph is None and self._graph_calls < self._GRAPH_WARMUP:
+      return False                           # eager warm-up updates run serially
     if self._hand_t is not None:
-      self._hand_t.refresh_if_stale()        # eagerly, outside any graph: the target net changes only through framework ops
-    if self._graphs:
-      loss, mtd = self._train_graphed()
+      self._hand_t.refresh_if_stale()
+    main, upd = torch.cuda.current_stream(self.device), self._upd_stream
+    self._replay_memory.refresh_schedules()
+    upd.wait_stream(main)                    # the weights of the previous update, the FIFO as the previous train() left it
+    with torch.cuda.stream(upd):
+      if not self._graphs:
+        out = self._forward_backward(peek=True)
+        for t in out:
+          if torch.is_tensor(t):
+            t.record_stream(main)            # allocated on the update stream, consumed by train() on the current one
+      else:
+        if self._grad_graph is None:
+          self._capture_early()
+        self._grad_graph.replay()
+        out = self._graph_out_early
+    self._pending = out
+    return True
+
+  def _capture_early(self):
+    """The early form of the graph-replayed update: one graph for the gradient half (captured and replayed on the update
+    stream), one for the rest (FIFO shift + draw, optimiser step, priorities) on the current stream; with more than one
+    rank the all-reduce sits between them as an ordinary stream-ordered call."""
+    mem = self._replay_memory
+    mem.tensor_schedules = True
+    g_eval, self._graphs = self._graphs, False       # the target evaluations are part of the graph
+    try:
+      g = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g, stream=self._upd_stream, capture_error_mode=CAPTURE_MODE):
+        self._graph_out_early = self._forward_backward(peek=True)
+      self._grad_graph = g
+    finally:
+      self._graphs = g_eval
+
+  def _finish_early(self):
+    loss, mtd, indexes, td_abs, new_logits = self._pending
+    self._pending = None
+    torch.cuda.current_stream(self.device).wait_stream(self._upd_stream)
+    if not self._graphs:
+      self._advance_fifo()
+      if self._world > 1:
+        self._all_reduce()
+      self._apply(indexes, td_abs, new_logits)
+      return loss, mtd
+    mem = self._replay_memory
+    if self._tail_graph is None:
+      g = torch.cuda.CUDAGraph()
+      g.register_generator_state(mem._gen)
+      with torch.cuda.graph(g, pool=self._grad_graph.pool(), capture_error_mode=CAPTURE_MODE):
+        self._advance_fifo()
+      self._fifo_graph = g
+      g2 = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g2, pool=self._grad_graph.pool(), capture_error_mode=CAPTURE_MODE):
+        self._apply(indexes, td_abs, new_logits)
+      self._tail_graph = g2
+    self._fifo_graph.replay()
+    if self._world > 1:
+      self._all_reduce()
+    self._tail_graph.replay()
+    return loss.clone(), mtd.clone()
+
+  def train(self):
+    if self._pending is not None:
+      loss, mtd = self._finish_early()
     else:
-      loss, mtd = self._update()
+      if self._hand_t is not None:
+        self._hand_t.refresh_if_stale()        # eagerly, outside any graph: the target net changes only through framework ops
+      if self._graphs and not (self._early and self._fifo is not None and self._graph_calls >= self._GRAPH_WARMUP):
+        loss, mtd = self._train_graphed()
+      else:
+        if self._graphs:
+          self._replay_memory.refresh_schedules()
+          self._graph_calls += 1
+        loss, mtd = self._update()
     self._iterations += 1
     # consumers that cache re-packed weights (qops.FastFeatures) key on this: a graph replay changes the parameters
     # without bumping any tensor version

@@ -104,6 +104,16 @@ class ReplayMemory(object):
     return float(self._beta(self._iters_counter())) if callable(self._beta) else self._beta
 
   # ------------------------------------------------------------------ add (memory.py:151-196)
+  def _extrema(self):
+    """((index, value) of the max logit, (index, value) of the min finite logit) over the whole memory.  On a HIP device one
+    hand-written two-launch scan (csrc/learner.hip srl_logit_extrema): the framework's single-launch multi-block reductions
+    are what returned garbage under the concurrent env step."""
+    if self._fused and not self.check:
+      from stackrl_amd import qops
+      (mv, mi), (nv, ni) = qops.logit_extrema(self._logits, self._ws)
+      return (mi, mv), (ni, nv)
+    return self._argmax_all(), self._argmin_finite()
+
   def _argmax_all(self):
     v, idx = torch.max(self._logits, dim=0)         # (value, index) in one op: indexing with a device scalar would sync
     return idx, v
@@ -135,12 +145,12 @@ class ReplayMemory(object):
       # tf.reduce_any(index == indexes) (memory.py:164, :168): the tracked slot was just overwritten -> recompute
       hit_max = (self._max_logit_index % L) == slot
       hit_min = (self._min_logit_index % L) == slot
-      i, v = self._argmax_all()
+      (i, v), (i2, v2) = self._extrema()
       self._max_logit_index.copy_(torch.where(hit_max, i, self._max_logit_index))    # in place: the trackers keep
       self._max_logit.copy_(torch.where(hit_max, v, self._max_logit))                # their addresses (hipGraph replay)
       if self.check and bool(hit_min):
         self._argmin_finite()
-      i, v = self._argmin_finite()
+      i, v = i2, v2
       self._min_logit_index.copy_(torch.where(hit_min, i, self._min_logit_index))
       self._min_logit.copy_(torch.where(hit_min, v, self._min_logit))
     # the transition n steps back becomes sampleable unless an episode boundary lies in between (memory.py:181-194)
@@ -224,11 +234,11 @@ class ReplayMemory(object):
     hit_max = (indexes == self._max_logit_index).any()
     hit_min = (indexes == self._min_logit_index).any()
     # memory.py:282-292: a larger maximum replaces the tracker; else if the tracked slot was rewritten, recompute
-    ri, rv = self._argmax_all()
+    (ri, rv), (ri2, rv2) = self._extrema()
     ge = max_logit >= self._max_logit
     self._max_logit_index.copy_(torch.where(ge, imax, torch.where(hit_max, ri, self._max_logit_index)))
     self._max_logit.copy_(torch.where(ge, max_logit, torch.where(hit_max, rv, self._max_logit)))
-    ri, rv = self._argmin_finite()                                 # memory.py:298-316
+    ri, rv = ri2, rv2                                              # memory.py:298-316
     le = min_logit <= self._min_logit
     self._min_logit_index.copy_(torch.where(le, imin, torch.where(hit_min, ri, self._min_logit_index)))
     self._min_logit.copy_(torch.where(le, min_logit, torch.where(hit_min, rv, self._min_logit)))

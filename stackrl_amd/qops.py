@@ -90,6 +90,10 @@ def load():
     L.srl_replay_scatter.argtypes = [VP, VP, I64, I64, VP, VP, VP, I32, I64, I64] + [VP] * 6 + [VP]
     L.srl_replay_gather.restype = ctypes.c_int
     L.srl_replay_gather.argtypes = [VP, I32, I64, I64, I32, VP, VP, VP, I64, I64] + [VP] * 15 + [VP]
+    L.srl_logit_extrema_scratch_bytes.restype = I64
+    L.srl_logit_extrema_scratch_bytes.argtypes = []
+    L.srl_logit_extrema.restype = ctypes.c_int
+    L.srl_logit_extrema.argtypes = [VP, I64, VP, VP, VP, VP]
     L.srl_learner_last_error.restype = ctypes.c_char_p
     _LIB = L
   return _LIB
@@ -839,6 +843,19 @@ def replay_scatter(state, reward, terminal, action, slot, part_len, mem_states, 
     _lchk(load().srl_replay_scatter(s0.data_ptr(), s1.data_ptr(), b0, b1, r.data_ptr(), t.data_ptr(), a.data_ptr(), B, int(slot),
                                     int(part_len), mem_states[0].data_ptr(), mem_states[1].data_ptr(), mem_reward.data_ptr(),
                                     mem_terminal.data_ptr(), mem_action.data_ptr(), mem_logits.data_ptr(), _stream(s0)))
+
+
+def logit_extrema(logits, ws):
+  """(max logit, its lowest index), (min finite logit, its lowest index) as four 0-dim tensors (`ReplayMemory`'s tracker
+  scans, memory.py:164-177, :282-316).  ws: a dict the caller keeps (scratch at a fixed address: hipGraph replay)."""
+  dev = logits.device
+  if 'ext' not in ws:
+    ws['ext'] = torch.empty(int(load().srl_logit_extrema_scratch_bytes()), dtype=torch.uint8, device=dev)
+  v = torch.empty(2, dtype=torch.float32, device=dev)
+  i = torch.empty(2, dtype=torch.int64, device=dev)
+  with torch.cuda.device(dev):
+    _lchk(load().srl_logit_extrema(logits.data_ptr(), logits.numel(), v.data_ptr(), i.data_ptr(), ws['ext'].data_ptr(), _stream(logits)))
+  return (v[0], i[0]), (v[1], i[1])
 
 
 def replay_gather(idx, part_len, n_steps, literal_next, mem_states, mem_reward, mem_terminal, mem_action, mem_logits,

@@ -40,6 +40,10 @@ def _lib():
     L.srl_tact_bwd.argtypes = [VP, I32, I32, VP, I32, I32, VP, VP, VP, VP] + [I32] * 6 + [VP]
     L.srl_trepack.restype = ctypes.c_int
     L.srl_trepack.argtypes = [VP, VP, VP, I32, I64, VP]
+    L.srl_thead_fwd.restype = ctypes.c_int
+    L.srl_thead_fwd.argtypes = [VP, VP, VP, VP, VP, I32, I32, VP]
+    L.srl_thead_bwd.restype = ctypes.c_int
+    L.srl_thead_bwd.argtypes = [VP] * 8 + [I32, I32, VP]
     L.srl_train_conv_last_error.restype = ctypes.c_char_p
     L._train_conv_ready = True
   return L
@@ -331,29 +335,41 @@ class HandNet(object):
     cin = Act(corr.reshape(B, O, O, 1))
     z1 = self._conv(net.pos[0], cin)
     z2 = self._conv(net.pos[2], z1)
-    # the 1 x 1 projection, the dueling head (models.py:179-192): small dense ops, left to the framework
-    z2t = z2.t.detach().requires_grad_(save)
+    # the 1 x 1 projection and the dueling combination (models.py:179-192): one hand-written pass per sample (srl_thead_fwd);
+    # the value MLP on the pooled bottom map — two small dense layers — stays with the framework
     x0t = x0.t.detach().requires_grad_(save)
     with torch.set_grad_enabled(save):
-      pw, pb = net.pos[4].weight.reshape(-1), net.pos[4].bias
-      a = (z2t * pw).sum(dim=-1).reshape(B, O * O) + pb
-      v = net.value(x0t.mean(dim=(1, 2)))
-      q = a - a.mean(dim=-1, keepdim=True) + v
+      v = net.value(x0t.mean(dim=(1, 2)))                                                          # [B, 1]
+    pw, pb = net.pos[4].weight.detach().reshape(-1), net.pos[4].bias.detach()
+    q = torch.empty((B, O * O), dtype=torch.float32, device=xm.device)
+    with torch.cuda.device(q.device):
+      _chk(_lib().srl_thead_fwd(z2.t.data_ptr(), pw.data_ptr(), pb.data_ptr(), v.detach().reshape(-1).contiguous().data_ptr(),
+                                q.data_ptr(), B, O * O, qops._stream(q)))
     if save:
-      self.saved = dict(tape_l=tape_l, tape_r=tape_r, fl=fl, fr=fr, xl_n=xl_n, xr_n=xr_n, cin=cin, z1=z1, z2=z2, z2t=z2t,
-                        x0t=x0t, q=q, x0=x0, B=B, O=O)
-    return q.detach() if not save else q
+      self.saved = dict(tape_l=tape_l, tape_r=tape_r, fl=fl, fr=fr, xl_n=xl_n, xr_n=xr_n, cin=cin, z1=z1, z2=z2, v=v,
+                        x0t=x0t, x0=x0, B=B, O=O)
+    return q
 
   def backward(self, grad_q):
     """Gradients of sum(q[:n] * grad_q) wrt every parameter, written into `p.grad` (n = grad_q.shape[0] <= the saved batch)."""
     S, net = self.saved, self.net
     n = int(grad_q.shape[0])
-    gq = grad_q
-    if n < S['B']:
-      gq = torch.cat([grad_q, torch.zeros((S['B'] - n,) + tuple(grad_q.shape[1:]), dtype=grad_q.dtype, device=grad_q.device)])
-    S['q'].backward(gq)                          # head: value MLP and projection gradients, z2.grad, x0.grad
     O = S['O']
-    g = self._layer_bwd(net.pos[2], S['z1'], S['z2'], Act(S['z2t'].grad[:n]), n)
+    A = O * O
+    dev = grad_q.device
+    z2 = S['z2'].t                                                      # [B, O, O, 16], contiguous
+    pj = net.pos[4]
+    for p_ in (pj.weight, pj.bias):
+      if p_.grad is None:
+        p_.grad = torch.zeros_like(p_)
+    gz2 = torch.empty((n, O, O, 16), dtype=torch.float32, device=dev)
+    gv = torch.zeros((S['B'], 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+      _chk(_lib().srl_thead_bwd(z2.data_ptr(), pj.weight.detach().reshape(-1).data_ptr(), grad_q.contiguous().data_ptr(),
+                                gz2.data_ptr(), gv.data_ptr(), pj.weight.grad.data_ptr(), pj.bias.grad.data_ptr(),
+                                self.scratch.get('head', 17 * n, dev).data_ptr(), n, A, qops._stream(gz2)))
+    S['v'].backward(gv)                          # value MLP gradients and x0.grad (dense layers: framework)
+    g = self._layer_bwd(net.pos[2], S['z1'], S['z2'], Act(gz2), n)
     g = self._layer_bwd(net.pos[0], S['cin'], S['z1'], g, n)                     # [n, O, O, 16], channel 0 = d / d corr
     gcorr = g.t[..., 0].contiguous()                                             # [n, O, O]
     kh = int(S['xr_n'].shape[-1])

@@ -174,6 +174,7 @@ class Trainer(object):
       for _ in range(max_num_iters):
         t0 = time.perf_counter()
         with self._collect_timer:
+          getattr(agent, 'train_begin', bool)()  # DQN(early_gradient=True): the gradient half of the update runs beside the collect step
           step = self.collect_step(env, step)   # non-blocking: the settle/render kernels overlap the update below
         t1 = time.perf_counter()
         with self._train_timer:

@@ -860,3 +860,61 @@ def test_groupwise_collection_equals_one_collect(ref_pool):
   for p, q in zip(a[1], b[1]):
     assert torch.equal(p, q)
   assert a[6] == b[6]
+
+
+@pytest.mark.parametrize('graphs', [False, True])
+def test_early_gradient_equals_the_serial_update(ref_pool, graphs):
+  """`DQN(early_gradient=True)`: the gradient half of an update (target evaluation, forward, loss, backward on the minibatch
+  at the head of the prefetch FIFO) runs on its own stream beside the collect step, the rest (new minibatch into the FIFO,
+  optimiser step, priorities) after it.  Same operands, same operations: losses, sampled indexes, priorities and weights are
+  those of the serial update, bit for bit — eager and replayed from hipGraphs, through a target sync."""
+  from stackrl_amd import env as envs, nets, qops
+  from stackrl_amd.dqn import DQN, PolynomialDecay
+  from stackrl_amd.training import Trainer
+  B, L = 64, 3
+  runs = []
+  for early in (False, True):
+    env = envs.make('Stack-v0', n_parallel=B, seed=5, pool=ref_pool, episode_length=L, side_stream=True)
+    net = nets.DeepQSiamFCN(env.observation_spec, seed=2).cuda()
+    agent = DQN(net, learning_rate=6.25e-5, adam_betas=(0.95, 0.95), minibatch_size=8, replay_memory_size=B * 8,
+                discount_factor=.966667, collect_batch_size=B, exploration=0.5, prioritization=0.6, target_update_period=4,
+                priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=9,
+                policy_op=qops.FusedPolicy(fast=True), xcorr='bf16x3', prefetch=2, graphs=graphs, early_gradient=early)
+    assert agent._early == early
+    tr = Trainer(env, agent)
+    tr.initialize(num_steps=2)
+    losses = tr.run(11)
+    started = agent._grad_graph is not None if graphs else None
+    mem = agent._replay_memory
+    runs.append((losses.clone(), [p.detach().clone() for p in net.parameters()], [p.detach().clone() for p in agent._target_q_net.parameters()],
+                 mem._logits.clone(), mem._actions.clone(), agent._last_sample_indexes.clone(), started))
+    env.close()
+  a, b = runs
+  assert b[6] in (None, True), 'the early form of the graph was never captured'
+  assert torch.equal(a[4], b[4]), 'actions'
+  assert torch.equal(a[0], b[0]), 'losses {} vs {}'.format(a[0].tolist(), b[0].tolist())
+  assert torch.equal(a[5], b[5]) and torch.equal(a[3], b[3]), 'sampled indexes / priorities'
+  for p, q in zip(a[1] + a[2], b[1] + b[2]):
+    assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize('n', [5, 1024, 65536, 300001])
+def test_logit_extrema_matches_torch(n):
+  """srl_logit_extrema (the replay memory's tracker scans, memory.py:164-177, :282-316): max logit and min FINITE logit with
+  their lowest indexes, against torch — with unsampleable rows (-inf), ties, and a memory without any finite row."""
+  from stackrl_amd import qops
+  g = torch.Generator(device='cuda').manual_seed(n)
+  x = torch.randn(n, generator=g, device='cuda')
+  x[torch.rand(n, generator=g, device='cuda') < 0.3] = -math.inf
+  x[n // 2] = x[n - 1] = 7.5                     # a tie at the maximum
+  x[1] = x[n // 3] = -9.25                       # a tie at the minimum
+  ws = {}
+  for t in (x, torch.full((n,), -math.inf, device='cuda')):
+    (mv, mi), (nv, ni) = qops.logit_extrema(t, ws)
+    assert float(mv) == float(t.max()) and int(mi) == int((t == t.max()).nonzero()[0, 0])
+    fin = torch.isfinite(t)
+    if bool(fin.any()):
+      ref = t[fin].min()
+      assert float(nv) == float(ref) and int(ni) == int((t == ref).nonzero()[0, 0])
+    else:
+      assert float(nv) == math.inf and int(ni) == 0
