@@ -378,8 +378,6 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
   groups = args.dqn_groups if args.dqn_groups else 2
   if groups > 1:
     kw['groups'] = groups
-  if os.environ.get('SRL_ENV_PRIO'):      # experiment: priority of the env streams
-    kw['stream_priority'] = int(os.environ['SRL_ENV_PRIO'])
   env = envs.make('Stack-v0', n_parallel=B, seed=args.seed, pool=pool, episode_length=L, side_stream=True,
                   env_index_offset=rank * B, **kw)
   net = nets.DeepQSiamFCN(env.observation_spec, seed=1).cuda()
