@@ -679,7 +679,7 @@ class DQN(object):
       self._gen.set_state(d['gen'].cpu())
     if 'replay_memory' in d:
       self._replay_memory.load_state_dict(d['replay_memory'])
-      if self._fifo is not None and self._train_graph is None:
+      if self._fifo is not None and self._train_graph is None and self._grad_graph is None:
         self._fifo = None                      # minibatches drawn from the memory that was just replaced
       elif self._fifo is not None:             # (a captured update reads the slots at their addresses: refill in place)
         for slot in self._fifo:
