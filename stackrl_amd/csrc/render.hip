@@ -65,7 +65,11 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_codec_table(DevParams P,
 // world-frame render plane of one face: z = a x + b y + c; w = 0 up-facing (z_hi = min), 1 down-facing
 // (z_lo = max).  |n_z| is clamped to >= 1e-6: a vertical face becomes a plane of enormous slope that never
 // limits z on its inner side and empties the interval on its outer side.
+#if SRL_BISECT & 4
+SRL_HELPER(2) float4 make_rplane(float4 pl, const m3& R, v3 x) {
+#else
 __device__ __forceinline__ float4 make_rplane(float4 pl, const m3& R, v3 x) {
+#endif
   v3 nw = mmul(R, V(pl.x, pl.y, pl.z));
   float dw = pl.w + dot(nw, x);
   float nz = nw.z;

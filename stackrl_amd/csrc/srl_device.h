@@ -50,11 +50,25 @@ __device__ __forceinline__ m3 ldm(const float* p) {
   for (int i = 0; i < 9; ++i) R.m[i] = p[i];
   return R;
 }
+// Diagnostic builds: -DSRL_BISECT=<bits> compiles single helpers without any optimisation, i.e.
+// without the SLP vectoriser's packed code, to find which one a concurrency-dependent result comes from.
+#ifndef SRL_BISECT
+#define SRL_BISECT 0
+#endif
+#define SRL_HELPER(bit) __device__ __attribute__((noinline, optnone))
+#if SRL_BISECT & 2
+SRL_HELPER(1) v3 mmul(const m3& R, v3 a) {
+#else
 __device__ __forceinline__ v3 mmul(const m3& R, v3 a) {
+#endif
   return V(fmaf(R.m[0], a.x, fmaf(R.m[1], a.y, R.m[2] * a.z)), fmaf(R.m[3], a.x, fmaf(R.m[4], a.y, R.m[5] * a.z)),
            fmaf(R.m[6], a.x, fmaf(R.m[7], a.y, R.m[8] * a.z)));
 }
+#if SRL_BISECT & 2
+SRL_HELPER(1) v3 mmul_add(const m3& R, v3 a, v3 x) {   // x + R * a
+#else
 __device__ __forceinline__ v3 mmul_add(const m3& R, v3 a, v3 x) {   // x + R * a
+#endif
   return V(fmaf(R.m[0], a.x, fmaf(R.m[1], a.y, fmaf(R.m[2], a.z, x.x))),
            fmaf(R.m[3], a.x, fmaf(R.m[4], a.y, fmaf(R.m[5], a.z, x.y))),
            fmaf(R.m[6], a.x, fmaf(R.m[7], a.y, fmaf(R.m[8], a.z, x.z))));
@@ -63,7 +77,11 @@ __device__ __forceinline__ v3 mtmul(const m3& R, v3 a) {
   return V(fmaf(R.m[0], a.x, fmaf(R.m[3], a.y, R.m[6] * a.z)), fmaf(R.m[1], a.x, fmaf(R.m[4], a.y, R.m[7] * a.z)),
            fmaf(R.m[2], a.x, fmaf(R.m[5], a.y, R.m[8] * a.z)));
 }
+#if SRL_BISECT & 1
+SRL_HELPER(0) m3 quat_to_mat(q4 q) {
+#else
 __device__ __forceinline__ m3 quat_to_mat(q4 q) {
+#endif
   float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
   float xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
   float wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;

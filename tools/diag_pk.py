@@ -19,6 +19,21 @@ filler = torch.randn(2048, 2048, device='cuda')
 with torch.no_grad():
   ff.pos(C); ff((xm, xo))
 torch.cuda.synchronize()
+PP = ctypes.CDLL(os.path.join(here, 'experiments', 'pk_partial.so'))
+PP.pk_partial.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+for gap in (0, 1):
+  for load in ('none', 'pos', 'ff', 'none'):
+    bad.zero_(); torch.cuda.synchronize()
+    side.wait_stream(torch.cuda.current_stream())
+    for _ in range(3):
+      PP.pk_partial(100000, 2048, gap, ctypes.c_void_p(side.cuda_stream), ctypes.c_void_p(bad.data_ptr()), ctypes.c_void_p(sink.data_ptr()))
+    with torch.no_grad():
+      for _ in range(40):
+        if load == 'pos': ff.pos(C)
+        elif load == 'ff': ff((xm, xo))
+    torch.cuda.synchronize()
+    print('halves from two scalar instructions, gap', gap, 'load', load, ': packed results that differ from the scalar ones:', int(bad.item()), flush=True)
+if os.environ.get('ONLY_PARTIAL'): sys.exit(0)
 V.pk_victim_dead.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
 for junk in (0x00000001, 0x7fa00000, 0x7f800000, 0xffffffff, 0x00400000, 0x80000001):
   for load in ('none', 'pos', 'ff'):
