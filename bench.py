@@ -15,7 +15,8 @@ Workloads (BASELINE.json `configs`):
          K timed steps (auto-reset calls, env.py:235-236, are stepped and timed but are not placements).  Weak scaling:
          every rank owns its own 1,024 envs; envs are independent (utils.py:424-448), no data-path collective.
   leg B  the DQN configs — rollout (Q-net forward on every env) + one minibatch-32 update per iteration
-         (training.py:338-380), reported under "dqn": configs[2] (4,096 envs x 16 rocks) at N = 1, configs[3]'s per-GPU
+         (training.py:338-380; the rank's envs as two handles served as their steps finish, the update's gradient half
+         beside the collect step: `env_groups`, `update_early_gradient` in the line), reported under "dqn": configs[2] (4,096 envs x 16 rocks) at N = 1, configs[3]'s per-GPU
          shard (2,048 x 16) at N = 2 / 4, configs[4]'s (2,048 x 32 rocks, 64 x 64 maps) at N = 8; the one collective is
          the RCCL all-reduce of the flat gradient bucket.  Rollout in fp32-class precision (bf16x3 products) and, as a second
          labelled entry, bf16.  `--config 2|3|4` makes that leg the headline `value` instead.
@@ -36,6 +37,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# Leg B keeps five HIP streams busy per rank (current, two env groups, the update's gradient half, RCCL's own); HIP
+# multiplexes streams over GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on one queue run their kernels one
+# after the other — a settle launch of tens of milliseconds in front of the forward.  A documented ROCm knob, read when the
+# runtime initialises: set here, before anything touches the GPU, unless the caller chose a value.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E (MI355X_MICROARCH.md)
 # dense MFMA peaks, same guide.  The fp32-class rollout computes every product as three bf16 MFMAs (hi hi + hi lo + lo hi,
