@@ -679,7 +679,9 @@ def test_fused_epilogue_net_matches_the_module_graph():
   assert float((q1 - q0).abs().max()) <= 1e-5 * float(q0.abs().max())
   for n, p in net.named_parameters():
     scale = max(float(ref[n].abs().max()), 1e-6)
-    assert float((p.grad - ref[n]).abs().max()) <= 1e-3 * scale, n
+    # 3e-3: both sides run the library's atomically accumulating weight-gradient kernels; 1.3e-3 of the scale was seen
+    # between two runs on a deep layer (left.down.3.0.weight) with nothing else changed
+    assert float((p.grad - ref[n]).abs().max()) <= 3e-3 * scale, n
 
 
 def test_update_stays_finite_under_the_concurrent_env_step():
