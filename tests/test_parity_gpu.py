@@ -346,7 +346,7 @@ def test_pipelined_env_equals_one_handle_and_the_oracle(ref_pool, oracle_mod):
   from stackrl_amd.config import StackConfig
   B, L, seed = 12, 12, 31
   a = envs.make('Stack-v0', n_parallel=B, seed=seed, pool=ref_pool, episode_length=L)
-  p = envs.make('Stack-v0', n_parallel=B, seed=seed, pool=ref_pool, episode_length=L, groups=3, concurrent_envs=4096)
+  p = envs.make('Stack-v0', n_parallel=B, seed=seed, pool=ref_pool, episode_length=L, groups=(2, 4, 6), concurrent_envs=4096)   # unequal groups
   q = envs.make('Stack-v0', n_parallel=B, seed=seed, pool=ref_pool, episode_length=L, groups=2)
   o = oracle_mod.OracleEnv(StackConfig(n_envs=B, episode_length=L), ref_pool, seed=seed)
   assert p.groups == 3 and p.batch_size == B and p.n_actions == a.n_actions
