@@ -383,19 +383,22 @@ def test_pipelined_env_equals_one_handle_and_the_oracle(ref_pool, oracle_mod):
     e.close()
 
 
-def test_env_step_under_the_concurrent_rollout_forward_equals_the_oracle(oracle_mod):
+@pytest.mark.parametrize('B,L,episodes,hint', [(512, 3, 2, None), (256, 8, 1, None), (96, 16, 1, 4096)])
+def test_env_step_under_the_concurrent_rollout_forward_equals_the_oracle(oracle_mod, B, L, episodes, hint):
   """The training loop steps the envs on a side stream while the Q-net's kernels run on the current one; the env's results
-  must not depend on that.  512 envs x 3 rocks over two episodes, every step in flight while the rollout forward (the
-  hand-written convolutions, the cross-correlation, the policy head) runs beside it, against the oracle in lock step: bytes,
-  rewards, poses, sub-step counts and height maps bit for bit.
+  must not depend on that.  512 envs x 3 rocks over two episodes (and 8 rocks; 16 rocks on the throughput-oriented settle
+  build, `concurrent_envs`), every step in flight while the rollout forward (the hand-written convolutions, the
+  cross-correlation, the policy head) runs beside it, against the oracle in lock step: bytes, rewards, poses, sub-step
+  counts and height maps bit for bit.
   This is the reproduction of round 2's "concurrency anomalies" (DESIGN.md section 6a): built with clang's SLP vectoriser
   (packed-fp32 code in the settle kernel) the env returned results that differ from the oracle's in 20 - 50 env steps of
   these 4,096 — only under this concurrency, never alone; csrc is built with -fno-slp-vectorize since (stackrl_amd/build.py)."""
   from stackrl_amd import assets, env as envs, nets, qops
   from stackrl_amd.config import StackConfig
-  B, L, seed = 512, 3, 5
+  seed = 5
   pool = assets.default_pool()
-  e = envs.make('Stack-v0', n_parallel=B, seed=seed, pool=pool, episode_length=L, side_stream=True)
+  e = envs.make('Stack-v0', n_parallel=B, seed=seed, pool=pool, episode_length=L, side_stream=True,
+                **({} if hint is None else dict(concurrent_envs=hint)))
   o = oracle_mod.OracleEnv(StackConfig(n_envs=B, episode_length=L), pool, seed=seed)
   net = nets.DeepQSiamFCN(e.observation_spec, seed=2).cuda()
   pol = qops.FusedPolicy(chunk=256, fast=True)
@@ -403,12 +406,13 @@ def test_env_step_under_the_concurrent_rollout_forward_equals_the_oracle(oracle_
   step = e.reset()()
   o.reset()
   bad = []
-  for t in range(2 * (L + 1)):
+  for t in range(episodes * (L + 1)):
     a = e.sample()
     ao = o.sample()
     assert np.array_equal(a.cpu().numpy(), ao)
     w = e.step(a, block=False)
-    pol(net, step[0], 1.0, gen)             # the forward on the previous observation, while the step is in flight
+    for _ in range(max(1, 512 // B)):
+      pol(net, step[0], 1.0, gen)             # the forward on the previous observation, while the step is in flight
     step = w()
     (om, oo), r, d = step
     (omo, ooo), ro, do = o.step(ao)
