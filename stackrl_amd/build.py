@@ -10,10 +10,14 @@ SOURCES = ['stackrl_hip.hip']
 DEPS = ['stackrl_hip.hip', 'settle.hip', 'render.hip', 'srl_device.h', 'srl_kernels.h',
         os.path.join('..', '..', 'include', 'stackrl_hip.h'), os.path.join('..', '..', 'include', 'srl_types.h')]
 # -ffp-contract=off: the solver/rasteriser definition is "one IEEE rounding per written operation"
-# -fno-slp-vectorize: with the SLP vectoriser's packed-fp32 code (v_pk_fma / v_pk_mul / v_pk_add_f32, v_mov_b64) the settle
-#   kernel returned, in a few envs per thousand, results that differ from the oracle's — but only while convolution kernels of
-#   the Q-net ran on another stream; alone it was bit-exact.  Without it no difference was ever seen (DESIGN.md section 6a,
-#   tests/diag/diag_conc.py, tests/test_parity_gpu.py::test_env_step_under_the_concurrent_rollout_forward...); speed is the same.
+# -fno-slp-vectorize: on gfx950 a packed-fp32 instruction whose LOW lane takes the HIGH half of its second source
+#   (v_pk_add_f32 / v_pk_mul_f32 ... op_sel:[x,1]) reads 0 for that operand now and then while wavefronts of an MFMA kernel
+#   share the CU (tools/experiments/pk_seq2.hip reproduces it in 30 lines).  clang's SLP vectoriser
+#   emits exactly that form when it packs scalars that sit in different halves of their pairs; with it the settle and render
+#   kernels returned results that differ from the oracle's in a few envs per thousand steps, only beside the Q-net's
+#   convolution kernels.  Without the vectoriser neither library contains the form (tests/test_isa_guard.py checks the
+#   ISA); the hand-written packed FMAs of the ray cast select halves of their FIRST source only, which is not affected.
+#   Speed: settle -3.4 %, everything else unchanged.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-fno-slp-vectorize',
          '-fno-fast-math', '-Wall', '-Wno-unused-function', '-Wno-unused-value', '-Wno-unused-result']
 
@@ -30,7 +34,8 @@ QSRC = ['qnet.hip', 'heuristics.hip', 'xcorr_mfma.hip', 'epilogue.hip', 'conv_mf
         'train_conv.hip']
 QDEPS = QSRC + [ os.path.join('..', '..', 'include', 'stackrl_qnet.h')]
 # the Q-net ops are ordinary fp32 kernels compared against a torch fp32 reference with a stated tolerance
-QFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wall', '-Wno-unused-function',
+# (-fno-slp-vectorize: see above; it costs the Q-net's kernels nothing measurable — 20.6 against 20.8 ms per 2,048-sample forward)
+QFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-slp-vectorize', '-Wall', '-Wno-unused-function',
           '-Wno-unused-value', '-Wno-unused-result']
 
 

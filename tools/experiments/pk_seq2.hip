@@ -1,0 +1,91 @@
+// Which ingredient of the failing sequence (pk_seq.hip) matters?  Packed producers with an SGPR-pair source write v[32:33];
+// three wait states later one packed consumer reads v[0:1] and v[32:33]; both lanes are compared with scalar subtracts / adds
+// of the same registers.  Consumer C: 0 half-swapped + negated source, 1 half-swapped only, 2 negated only, 3 plain,
+// 4 = form 0 with v[32:33] written by two 32-bit moves instead of a packed instruction, 5 = form 0 with VGPR-pair sources in
+// the producers instead of SGPR pairs, 6 first source half-swapped, 7 / 8 low / high half of the second source for both
+// lanes, 9 the ray cast's hand-written fma form (high half of the first source for both lanes), 10 multiply half-swapped.
+// hipcc --offload-arch=gfx950 -O2 -fno-slp-vectorize -shared -fPIC -o pk_seq2.so pk_seq2.hip
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#define PROD_SGPR "v_pk_mul_f32 v[10:11], v[10:11], s[28:29]\n v_pk_add_f32 v[32:33], v[10:11], s[30:31] neg_lo:[1,0] neg_hi:[1,0]\n"
+#define PROD_VGPR "v_mov_b32 v20, s28\n v_mov_b32 v21, s29\n v_mov_b32 v22, s30\n v_mov_b32 v23, s31\n s_nop 2\n v_pk_mul_f32 v[10:11], v[10:11], v[20:21]\n v_pk_add_f32 v[32:33], v[10:11], v[22:23] neg_lo:[1,0] neg_hi:[1,0]\n"
+#define PROD_MOV  "v_mul_f32 v10, v10, s28\n v_mul_f32 v11, v11, s29\n s_nop 2\n v_sub_f32 v32, s30, v10\n v_sub_f32 v33, s31, v11\n"
+#define TAIL "s_nop 7\n v_cmp_ne_u32 vcc, v40, v34\n v_cndmask_b32 %0, 0, 1, vcc\n v_cmp_ne_u32 vcc, v41, v35\n v_cndmask_b32 v42, 0, 1, vcc\n v_or_b32 %0, %0, v42\n"
+#define HEAD "v_mov_b32 v0, %1\n v_mov_b32 v1, %2\n v_mov_b32 v10, %3\n v_mov_b32 v11, %4\n s_mov_b32 s28, %5\n s_mov_b32 s29, %6\n s_mov_b32 s30, %7\n s_mov_b32 s31, %8\n s_nop 4\n"
+#define OPS : "=&v"(bad) : "v"(a0), "v"(a1), "v"(x0), "v"(x1), "s"(k0), "s"(k1), "s"(o0), "s"(o1) \
+            : "v0", "v1", "v10", "v11", "v20", "v21", "v22", "v23", "v32", "v33", "v34", "v35", "v40", "v41", "v42", "s28", "s29", "s30", "s31", "vcc"
+#define HEAD5 "v_mov_b32 v0, %5\n v_mov_b32 v1, %6\n v_mov_b32 v10, %7\n v_mov_b32 v11, %8\n s_mov_b32 s28, %9\n s_mov_b32 s29, %10\n s_mov_b32 s30, %11\n s_mov_b32 s31, %12\n s_nop 4\n"
+#define OPS2 : "=&v"(bad) : "v"(a0), "v"(a1), "v"(x0), "v"(x1), "s"(k0), "s"(k1), "s"(o0), "s"(o1) \
+            : "v0", "v1", "v10", "v11", "v32", "v33", "v34", "v35", "v40", "v41", "v42", "v43", "v44", "s28", "s29", "s30", "s31", "vcc"
+template <int C>
+__device__ __forceinline__ uint32_t seq(float a0, float a1, float x0, float x1, float k0, float k1, float o0, float o1) {
+  uint32_t bad;
+  if (C == 0)
+    asm volatile(HEAD PROD_SGPR "s_nop 3\n v_pk_add_f32 v[34:35], v[0:1], v[32:33] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n s_nop 7\n v_sub_f32 v40, v0, v33\n v_sub_f32 v41, v1, v32\n" TAIL OPS);
+  else if (C == 1)   // (+ bit 1: the low lane holds v0 + v32, what the instruction returns when its half selection is ignored;
+                     //    bit 2: the high lane is wrong)
+    asm volatile(HEAD PROD_SGPR "s_nop 3\n v_pk_add_f32 v[34:35], v[0:1], v[32:33] op_sel:[0,1] op_sel_hi:[1,0]\n s_nop 7\n v_add_f32 v40, v0, v33\n v_add_f32 v41, v1, v32\n"
+                 "v_add_f32 v43, v0, v32\n" TAIL
+                 "v_cmp_ne_u32 vcc, v40, v34\n v_cndmask_b32 v44, 0, 1, vcc\n v_cmp_eq_u32 vcc, v43, v34\n v_cndmask_b32 v42, 0, 2, vcc\n v_and_b32 v42, v42, v44\n v_lshlrev_b32 v42, 1, v42\n v_and_b32 v42, 2, v42\n"
+                 "v_or_b32 %0, %0, v42\n v_cmp_ne_u32 vcc, v41, v35\n v_cndmask_b32 v42, 0, 4, vcc\n v_or_b32 %0, %0, v42\n" OPS2);
+  else if (C == 2)
+    asm volatile(HEAD PROD_SGPR "s_nop 3\n v_pk_add_f32 v[34:35], v[0:1], v[32:33] neg_lo:[0,1] neg_hi:[0,1]\n s_nop 7\n v_sub_f32 v40, v0, v32\n v_sub_f32 v41, v1, v33\n" TAIL OPS);
+  else if (C == 3)
+    asm volatile(HEAD PROD_SGPR "s_nop 3\n v_pk_add_f32 v[34:35], v[0:1], v[32:33]\n s_nop 7\n v_add_f32 v40, v0, v32\n v_add_f32 v41, v1, v33\n" TAIL OPS);
+  else if (C == 4)
+    asm volatile(HEAD PROD_MOV "s_nop 3\n v_pk_add_f32 v[34:35], v[0:1], v[32:33] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n s_nop 7\n v_sub_f32 v40, v0, v33\n v_sub_f32 v41, v1, v32\n" TAIL OPS);
+  else if (C == 6)   // first source half-swapped
+    asm volatile(HEAD PROD_SGPR "s_nop 3\n v_pk_add_f32 v[34:35], v[32:33], v[0:1] op_sel:[1,0] op_sel_hi:[0,1]\n s_nop 7\n v_add_f32 v40, v33, v0\n v_add_f32 v41, v32, v1\n" TAIL OPS);
+  else if (C == 7)   // broadcast of the low half of the second source
+    asm volatile(HEAD PROD_SGPR "s_nop 3\n v_pk_add_f32 v[34:35], v[0:1], v[32:33] op_sel_hi:[1,0]\n s_nop 7\n v_add_f32 v40, v0, v32\n v_add_f32 v41, v1, v32\n" TAIL OPS);
+  else if (C == 8)   // broadcast of the high half of the second source
+    asm volatile(HEAD PROD_SGPR "s_nop 3\n v_pk_add_f32 v[34:35], v[0:1], v[32:33] op_sel:[0,1]\n s_nop 7\n v_add_f32 v40, v0, v33\n v_add_f32 v41, v1, v33\n" TAIL OPS);
+  else if (C == 9)   // the ray cast's hand-written form: fma, the high half of the first source for both lanes
+    asm volatile(HEAD PROD_SGPR "s_nop 3\n v_pk_fma_f32 v[34:35], v[32:33], v[0:1], v[0:1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n s_nop 7\n v_fma_f32 v40, v33, v0, v0\n v_fma_f32 v41, v33, v1, v1\n" TAIL OPS);
+  else if (C == 10)  // packed multiply, second source half-swapped
+    asm volatile(HEAD PROD_SGPR "s_nop 3\n v_pk_mul_f32 v[34:35], v[0:1], v[32:33] op_sel:[0,1] op_sel_hi:[1,0]\n s_nop 7\n v_mul_f32 v40, v0, v33\n v_mul_f32 v41, v1, v32\n" TAIL OPS);
+  else
+    asm volatile(HEAD PROD_VGPR "s_nop 3\n v_pk_add_f32 v[34:35], v[0:1], v[32:33] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n s_nop 7\n v_sub_f32 v40, v0, v33\n v_sub_f32 v41, v1, v32\n" TAIL OPS);
+  return bad;
+}
+
+// form 1 once more, returning the registers so that the host can look at a failing case
+__device__ __forceinline__ void seq1_debug(float a0, float a1, float x0, float x1, float k0, float k1, float o0, float o1, float* r) {
+  float p_lo, p_hi, s_lo, v32_, v33_;
+  asm volatile(HEAD5 PROD_SGPR "s_nop 3\n v_pk_add_f32 v[34:35], v[0:1], v[32:33] op_sel:[0,1] op_sel_hi:[1,0]\n s_nop 7\n v_add_f32 v40, v0, v33\n"
+               "v_mov_b32 %0, v34\n v_mov_b32 %1, v35\n v_mov_b32 %2, v40\n v_mov_b32 %3, v32\n v_mov_b32 %4, v33\n"
+               : "=&v"(p_lo), "=&v"(p_hi), "=&v"(s_lo), "=&v"(v32_), "=&v"(v33_)
+               : "v"(a0), "v"(a1), "v"(x0), "v"(x1), "s"(k0), "s"(k1), "s"(o0), "s"(o1), "v"(0), "v"(0), "v"(0)
+               : "v0", "v1", "v10", "v11", "v32", "v33", "v34", "v35", "v40", "s28", "s29", "s30", "s31");
+  r[0] = p_lo; r[1] = p_hi; r[2] = s_lo; r[3] = v32_; r[4] = v33_;
+}
+
+extern "C" __global__ void __launch_bounds__(128, 2) k_pk_seq2(int iters, uint32_t* bad, float* sink) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t n[13] = {0};
+  float a0 = 1.0f + 1e-3f * (float)(t & 1023), a1 = 0.5f + 2e-3f * (float)(t & 511);
+  for (int i = 0; i < iters; ++i) {
+    const float x0 = (float)((t + 3 * i) & 255), x1 = (float)((t + 7 * i) & 127);
+    n[0] += seq<0>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
+    { const uint32_t r = seq<1>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f); n[1] += r & 1u; n[11] += (r >> 1) & 1u; n[12] += (r >> 2) & 1u; }
+    n[2] += seq<2>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
+    n[3] += seq<3>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
+    n[4] += seq<4>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
+    n[5] += seq<5>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
+    n[6] += seq<6>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
+    n[7] += seq<7>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
+    n[8] += seq<8>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
+    n[9] += seq<9>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
+    n[10] += seq<10>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
+    { float r[5]; seq1_debug(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f, r);
+      if (__float_as_uint(r[0]) != __float_as_uint(r[2]) && atomicAdd(bad + 15, 1u) == 0u) {
+        sink[8] = a0; sink[9] = a1; sink[10] = r[3]; sink[11] = r[4]; sink[12] = r[0]; sink[13] = r[1]; sink[14] = r[2]; } }
+    a0 = 1.0f + 1e-3f * (float)((t + i) & 1023); a1 = 0.5f + 2e-3f * (float)((t ^ i) & 511);
+  }
+  for (int f = 0; f < 13; ++f) if (n[f]) atomicAdd(bad + f, n[f]);
+  if (a0 == 12345.0f) sink[0] = a0 + a1;
+}
+extern "C" int pk_seq2(int iters, int blocks, void* stream, void* bad, void* sink) {
+  hipLaunchKernelGGL(k_pk_seq2, dim3(blocks), dim3(128), 0, (hipStream_t)stream, iters, (uint32_t*)bad, (float*)sink);
+  return (int)hipGetLastError();
+}
