@@ -10,16 +10,62 @@ SOURCES = ['stackrl_hip.hip']
 DEPS = ['stackrl_hip.hip', 'settle.hip', 'render.hip', 'srl_device.h', 'srl_kernels.h',
         os.path.join('..', '..', 'include', 'stackrl_hip.h'), os.path.join('..', '..', 'include', 'srl_types.h')]
 # -ffp-contract=off: the solver/rasteriser definition is "one IEEE rounding per written operation"
-# -fno-slp-vectorize: on gfx950 a packed-fp32 instruction whose LOW lane takes the HIGH half of its second source
-#   (v_pk_add_f32 / v_pk_mul_f32 ... op_sel:[x,1]) reads 0 for that operand now and then while wavefronts of an MFMA kernel
-#   share the CU (tools/experiments/pk_seq2.hip reproduces it in 30 lines).  clang's SLP vectoriser
-#   emits exactly that form when it packs scalars that sit in different halves of their pairs; with it the settle and render
-#   kernels returned results that differ from the oracle's in a few envs per thousand steps, only beside the Q-net's
-#   convolution kernels.  Without the vectoriser neither library contains the form (tests/test_isa_guard.py checks the
-#   ISA); the hand-written packed FMAs of the ray cast select halves of their FIRST source only, which is not affected.
-#   Speed: settle -3.4 %, everything else unchanged.
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-fno-slp-vectorize',
+# The packed-fp32 erratum: on gfx950 a v_pk_add_f32 / v_pk_mul_f32 whose LOW lane takes the HIGH half
+#   of its SECOND source (op_sel:[x,1]) reads 0 for that operand now and then while wavefronts of an MFMA kernel share the CU
+#   (tools/experiments/pk_seq2.hip reproduces it in 30 lines).  clang's SLP vectoriser emits exactly that form when it packs
+#   scalars that sit in different halves of their pairs; with it the settle and render kernels returned results that differ
+#   from the oracle's in a few envs per thousand steps, only beside the Q-net's convolution kernels.  The env library is
+#   therefore built in steps: device assembly (vectoriser on: it is worth 3.4 % of the settle kernel), `isa_fix.rewrite`
+#   (the two commuting sources of every flagged instruction swapped — the same selection on the FIRST source is clean),
+#   assembler, code object, fat binary, host object, link: what hipcc does in one go, with the pass in the middle.  If any step
+#   fails the library is built in one go WITHOUT the vectoriser instead (FLAGS_SAFE: no flagged instruction either, slower).
+#   tests/test_isa_guard.py checks the compiled ISA of every source file of both libraries.
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
          '-fno-fast-math', '-Wall', '-Wno-unused-function', '-Wno-unused-value', '-Wno-unused-result']
+FLAGS_SAFE = FLAGS + ['-fno-slp-vectorize']
+LLVM_BIN = os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'lib', 'llvm', 'bin')
+DEPS = DEPS + [os.path.join('..', 'isa_fix.py'), os.path.join('..', 'build.py')]
+
+
+def device_asm(hipcc, flags, src):
+  """gfx950 assembly of one source file, compiled with `flags` (no GPU needed)."""
+  keep = [f for f in flags if f not in ('-shared', '-fPIC')]
+  return subprocess.run([hipcc] + keep + ['--cuda-device-only', '-S', '-w', '-o', '-', src], check=True,
+                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, universal_newlines=True).stdout
+
+
+def fixed_env_asm(hipcc):
+  """The env library's device assembly after the rewrite; raises if a flagged instruction is left."""
+  from stackrl_amd import isa_fix
+  text, n, left = isa_fix.rewrite(device_asm(hipcc, FLAGS, os.path.join(CSRC, SOURCES[0])))
+  bad = isa_fix.flagged(text)
+  if left or bad:
+    raise RuntimeError('{} packed instructions of the failing form could not be rewritten: {}'.format(left or len(bad), bad[:3]))
+  return text, n
+
+
+def _build_env_fixed(hipcc, verbose):
+  import tempfile
+  src = os.path.join(CSRC, SOURCES[0])
+  with tempfile.TemporaryDirectory() as tmp:
+    def run(cmd):
+      if verbose:
+        print(' '.join(cmd), file=sys.stderr)
+      subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL if not verbose else None)
+    text, n = fixed_env_asm(hipcc)
+    asm, obj, co, fb, host = (os.path.join(tmp, f) for f in ('dev.s', 'dev.o', 'dev.out', 'dev.hipfb', 'host.o'))
+    with open(asm, 'w') as f:
+      f.write(text)
+    run([os.path.join(LLVM_BIN, 'clang'), '-x', 'assembler', '-target', 'amdgcn-amd-amdhsa', '-mcpu=gfx950', '-c', asm, '-o', obj])
+    run([os.path.join(LLVM_BIN, 'lld'), '-flavor', 'gnu', '-m', 'elf64_amdgpu', '--no-undefined', '-shared', '-o', co, obj])
+    run([os.path.join(LLVM_BIN, 'clang-offload-bundler'), '-type=o', '-bundle-align=4096',
+         '-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950', '-input=/dev/null', '-input=' + co, '-output=' + fb])
+    run([hipcc] + [f for f in FLAGS if f != '-shared'] + ['--cuda-host-only', '-Xclang', '-fcuda-include-gpubinary', '-Xclang', fb,
+                                                         '-c', src, '-o', host])
+    run([hipcc, '-shared', '-fPIC', host, '-o', LIB + '.tmp'])
+    os.replace(LIB + '.tmp', LIB)
+  if verbose:
+    print('env library: {} packed instructions rewritten'.format(n), file=sys.stderr)
 
 
 def stale():
@@ -49,10 +95,16 @@ def qstale():
 def build(force=False, verbose=False):
   hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
   if force or stale():
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
-    if verbose:
-      print(' '.join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    try:
+      if os.environ.get('SRL_BUILD_SAFE'):
+        raise RuntimeError('SRL_BUILD_SAFE is set')
+      _build_env_fixed(hipcc, verbose)
+    except Exception as e:       # any step of the long way round: the plain build without the vectoriser (same results, slower)
+      print('stackrl_amd.build: env library built without the SLP vectoriser ({})'.format(str(e)[:200]), file=sys.stderr)
+      cmd = [hipcc] + FLAGS_SAFE + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
+      if verbose:
+        print(' '.join(cmd), file=sys.stderr)
+      subprocess.check_call(cmd)
   if force or qstale():
     cmd = [hipcc] + QFLAGS + [os.path.join(CSRC, f) for f in QSRC] + ['-o', QLIB]
     if verbose:

@@ -1,0 +1,63 @@
+"""Work-around for the packed-fp32 instruction form that misbehaves on gfx950 beside MFMA wavefronts.
+
+A `v_pk_add_f32` / `v_pk_mul_f32` / `v_pk_fma_f32` whose LOW lane takes the HIGH half of its SECOND source (`op_sel:[x,1..]`)
+reads 0 for that operand now and then while wavefronts of an MFMA kernel share the CU (tools/experiments/pk_seq2.hip).  The same
+selection on the FIRST source is clean (same experiment), and the first two sources of all three instructions commute, so the
+form is removed from compiled assembly by swapping the two sources together with their modifier bits — the instruction
+computes the same lanes from the same registers.  `rewrite` does that on the text of a gfx950 assembly file; `flagged` lists
+what is (still) there.  Used by build.py on the env library (which is compiled with clang's SLP vectoriser, the producer of the
+form) and by tests/test_isa_guard.py."""
+import re
+
+_INSN = re.compile(r'^(\s*)(v_pk_(?:add|mul|fma)_f32)\s+([^;]*?)(\s*;.*)?$')
+_MOD = re.compile(r'\b(op_sel|op_sel_hi|neg_lo|neg_hi):\[([01,]+)\]')
+BAD = re.compile(r'^\s*(v_pk_(?:add|mul|fma)_f32)\b.*\bop_sel:\[[01],1')
+_ORDER = ('op_sel', 'op_sel_hi', 'neg_lo', 'neg_hi')
+
+
+def flagged(text):
+  """[(line number, kernel label, instruction)] of the instructions of the failing form in an assembly text."""
+  out, label = [], None
+  for i, line in enumerate(text.splitlines(), 1):
+    if line and not line[0].isspace() and line.endswith(':') and not line.startswith('.'):
+      label = line[:-1]
+    if BAD.match(line):
+      out.append((i, label, line.strip()))
+  return out
+
+
+def _fix(line):
+  m = _INSN.match(line)
+  if not m:
+    return line, False
+  indent, op, rest, comment = m.groups()
+  mm = _MOD.search(rest)
+  operands = [o.strip() for o in (rest[:mm.start()] if mm else rest).strip().rstrip(',').split(',')]
+  nsrc = len(operands) - 1
+  mods = {k: [int(x) for x in v.split(',')] for k, v in _MOD.findall(rest)}
+  sel = mods.get('op_sel')
+  if nsrc < 2 or sel is None or len(sel) < 2 or sel[1] != 1:
+    return line, False
+  if sel[0] == 1:
+    return line, None                      # both sources select their high half for the low lane: a swap does not help
+  if any(len(v) != nsrc for v in mods.values()):
+    return line, None
+  operands[1], operands[2] = operands[2], operands[1]
+  for v in mods.values():
+    v[0], v[1] = v[1], v[0]
+  default = {'op_sel': [0] * nsrc, 'op_sel_hi': [1] * nsrc, 'neg_lo': [0] * nsrc, 'neg_hi': [0] * nsrc}
+  tail = ' '.join('%s:[%s]' % (k, ','.join(map(str, mods[k]))) for k in _ORDER if k in mods and mods[k] != default[k])
+  return '%s%s %s%s%s' % (indent, op, ', '.join(operands), (' ' + tail) if tail else '', comment or ''), True
+
+
+def rewrite(text):
+  """(new text, number rewritten, number that could not be rewritten)."""
+  out, n, left = [], 0, 0
+  for line in text.split('\n'):
+    new, done = _fix(line)
+    if done:
+      n += 1
+    elif done is None:
+      left += 1
+    out.append(new)
+  return '\n'.join(out), n, left

@@ -2,50 +2,54 @@
 
 Found in round 3 (tools/experiments/pk_seq2.hip is the 30-line reproduction): a packed-fp32
 instruction whose LOW lane takes the HIGH half of its SECOND source — `v_pk_add_f32` / `v_pk_mul_f32` (and, not ruled out,
-`v_pk_fma_f32`) with `op_sel:[x,1...]` — reads 0 for that operand in about 2 of 10,000 executions while wavefronts of an
-MFMA kernel share the CU, and never alone.  clang's SLP vectoriser emits the form; both libraries are built without it
-(stackrl_amd/build.py).  This test compiles every source to gfx950 assembly with the product's flags (no GPU needed) and
-greps the ISA, so that a later flag or compiler change cannot bring the form back unnoticed."""
+`v_pk_fma_f32`) with `op_sel:[x,1...]` — reads 0 for that operand in 2 - 4 of 10,000 executions while wavefronts of an MFMA
+kernel share the CU, and never alone.  clang's SLP vectoriser emits the form.  The env library is compiled with the
+vectoriser and a pass over its assembly that swaps the two (commuting) sources of every such instruction
+(stackrl_amd/isa_fix.py; the same selection on the first source is clean); the Q-net library is built without the
+vectoriser.  This test compiles every source to gfx950 assembly the way stackrl_amd/build.py does (no GPU needed) and checks
+the ISA, so that a later flag, compiler or source change cannot bring the form back unnoticed."""
 import os
-import re
-import subprocess
 from concurrent.futures import ThreadPoolExecutor
 
-from stackrl_amd import build
+from stackrl_amd import build, isa_fix
 
-# second entry of op_sel = the second source's half for the LOW lane
-BAD = re.compile(r'^\s*(v_pk_(?:add|mul|fma)_f32)\b.*\bop_sel:\[[01],1')
-
-
-def _asm(args):
-  flags, src = args
-  keep = [f for f in flags if f not in ('-shared', '-fPIC')]
-  out = subprocess.run([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')] + keep + ['--cuda-device-only', '-S', '-w', '-o', '-', src],
-                       check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
-  hits, kernel = [], None
-  for line in out.splitlines():
-    if line and not line[0].isspace() and line.endswith(':') and not line.startswith('.'):
-      kernel = line[:-1]
-    if BAD.match(line):
-      hits.append((os.path.basename(src), kernel, line.strip()))
-  return hits, out.count('v_pk_')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 
 
 def test_no_kernel_contains_the_packed_form_that_fails_beside_mfma_wavefronts():
-  jobs = [(build.FLAGS, os.path.join(build.CSRC, s)) for s in build.SOURCES]
-  jobs += [(build.QFLAGS, os.path.join(build.CSRC, s)) for s in build.QSRC]
+  jobs = [lambda: build.fixed_env_asm(HIPCC)[0],                                                      # the product's env library
+          lambda: build.device_asm(HIPCC, build.FLAGS_SAFE, os.path.join(build.CSRC, build.SOURCES[0]))]   # and its fall-back build
+  jobs += [(lambda s=s: build.device_asm(HIPCC, build.QFLAGS, os.path.join(build.CSRC, s))) for s in build.QSRC]
   with ThreadPoolExecutor(max_workers=6) as ex:
-    res = list(ex.map(_asm, jobs))
-  hits = [h for r in res for h in r[0]]
-  assert not hits, 'packed instructions that take the high half of their second source for the low lane: {}'.format(hits[:8])
-  # the scan saw real code: the ray cast's hand-written packed FMAs (halves of the FIRST source only) are still there
-  assert res[0][1] > 50
+    texts = list(ex.map(lambda f: f(), jobs))
+  names = ['env (vectorised + rewritten)', 'env (fall-back)'] + build.QSRC
+  for name, text in zip(names, texts):
+    hits = isa_fix.flagged(text)
+    assert not hits, '{}: packed instructions that take the high half of their second source for the low lane: {}'.format(name, hits[:5])
+  # the scan saw real code: the vectorised env library is full of packed instructions, the ray cast's hand-written ones
+  # (halves of the FIRST source only) are in the fall-back build too
+  assert texts[0].count('v_pk_') > 1000 and texts[1].count('v_pk_') > 50
 
 
-def test_the_guard_recognises_the_form():
-  assert BAD.match('\tv_pk_add_f32 v[34:35], v[0:1], v[32:33] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]')
-  assert BAD.match('\tv_pk_fma_f32 v[114:115], v[112:113], s[4:5], v[114:115] op_sel:[0,1,0]')
-  assert BAD.match('\tv_pk_mul_f32 v[34:35], v[0:1], v[32:33] op_sel:[1,1]')
-  assert not BAD.match('\tv_pk_fma_f32 v[8:9], v[6:7], v[24:25], v[8:9] op_sel:[1,0,0] op_sel_hi:[1,1,0]')   # first source only
-  assert not BAD.match('\tv_pk_mul_f32 v[8:9], v[20:21], v[8:9] op_sel_hi:[0,1]')
-  assert not BAD.match('\tv_pk_add_f32 v[50:51], v[52:53], v[50:51] neg_lo:[0,1] neg_hi:[0,1]')
+def test_the_vectoriser_does_emit_the_form_and_the_pass_removes_all_of_it():
+  raw = build.device_asm(HIPCC, build.FLAGS, os.path.join(build.CSRC, build.SOURCES[0]))
+  assert len(isa_fix.flagged(raw)) > 100          # (955 with the compiler of this image)
+  text, n, left = isa_fix.rewrite(raw)
+  assert n == len(isa_fix.flagged(raw)) and left == 0 and not isa_fix.flagged(text)
+  # nothing but the flagged lines changes
+  assert sum(a != b for a, b in zip(raw.split('\n'), text.split('\n'))) == n
+
+
+def test_the_rewrite_swaps_sources_and_modifier_bits():
+  f = isa_fix._fix
+  assert f('\tv_pk_add_f32 v[34:35], v[0:1], v[32:33] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]') == \
+      ('\tv_pk_add_f32 v[34:35], v[32:33], v[0:1] op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,0]', True)
+  assert f('\tv_pk_fma_f32 v[114:115], v[112:113], s[4:5], v[114:115] op_sel:[0,1,0] ; c') == \
+      ('\tv_pk_fma_f32 v[114:115], s[4:5], v[112:113], v[114:115] op_sel:[1,0,0] ; c', True)
+  assert f('\tv_pk_mul_f32 v[2:3], v[2:3], v[8:9] op_sel:[0,1]')[0] == '\tv_pk_mul_f32 v[2:3], v[8:9], v[2:3] op_sel:[1,0]'
+  assert f('\tv_pk_mul_f32 v[34:35], v[0:1], v[32:33] op_sel:[1,1]')[1] is None                     # a swap cannot help
+  for clean in ('\tv_pk_fma_f32 v[8:9], v[6:7], v[24:25], v[8:9] op_sel:[1,0,0] op_sel_hi:[1,1,0]',    # first source only
+                '\tv_pk_mul_f32 v[8:9], v[20:21], v[8:9] op_sel_hi:[0,1]',
+                '\tv_pk_add_f32 v[50:51], v[52:53], v[50:51] neg_lo:[0,1] neg_hi:[0,1]',
+                '\tv_add_f32_e32 v1, v2, v3'):
+    assert f(clean) == (clean, False) and not isa_fix.BAD.match(clean)
