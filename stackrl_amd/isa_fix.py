@@ -1,17 +1,20 @@
 """Work-around for the packed-fp32 instruction form that misbehaves on gfx950 beside MFMA wavefronts.
 
-A `v_pk_add_f32` / `v_pk_mul_f32` / `v_pk_fma_f32` whose LOW lane takes the HIGH half of its SECOND source (`op_sel:[x,1..]`)
-reads 0 for that operand now and then while wavefronts of an MFMA kernel share the CU (tools/experiments/pk_seq2.hip).  The same
-selection on the FIRST source is clean (same experiment), and the first two sources of all three instructions commute, so the
-form is removed from compiled assembly by swapping the two sources together with their modifier bits — the instruction
-computes the same lanes from the same registers.  `rewrite` does that on the text of a gfx950 assembly file; `flagged` lists
+A `v_pk_add_f32` / `v_pk_mul_f32` / `v_pk_fma_f32` whose LOW lane takes the HIGH half of its SECOND source (`op_sel:[x,1..]`) —
+or, for the fma, of its addend (`op_sel:[x,x,1]`) — reads 0 for that operand now and then while wavefronts of an MFMA kernel
+share the CU (tools/experiments/pk_seq2.hip).  The same selection on the FIRST source is clean (same experiment), and the
+first two sources of all three instructions commute, so the second-source form is removed from compiled assembly by swapping
+the two sources together with their modifier bits — the instruction computes the same lanes from the same registers.  (An
+addend with the selection cannot be repaired that way: `rewrite` reports it and build.py falls back to the build without the
+vectoriser; the compiler of this image emits none.)  `rewrite` does that on the text of a gfx950 assembly file; `flagged` lists
 what is (still) there.  Used by build.py on the env library (which is compiled with clang's SLP vectoriser, the producer of the
 form) and by tests/test_isa_guard.py."""
 import re
 
 _INSN = re.compile(r'^(\s*)(v_pk_(?:add|mul|fma)_f32)\s+([^;]*?)(\s*;.*)?$')
 _MOD = re.compile(r'\b(op_sel|op_sel_hi|neg_lo|neg_hi):\[([01,]+)\]')
-BAD = re.compile(r'^\s*(v_pk_(?:add|mul|fma)_f32)\b.*\bop_sel:\[[01],1')
+# second entry of op_sel = 1 (the second source's high half for the LOW lane), or the third (the fma's addend): both fail
+BAD = re.compile(r'^\s*(v_pk_(?:add|mul|fma)_f32)\b.*\bop_sel:\[(?:[01],1|[01],[01],1)')
 _ORDER = ('op_sel', 'op_sel_hi', 'neg_lo', 'neg_hi')
 
 
@@ -36,7 +39,11 @@ def _fix(line):
   nsrc = len(operands) - 1
   mods = {k: [int(x) for x in v.split(',')] for k, v in _MOD.findall(rest)}
   sel = mods.get('op_sel')
-  if nsrc < 2 or sel is None or len(sel) < 2 or sel[1] != 1:
+  if nsrc < 2 or sel is None or len(sel) < 2:
+    return line, False
+  if len(sel) > 2 and sel[2] == 1:
+    return line, None                      # the addend selects its high half for the low lane: no commuting partner
+  if sel[1] != 1:
     return line, False
   if sel[0] == 1:
     return line, None                      # both sources select their high half for the low lane: a swap does not help

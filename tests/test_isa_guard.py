@@ -1,8 +1,8 @@
 """No kernel of either library may contain the instruction form that misbehaves on gfx950 beside MFMA wavefronts.
 
 Found in round 3 (tools/experiments/pk_seq2.hip is the 30-line reproduction): a packed-fp32
-instruction whose LOW lane takes the HIGH half of its SECOND source — `v_pk_add_f32` / `v_pk_mul_f32` (and, not ruled out,
-`v_pk_fma_f32`) with `op_sel:[x,1...]` — reads 0 for that operand in 2 - 4 of 10,000 executions while wavefronts of an MFMA
+instruction whose LOW lane takes the HIGH half of its SECOND source — `v_pk_add_f32` / `v_pk_mul_f32` / `v_pk_fma_f32` with
+`op_sel:[x,1...]`, and the fma's addend likewise (`op_sel:[x,x,1]`) — reads 0 for that operand in 2 - 4 of 10,000 executions while wavefronts of an MFMA
 kernel share the CU, and never alone.  clang's SLP vectoriser emits the form.  The env library is compiled with the
 vectoriser and a pass over its assembly that swaps the two (commuting) sources of every such instruction
 (stackrl_amd/isa_fix.py; the same selection on the first source is clean); the Q-net library is built without the
@@ -48,6 +48,8 @@ def test_the_rewrite_swaps_sources_and_modifier_bits():
       ('\tv_pk_fma_f32 v[114:115], s[4:5], v[112:113], v[114:115] op_sel:[1,0,0] ; c', True)
   assert f('\tv_pk_mul_f32 v[2:3], v[2:3], v[8:9] op_sel:[0,1]')[0] == '\tv_pk_mul_f32 v[2:3], v[8:9], v[2:3] op_sel:[1,0]'
   assert f('\tv_pk_mul_f32 v[34:35], v[0:1], v[32:33] op_sel:[1,1]')[1] is None                     # a swap cannot help
+  bad_addend = '\tv_pk_fma_f32 v[34:35], v[0:1], v[0:1], v[32:33] op_sel:[0,0,1] op_sel_hi:[1,1,0]'    # the addend fails as well
+  assert f(bad_addend)[1] is None and isa_fix.BAD.match(bad_addend) and isa_fix.rewrite(bad_addend)[2] == 1
   for clean in ('\tv_pk_fma_f32 v[8:9], v[6:7], v[24:25], v[8:9] op_sel:[1,0,0] op_sel_hi:[1,1,0]',    # first source only
                 '\tv_pk_mul_f32 v[8:9], v[20:21], v[8:9] op_sel_hi:[0,1]',
                 '\tv_pk_add_f32 v[50:51], v[52:53], v[50:51] neg_lo:[0,1] neg_hi:[0,1]',

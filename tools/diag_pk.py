@@ -21,7 +21,7 @@ with torch.no_grad():
 torch.cuda.synchronize()
 PS2 = ctypes.CDLL(os.path.join(here, 'experiments', 'pk_seq2.so'))
 PS2.pk_seq2.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-bad8 = torch.zeros(16, dtype=torch.int32, device='cuda'); sink = torch.zeros(16, device='cuda')
+bad8 = torch.zeros(24, dtype=torch.int32, device='cuda'); sink = torch.zeros(16, device='cuda')
 for load in ('none', 'ff', 'none'):
   bad8.zero_(); torch.cuda.synchronize()
   side.wait_stream(torch.cuda.current_stream())
@@ -31,7 +31,7 @@ for load in ('none', 'ff', 'none'):
     for _ in range(60):
       if load == 'ff': ff((xm, xo))
   torch.cuda.synchronize()
-  print('consumer [0 swap+neg, 1 swap, 2 neg, 3 plain, 4 swap+neg after 32-bit producers, 5 swap+neg after packed producers with VGPR sources, 6 swap of src0, 7 low half of src1 for both, 8 high half of src1 for both, 9 fma high half of src0 for both, 10 mul swap] load', load, ': mismatches', bad8[:11].tolist(), '; of form 1: low lane = the UNSWAPPED sum', int(bad8[11]), ', high lane wrong', int(bad8[12]), '; SGPR pair with its high half for the low lane: as FIRST source', int(bad8[13]), ', as SECOND source', int(bad8[14]), flush=True)
+  print('consumer [0 swap+neg, 1 swap, 2 neg, 3 plain, 4 swap+neg after 32-bit producers, 5 swap+neg after packed producers with VGPR sources, 6 swap of src0, 7 low half of src1 for both, 8 high half of src1 for both, 9 fma high half of src0 for both, 10 mul swap] load', load, ': mismatches', bad8[:11].tolist(), '; of form 1: low lane = the UNSWAPPED sum', int(bad8[11]), ', high lane wrong', int(bad8[12]), '; SGPR pair with its high half for the low lane: as FIRST source', int(bad8[13]), ', as SECOND source', int(bad8[14]), '; packed fma with the second source half-swapped', int(bad8[16]), ', with the addend half-swapped', int(bad8[17]), flush=True)
   if int(bad8[15]):
     x = sink[8:15].tolist(); print('   a failing case of form 1: v[0:1] =', x[0:2], 'v[32:33] =', x[2:4], 'packed result (lo, hi) =', x[4:6], 'expected lo = v0 + v33 =', x[6], '; v0 + v32 =', x[0] + x[2], flush=True)
 if os.environ.get('ONLY_SEQ2'): sys.exit(0)

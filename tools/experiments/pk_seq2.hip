@@ -46,6 +46,10 @@ __device__ __forceinline__ uint32_t seq(float a0, float a1, float x0, float x1, 
     asm volatile(HEAD PROD_SGPR "s_nop 3\n v_pk_mul_f32 v[34:35], s[30:31], v[0:1] op_sel:[1,0]\n s_nop 7\n v_mul_f32 v40, s31, v0\n v_mul_f32 v41, s31, v1\n" TAIL OPS);
   else if (C == 12)  // the same operand as the SECOND source (the compiler's original form)
     asm volatile(HEAD PROD_SGPR "s_nop 3\n v_pk_mul_f32 v[34:35], v[0:1], s[30:31] op_sel:[0,1]\n s_nop 7\n v_mul_f32 v40, s31, v0\n v_mul_f32 v41, s31, v1\n" TAIL OPS);
+  else if (C == 13)  // packed fma, second source half-swapped
+    asm volatile(HEAD PROD_SGPR "s_nop 3\n v_pk_fma_f32 v[34:35], v[0:1], v[32:33], v[0:1] op_sel:[0,1,0] op_sel_hi:[1,0,1]\n s_nop 7\n v_fma_f32 v40, v0, v33, v0\n v_fma_f32 v41, v1, v32, v1\n" TAIL OPS);
+  else if (C == 14)  // packed fma, the ADDEND half-swapped
+    asm volatile(HEAD PROD_SGPR "s_nop 3\n v_pk_fma_f32 v[34:35], v[0:1], v[0:1], v[32:33] op_sel:[0,0,1] op_sel_hi:[1,1,0]\n s_nop 7\n v_fma_f32 v40, v0, v0, v33\n v_fma_f32 v41, v1, v1, v32\n" TAIL OPS);
   else if (C == 10)  // packed multiply, second source half-swapped
     asm volatile(HEAD PROD_SGPR "s_nop 3\n v_pk_mul_f32 v[34:35], v[0:1], v[32:33] op_sel:[0,1] op_sel_hi:[1,0]\n s_nop 7\n v_mul_f32 v40, v0, v33\n v_mul_f32 v41, v1, v32\n" TAIL OPS);
   else
@@ -66,7 +70,7 @@ __device__ __forceinline__ void seq1_debug(float a0, float a1, float x0, float x
 
 extern "C" __global__ void __launch_bounds__(128, 2) k_pk_seq2(int iters, uint32_t* bad, float* sink) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t n[15] = {0};
+  uint32_t n[18] = {0};
   float a0 = 1.0f + 1e-3f * (float)(t & 1023), a1 = 0.5f + 2e-3f * (float)(t & 511);
   for (int i = 0; i < iters; ++i) {
     const float x0 = (float)((t + 3 * i) & 255), x1 = (float)((t + 7 * i) & 127);
@@ -83,12 +87,14 @@ extern "C" __global__ void __launch_bounds__(128, 2) k_pk_seq2(int iters, uint32
     n[10] += seq<10>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
     n[13] += seq<11>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
     n[14] += seq<12>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
+    n[16] += seq<13>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
+    n[17] += seq<14>(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f);
     { float r[5]; seq1_debug(a0, a1, x0, x1, 1e-3f, 3e-3f, 0.75f, 1.25f, r);
       if (__float_as_uint(r[0]) != __float_as_uint(r[2]) && atomicAdd(bad + 15, 1u) == 0u) {
         sink[8] = a0; sink[9] = a1; sink[10] = r[3]; sink[11] = r[4]; sink[12] = r[0]; sink[13] = r[1]; sink[14] = r[2]; } }
     a0 = 1.0f + 1e-3f * (float)((t + i) & 1023); a1 = 0.5f + 2e-3f * (float)((t ^ i) & 511);
   }
-  for (int f = 0; f < 15; ++f) if (n[f]) atomicAdd(bad + f, n[f]);
+  for (int f = 0; f < 18; ++f) if (n[f]) atomicAdd(bad + f, n[f]);
   if (a0 == 12345.0f) sink[0] = a0 + a1;
 }
 extern "C" int pk_seq2(int iters, int blocks, void* stream, void* bad, void* sink) {
