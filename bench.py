@@ -62,6 +62,8 @@ def parse_args(argv=None):
   ap.add_argument('--res', type=int, default=128, choices=[64, 128], help='leg A: overhead map side')
   ap.add_argument('--solver', default='pybullet', help="solver definition: 'pybullet' (default) or 'bullet10'")
   ap.add_argument('--seed', type=int, default=11)
+  ap.add_argument('--launch-order', default='auto', choices=['auto', 'index', 'ordered'],
+                  help='settle workgroups take the envs in index order, highest release first, or by batch size (srl_set_launch_order)')
   ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline / reward-MSE legs')
   ap.add_argument('--no-dqn', action='store_true', help='skip leg B')
   ap.add_argument('--dqn-iters', type=int, default=None, help='leg B: timed iterations (default: one whole episode, L + 1 calls)')
@@ -261,6 +263,8 @@ def env_leg(args, rank, world, pool, barrier, solver_kw):
   kw = dict(solver_kw)
   if args.res == 64:
     kw['resolution_factor'] = 4
+  if args.launch_order != 'auto':
+    kw['launch_order'] = args.launch_order == 'ordered'
   env = envs.VecStackEnv(n_parallel=B, seed=args.seed, pool=pool, block=False, episode_length=L,
                          env_index_offset=rank * B, **kw)
   phase = {'k': 0}   # lock-step bookkeeping: calls since reset(): 1..L placements, L+1 auto-reset
@@ -382,6 +386,8 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
   kw = dict(solver_kw)
   if res == 64:
     kw['resolution_factor'] = 4
+  if args.launch_order != 'auto':
+    kw['launch_order'] = args.launch_order == 'ordered'
   groups = args.dqn_groups if args.dqn_groups else 2
   if groups > 1:
     kw['groups'] = groups

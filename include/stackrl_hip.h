@@ -129,6 +129,15 @@ int srl_set_profiling(srl_env* env, int32_t enable);
  * the settle kernel comes in a latency-oriented and a throughput-oriented build (9 - 16 rocks) and this number, not the
  * handle's own n_envs, says which one fits.  Results do not depend on it (the parity tests run both builds). */
 int srl_set_concurrent_envs(srl_env* env, int32_t n_envs_on_device);
+
+/* Launch order of the settle kernel's workgroups (one per env).  The reference's `ParallelEnv` collects its worker
+ * processes' results as they come (utils.py:540-543) and a vectorised step lasts as long as its slowest env (the stop
+ * criterion of simulator.py:322-335); a batch that outnumbers the workgroups the device holds at once therefore starts the
+ * envs with the longest expected settle first — those whose rock `Observer.pose` (observer.py:405-413) will release highest,
+ * evaluated and sorted on the device before the step kernel.  mode -1 (default): by batch size (>= 2,048 envs), 0: index
+ * order, 1: always ordered (at most 16,384 envs per handle).  Envs are independent: results do not depend on the order
+ * (the parity tests run both). */
+int srl_set_launch_order(srl_env* env, int32_t mode);
 int srl_get_kernel_times(srl_env* env, float* ms3, int32_t* launches3);
 
 #ifdef __cplusplus

@@ -927,10 +927,12 @@ __device__ int newest_contacts(const Lds& L, int nb, int tid, int T) {
 // kernel argument whose address is taken is copied to scratch and every access becomes a scratch load.)
 template <int T, int PP>
 __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, const int64_t* __restrict__ action,
-                                          int force_reset) {
+                                          int force_reset, const int32_t* __restrict__ order) {
   const DevParams& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int e = blockIdx.x, tid = threadIdx.x;
+  // order (may be NULL): the env this workgroup serves — a permutation of the batch written by srl_k_order_* below, envs
+  // with the longest expected settle first.  Envs are independent, so the results do not depend on it.
+  const int e = order ? order[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
   Lds L; L.init(sm, Pp);
   int* misc = L.MISC();
   EnvHdr* h = &P.hdr[e];
@@ -1135,26 +1137,86 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
 // envs x 16 rocks) are throughput-bound, and a third workgroup per CU is worth more than the spills cost — 60.7 -> 50.1 ms
 // per launch at 4,096 envs; four waves per SIMD (128 VGPRs) spill 108 registers and lose: 80 ms.
 extern "C" __global__ void __launch_bounds__(128, 2) srl_k_step(const DevParams* __restrict__ Pp,
-    const int64_t* __restrict__ action, int force_reset) {
-  step_body<128, 1>(Pp, action, force_reset);
+    const int64_t* __restrict__ action, int force_reset, const int32_t* __restrict__ order) {
+  step_body<128, 1>(Pp, action, force_reset, order);
 }
 extern "C" __global__ void __launch_bounds__(256, 3) srl_k_step_pp1(const DevParams* __restrict__ Pp,
-    const int64_t* __restrict__ action, int force_reset) {
-  step_body<256, 1>(Pp, action, force_reset);
+    const int64_t* __restrict__ action, int force_reset, const int32_t* __restrict__ order) {
+  step_body<256, 1>(Pp, action, force_reset, order);
 }
 // Above 16 rocks: four waves with two points per thread (128 slots) and no LDS copy of the local vertices — 70 KB per env,
 // two workgroups per CU.  (Eight waves with one point per thread and the vertex copy, 97 KB and one workgroup per CU:
 // 145.5 against 104.9 ms per launch at 2,048 envs x 32 rocks.)
 extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp2(const DevParams* __restrict__ Pp,
-    const int64_t* __restrict__ action, int force_reset) {
-  step_body<256, 2>(Pp, action, force_reset);
+    const int64_t* __restrict__ action, int force_reset, const int32_t* __restrict__ order) {
+  step_body<256, 2>(Pp, action, force_reset, order);
 }
 
 // 9 - 16 rocks, large batches: two waves per env with two points per thread and no LDS copy of the local vertices —
 // 35 KB per env, four workgroups per CU instead of three (the shapes with >= 2,048 envs are throughput-bound)
 extern "C" __global__ void __launch_bounds__(128, 2) srl_k_step_t128(const DevParams* __restrict__ Pp,
-    const int64_t* __restrict__ action, int force_reset) {
-  step_body<128, 2>(Pp, action, force_reset);
+    const int64_t* __restrict__ action, int force_reset, const int32_t* __restrict__ order) {
+  step_body<128, 2>(Pp, action, force_reset, order);
+}
+
+// ------------------------------------------------------------------ launch order of a batch that outnumbers the resident slots
+// A settle launch lasts as long as its slowest env (stop criterion simulator.py:322-335) and the dispatcher hands workgroups
+// out in index order: with more envs than resident workgroups (4,096 x 16 rocks: four rounds) a long chain that starts in
+// the last round sets the end of the launch.  What can be known before the launch is where the rock is released:
+// the height `Observer.pose` will compute (observer.py:405-413: max of H[window] + O over the rock's pixels) — the higher the
+// release, the more rocks lie underneath and the longer the settle (Spearman 0.5 - 0.75 against the oracle's sweep counts,
+// tests/diag/sched_predictors.py).  srl_k_order_keys evaluates it per env (one wave each), srl_k_order_sort sorts the batch
+// by it (one workgroup, bitonic network in LDS), highest first; srl_k_step then serves env order[blockIdx.x].
+extern "C" __global__ void __launch_bounds__(64) srl_k_order_keys(const DevParams* __restrict__ Pp,
+    const int64_t* __restrict__ action, unsigned long long* __restrict__ keys) {
+  const DevParams& P = *Pp;
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const EnvHdr* h = &P.hdr[e];
+  float z = -1.0f;                                   // auto-reset calls, held envs, rejected actions: no settle, last
+  int64_t a = action[e];
+  if (a != (int64_t)SRL_ACTION_HOLD && !h->done && a >= 0) {
+    int slot = 0, mesh = h->pending, nvalid = 1;
+    if (P.n_slots > 1) {
+      nvalid = P.c.ordering_freedom ? h->list_pos * P.n_orient : P.n_orient;
+      slot = (int)(a / (int64_t)P.A);
+      a = a % (int64_t)P.A;
+      if (P.c.ordering_freedom && slot < nvalid) mesh = h->ids[slot / P.n_orient];
+    }
+    if (slot < nvalid && a < (int64_t)P.A && mesh >= 0) {
+      const int res = P.c.overhead_res, r = P.c.object_res;
+      const int u = (int)(a / P.AW), v = (int)(a % P.AW);
+      const float* Hm = P.H + (size_t)e * res * res;
+      const float* Om = P.objmap + ((size_t)mesh * P.n_orient + slot % P.n_orient) * r * r;
+      float best = 0.0f;
+      for (int k = lane; k < r * r; k += 64) {
+        const float o = Om[k];
+        if (o > 1e-4f) best = fmaxf(best, Hm[(u + k / r) * res + (v + k % r)] + o);
+      }
+      for (int s = 32; s >= 1; s >>= 1) best = fmaxf(best, __shfl_xor(best, s));
+      z = best;
+    }
+  }
+  // ascending sort -> highest release first, ties in index order; non-negative floats order like their bit patterns
+  if (lane == 0) keys[e] = ((unsigned long long)(z < 0.0f ? 0xffffffffu : ~__float_as_uint(z)) << 32) | (unsigned)e;
+}
+
+extern "C" __global__ void __launch_bounds__(1024) srl_k_order_sort(const unsigned long long* __restrict__ keys, int n, int np2,
+                                                                    int32_t* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < np2; i += 1024) sk[i] = i < n ? keys[i] : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1)
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      for (int t = tid; t < (np2 >> 1); t += 1024) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;      // the pair (i, i + j) of this stage
+        const unsigned long long a = sk[i], b = sk[p];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { sk[i] = b; sk[p] = a; }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < n; i += 1024) order[i] = (int32_t)(unsigned)(sk[i] & 0xffffffffull);
 }
 
 // ------------------------------------------------------------------ ParallelEnv.sample (utils.py:534-538)

@@ -55,6 +55,11 @@ struct srl_env {
   int step_threads = 256;
   int step_pp = 1;
   int concurrent_envs = 0;   // srl_set_concurrent_envs: envs stepping on the device at the same time, over all handles
+  // launch order of srl_k_step (settle.hip, srl_k_order_*): -1 = by batch size (on when the envs outnumber the resident
+  // workgroups), 0 = index order, 1 = highest release first (srl_set_launch_order)
+  int order_mode = -1;
+  unsigned long long* d_order_keys = nullptr;
+  int32_t* d_order = nullptr;
   size_t step_lds = 0, render_lds = 0, objmap_lds = 0;
   bool profiling = false;
   std::vector<EventPair> pending;
@@ -190,6 +195,16 @@ EventPair prof_pair(srl_env* env, int which) {
     else hipLaunchKernelGGL(kernel_, grid_, block_, lds_, st_, __VA_ARGS__);                                       \
   } while (0)
 
+// Ordered launch (settle.hip, srl_k_order_*): worth its two small kernels only when a launch takes several rounds of
+// resident workgroups — 2,048 envs or more on this 256-CU part (at most four env workgroups per CU) — and possible while the
+// batch's keys fit the sort's LDS (16,384 envs = 128 KB).
+constexpr int SRL_ORDER_MIN_ENVS = 2048, SRL_ORDER_MAX_ENVS = 16384;
+bool launch_ordered(const srl_env* env) {
+  const int n = env->P.c.n_envs;
+  if (n > SRL_ORDER_MAX_ENVS || n < 2 || !env->d_order) return false;
+  return env->order_mode == 1 || (env->order_mode < 0 && n >= SRL_ORDER_MIN_ENVS);
+}
+
 int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void* obs_obj, float* reward, uint8_t* done,
                        hipStream_t st, int force_reset) {
   if (!env->d_mh) return fail(SRL_ENOMESH, "srl_load_meshes must be called first");
@@ -201,10 +216,18 @@ int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void*
     env->P_dirty = false;
   }
   const DevParams* dP = env->d_P;
-  if (env->step_pp == 0) SRL_LAUNCH(env, 0, srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
-  else if (env->step_pp == 2) SRL_LAUNCH(env, 0, srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
-  else if (env->step_pp == 3) SRL_LAUNCH(env, 0, srl_k_step_t128, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
-  else SRL_LAUNCH(env, 0, srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset);
+  const int32_t* order = nullptr;
+  if (force_reset == 0 && launch_ordered(env)) {   // a placement call of a batch that outnumbers the resident workgroups
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    hipLaunchKernelGGL(srl_k_order_keys, dim3(n), dim3(64), 0, st, dP, action, env->d_order_keys);
+    hipLaunchKernelGGL(srl_k_order_sort, dim3(1), dim3(1024), (size_t)np2 * 8, st, env->d_order_keys, n, np2, env->d_order);
+    order = env->d_order;
+  }
+  if (env->step_pp == 0) SRL_LAUNCH(env, 0, srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset, order);
+  else if (env->step_pp == 2) SRL_LAUNCH(env, 0, srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset, order);
+  else if (env->step_pp == 3) SRL_LAUNCH(env, 0, srl_k_step_t128, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset, order);
+  else SRL_LAUNCH(env, 0, srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset, order);
   if (force_reset < 0) {   // srl_step_simulation: sub-steps only
     HIP_TRY(hipGetLastError());
     return SRL_OK;
@@ -258,6 +281,12 @@ int srl_create(const srl_config* cfg, srl_env** out) {
   HIP_TRY(hipMalloc((void**)&P.flags, sizeof(int32_t)));
   HIP_TRY(hipMalloc((void**)&env->d_P, sizeof(DevParams)));
   HIP_TRY(hipMalloc((void**)&env->d_reset_r, sizeof(float) * 4 * (size_t)n));   // up to 4 rewards per env (metric 'all')
+  if (n <= SRL_ORDER_MAX_ENVS) {   // launch order of the settle kernel (srl_k_order_*): keys + permutation, owned by the handle
+    HIP_TRY(hipMalloc((void**)&env->d_order_keys, sizeof(unsigned long long) * (size_t)n));
+    HIP_TRY(hipMalloc((void**)&env->d_order, sizeof(int32_t) * (size_t)n));
+    if (n > 8192)
+      HIP_TRY(hipFuncSetAttribute((const void*)srl_k_order_sort, hipFuncAttributeMaxDynamicSharedMemorySize, SRL_ORDER_MAX_ENVS * 8));
+  }
   HIP_TRY(hipMalloc((void**)&env->d_reset_d, (size_t)n));
   HIP_TRY(hipMemset(P.blob, 0, sizeof(float) * (size_t)n * P.BLOB));
   HIP_TRY(hipMemset(P.H, 0, sizeof(float) * (size_t)n * res * res));
@@ -302,6 +331,7 @@ void srl_destroy(srl_env* env) {
   (void)hipFree(env->d_mh); (void)hipFree(env->d_mv); (void)hipFree(env->d_mt); (void)hipFree(env->d_mp); (void)hipFree(env->d_objmap); (void)hipFree(env->d_objmap_u8);
   (void)hipFree(env->d_codec); (void)hipFree(env->d_me);
   (void)hipFree(env->d_reset_r); (void)hipFree(env->d_reset_d);
+  (void)hipFree(env->d_order_keys); (void)hipFree(env->d_order);
   delete env;
 }
 
@@ -435,6 +465,14 @@ int srl_set_concurrent_envs(srl_env* env, int32_t n_envs_on_device) {
   if (n_envs_on_device < 0) return fail(SRL_EINVAL, "n_envs_on_device must be >= 0");
   if (env->d_mh) return fail(SRL_EINVAL, "srl_set_concurrent_envs must precede srl_load_meshes");
   env->concurrent_envs = n_envs_on_device;
+  return SRL_OK;
+}
+
+int srl_set_launch_order(srl_env* env, int32_t mode) {
+  if (!env) return fail(SRL_EINVAL, "null env");
+  if (mode < -1 || mode > 1) return fail(SRL_EINVAL, "launch order mode must be -1 (by batch size), 0 (index order) or 1 (highest release first)");
+  if (mode == 1 && !env->d_order) return fail(SRL_EINVAL, "ordered launch supports at most 16,384 envs per handle");
+  env->order_mode = mode;
   return SRL_OK;
 }
 

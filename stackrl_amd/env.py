@@ -45,7 +45,8 @@ class VecStackEnv(object):
   """B independent Stack-v0 envs on one GPU (drop-in for `ParallelEnv`, utils.py:302)."""
 
   def __init__(self, n_parallel=None, block=None, seed=None, pool=None, device=None,
-               env_index_offset=0, side_stream=False, concurrent_envs=None, stream_priority=None, **kwargs):
+               env_index_offset=0, side_stream=False, concurrent_envs=None, stream_priority=None, launch_order=None,
+               **kwargs):
     """
     Args:
       n_parallel: number of environments B (utils.py:324).
@@ -61,6 +62,8 @@ class VecStackEnv(object):
         before the kernels of the current stream; None / 0 = default).
       concurrent_envs: envs that step on the device at the same time over all handles of the caller (a tuning hint for
         the settle kernel's build, `srl_set_concurrent_envs`; results do not depend on it).  None -> this handle alone.
+      launch_order: order in which the settle kernel's workgroups take the envs (`srl_set_launch_order`): None -> by batch
+        size, False -> index order, True -> the envs with the highest release first.  Results do not depend on it.
       kwargs: StackEnv arguments (env.py:28-51), e.g. episode_length, sim_time_step, rewarder.
     """
     if not torch.cuda.is_available():
@@ -75,6 +78,8 @@ class VecStackEnv(object):
       _check(self._lib.srl_create(ctypes.byref(self._c), ctypes.byref(self._h)))
       if concurrent_envs:
         _check(self._lib.srl_set_concurrent_envs(self._h, int(concurrent_envs)))
+      if launch_order is not None:
+        _check(self._lib.srl_set_launch_order(self._h, int(bool(launch_order))))
       self.pool = pool if pool is not None else _assets.default_pool()
       p = self.pool
       _check(self._lib.srl_load_meshes(self._h, _np_ptr(p.verts), _np_ptr(p.vert_off), _np_ptr(p.tris),

@@ -33,6 +33,7 @@ _SIGS = {
   'srl_set_profiling': (ctypes.c_int, [_VP, ctypes.c_int32]),
   'srl_get_kernel_times': (ctypes.c_int, [_VP, _VP, _VP]),
   'srl_set_concurrent_envs': (ctypes.c_int, [_VP, ctypes.c_int32]),
+  'srl_set_launch_order': (ctypes.c_int, [_VP, ctypes.c_int32]),
 }
 EXPORTS = tuple(sorted(_SIGS))
 

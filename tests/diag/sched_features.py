@@ -10,7 +10,7 @@ def work(a):
   env = OracleEnv(cfg, pool, seed=seed)
   env.reset()
   AW = cfg.overhead_res - cfg.object_res + 1; r = cfg.object_res
-  sub = np.zeros((L, n), np.int32); sw = np.zeros((L, n), np.int32); F = np.zeros((L, n, 6), np.float32)
+  sub = np.zeros((L, n), np.int32); sw = np.zeros((L, n), np.int32); F = np.zeros((L, n, 10), np.float32)
   for t in range(L):
     a = env.sample()
     Hm, Om, g = env.maps()
@@ -22,7 +22,13 @@ def work(a):
       if m.sum() == 0: m = np.ones_like(O, bool)
       s = P + 0.0
       d = (P - O)[m]
-      F[t, e] = [P[m].max(), P[m].mean(), d.max(), np.sort(d)[-max(1, d.size // 10):].mean() - d.max(), (P[m] > 0).mean(), P.max()]
+      S = np.where(m, P + O, -1.0)          # release surface: the rock comes to touch at the argmax (observer.py:405-413)
+      k = int(S.argmax()); ci, cj = divmod(k, r)
+      ii, jj = np.nonzero(m)
+      gap = S.max() - S[m]
+      off = np.hypot(ci - ii.mean(), cj - jj.mean())
+      F[t, e] = [P[m].max(), P[m].mean(), d.max(), np.sort(d)[-max(1, d.size // 10):].mean() - d.max(), (P[m] > 0).mean(), P.max(),
+                 gap.mean(), off, S.max(), gap.mean() * off]
     env.step(a)
     s = env.state()[2]
     sub[t] = s.sum(1); sw[t] = env.sweeps()

@@ -3,7 +3,7 @@ from scipy.stats import spearmanr
 d = np.load('/tmp/feat_L16.npz'); sub, sw, F = d['sub'].astype(float), d['sw'].astype(float), d['F']
 c = 1.6 * sw + 15 * sub
 L, N = c.shape
-names = ['Pmax', 'Pmean', 'dmax', 'd10-dmax', 'cover', 'Pall']
+names = ['Pmax', 'Pmean', 'dmax', 'd10-dmax', 'cover', 'Pall', 'gapmean', 'off', 'Smax', 'gapoff']
 for t in [0, 1, 3, 7, 11, 15]:
   print(t, 'mean %.0f max %.0f' % (c[t].mean(), c[t].max()), ' '.join('%s %.2f' % (n, spearmanr(F[t, :, k], c[t])[0]) for k, n in enumerate(names)), 'prev %.2f' % (spearmanr(c[t - 1], c[t])[0] if t else 0))
 import heapq
@@ -14,7 +14,7 @@ def fcfs(c, C, order):
   return end
 C = N // 4
 tot = {}
-for name, key in [('random', None), ('Pmax', 0), ('Pmean', 1), ('dmax', 2), ('Pall', 5), ('Pmax+dmax', -1), ('LPT', -2)]:
+for name, key in [('random', None), ('Pmax', 0), ('Pmean', 1), ('dmax', 2), ('Pall', 5), ('gapmean', 6), ('off', 7), ('Smax', 8), ('gapoff', 9), ('Pmax+dmax', -1), ('LPT', -2)]:
   r = []
   for t in range(L):
     if key is None: o = np.arange(N)

@@ -175,6 +175,25 @@ def test_two_wave_settle_variant_matches_the_oracle(ref_pool, oracle_mod, monkey
     _cmp_step(g, o, g.step(ga), o.step(oa), 'step {}'.format(k))
 
 
+@pytest.mark.parametrize('L,n,kw', [(8, 37, {}), (12, 70, dict(resolution_factor=4))])
+def test_ordered_launch_matches_the_oracle(ref_pool, oracle_mod, L, n, kw):
+  """`srl_set_launch_order`: batches of >= 2,048 envs hand the settle kernel's workgroups the envs with the highest release
+  first (`srl_k_order_keys` / `srl_k_order_sort`, settle.hip).  Forced here on small batches whose size is not a power of
+  two (padding of the sorting network) and held bit-exact against the oracle through an episode, its `done` step and the
+  auto-reset call: envs are independent, so the permutation must not show in any result."""
+  from stackrl_amd import env as envs
+  from stackrl_amd.config import StackConfig
+  g = envs.VecStackEnv(n_parallel=n, seed=29, pool=ref_pool, block=True, episode_length=L, launch_order=True, **kw)
+  o = oracle_mod.OracleEnv(StackConfig(n_envs=n, episode_length=L, **kw), ref_pool, seed=29)
+  gout, oout = g.reset(), o.reset()
+  assert np.array_equal(gout[0][0].cpu().numpy(), oout[0][0])
+  for k in range(L + 3):
+    ga, oa = g.sample(), o.sample()
+    assert np.array_equal(ga.cpu().numpy(), oa)
+    _cmp_step(g, o, g.step(ga), o.step(oa), 'step {}'.format(k))
+  g.close()
+
+
 def test_full_size_batch_properties(ref_pool):
   """BASELINE configs[1] size (1,024 envs x 8 rocks): size-independent properties instead of the oracle —
   every env places exactly L rocks, done on the L-th step, rocks at rest above the ground inside the time cap,

@@ -8,8 +8,11 @@ pool = assets.default_pool()
 shapes = [(1024, 8, 5), (1024, 16, 5), (4096, 16, 5), (2048, 32, 4)]
 if len(sys.argv) > 1:
   shapes = [tuple(int(x) for x in a.split('x')) for a in sys.argv[1:]]
+# LAUNCH_ORDER=0 | 1: settle workgroups in index order / highest release first (srl_set_launch_order); unset: by batch size
+lo = os.environ.get('LAUNCH_ORDER')
+okw = {} if lo is None else {'launch_order': bool(int(lo))}
 for B, L, rf in shapes:
-  g = envs.VecStackEnv(n_parallel=B, seed=11, pool=pool, block=False, episode_length=L, resolution_factor=rf)
+  g = envs.VecStackEnv(n_parallel=B, seed=11, pool=pool, block=False, episode_length=L, resolution_factor=rf, **okw)
   g.reset()()
   for _ in range(L + 1): out = g.step(g.sample())
   out(); torch.cuda.synchronize()
