@@ -140,6 +140,11 @@ int srl_set_concurrent_envs(srl_env* env, int32_t n_envs_on_device);
 int srl_set_launch_order(srl_env* env, int32_t mode);
 int srl_get_kernel_times(srl_env* env, float* ms3, int32_t* launches3);
 
+/* How this library was built: "SRL_BUILD_INFO<variant|hash>" — variant "vectorised+rewritten" (clang's SLP vectoriser on and
+ * the pass of stackrl_amd/isa_fix.py over the compiled assembly) or "safe" (built in one go without the vectoriser), hash =
+ * sha256 prefix of the sources and flags (stackrl_amd/build.py; bench.py prints both). */
+const char* srl_build_info(void);
+
 #ifdef __cplusplus
 }
 #endif

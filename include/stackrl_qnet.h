@@ -166,6 +166,8 @@ int srl_baseline_select(const double* values_dev, const uint8_t* mask_dev, int32
                         int64_t* actions_dev, double* neg_values_dev, int32_t B, int32_t OH, void* stream);
 
 const char* srl_qnet_last_error(void);
+/* "SRL_BUILD_INFO<variant|hash of the sources and flags>" (stackrl_amd/build.py) */
+const char* srl_qnet_build_info(void);
 
 /* ---- update path (csrc/learner.hip).  Device pointers, contiguous, `stream` a hipStream_t; nothing is allocated, so a
  * captured hipGraph can replay every call.

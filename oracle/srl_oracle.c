@@ -226,6 +226,12 @@ struct srlo_env {
 };
 
 /* ------------------------------------------------------------------ create */
+/* `int(MAX_STEP_TIME / time_step)` (simulator.py:6, :46) */
+static int c_max_substeps(const srl_config* c) {
+  /* the quotient of the float32 time step nudged by 1e-6 of itself: 300 / 0.0125f = 23999.9996, the reference has 24000 */
+  return c->max_substeps > 0 ? c->max_substeps : (int)(300.0 / (double)c->sim_time_step * (1.0 + 1e-6));
+}
+
 static int derive(struct srlo_env* e) {
   srl_config* c = &e->c;
   if (c->n_envs < 1 || c->episode_length < 1 || c->episode_length > MAXB)
@@ -236,8 +242,7 @@ static int derive(struct srlo_env* e) {
   e->inv_px = (float)c->object_res / c->object_max_dimension;
   e->lin_damp = (float)pow(1.0 - (double)c->linear_damping, (double)c->sim_time_step);
   e->ang_damp = (float)pow(1.0 - (double)c->angular_damping, (double)c->sim_time_step);
-  e->max_substeps = c->max_substeps > 0 ? c->max_substeps
-                                        : (int)(300.0 / (double)c->sim_time_step); /* simulator.py:46 */
+  e->max_substeps = c_max_substeps(c);
   int H = c->overhead_res, h = c->object_res;
   /* rewarder.py:65-80 */
   e->goal_min_h = h; e->goal_min_w = h; e->goal_max_h = H; e->goal_max_w = H;
@@ -1255,69 +1260,163 @@ static void substep(const struct srlo_env* e, env_t* s) {
   }
 }
 
-/* simulator.py:322-335 (velocity criterion; angular velocity is ignored) */
-static int sim_stop(const struct srlo_env* e, const env_t* s) {
-  float thr = e->c.velocity_threshold;
-  for (int b = s->nb - 1; b >= 0; --b)
-    if (sqrtf(vdot(s->v[b], s->v[b])) > thr) return 0;
+/* ------------------------------------------------------------------ Simulator.step (simulator.py:190-258)
+ * The loop is written over the WORLD the reference drives — one entry per pybullet call site of simulator.py — so that the
+ * same code serves the oracle's env (its own rigid-body step behind `step`) and a scripted world
+ * (srlo_sim_step_scripted, below): tests/test_simulator_golden.py compares the sequence of calls, the counters and the
+ * exits of this function with those of the reference's own simulator.py run over a recording pybullet placeholder
+ * (tests/golden/make_simulator_golden.py). */
+typedef struct sim_world {
+  void* ctx;
+  int (*has_new)(void* ctx);                 /* `if self._new:` (simulator.py:312) */
+  void (*place)(void* ctx);                  /* resetBasePositionAndOrientation(new, ...); objects.append (simulator.py:313-318) */
+  void (*step)(void* ctx);                   /* stepSimulation (simulator.py:219, :240, :320) */
+  void (*zero_newest)(void* ctx);            /* resetBaseVelocity(objects[-1], 0, 0) (simulator.py:214-218) */
+  int (*newest_contacts)(void* ctx);         /* len(getContactPoints(objects[-1])) (simulator.py:340) */
+  int (*n_objects)(void* ctx);               /* len(objects) */
+  float (*linear_speed)(void* ctx, int b);   /* norm(getBaseVelocity(objects[b])[0]) (simulator.py:332-333) */
+  void (*store_place_pose)(void* ctx);       /* place_poses.append(getBasePositionAndOrientation(objects[-1])) (simulator.py:227) */
+} sim_world;
+
+/* simulator.py:322-335 (velocity criterion, newest body first; angular velocity is ignored) */
+static int sim_stop(const sim_world* w, float thr) {
+  for (int b = w->n_objects(w->ctx) - 1; b >= 0; --b)
+    if (w->linear_speed(w->ctx, b) > thr) return 0;
   return 1;
 }
-static int newest_contacts(const env_t* s) {
+/* simulator.py:337-341 */
+static int sim_drop(const sim_world* w, float thr) {
+  return w->newest_contacts(w->ctx) >= 3 || sim_stop(w, thr);
+}
+
+/* returns 1 where the reference raises RuntimeError (simulator.py:221-224, :242-245); substeps = `Simulator.n_steps` */
+static int sim_step_world(const sim_world* w, int smooth_placing, float thr, int max_substeps, int32_t* substeps) {
+  int counter, diverged = 0;
+  if (w->has_new(w->ctx)) {          /* _place, simulator.py:310-320 */
+    w->place(w->ctx);
+    w->step(w->ctx);
+  }
+  counter = 1;
+  if (smooth_placing) {
+    while (!sim_drop(w, thr)) {
+      w->zero_newest(w->ctx);
+      w->step(w->ctx);
+      counter++;
+      if (counter > max_substeps) { diverged = 1; break; }
+    }
+  }
+  if (diverged) { substeps[0] = counter; substeps[1] = 0; return 1; }
+  w->store_place_pose(w->ctx);
+  substeps[0] = counter;
+  while (!sim_stop(w, thr)) {
+    w->step(w->ctx);
+    counter++;
+    if (counter > max_substeps) { diverged = 1; break; }
+  }
+  substeps[1] = counter - substeps[0];
+  return diverged;
+}
+
+/* the oracle's env as that world */
+typedef struct { const struct srlo_env* e; env_t* s; v3 pos; int oi; } env_world;
+static int ew_has_new(void* c) { return ((env_world*)c)->s->pending >= 0; }
+static void ew_place(void* c) {
+  env_world* w = (env_world*)c;
+  const struct srlo_env* e = w->e; env_t* s = w->s;
+  int b = s->nb;
+  const mesh_t* M = &e->mesh[s->pending];
+  s->mesh[b] = s->pending;
+  /* resetBasePositionAndOrientation moves the inertial (COM) frame; loadURDF placed the link frame */
+  if (e->n_orient == 1) {
+    s->x[b] = e->c.place_at_com ? w->pos : vadd(w->pos, M->com);
+    s->q[b].x = 0.0f; s->q[b].y = 0.0f; s->q[b].z = 0.0f; s->q[b].w = 1.0f;
+  } else {   /* the chosen orientation (observer.py:416-417 -> simulator.py:313) */
+    m3 Ro = quat_to_mat(e->orient_q[w->oi]);
+    s->x[b] = e->c.place_at_com ? w->pos : vadd(w->pos, mmul(&Ro, M->com));
+    s->q[b] = e->orient_q[w->oi];
+  }
+  s->v[b] = V(0, 0, 0); s->w[b] = V(0, 0, 0);
+  s->gm[b].np = 0;
+  s->nb = b + 1;
+  s->pending = -1;
+}
+static void ew_step(void* c) { env_world* w = (env_world*)c; substep(w->e, w->s); }
+static void ew_zero_newest(void* c) { env_t* s = ((env_world*)c)->s; s->v[s->nb - 1] = V(0, 0, 0); s->w[s->nb - 1] = V(0, 0, 0); }
+static int ew_newest_contacts(void* c) {
+  const env_t* s = ((env_world*)c)->s;
   int b = s->nb - 1;
   int n = s->gm[b].np;
   for (int sl = 0; sl < MAXSLOT; ++sl)
     if (s->pair_of_slot[sl] >= 0 && (s->slot_a[sl] == b || s->slot_b[sl] == b)) n += s->man[sl].np;
   return n;
 }
-/* simulator.py:337-341 */
-static int sim_drop(const struct srlo_env* e, const env_t* s) {
-  return newest_contacts(s) >= 3 || sim_stop(e, s);
-}
-
-/* Simulator.step, simulator.py:190-258 */
-static void sim_step(const struct srlo_env* e, env_t* s, v3 pos, int oi) {
-  int counter = 0, diverged = 0;
-  s->sweeps = 0;
-  if (s->pending >= 0) {             /* _place, simulator.py:310-320 */
-    int b = s->nb;
-    const mesh_t* M = &e->mesh[s->pending];
-    s->mesh[b] = s->pending;
-    /* resetBasePositionAndOrientation moves the inertial (COM) frame; loadURDF placed the link frame */
-    if (e->n_orient == 1) {
-      s->x[b] = e->c.place_at_com ? pos : vadd(pos, M->com);
-      s->q[b].x = 0.0f; s->q[b].y = 0.0f; s->q[b].z = 0.0f; s->q[b].w = 1.0f;
-    } else {   /* the chosen orientation (observer.py:416-417 -> simulator.py:313) */
-      m3 Ro = quat_to_mat(e->orient_q[oi]);
-      s->x[b] = e->c.place_at_com ? pos : vadd(pos, mmul(&Ro, M->com));
-      s->q[b] = e->orient_q[oi];
-    }
-    s->v[b] = V(0, 0, 0); s->w[b] = V(0, 0, 0);
-    s->gm[b].np = 0;
-    s->nb = b + 1;
-    s->pending = -1;
-    substep(e, s);
-  }
-  counter = 1;
-  if (e->c.smooth_placing) {
-    while (!sim_drop(e, s)) {
-      s->v[s->nb - 1] = V(0, 0, 0); s->w[s->nb - 1] = V(0, 0, 0);
-      substep(e, s);
-      counter++;
-      if (counter > e->max_substeps) { diverged = 1; break; }
-    }
-  }
+static int ew_n_objects(void* c) { return ((env_world*)c)->s->nb; }
+static float ew_linear_speed(void* c, int b) { const env_t* s = ((env_world*)c)->s; return sqrtf(vdot(s->v[b], s->v[b])); }
+static void ew_store_place_pose(void* c) {
+  env_t* s = ((env_world*)c)->s;
   s->place_x[s->nb - 1] = s->x[s->nb - 1];
   s->place_q[s->nb - 1] = s->q[s->nb - 1];
-  s->substeps[0] = counter;
-  while (!diverged && !sim_stop(e, s)) {
-    substep(e, s);
-    counter++;
-    if (counter > e->max_substeps) { diverged = 1; break; }
-  }
-  s->substeps[1] = counter - s->substeps[0];
-  /* the reference raises RuntimeError here (simulator.py:221-224, :242-245); the flag stays set
-   * until the next reset so the caller can see which env it was */
-  if (diverged) s->status |= SRL_ST_DIVERGED;
+}
+
+static void sim_step(const struct srlo_env* e, env_t* s, v3 pos, int oi) {
+  env_world ctx = {e, s, pos, oi};
+  const sim_world w = {&ctx, ew_has_new, ew_place, ew_step, ew_zero_newest, ew_newest_contacts, ew_n_objects, ew_linear_speed,
+                       ew_store_place_pose};
+  s->sweeps = 0;
+  /* the reference raises RuntimeError at the cap (simulator.py:221-224, :242-245); here the flag stays set until the next
+   * reset so the caller can see which env it was */
+  if (sim_step_world(&w, e->c.smooth_placing, e->c.velocity_threshold, e->max_substeps, s->substeps)) s->status |= SRL_ST_DIVERGED;
+}
+
+/* `Simulator.distances_from_place` (simulator.py:113-128) of one rock: translation |p_place - p_now| and rotation
+ * 2 acos(min(w, 1)) with w the scalar part of the difference quaternion (pybullet's getDifferenceQuaternion; here the
+ * quaternions' dot product, of the nearer of q and -q) */
+static void distance_from_place(v3 px, q4 a, v3 x, q4 q, float* dp_out, float* do_out) {
+  v3 dp = vsub(px, x);
+  float dw = fabsf((a.x * q.x + a.y * q.y) + (a.z * q.z + a.w * q.w));
+  *dp_out = sqrtf(vdot(dp, dp));
+  *do_out = 2.0f * srlo_acosf(fminf(dw, 1.0f));
+}
+
+/* The same loop over a SCRIPTED world (the fixture entry point: tests/golden/simulator_golden.npz).  After k calls of
+ * stepSimulation inside this Simulator.step, body b moves at speeds[k * nb + b] and the newest body has contacts[k]
+ * contact points (k is clamped to n_rows - 1).  log receives the calls in order as codes: 1 place, 2 stepSimulation,
+ * 3 resetBaseVelocity(newest, 0, 0), 4 getContactPoints(newest), 5 getBasePositionAndOrientation(newest) for the place
+ * pose, 16 + b getBaseVelocity(objects[b]).  Returns the number of codes (or -1 if log_cap is too small). */
+typedef struct {
+  int has_new, nb, k, n_rows, nb_cols, n_log, log_cap;
+  const float* speeds; const int32_t* contacts; int32_t* log;
+} script_world;
+static void sw_log(script_world* w, int code) { if (w->n_log < w->log_cap) w->log[w->n_log] = code; w->n_log++; }
+static int sw_row(const script_world* w) { return w->k < w->n_rows ? w->k : w->n_rows - 1; }
+static int sw_has_new(void* c) { return ((script_world*)c)->has_new; }
+static void sw_place(void* c) { script_world* w = (script_world*)c; w->nb += 1; w->has_new = 0; sw_log(w, 1); }
+static void sw_step(void* c) { script_world* w = (script_world*)c; w->k += 1; sw_log(w, 2); }
+static void sw_zero(void* c) { sw_log((script_world*)c, 3); }
+static int sw_contacts(void* c) { script_world* w = (script_world*)c; sw_log(w, 4); return w->contacts[sw_row(w)]; }
+static int sw_n(void* c) { return ((script_world*)c)->nb; }
+static float sw_speed(void* c, int b) { script_world* w = (script_world*)c; sw_log(w, 16 + b); return w->speeds[sw_row(w) * w->nb_cols + b]; }
+static void sw_store(void* c) { sw_log((script_world*)c, 5); }
+
+int srlo_sim_step_scripted(int32_t has_new, int32_t n_objects_before, int32_t smooth_placing, float velocity_threshold,
+                           int32_t max_substeps, int32_t n_rows, int32_t n_cols, const float* speeds, const int32_t* contacts,
+                           int32_t* substeps2, int32_t* raised, int32_t* log, int32_t log_cap) {
+  script_world ctx = {has_new, n_objects_before, 0, n_rows, n_cols, 0, log_cap, speeds, contacts, log};
+  const sim_world w = {&ctx, sw_has_new, sw_place, sw_step, sw_zero, sw_contacts, sw_n, sw_speed, sw_store};
+  *raised = sim_step_world(&w, smooth_placing, velocity_threshold, max_substeps, substeps2);
+  return ctx.n_log <= log_cap ? ctx.n_log : -1;
+}
+
+/* `Simulator.distances_from_place` of one rock from explicit poses (x, y, z, qx, qy, qz, qw) */
+void srlo_distance_from_place(const float* place7, const float* now7, float* out2) {
+  q4 a = {place7[3], place7[4], place7[5], place7[6]}, q = {now7[3], now7[4], now7[5], now7[6]};
+  distance_from_place(V(place7[0], place7[1], place7[2]), a, V(now7[0], now7[1], now7[2]), q, &out2[0], &out2[1]);
+}
+
+/* `int(MAX_STEP_TIME / time_step)` (simulator.py:6, :46) as the library derives it from a configuration */
+int32_t srlo_max_substeps(const srl_config* cfg) {
+  struct srlo_env e; memset(&e, 0, sizeof e); e.c = *cfg;
+  return c_max_substeps(&e.c);
 }
 
 /* ------------------------------------------------------------------ reward (rewarder.py:162-179, :261-295) */
@@ -1403,12 +1502,8 @@ static void rewarder_call(const struct srlo_env* e, const rew_in_t* s, float* me
 static void step_rewards(const struct srlo_env* e, env_t* s, float* out) {
   float pos[3 * MAXB], dist[2 * MAXB];
   for (int b = 0; b < s->nb; ++b) {
-    v3 dp = vsub(s->place_x[b], s->x[b]);
-    q4 a = s->place_q[b], q = s->q[b];
-    float dw = fabsf((a.x * q.x + a.y * q.y) + (a.z * q.z + a.w * q.w));
     pos[3 * b] = s->x[b].x; pos[3 * b + 1] = s->x[b].y; pos[3 * b + 2] = s->x[b].z;
-    dist[2 * b] = sqrtf(vdot(dp, dp));
-    dist[2 * b + 1] = 2.0f * srlo_acosf(fminf(dw, 1.0f));
+    distance_from_place(s->place_x[b], s->place_q[b], s->x[b], s->q[b], &dist[2 * b], &dist[2 * b + 1]);
   }
   int32_t goal[4] = {s->goal[0], s->goal[1], s->goal[2], s->goal[3]};
   rew_in_t in = {s->H, goal, s->nb, pos, dist};

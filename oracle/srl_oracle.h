@@ -108,6 +108,21 @@ int srlo_debug_substeps(srlo_env* e, int32_t env_index, int32_t n);
  * srlo_get_velocities; NULL = leave as is) and n raw sub-steps on every env: the hooks of the closed-form physics tests */
 int srlo_set_body_state(srlo_env* e, const float* poses, const float* velocities);
 int srlo_step_simulation(srlo_env* e, int32_t n);
+/* `Simulator.step` (simulator.py:190-258) — the very loop the oracle's env steps with (sim_step_world) — over a SCRIPTED world
+ * (the fixture entry point of tests/golden/simulator_golden.npz): after k stepSimulation calls inside this step, body b moves
+ * at speeds[min(k, n_rows - 1) * n_cols + b] and the newest body has contacts[min(k, n_rows - 1)] contact points.  log
+ * receives the calls made of the world, in order: 1 place, 2 stepSimulation, 3 resetBaseVelocity(newest, 0, 0),
+ * 4 getContactPoints(newest), 5 getBasePositionAndOrientation(newest) for the place pose, 16 + b getBaseVelocity(objects[b]).
+ * substeps2 = `Simulator.n_steps`; *raised = 1 where the reference raises RuntimeError.  Returns the number of log entries
+ * (-1: log_cap too small). */
+int srlo_sim_step_scripted(int32_t has_new, int32_t n_objects_before, int32_t smooth_placing, float velocity_threshold,
+                           int32_t max_substeps, int32_t n_rows, int32_t n_cols, const float* speeds, const int32_t* contacts,
+                           int32_t* substeps2, int32_t* raised, int32_t* log, int32_t log_cap);
+/* `Simulator.distances_from_place` (simulator.py:113-128) of one rock from explicit poses (x, y, z, qx, qy, qz, qw):
+ * out2 = (translation, rotation); the code path of the env's reward (step_rewards) */
+void srlo_distance_from_place(const float* place7, const float* now7, float* out2);
+/* `int(MAX_STEP_TIME / time_step)` (simulator.py:6, :46) as the library derives it from a configuration */
+int32_t srlo_max_substeps(const srl_config* cfg);
 
 #ifdef __cplusplus
 }

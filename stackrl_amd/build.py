@@ -22,9 +22,48 @@ DEPS = ['stackrl_hip.hip', 'settle.hip', 'render.hip', 'srl_device.h', 'srl_kern
 #   tests/test_isa_guard.py checks the compiled ISA of every source file of both libraries.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
          '-fno-fast-math', '-Wall', '-Wno-unused-function', '-Wno-unused-value', '-Wno-unused-result']
+FLAGS = FLAGS + os.environ.get('SRL_EXTRA_FLAGS', '').split()      # experiments only (e.g. -DSRL_STEP_PRIO=3)
 FLAGS_SAFE = FLAGS + ['-fno-slp-vectorize']
 LLVM_BIN = os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'lib', 'llvm', 'bin')
 DEPS = DEPS + [os.path.join('..', 'isa_fix.py'), os.path.join('..', 'build.py')]
+
+
+def source_hash(deps, flags):
+  """sha256 over the contents of the files a library is built from and the flags it is built with (first 16 hex digits)."""
+  import hashlib
+  h = hashlib.sha256()
+  for d in deps:
+    with open(os.path.join(CSRC, d), 'rb') as f:
+      h.update(d.encode() + b'\0' + f.read() + b'\0')
+  h.update(' '.join(flags).encode())
+  return h.hexdigest()[:16]
+
+
+INFO_MARK = b'SRL_BUILD_INFO<'
+
+
+def info(path):
+  """What a built library says about itself — {'variant': ..., 'hash': ...} — read from the bytes of the file (the string
+  `srl_build_info()` returns), or None for a file without it.  `stale()` compares the hash with the sources'."""
+  try:
+    with open(path, 'rb') as f:
+      data = f.read()
+  except OSError:
+    return None
+  i = data.find(INFO_MARK)
+  if i < 0:
+    return None
+  j = data.find(b'>', i)
+  variant, _, digest = data[i + len(INFO_MARK):j].decode().partition('|')
+  return {'variant': variant, 'hash': digest}
+
+
+def _info_flag(variant, digest):
+  return '-DSRL_BUILD_INFO="{}{}|{}>"'.format(INFO_MARK.decode(), variant, digest)
+
+
+VARIANT_FIXED = 'vectorised+rewritten'     # SLP vectoriser on, isa_fix.rewrite over the assembly
+VARIANT_SAFE = 'safe'                      # one go without the SLP vectoriser (the fall-back; ~3 % slower settle kernel)
 
 
 def device_asm(hipcc, flags, src):
@@ -60,8 +99,8 @@ def _build_env_fixed(hipcc, verbose):
     run([os.path.join(LLVM_BIN, 'lld'), '-flavor', 'gnu', '-m', 'elf64_amdgpu', '--no-undefined', '-shared', '-o', co, obj])
     run([os.path.join(LLVM_BIN, 'clang-offload-bundler'), '-type=o', '-bundle-align=4096',
          '-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950', '-input=/dev/null', '-input=' + co, '-output=' + fb])
-    run([hipcc] + [f for f in FLAGS if f != '-shared'] + ['--cuda-host-only', '-Xclang', '-fcuda-include-gpubinary', '-Xclang', fb,
-                                                         '-c', src, '-o', host])
+    run([hipcc] + [f for f in FLAGS if f != '-shared'] + [_info_flag(VARIANT_FIXED, source_hash(DEPS, FLAGS)), '--cuda-host-only',
+                                                         '-Xclang', '-fcuda-include-gpubinary', '-Xclang', fb, '-c', src, '-o', host])
     run([hipcc, '-shared', '-fPIC', host, '-o', LIB + '.tmp'])
     os.replace(LIB + '.tmp', LIB)
   if verbose:
@@ -69,10 +108,9 @@ def _build_env_fixed(hipcc, verbose):
 
 
 def stale():
-  if not os.path.isfile(LIB):
-    return True
-  t = os.path.getmtime(LIB)
-  return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+  """The library is missing, or was not built from these sources with these flags (the hash it carries, not file times)."""
+  i = info(LIB)
+  return i is None or i['hash'] != source_hash(DEPS, FLAGS)
 
 
 QLIB = os.path.join(HERE, 'libstackrl_qnet.so')
@@ -86,10 +124,8 @@ QFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fn
 
 
 def qstale():
-  if not os.path.isfile(QLIB):
-    return True
-  t = os.path.getmtime(QLIB)
-  return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in QDEPS)
+  i = info(QLIB)
+  return i is None or i['hash'] != source_hash(QDEPS, QFLAGS)
 
 
 def build(force=False, verbose=False):
@@ -101,12 +137,12 @@ def build(force=False, verbose=False):
       _build_env_fixed(hipcc, verbose)
     except Exception as e:       # any step of the long way round: the plain build without the vectoriser (same results, slower)
       print('stackrl_amd.build: env library built without the SLP vectoriser ({})'.format(str(e)[:200]), file=sys.stderr)
-      cmd = [hipcc] + FLAGS_SAFE + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
+      cmd = [hipcc] + FLAGS_SAFE + [_info_flag(VARIANT_SAFE, source_hash(DEPS, FLAGS))] + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
       if verbose:
         print(' '.join(cmd), file=sys.stderr)
       subprocess.check_call(cmd)
   if force or qstale():
-    cmd = [hipcc] + QFLAGS + [os.path.join(CSRC, f) for f in QSRC] + ['-o', QLIB]
+    cmd = [hipcc] + QFLAGS + [_info_flag('no-slp', source_hash(QDEPS, QFLAGS))] + [os.path.join(CSRC, f) for f in QSRC] + ['-o', QLIB]
     if verbose:
       print(' '.join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

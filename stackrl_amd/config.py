@@ -186,7 +186,9 @@ class StackConfig:
       object_res=self.object_res, object_max_dimension=self.object_max_dimension,
       max_z=self.max_z, sim_time_step=self.sim_time_step, gravity=self.gravity,
       velocity_threshold=self.velocity_threshold, smooth_placing=int(bool(self.smooth_placing)),
-      max_substeps=self.max_substeps, metric=self.metric_id,
+      # simulator.py:46 `int(MAX_STEP_TIME / time_step)` in Python's doubles, like the reference (the C struct carries the time
+      # step as a float32: 300 / float32(0.0125) = 23999.9996, one step short of the reference's 24000)
+      max_substeps=int(self.max_substeps) or int(300 / self.sim_time_step), metric=self.metric_id,
       goal_size_ratio=self.goal_size_ratio,
       reward_scale=-1. if self.reward_scale is None else float(self.reward_scale),
       reward_pexp=pe, reward_oexp=oe, solver_iterations=self.solver_iterations,

@@ -85,6 +85,11 @@ extern "C" {
 
 const char* srl_qnet_last_error(void) { return q_err; }
 
+#ifndef SRL_BUILD_INFO
+#define SRL_BUILD_INFO "SRL_BUILD_INFO<unknown|>"
+#endif
+const char* srl_qnet_build_info(void) { static const char info[] = SRL_BUILD_INFO; return info; }
+
 int srl_xcorr_forward(const float* x, const float* w, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
                       int32_t kh, int32_t kw, void* stream) {
   if (!x || !w || !out || B < 1 || C < 1 || kh < 1 || H < kh || W < kw) {

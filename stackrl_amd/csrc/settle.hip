@@ -930,6 +930,9 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
                                           int force_reset, const int32_t* __restrict__ order) {
   const DevParams& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float sm[];
+#ifdef SRL_STEP_PRIO
+  __builtin_amdgcn_s_setprio(SRL_STEP_PRIO);
+#endif
   // order (may be NULL): the env this workgroup serves — a permutation of the batch written by srl_k_order_* below, envs
   // with the longest expected settle first.  Envs are independent, so the results do not depend on it.
   const int e = order ? order[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
@@ -1103,7 +1106,7 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
       if (leave) phase = PH_ENTER;
     }
     if (phase == PH_ENTER) {   // simulator.py:227-230: pose where the rock was left, steps before the drop
-      if (tid == 0) {
+      if (tid == 0 && !diverged) {   // (the reference raises out of the smooth-placing loop at the cap: no place pose then)
         st3(L.PX(nb - 1), ld3(L.X(nb - 1)));
         for (int k = 0; k < 4; ++k) L.PQ(nb - 1)[k] = L.Q(nb - 1)[k];
       }

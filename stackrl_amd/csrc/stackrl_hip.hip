@@ -93,7 +93,10 @@ int derive(DevParams& P) {
   P.inv_px = (float)c.object_res / c.object_max_dimension;
   P.lin_damp = (float)pow(1.0 - (double)c.linear_damping, (double)c.sim_time_step);
   P.ang_damp = (float)pow(1.0 - (double)c.angular_damping, (double)c.sim_time_step);
-  P.max_substeps = c.max_substeps > 0 ? c.max_substeps : (int)(300.0 / (double)c.sim_time_step);   // simulator.py:46
+  // simulator.py:46 int(MAX_STEP_TIME / time_step).  The host mirror passes the value computed from its double (config.py);
+  // for a C caller the quotient of the float32 time step is nudged by 1e-6 of itself so that 0.0125f (23999.9996) gives
+  // the reference's 24000
+  P.max_substeps = c.max_substeps > 0 ? c.max_substeps : (int)(300.0 / (double)c.sim_time_step * (1.0 + 1e-6));
   int H = c.overhead_res, h = c.object_res;
   P.goal_min_h = h; P.goal_min_w = h; P.goal_max_h = H; P.goal_max_w = H;   // rewarder.py:65-80
   P.goal_size = (int)((double)c.goal_size_ratio * H * H);
@@ -243,6 +246,12 @@ int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void*
 extern "C" {
 
 const char* srl_last_error(void) { return g_err; }
+
+#ifndef SRL_BUILD_INFO
+#define SRL_BUILD_INFO "SRL_BUILD_INFO<unknown|>"
+#endif
+// how this library was built (stackrl_amd/build.py): "SRL_BUILD_INFO<variant|hash of the sources and flags>"
+const char* srl_build_info(void) { static const char info[] = SRL_BUILD_INFO; return info; }
 
 int srl_config_default(srl_config* c) {
   if (!c) return fail(SRL_EINVAL, "null config");

@@ -18,12 +18,17 @@ BAD = re.compile(r'^\s*(v_pk_(?:add|mul|fma)_f32)\b.*\bop_sel:\[(?:[01],1|[01],[
 _ORDER = ('op_sel', 'op_sel_hi', 'neg_lo', 'neg_hi')
 
 
+_OBJDUMP_LABEL = re.compile(r'^[0-9a-f]+ <([^>]+)>:$')
+
+
 def flagged(text):
-  """[(line number, kernel label, instruction)] of the instructions of the failing form in an assembly text."""
+  """[(line number, kernel label, instruction)] of the instructions of the failing form in an assembly text (compiler
+  output or `llvm-objdump -d` of a code object)."""
   out, label = [], None
   for i, line in enumerate(text.splitlines(), 1):
     if line and not line[0].isspace() and line.endswith(':') and not line.startswith('.'):
-      label = line[:-1]
+      m = _OBJDUMP_LABEL.match(line)
+      label = m.group(1) if m else line[:-1]
     if BAD.match(line):
       out.append((i, label, line.strip()))
   return out
@@ -68,3 +73,45 @@ def rewrite(text):
       left += 1
     out.append(new)
   return '\n'.join(out), n, left
+
+
+# ------------------------------------------------------------------------------------------------ shipped artefacts
+_MAGIC = b'__CLANG_OFFLOAD_BUNDLE__'
+
+
+def code_objects(path, arch='gfx950', llvm_bin='/opt/rocm/lib/llvm/bin'):
+  """The device code objects (bytes) embedded in a built shared library: the `.hip_fatbin` section holds one clang offload
+  bundle per translation unit, each a table of (offset, size, target triple) entries."""
+  import struct
+  import subprocess
+  import tempfile
+  with tempfile.TemporaryDirectory() as tmp:
+    fat = tmp + '/fat.bin'
+    subprocess.run([llvm_bin + '/llvm-objcopy', '--dump-section', '.hip_fatbin=' + fat, path, tmp + '/stripped'], check=True)
+    data = open(fat, 'rb').read()
+  out, pos = [], data.find(_MAGIC)
+  while pos >= 0:
+    n, = struct.unpack_from('<Q', data, pos + len(_MAGIC))
+    q = pos + len(_MAGIC) + 8
+    for _ in range(n):
+      off, size, tlen = struct.unpack_from('<QQQ', data, q)
+      triple = data[q + 24:q + 24 + tlen].decode()
+      q += 24 + tlen
+      if triple.endswith(arch) and size:
+        out.append(data[pos + off:pos + off + size])
+    pos = data.find(_MAGIC, pos + len(_MAGIC))
+  return out
+
+
+def shipped_asm(path, arch='gfx950', llvm_bin='/opt/rocm/lib/llvm/bin'):
+  """Disassembly (`llvm-objdump -d`) of every device code object of a built library, one text per translation unit."""
+  import subprocess
+  import tempfile
+  texts = []
+  for co in code_objects(path, arch, llvm_bin):
+    with tempfile.NamedTemporaryFile(suffix='.co') as f:
+      f.write(co)
+      f.flush()
+      texts.append(subprocess.run([llvm_bin + '/llvm-objdump', '-d', '--mcpu=' + arch, f.name], check=True,
+                                  stdout=subprocess.PIPE, universal_newlines=True).stdout)
+  return texts

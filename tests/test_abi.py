@@ -35,7 +35,7 @@ def test_qnet_library_exports_every_declared_symbol():
   assert names == ['srl_adam_step', 'srl_baseline_select', 'srl_bias_act', 'srl_bias_act_bwd_f32', 'srl_bias_act_bwd_scratch_floats', 'srl_bias_act_f32', 'srl_bias_act_pool', 'srl_bias_act_pool_f32', 'srl_conv3x3_bias_relu', 'srl_conv3x3_bias_relu_f32', 'srl_conv3x3_gemm_batch_multiple', 'srl_conv3x3_gemm_bias_relu', 'srl_conv3x3_gemm_supported', 'srl_conv3x3_gemm_wfrag_elems', 'srl_conv3x3_relu_project', 'srl_conv3x3_relu_project_f32', 'srl_conv3x3_thin', 'srl_conv3x3_thin_f32', 'srl_conv3x3_wfrag_elems', 'srl_conv_gemm_last_error',
                    'srl_conv_last_error', 'srl_convt2x2_bias_relu', 'srl_convt2x2_bias_relu_f32', 'srl_convt2x2_gemm_bias_relu', 'srl_convt2x2_gemm_supported', 'srl_convt2x2_wfrag_elems', 'srl_epilogue_last_error', 'srl_gumbel_topk',
                    'srl_gumbel_topk_scratch_bytes', 'srl_heuristic', 'srl_learner_last_error', 'srl_logit_extrema', 'srl_logit_extrema_scratch_bytes',
-                   'srl_policy_head', 'srl_pool2x2', 'srl_qnet_last_error', 'srl_replay_gather', 'srl_replay_scatter', 'srl_tact_bwd', 'srl_tact_bwd_blocks',
+                   'srl_policy_head', 'srl_pool2x2', 'srl_qnet_build_info', 'srl_qnet_last_error', 'srl_replay_gather', 'srl_replay_scatter', 'srl_tact_bwd', 'srl_tact_bwd_blocks',
                    'srl_tact_bwd_scratch_floats', 'srl_tconv', 'srl_td_epilogue', 'srl_thead_bwd', 'srl_thead_fwd', 'srl_train_conv_last_error', 'srl_trepack', 'srl_twrw', 'srl_twrw_scratch_floats', 'srl_xcorr_forward',
                    'srl_xcorr_mfma', 'srl_xcorr_mfma_last_error', 'srl_xcorr_mfma_scratch_bytes']
   L = ctypes.CDLL(build.QLIB)
@@ -55,6 +55,9 @@ def test_config_struct_matches_header():
   assert L.srl_config_default(ctypes.byref(c)) == 0
   d = StackConfig(episode_length=30).to_c()
   for name, _ in CConfig._fields_:
+    if name == 'max_substeps':     # 0 = "derive it" in the C default; the host mirror hands over int(300 / time_step) (simulator.py:46)
+      assert c.max_substeps == 0 and d.max_substeps == 30000
+      continue
     assert getattr(c, name) == pytest.approx(getattr(d, name)), name
 
 

@@ -31,6 +31,29 @@ def test_no_kernel_contains_the_packed_form_that_fails_beside_mfma_wavefronts():
   assert texts[0].count('v_pk_') > 1000 and texts[1].count('v_pk_') > 50
 
 
+def test_the_shipped_libraries_are_built_from_these_sources_and_contain_no_flagged_instruction():
+  """The ARTEFACTS, not the recipe: the two .so files that travel to the GPU box are taken apart (`.hip_fatbin` section ->
+  the gfx950 code object of every translation unit -> llvm-objdump) and scanned; the hash each carries (`srl_build_info`)
+  must be that of the sources and flags in the tree, so a stale or hand-copied library fails here; and the env library
+  says which variant it is (the bench line prints it)."""
+  build.build()                                   # a no-op unless a library is missing or stale
+  for lib, deps, flags, variants in ((build.LIB, build.DEPS, build.FLAGS, (build.VARIANT_FIXED, build.VARIANT_SAFE)),
+                                     (build.QLIB, build.QDEPS, build.QFLAGS, ('no-slp',))):
+    i = build.info(lib)
+    assert i is not None and i['hash'] == build.source_hash(deps, flags), '{} was not built from the sources in the tree'.format(lib)
+    assert i['variant'] in variants
+    texts = isa_fix.shipped_asm(lib)
+    assert len(texts) == (1 if lib == build.LIB else len(build.QSRC))
+    for t in texts:
+      hits = isa_fix.flagged(t)
+      assert not hits, '{}: {}'.format(os.path.basename(lib), hits[:5])
+    if lib == build.LIB:        # the scan saw the env kernels: packed instructions by the hundred, the step kernel by name
+      assert sum(t.count('v_pk_') for t in texts) > (1000 if i['variant'] == build.VARIANT_FIXED else 50)
+      assert any('<srl_k_step>:' in t for t in texts) and any('<srl_k_render>:' in t for t in texts)
+    else:
+      assert sum(t.count('v_mfma_') for t in texts) > 1000
+
+
 def test_the_vectoriser_does_emit_the_form_and_the_pass_removes_all_of_it():
   raw = build.device_asm(HIPCC, build.FLAGS, os.path.join(build.CSRC, build.SOURCES[0]))
   assert len(isa_fix.flagged(raw)) > 100          # (955 with the compiler of this image)

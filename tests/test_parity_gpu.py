@@ -194,6 +194,46 @@ def test_ordered_launch_matches_the_oracle(ref_pool, oracle_mod, L, n, kw):
   g.close()
 
 
+@pytest.mark.parametrize('cap,smooth', [(3, True), (12, True), (9, False)])
+def test_step_cap_exits_match_the_oracle(ref_pool, oracle_mod, cap, smooth):
+  """The `MAX_STEP_TIME` cap (simulator.py:46, :221-224, :242-245; pinned for the oracle by tests/test_simulator_golden.py):
+  with a cap of a few sub-steps some envs leave the smooth-placing loop at it, others the settle loop, others finish below
+  it.  The reference raises RuntimeError; the kernel flags the env (SRL_ST_DIVERGED), `step` raises, and the state it leaves
+  — counters, poses, place poses' effect on the next reward — equals the oracle's bit for bit."""
+  from stackrl_amd import env as envs
+  from stackrl_amd.config import StackConfig
+  n, L = 24, 5
+  kw = dict(max_substeps=cap, smooth_placing=smooth)
+  g = envs.VecStackEnv(n_parallel=n, seed=3, pool=ref_pool, block=True, episode_length=L, **kw)
+  o = oracle_mod.OracleEnv(StackConfig(n_envs=n, episode_length=L, **kw), ref_pool, seed=3)
+  g.reset(); o.reset()
+  seen = set()
+  for k in range(L):
+    ga, oa = g.sample(), o.sample()
+    assert np.array_equal(ga.cpu().numpy(), oa)
+    o.step(oa)
+    try:
+      g.step(ga)
+      raised = False
+    except RuntimeError:
+      raised = True
+    gp, gnb, gsub, gst = g.state()
+    op, onb, osub, ost = o.state()
+    assert np.array_equal(gst, ost) and np.array_equal(gsub, osub) and np.array_equal(gnb, onb), 'step {}'.format(k)
+    assert raised == bool((ost & 1).any())
+    np.testing.assert_allclose(gp, op, rtol=0, atol=POSE_ATOL)
+    gH, _, _ = g.maps(); oH, _, _ = o.maps()
+    assert np.array_equal(gH, oH)
+    for e in range(n):
+      if ost[e] & 1:
+        seen.add('smooth' if osub[e, 1] == 0 and smooth else 'settle')
+      else:
+        seen.add('below')
+  assert 'below' in seen or cap < 6
+  assert ('smooth' in seen or 'settle' in seen), seen
+  g.close()
+
+
 def test_full_size_batch_properties(ref_pool):
   """BASELINE configs[1] size (1,024 envs x 8 rocks): size-independent properties instead of the oracle —
   every env places exactly L rocks, done on the L-th step, rocks at rest above the ground inside the time cap,
