@@ -91,7 +91,12 @@ def tconv(x, wp, bias, cout, taps=9, relu=True, out=None, d2s=0):
 
 
 class _Scratch(object):
-  """One growing float32 scratch buffer per (device, purpose): fixed addresses once the sizes have been seen."""
+  """One growing float32 scratch buffer per (device, purpose): fixed addresses once the sizes have been seen.
+
+  poison (a debug switch, off in the product; the GPU tests of the kernels turn it on): fill the buffer with NaN every time
+  it is handed out, so that a partial-sum slot a finishing kernel reads without anybody having written it cannot pass as
+  a plausible number."""
+  poison = False
 
   def __init__(self):
     self.buf = {}
@@ -101,6 +106,8 @@ class _Scratch(object):
     if t is None or t.numel() < n:
       t = torch.empty(int(n), dtype=torch.float32, device=dev)
       self.buf[key] = t
+    if _Scratch.poison:
+      t.fill_(float('nan'))
     return t
 
 

@@ -661,27 +661,66 @@ def test_bias_act_autograd_matches_torch(C, shape, relu):
 
 
 def test_fused_epilogue_net_matches_the_module_graph():
-  """`DeepQSiamFCN.set_fused_epilogues` (the GPU update path) against the plain module graph: Q-values and every
-  parameter gradient agree to float32 accumulation noise (the fused path changes no arithmetic, only the order of the
-  bias-gradient sums; the library's weight-gradient kernels accumulate atomically in a run-dependent order, which alone moves
-  the first layer's gradient by a few 1e-4 of its scale between two runs of the same graph)."""
+  """`DeepQSiamFCN.set_fused_epilogues` (the library update path, `DQN(hand_convs=False)`) against the plain module graph:
+  the fused path changes no arithmetic, only the order of the bias-gradient sums.  Both run the library's atomically
+  accumulating weight-gradient kernels, so they are not compared with each other but EACH with the module graph in float64
+  on the host, parameter by parameter, at 1e-3 of the parameter's gradient scale (re-association noise of float32 sums is
+  1e-6 ... 1e-5).  Round 3 saw 1.33e-3 between the two paths once on `left.down.3.0.weight` and widened the tolerance; the
+  record could not tell which side had moved or where.  A failure here now names the side, the elements, and how close to
+  zero the reference's pre-activations come (a ReLU mask that flips between two roundings of the same forward moves a
+  deep layer's gradient by x . g of one pixel — 1e-3 ... 1e-2 of its scale, confined to one output channel)."""
+  import copy
   from stackrl_amd import nets
   net = nets.DeepQSiamFCN(seed=3).cuda()
   g = torch.Generator(device='cuda').manual_seed(8)
   xm = torch.randint(0, 256, (4, 128, 128, 2), generator=g, device='cuda', dtype=torch.uint8)
   xo = torch.randint(0, 256, (4, 32, 32, 1), generator=g, device='cuda', dtype=torch.uint8)
   gq = torch.randn((4, net.n_actions), generator=g, device='cuda')
+  # float64 on the host, with the smallest |pre-activation| of every convolution recorded
+  ref = copy.deepcopy(net).double().cpu()
+  closest = {}
+  for name, m in ref.named_modules():
+    if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+      m.register_forward_hook(lambda mod, i, o, name=name: closest.__setitem__(name, float(o.detach().abs().min())))
+  fx, fx0 = ref.left(xm.cpu().permute(0, 3, 1, 2).double() / 255.0)          # models.py:144-147 in float64
+  fw, _ = ref.right(xo.cpu().permute(0, 3, 1, 2).double() / 255.0)
+  qd = ref.head(ref.correlation(fx, fw), fx0)
+  qd.backward(gq.double().cpu())
+  want = {n: p.grad.cuda() for n, p in ref.named_parameters()}
   q0 = net((xm, xo)); q0.backward(gq)
-  ref = {n: p.grad.clone() for n, p in net.named_parameters()}
+  plain = {n: p.grad.clone() for n, p in net.named_parameters()}
   net.zero_grad(set_to_none=True)
   net.set_fused_epilogues(True)
   q1 = net((xm, xo)); q1.backward(gq)
+  fused = {n: p.grad.clone() for n, p in net.named_parameters()}
   assert float((q1 - q0).abs().max()) <= 1e-5 * float(q0.abs().max())
-  for n, p in net.named_parameters():
-    scale = max(float(ref[n].abs().max()), 1e-6)
-    # 3e-3: both sides run the library's atomically accumulating weight-gradient kernels; 1.3e-3 of the scale was seen
-    # between two runs on a deep layer (left.down.3.0.weight) with nothing else changed
-    assert float((p.grad - ref[n]).abs().max()) <= 3e-3 * scale, n
+  assert float((q0.double() - qd.cuda()).abs().max()) <= 1e-4 * float(qd.abs().max())
+  # A deviation above 1e-3 is accepted only in the shape a flipped ReLU mask gives it (the float64 forward's smallest
+  # |pre-activation| is 1e-8 ... 1e-7 with these inputs — below the rounding of a float32 convolution, whose library kernels
+  # split the reduction and add atomically for some shapes, so the mask of such a pixel can differ between roundings of the
+  # same forward): below 5e-2 of the scale and confined to at most two output channels of the layer.  Anything else — a
+  # block of elements, several channels, a larger error — is corruption and fails with its location.
+  bad, flips = [], []
+  for n in want:
+    scale = float(want[n].abs().max())
+    if scale < 1e-9:
+      continue
+    for side, got in (('plain', plain[n]), ('fused', fused[n])):
+      diff = (got.double() - want[n]).abs()
+      e = float(diff.max()) / scale
+      if e <= 1e-3:
+        continue
+      d = (diff > 1e-4 * scale).nonzero()
+      rng = [(int(d[:, k].min()), int(d[:, k].max())) for k in range(d.shape[1])]
+      oc_dim = 1 if ('.up.' in n and n.endswith('weight')) else 0          # ConvTranspose2d weights are [cin, cout, 2, 2]
+      channels = sorted(set(d[:, oc_dim].tolist()))
+      rec = '{} [{}]: {:.2e} of scale {:.3g}; {} elements off by > 1e-4 in output channels {}, index ranges {}'.format(
+        n, side, e, scale, d.shape[0], channels[:8], rng)
+      (flips if (e <= 5e-2 and len(channels) <= 2) else bad).append(rec)
+  near = sorted(closest.items(), key=lambda kv: kv[1])[:4]
+  if flips:
+    print('accepted as ReLU-mask flips:', '; '.join(flips), '| smallest |pre-activation| of the float64 forward:', near)
+  assert not bad, '; '.join(bad) + ' | smallest |pre-activation| of the float64 forward: {}'.format(near)
 
 
 def test_update_stays_finite_under_the_concurrent_env_step():
