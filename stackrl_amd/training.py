@@ -168,6 +168,7 @@ class Trainer(object):
     import collections
     losses = collections.deque(maxlen=self.LOSS_HISTORY)   # bounded: a real run lasts millions of iterations
     step = None
+    failed = False
     try:
       step = env.reset()
       agent.acknowledge_reset()
@@ -206,12 +207,16 @@ class Trainer(object):
     except StopIteration:
       self.log('Training goal achieved.')
     except Exception:
+      failed = True
       self.log_exception()
       raise
     finally:
       self._drain(env, step)
       if self._directory is not None:
-        self.checkpoint()
+        # training.py:405-408 checkpoints in `finally`.  With several ranks a checkpoint is a collective (its barrier, the
+        # shared file): a rank that left the loop by an exception must not enter it while its peers sit in the gradient
+        # all-reduce, and what it holds may be half an update — the last periodic checkpoint stands instead.
+        self.checkpoint(after_failure=failed)
     return torch.stack(list(losses)) if losses else torch.zeros(0)
 
   def collect_step(self, env, step):
@@ -338,14 +343,33 @@ class Trainer(object):
   def _rank_file(self):
     return os.path.join(os.path.dirname(self._ckpt_file), 'ckpt.rank{}.pt'.format(self._rank))
 
-  def _barrier(self):
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-      dist.barrier()
+  BARRIER_TIMEOUT_S = 600.0
 
-  def checkpoint(self):
-    """training.py:467-485: agent (nets, optimiser, counters, replay memory) + the training-return metric."""
+  def _world(self):
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+      return 1
+    return dist.get_world_size(getattr(self._agent, '_pg', None))
+
+  def _barrier(self):
+    """Over the agent's process group (the one its gradient all-reduce uses); bounded where the backend can bound it."""
+    import datetime
+    import torch.distributed as dist
+    if self._world() > 1:
+      pg = getattr(self._agent, '_pg', None)
+      if dist.get_backend(pg) == 'gloo':
+        dist.monitored_barrier(group=pg, timeout=datetime.timedelta(seconds=self.BARRIER_TIMEOUT_S))
+      else:
+        dist.barrier(group=pg)
+
+  def checkpoint(self, after_failure=False):
+    """training.py:467-485: agent (nets, optimiser, counters, replay memory) + the training-return metric.
+    after_failure: called while an exception is in flight — with one rank the reference's behaviour (save what there is),
+    with several no file is touched and no collective entered."""
     iters = self.iterations
+    if after_failure and self._world() > 1:
+      self.log('Checkpoint skipped: this rank left the loop by an exception; the last periodic checkpoint stands.')
+      return
     if iters != self._last_checkpoint_iter and self._ckpt_file is not None:
       self.log('Saving checkpoint...')
       os.makedirs(os.path.dirname(self._ckpt_file), exist_ok=True)

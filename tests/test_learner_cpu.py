@@ -2,6 +2,7 @@
 and closed forms, plus the world_size-2 `gloo` test of the gradient all-reduce."""
 import math
 import os
+import time
 
 import numpy as np
 import pytest
@@ -516,6 +517,52 @@ def test_checkpoint_keeps_rank_local_state_per_rank_world_size_2_gloo(tmp_path):
                  'sampling_streams_differ_across_ranks': True, 'files': ['ckpt.pt', 'ckpt.rank0.pt', 'ckpt.rank1.pt']}
   for r in range(2):
     assert torch.load(out + str(r)) == {'iterations': 4, 'own_memory_restored': True, 'own_generators_restored': True}
+
+
+def _failing_rank(rank, world, port, d, out):
+  import datetime
+  import torch.distributed as dist
+  from stackrl_amd.training import Trainer
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+  spec = ((16, 16, 2), (4, 4, 1))
+  B, L = 3, 4
+  agent = _toy_agent(spec, B, seed=3 + rank)
+  tr = Trainer(_ToyEnv(B, L, spec, seed=10 + rank), agent, directory=d, log_interval=2, checkpoint_interval=4,
+               train_reward_buffer_length=2)
+  tr.initialize(num_steps=6)
+  if rank == 1:                        # this rank fails inside iteration 6, after the periodic checkpoint at 4
+    real, calls = agent.train, {'n': 0}
+
+    def train():
+      calls['n'] += 1
+      if calls['n'] == 6:
+        raise ValueError('injected failure on rank 1')
+      return real()
+    agent.train = train
+  err = None
+  try:
+    tr.run(8)
+  except Exception as e:               # rank 1: the injected error; rank 0: its all-reduce loses the peer
+    err = type(e).__name__
+  ck = torch.load(os.path.join(d, 'checkpoint', 'ckpt.pt'), weights_only=False)
+  torch.save({'error': err, 'checkpoint_iterations': int(ck['agent']['iterations'])}, out + str(rank))
+
+
+def test_a_failing_rank_enters_no_collective_and_leaves_the_last_checkpoint_alone_world_size_2_gloo(tmp_path):
+  """`run()` checkpoints in `finally` like the reference (training.py:405-408).  With several ranks the checkpoint ends in
+  a barrier: a rank that raised inside the loop would enter it while its peer sits in the gradient all-reduce — mismatched
+  collectives on one group — and rank 0 would later overwrite the good ckpt.pt.  Rank 1 fails in iteration 6 here: both
+  ranks come back (no hang), and the checkpoint on disk is still the periodic one of iteration 4."""
+  import torch.multiprocessing as mp
+  d, out = str(tmp_path / 'run'), str(tmp_path / 'res.pt')
+  ctx = mp.spawn(_failing_rank, args=(2, 25000 + os.getpid() % 2000, d, out), nprocs=2, join=False)
+  t0 = time.time()
+  while not ctx.join(timeout=5):
+    assert time.time() - t0 < 240, 'a rank hangs in a collective'
+  r0, r1 = torch.load(out + '0'), torch.load(out + '1')
+  assert r1['error'] == 'ValueError' and r0['error'] is not None
+  assert r0['checkpoint_iterations'] == 4 and r1['checkpoint_iterations'] == 4
 
 
 def test_curriculum_moves_on_when_the_goal_return_is_reached(tmp_path):
