@@ -120,7 +120,7 @@ int srl_get_object_map(srl_env* env, int32_t mesh_id, float* object_map);
 /* Per-kernel HIP-event timing (bench.py's roofline leg).  enable != 0 brackets every kernel launch of
  * srl_reset/srl_step with events on the launch stream; srl_get_kernel_times synchronises and returns the
  * accumulated milliseconds and launch counts since the last call: index 0 = settle (K1+K4),
- * 1 = render (K2+K5+obs pack), 2 = reserved. */
+ * 1 = render (K2+K5+obs pack), 2 = staging of the rocks' planes and outlines for the render (one wave per rock). */
 int srl_set_profiling(srl_env* env, int32_t enable);
 
 /* Tuning hint, between srl_create and srl_load_meshes: the number of envs that step on this device at the same time over

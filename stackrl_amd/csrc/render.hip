@@ -172,16 +172,23 @@ __device__ __forceinline__ uint32_t goal_pair(uint32_t m, uint32_t gdiff) {
 #endif
 #define SRL_PLANE_ROUNDS ((SRL_PLANE_CAP + SRL_RENDER_THREADS - 1) / SRL_RENDER_THREADS)
 
-// LDS carve of srl_k_render (64 KB tile + 12 KB planes + 3 KB per-rock records at 128^2: two workgroups per CU)
+// ---- the staged record of one rock (srl_k_stage -> srl_k_render), SRL_STAGE_STRIDE float4s per (env, body slot) in HBM:
+//   [0] ints  i0 | i1 << 16, j0 | j1 << 16 (pixel bounding box), nup (up-facing planes), nsil (outline sides)
+//   [1] ints  items (of SRL_ITEM_ROWS x 2 pixels), nir (item rows with a span below; 0: items fill the bounding box), 0, 0
+//   [2..5]    16 ints, one per item row r: first item of the row << 8 | first column — the columns of the bounding box
+//             the outline can reach in the row's SRL_ITEM_ROWS pixel rows (a superset: the ray cast still tests every pixel)
+//   [6..]     the nup up-facing world-frame planes (a, b, c, -), then the nsil outline sides (ea, eb, ec, -)
+#define SRL_STAGE_HDR 6
+#define SRL_STAGE_SPANS 16
+#define SRL_STAGE_STRIDE (SRL_STAGE_HDR + SRL_MAX_TRIS + 2)
+
+// LDS carve of srl_k_render (64 KB tile + 12 KB planes + 3.5 KB per-rock records at 128^2: two workgroups per CU)
 struct RenderLds {
   float* tile;      // [res*res]
-  float4* planes;   // [SRL_PLANE_CAP] per rock region: up-facing from the front, down-facing from the back
-  float* sx;        // [32][3]
-  float* sR;        // [32][9]
-  int* mhdr;        // [32][4] vo, nv, to, nt
-  int* prange;      // [32][4] i0|i1<<16, j0|j1<<16, w2 (items per row of items), items (SRL_ITEM_ROWS x 2 pixels each)
-  int* reg;         // [32][4] region base in its group, end of its up-facing planes, start of its outline sides, slots before this rock
-  int* ehdr;        // [32][2] edge offset, edge count of the rock's mesh
+  float4* planes;   // [SRL_PLANE_CAP] per rock region: its up-facing planes, then its outline sides
+  int* prange;      // [32][4] i0|i1<<16, j0|j1<<16, nir (item rows with spans; 0 = bounding-box items), items
+  int* reg;         // [32][4] region base in its group, nup, nsil, slots before this rock (over all rocks)
+  int* span;        // [32][16] per item row: first item << 8 | first column
   uint32_t* rowmask;   // [8] bit i set: tile row i may hold a rock pixel (union of the rocks' row ranges)
   int* misc;        // [4] rocks in the first group
   float* pi;        // [512]  (pi and pu alias the plane staging area: used after the ray cast)
@@ -190,7 +197,7 @@ struct RenderLds {
 
 __host__ __device__ inline size_t render_lds_bytes(int res) {
   return sizeof(float) * (size_t)res * res + sizeof(float4) * SRL_PLANE_CAP +
-         sizeof(float) * (3 + 9 + 4 + 4 + 4 + 2) * SRL_MAX_BODIES + sizeof(uint32_t) * (8 + 4);
+         sizeof(int) * (4 + 4 + SRL_STAGE_SPANS) * SRL_MAX_BODIES + sizeof(uint32_t) * (8 + 4);
 }
 
 // one min / max sweep over planes [0, n) of a region for a lane's item of SRL_ITEM_ROWS x 2 pixels, this lane taking
@@ -273,10 +280,168 @@ __device__ __forceinline__ float wave_minmax(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// ------------------------------------------------------------------ staging: one wave per (env, rock)
+// What the ray cast needs of a rock — its pixel bounding box, its up-facing face planes in the world frame, the sides of
+// its outline, and per item row the columns the outline can reach — depends on the rock's pose and mesh alone.  Until
+// round 4 srl_k_render did this itself, two wave tasks per rock between two block barriers, with a 64 KB tile per workgroup
+// limiting a CU to 16 waves: four dependent memory round trips (pose -> mesh header -> vertices / planes / edges -> the two
+// faces of every edge) that two workgroups per CU could not hide (7 us of a 43 us launch).  Here the same arithmetic runs
+// with one wave per rock and no tile, so a CU holds as many waves as it has slots, and srl_k_render starts from
+// finished records (one contiguous read per rock).
+//   xy bounds: vertices over the lanes, DPP min / max -> pixel range (pixel_range)
+//   planes:    world-frame plane of every face (make_rplane); the up-facing ones packed by ballot ranks
+//   outline:   lanes over the mesh's edge list (edge -> its two faces, built at srl_load_meshes); facing of the two faces
+//              from their normals (the very expression make_rplane classifies by); side through the projected end points
+//              A, B (A the lower vertex index): E(p) = fma(ea, p.x, fma(eb, p.y, ec)) >= 0 inside, oriented by the centre
+//              of mass
+//   spans:     lane r = item row r (SRL_ITEM_ROWS pixel rows, x in [xa, xb]): a side with eb > 0 bounds y from below by
+//              its line, one with eb < 0 from above; over the slab a line is at least / at most its value at one of the
+//              two ends, so max_k min(L_k(xa), L_k(xb)) <= y <= min_k max(L_k(xa), L_k(xb)) holds for every inside
+//              point — widened by a pixel on either side against rounding.  A superset is all that is needed: the ray
+//              cast evaluates the definition's side functions at every pixel it visits.
+// Lists are sets here: the ray cast takes minima over them, so their order does not enter any result.
+extern "C" __global__ void __launch_bounds__(256) srl_k_stage(DevParams P, float4* __restrict__ stage, int slots,
+    const float* __restrict__ poses_ext, const int32_t* __restrict__ mesh_ext, const int32_t* __restrict__ nb_ext) {
+  __shared__ float4 sides[4][SRL_MAX_TRIS + 2];
+  const int e = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.y * 4 + wave;
+  const bool ext = poses_ext != nullptr;
+  const int nb = ext ? nb_ext[e] : P.hdr[e].nb;
+  if (b >= nb || b >= slots) return;                 // (wave-uniform; nothing below synchronises across waves)
+  q4 q; v3 xb; int m;
+  if (ext) {
+    const float* p = poses_ext + ((size_t)e * SRL_MAX_BODIES + b) * 7;
+    xb = V(p[0], p[1], p[2]); q.x = p[3]; q.y = p[4]; q.z = p[5]; q.w = p[6];
+    m = mesh_ext[(size_t)e * SRL_MAX_BODIES + b];
+  } else {
+    const float* gb = P.blob + (size_t)e * P.BLOB;
+    xb = ld3(gb + P.OFF_X + 4 * b);
+    const float* qq = gb + P.OFF_Q + 4 * b;
+    q.x = qq[0]; q.y = qq[1]; q.z = qq[2]; q.w = qq[3];
+    m = ((const int*)gb)[P.OFF_MESH + b];
+  }
+  m = min(max(m, 0), P.n_mesh - 1);
+  const MeshHdr mh = P.mh[m];
+  const int vo = mh.vo, nv = mh.nv, to = mh.to, nt = mh.nt, eo = mh.eo, ne = mh.ne;
+  const int res = P.c.overhead_res;
+  float4* rec = stage + ((size_t)e * slots + b) * SRL_STAGE_STRIDE;
+  // the first two chunks of faces and the first chunk of edges are requested before the vertex pass
+  float4 pl0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pl1 = pl0;
+  if (lane < nt) pl0 = P.mp[to + lane];
+  if (64 + lane < nt) pl1 = P.mp[to + 64 + lane];
+  const m3 R = quat_to_mat(q);
+  // world xy of the vertices, one (two) per lane; the outline's end points are cross-lane reads of these
+  float wx0 = 0.0f, wy0 = 0.0f, wx1 = 0.0f, wy1 = 0.0f;
+  float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+  for (int v = lane; v < nv; v += 64) {
+    const float4 lv = P.mv[vo + v];
+    const v3 a = mmul_add(R, V(lv.x, lv.y, lv.z), xb);
+    if (v < 64) { wx0 = a.x; wy0 = a.y; } else { wx1 = a.x; wy1 = a.y; }
+    xmin = fminf(xmin, a.x); xmax = fmaxf(xmax, a.x); ymin = fminf(ymin, a.y); ymax = fmaxf(ymax, a.y);
+  }
+  xmin = wave_minmax<true>(xmin); xmax = wave_minmax<false>(xmax);
+  ymin = wave_minmax<true>(ymin); ymax = wave_minmax<false>(ymax);
+  int i0 = 0, i1 = -1, j0 = 0, j1 = -1;
+  const bool okx = pixel_range(xmin, xmax, P.inv_px, res, i0, i1);
+  const bool oky = pixel_range(ymin, ymax, P.inv_px, res, j0, j1);
+  if (!(okx && oky)) {                               // the rock lies outside the window: nothing to cast
+    if (lane == 0) {
+      rec[0] = make_float4(__int_as_float(-65536), __int_as_float(-65536), __int_as_float(0), __int_as_float(0));   // i0 = 0, i1 = -1
+      rec[1] = make_float4(__int_as_float(0), __int_as_float(0), __int_as_float(0), __int_as_float(0));
+    }
+    return;
+  }
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // ---- up-facing planes
+  int nup = 0;
+  for (int c = 0; c < nt; c += 64) {
+    const bool act = c + lane < nt;
+    float4 pl = c == 0 ? pl0 : pl1;
+    if (c >= 128 && act) pl = P.mp[to + c + lane];
+    const float4 wp = make_rplane(pl, R, xb);
+    const bool up = act && __float_as_int(wp.w) == 0;
+    const unsigned long long mu = __ballot(up);
+    if (up) rec[SRL_STAGE_HDR + nup + __popcll(mu & below)] = wp;
+    nup += __popcll(mu);
+  }
+  // ---- outline sides (at most nt + 2 - nup: a closed triangulated cap with an s-edge rim has >= s - 2 triangles)
+  const int cap = nt + 2 - nup;
+  int nsil = 0;
+  for (int c = 0; c < ne; c += 64) {
+    const bool act = c + lane < ne;
+    uchar4 ed = make_uchar4(0, 0, 0, 0);
+    if (act) ed = P.me[eo + c + lane];
+    const float4 na = P.mp[to + ed.z], nb_ = P.mp[to + ed.w];
+    const bool da = !(mmul(R, V(na.x, na.y, na.z)).z >= 0.0f), db = !(mmul(R, V(nb_.x, nb_.y, nb_.z)).z >= 0.0f);
+    const bool sil = act && (da != db);
+    const unsigned long long ms = __ballot(sil);
+    float Ax = __shfl(wx0, ed.x & 63), Ay = __shfl(wy0, ed.x & 63), Bx = __shfl(wx0, ed.y & 63), By = __shfl(wy0, ed.y & 63);
+    if (nv > 64) {
+      const float ax1 = __shfl(wx1, ed.x & 63), ay1 = __shfl(wy1, ed.x & 63), bx1 = __shfl(wx1, ed.y & 63), by1 = __shfl(wy1, ed.y & 63);
+      if (ed.x >= 64) { Ax = ax1; Ay = ay1; }
+      if (ed.y >= 64) { Bx = bx1; By = by1; }
+    }
+    if (sil) {
+      float ea = Ay - By, eb = Bx - Ax;
+      float ec = -fmaf(ea, Ax, eb * Ay);
+      if (fmaf(ea, xb.x, fmaf(eb, xb.y, ec)) < 0.0f) { ea = -ea; eb = -eb; ec = -ec; }
+      const int r = nsil + __popcll(ms & below);
+      if (r < cap) {
+        const float4 sd = make_float4(ea, eb, ec, 0.0f);
+        rec[SRL_STAGE_HDR + nup + r] = sd;
+        sides[wave][r] = sd;
+      }
+    }
+    nsil += __popcll(ms);
+  }
+  if (nsil > cap) nsil = cap;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the wave's own LDS writes have landed
+  // ---- items: SRL_ITEM_ROWS x 2 pixels; per item row the columns the outline can reach
+  const int nirows = (i1 - i0 + SRL_ITEM_ROWS) / SRL_ITEM_ROWS;
+  int items, nir;
+  if (nirows <= SRL_STAGE_SPANS) {
+    nir = nirows;
+    int cnt = 0, jlo = j0;
+    if (lane < nirows) {
+      const int ia = i0 + SRL_ITEM_ROWS * lane, ib = min(ia + SRL_ITEM_ROWS - 1, i1);
+      const float xa = ((float)ia + 0.5f) * P.px, xe = ((float)ib + 0.5f) * P.px;
+      float ylo = -1e30f, yhi = 1e30f;
+      bool empty = false;
+      for (int k = 0; k < nsil; ++k) {
+        const float4 sd = sides[wave][k];
+        const float fa = fmaf(sd.x, xa, sd.z), fe = fmaf(sd.x, xe, sd.z);   // E = f + eb y
+        if (fabsf(sd.y) < 1e-12f) { empty = empty || (fa < 0.0f && fe < 0.0f); continue; }
+        const float rcp = -__builtin_amdgcn_rcpf(sd.y);                        // (1 ulp: the spans carry a pixel of margin)
+        const float la = fa * rcp, le = fe * rcp;                              // the side's line at the two ends of the slab
+        if (sd.y > 0.0f) ylo = fmaxf(ylo, fminf(la, le)); else yhi = fminf(yhi, fmaxf(la, le));
+      }
+      // pixel centres ((j + 0.5) px) between the bounds, one pixel of margin on either side, inside the bounding box
+      const float fl = floorf(ylo * P.inv_px - 0.5f) - 1.0f, fh = ceilf(yhi * P.inv_px - 0.5f) + 1.0f;
+      const int a = fl > (float)j0 ? (fl < (float)(j1 + 1) ? (int)fl : j1 + 1) : j0;
+      const int z = fh < (float)j1 ? (fh > (float)(j0 - 1) ? (int)fh : j0 - 1) : j1;
+      if (!empty && a <= z) { jlo = a; cnt = (z - a + 2) >> 1; }
+    }
+    int pre = cnt;                                   // inclusive prefix over the item rows (lanes 0 .. 15)
+#pragma unroll
+    for (int d = 1; d < SRL_STAGE_SPANS; d <<= 1) { const int v = __shfl_up(pre, d); if (lane >= d) pre += v; }
+    items = __shfl(pre, SRL_STAGE_SPANS - 1);
+    if (lane < SRL_STAGE_SPANS) ((int*)(rec + 2))[lane] = ((pre - cnt) << 8) | jlo;
+  } else {                                           // more item rows than the table holds: items fill the bounding box
+    nir = 0;
+    items = nirows * ((j1 - j0 + 2) >> 1);
+  }
+  if (lane == 0) {
+    if (items == 0) { nup = 0; nsil = 0; }
+    rec[0] = make_float4(__int_as_float(i0 | (i1 << 16)), __int_as_float(j0 | (j1 << 16)), __int_as_float(nup), __int_as_float(nsil));
+    rec[1] = make_float4(__int_as_float(items), __int_as_float(nir), __int_as_float(0), __int_as_float(0));
+  }
+}
+
 // poses_ext != nullptr: test/profiling hook rendering explicit poses (srl_render_heightmap)
 extern "C" __global__ void __launch_bounds__(SRL_RENDER_THREADS, 4)
-srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ obs_obj, float* __restrict__ reward,
-             uint8_t* __restrict__ done, const float* __restrict__ poses_ext, const int32_t* __restrict__ mesh_ext,
+srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* __restrict__ obs_map,
+             uint8_t* __restrict__ obs_obj, float* __restrict__ reward, uint8_t* __restrict__ done,
              const int32_t* __restrict__ nb_ext, float* __restrict__ height_ext) {
   extern __shared__ float4 lds_raw[];
 #ifdef SRL_ABL_EMPTY
@@ -287,48 +452,36 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   RenderLds L;
   L.tile = (float*)lds_raw;
   L.planes = (float4*)(L.tile + npx);
-  L.sx = (float*)(L.planes + SRL_PLANE_CAP);
-  L.sR = L.sx + 3 * SRL_MAX_BODIES;
-  L.mhdr = (int*)(L.sR + 9 * SRL_MAX_BODIES);
-  L.prange = L.mhdr + 4 * SRL_MAX_BODIES;
+  L.prange = (int*)(L.planes + SRL_PLANE_CAP);
   L.reg = L.prange + 4 * SRL_MAX_BODIES;
-  L.ehdr = L.reg + 4 * SRL_MAX_BODIES;
-  L.rowmask = (uint32_t*)(L.ehdr + 2 * SRL_MAX_BODIES);
+  L.span = L.reg + 4 * SRL_MAX_BODIES;
+  L.rowmask = (uint32_t*)(L.span + SRL_STAGE_SPANS * SRL_MAX_BODIES);
   L.misc = (int*)(L.rowmask + 8);
   L.pi = (float*)L.planes;
   L.pu = L.pi + SRL_RENDER_THREADS;
   EnvHdr* h = &P.hdr[e];
   const float* gb = P.blob + (size_t)e * P.BLOB;
-  const bool ext = poses_ext != nullptr;
+  const bool ext = nb_ext != nullptr;
 #ifdef SRL_STAMPS
   long long _t0 = wall_clock64();
 #endif
-  // ---- prologue.  Pose, mesh id and mesh header of every body slot are requested before the rock count is
-  //      known (one memory round trip less); the header fields and the object map are requested up front too:
-  //      their latency overlaps the ray cast.
-  q4 q; v3 x = V(0.0f, 0.0f, 0.0f); MeshHdr mh;
-  q.x = q.y = q.z = 0.0f; q.w = 1.0f;
-  mh.vo = mh.nv = mh.to = mh.nt = 0; mh.eo = mh.ne = 0;
-  if (tid < (ext ? SRL_MAX_BODIES : P.c.episode_length)) {
-    int m;
-    if (ext) {
-      const float* p = poses_ext + ((size_t)e * SRL_MAX_BODIES + tid) * 7;
-      x = V(p[0], p[1], p[2]); q.x = p[3]; q.y = p[4]; q.z = p[5]; q.w = p[6];
-      m = mesh_ext[(size_t)e * SRL_MAX_BODIES + tid];
-    } else {
-      x = ld3(gb + P.OFF_X + 4 * tid);
-      const float* qq = gb + P.OFF_Q + 4 * tid;
-      q.x = qq[0]; q.y = qq[1]; q.z = qq[2]; q.w = qq[3];
-      m = ((const int*)gb)[P.OFF_MESH + tid];
-    }
-    m = min(max(m, 0), P.n_mesh - 1);   // slots past the rock count hold stale or no data
-    mh = P.mh[m];
+  // ---- prologue.  The record headers of every body slot are requested before the rock count is known (one memory round
+  //      trip less); so are the words of the episode state the tail needs: their latency overlaps the ray cast.
+  const float4* srec = stage + (size_t)e * slots * SRL_STAGE_STRIDE;
+  int4 hd0 = make_int4(0, -65536, 0, 0), hd1 = make_int4(0, 0, 0, 0);
+  if (tid < slots) {
+    const float4 a = srec[(size_t)tid * SRL_STAGE_STRIDE], c = srec[(size_t)tid * SRL_STAGE_STRIDE + 1];
+    hd0 = make_int4(__float_as_int(a.x), __float_as_int(a.y), __float_as_int(a.z), __float_as_int(a.w));
+    hd1 = make_int4(__float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
   }
   const int nb = ext ? nb_ext[e] : h->nb;
-  int g0 = 0, g1 = 0, g2 = 0, g3 = 0, pending = -1, mode = 0, hdone = 0;
+  int g0 = 0, g1 = 0, g2 = 0, g3 = 0, pending = -1, mode = 0, hdone = 0, left = 0;
+  float prev_m[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if (!ext) {
     g0 = h->goal[0]; g1 = h->goal[1]; g2 = h->goal[2]; g3 = h->goal[3]; pending = h->pending;
-    mode = h->mode; hdone = h->done;
+    mode = h->mode; hdone = h->done; left = h->list_pos;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) prev_m[k] = h->prev_metric[k];
   }
   const int rr = P.c.object_res * P.c.object_res * P.n_orient;   // all observable orientations of the pending rock
   {
@@ -336,27 +489,32 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     float4* t4 = (float4*)L.tile;
     for (int k = tid; k < npx / 4; k += SRL_RENDER_THREADS) t4[k] = z4;
   }
-  if (tid < 8) L.rowmask[tid] = 0u;
+  if (tid < 8) L.rowmask[tid] = 0u;                  // (wave 0, like the atomicOr below: LDS keeps a wave's order)
   if (tid < SRL_MAX_BODIES) {
-    // a rock's region holds its up-facing planes and the sides of its outline: at most nt + 2 slots (the down-facing
-    // cap of a closed triangulated surface whose rim has s edges has at least s - 2 triangles)
-    const int nt = tid < nb ? mh.nt + 2 : 0;
+    // a rock's region holds its up-facing planes and the sides of its outline (a rock outside the window has neither)
+    const int nt = tid < nb ? hd0.z + hd0.w : 0;
     int pre = nt;   // inclusive prefix of the region sizes over the rocks (lanes 0..31 of wave 0)
 #pragma unroll
     for (int d = 1; d < SRL_MAX_BODIES; d <<= 1) { const int v = __shfl_up(pre, d); if (lane >= d) pre += v; }
     const int be0 = __popcll(__ballot(tid < nb && pre <= SRL_PLANE_CAP));   // rocks whose planes fit the first group
     if (tid == 0) L.misc[0] = be0;
     if (tid < nb) {
-      m3 R = quat_to_mat(q);
-      st3(L.sx + 3 * tid, x);
-#pragma unroll
-      for (int i = 0; i < 9; ++i) L.sR[9 * tid + i] = R.m[i];
-      L.mhdr[4 * tid + 0] = mh.vo; L.mhdr[4 * tid + 1] = mh.nv; L.mhdr[4 * tid + 2] = mh.to; L.mhdr[4 * tid + 3] = mh.nt;
+      L.prange[4 * tid + 0] = hd0.x; L.prange[4 * tid + 1] = hd0.y; L.prange[4 * tid + 2] = hd1.y; L.prange[4 * tid + 3] = hd1.x;
       // cursors as for the first group (later groups reset theirs)
-      L.reg[4 * tid + 0] = pre - nt; L.reg[4 * tid + 1] = pre - nt; L.reg[4 * tid + 2] = pre; L.reg[4 * tid + 3] = pre - nt;
-      L.ehdr[2 * tid + 0] = mh.eo; L.ehdr[2 * tid + 1] = mh.ne;
-      L.prange[4 * tid + 3] = 0;
+      L.reg[4 * tid + 0] = pre - nt; L.reg[4 * tid + 1] = hd0.z; L.reg[4 * tid + 2] = hd0.w; L.reg[4 * tid + 3] = pre - nt;
+      if (hd1.x > 0) {
+        const int i0 = hd0.x & 0xffff, i1 = hd0.x >> 16;
+        for (int w = i0 >> 5; w <= i1 >> 5; ++w) {
+          const int lo = max(i0 - 32 * w, 0), hi = min(i1 - 32 * w, 31);
+          atomicOr(&L.rowmask[w], (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo));
+        }
+      }
     }
+  }
+  // the span tables of the rocks: four 16-byte words each, one per thread
+  if (tid < 4 * nb) {
+    const int b = tid >> 2, k = tid & 3;
+    ((float4*)L.span)[4 * b + k] = srec[(size_t)b * SRL_STAGE_STRIDE + 2 + k];
   }
   // epilogue constants
   const float nearp = SRL_FAR - P.c.max_z;
@@ -380,121 +538,40 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     const int lo = max(g1 - walk_j0, 0), hi = min(g1 + g3 - walk_j0, 4);
     colmask = hi > lo ? (1u << hi) - (1u << lo) : 0u;
   }
+  // ---- object observation (O2 from the per-mesh cache; empty map when nothing is pending): its inputs are known here,
+  //      so it leaves now and drains under everything else
+#ifndef SRL_ABL_NOOBJ
+  if (!ext) {
+    // the pending rock's maps, or with ordering freedom (observer.py:310-327) those of the rocks still unplaced, in list
+    // order, then empty maps; bytes from the per-mesh cache, four pixels per lane (the map size is a multiple of 4)
+    const int shown = P.c.ordering_freedom ? P.c.episode_length : 1;
+    uint32_t* oo = (uint32_t*)(obs_obj + (size_t)e * rr * shown);
+    const uint32_t eb4 = P.obj_empty_byte * 0x01010101u;
+    for (int k = 0; k < shown; ++k) {
+      const int m = P.c.ordering_freedom ? (k < left ? h->ids[k] : -1) : pending;
+      const uint32_t* src = (const uint32_t*)(P.objmap_u8 + (size_t)(m < 0 ? 0 : m) * rr);
+      for (int idx = tid; idx < rr / 4; idx += SRL_RENDER_THREADS) oo[(size_t)k * (rr / 4) + idx] = m >= 0 ? src[idx] : eb4;
+    }
+  }
+#endif
   __syncthreads();
   RSTAMP(0);
   // ---- groups of rocks whose planes fit the staging area
-  int bs = 0, be = L.misc[0];   // (be >= 1 when nb >= 1: a mesh has at most SRL_MAX_TRIS <= SRL_PLANE_CAP faces)
+  int bs = 0, be = L.misc[0];   // (be >= 1 when nb >= 1: a mesh has at most SRL_MAX_TRIS + 2 <= SRL_PLANE_CAP slots)
   uint32_t cov = 0u, goalm = 0u;
   bool first = true;
   do {
-    // (a) staging.  Two independent tasks per rock, handed to the 8 waves round robin (with few rocks they run side by
-    //     side, with 8 rocks every wave does both for its rock):
-    //     F(b)  first trip: xy bounds of the rock (vertices over the lanes, DPP min / max) -> pixel range, item count,
-    //           row mask; every trip (rocks of the group): its up-facing world-frame planes, packed from the front of the
-    //           rock's region by ballot ranks
-    //     E(b)  (rocks of the group) its outline: the edges shared by an up-facing and a down-facing face, projected; side
-    //           through A, B (A the lower vertex index): E(p) = fma(ea, p.x, fma(eb, p.y, ec)) >= 0 inside (oriented by
-    //           the centre of mass = the body position), packed from the back of the region.  The facing of the two faces
-    //           is recomputed here from their normals (the very expression make_rplane classifies by), so E does not wait
-    //           for F.
-    {
-      const unsigned long long below = (1ull << lane) - 1ull;
-      const int f0 = first ? 0 : bs, nf = (first ? nb : be) - f0, ne_tasks = be - bs;
+    // (a) the group's planes and outline sides from their records (srl_k_stage) into the regions, the rocks handed to the
+    //     8 waves round robin, lanes over a rock's slots: the first 64 slots of a wave's first rock are requested now and
+    //     written to LDS after the early stores below (their latency hides under those), the rest follows there
+    const int pb = bs + wave;
+    int pbase = 0, pcnt = 0;
+    if (pb < be) { pbase = L.reg[4 * pb + 0]; pcnt = L.reg[4 * pb + 1] + L.reg[4 * pb + 2]; }
+    float4 pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #ifdef SRL_ABL_NOSTAGE
-      for (int task = wave; task < (P.px == 12345.0f ? nf + ne_tasks : 0); task += SRL_RENDER_THREADS / 64) {
-#else
-      for (int task = wave; task < nf + ne_tasks; task += SRL_RENDER_THREADS / 64) {
+    if (P.px == 12345.0f)
 #endif
-        const bool outline = task >= nf;
-        const int b = outline ? bs + (task - nf) : f0 + task;
-        const m3 R = ldm(L.sR + 9 * b);
-        const v3 xb = ld3(L.sx + 3 * b);
-        const int vo = L.mhdr[4 * b + 0], nv = L.mhdr[4 * b + 1], to = L.mhdr[4 * b + 2], nt = L.mhdr[4 * b + 3];
-        const int base = L.reg[4 * b + 0];
-        if (!outline) {
-          const bool planes = b >= bs && b < be;
-          float4 pl0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pl1 = pl0;
-          if (planes) {   // the first two chunks are requested before the vertex pass
-            if (lane < nt) pl0 = P.mp[to + lane];
-            if (64 + lane < nt) pl1 = P.mp[to + 64 + lane];
-          }
-          if (first) {
-            float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
-            for (int v = lane; v < nv; v += 64) {
-              const float4 lv = P.mv[vo + v];
-              const v3 a = mmul_add(R, V(lv.x, lv.y, lv.z), xb);
-              xmin = fminf(xmin, a.x); xmax = fmaxf(xmax, a.x); ymin = fminf(ymin, a.y); ymax = fmaxf(ymax, a.y);
-            }
-            xmin = wave_minmax<true>(xmin); xmax = wave_minmax<false>(xmax);
-            ymin = wave_minmax<true>(ymin); ymax = wave_minmax<false>(ymax);
-            if (lane == 0) {
-              int i0 = 0, i1 = -1, j0 = 0, j1 = -1;
-              const bool okx = pixel_range(xmin, xmax, P.inv_px, res, i0, i1);
-              const bool oky = pixel_range(ymin, ymax, P.inv_px, res, j0, j1);
-              int w2 = 0, items = 0;
-              if (okx && oky) { w2 = (j1 - j0 + 2) >> 1; items = ((i1 - i0 + SRL_ITEM_ROWS) / SRL_ITEM_ROWS) * w2; }   // items of SRL_ITEM_ROWS x 2 pixels
-              L.prange[4 * b + 0] = i0 | (i1 << 16); L.prange[4 * b + 1] = j0 | (j1 << 16); L.prange[4 * b + 2] = w2; L.prange[4 * b + 3] = items;
-              if (items > 0)
-                for (int w = i0 >> 5; w <= i1 >> 5; ++w) {
-                  const int lo = max(i0 - 32 * w, 0), hi = min(i1 - 32 * w, 31);
-                  atomicOr(&L.rowmask[w], (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo));
-                }
-            }
-          }
-          if (planes) {
-            int nup = 0;
-            for (int c = 0; c < nt; c += 64) {
-              const bool act = c + lane < nt;
-              float4 pl = c == 0 ? pl0 : pl1;
-              if (c >= 128 && act) pl = P.mp[to + c + lane];
-              const float4 wp = make_rplane(pl, R, xb);
-              const bool up = act && __float_as_int(wp.w) == 0;
-              const unsigned long long mu = __ballot(up);
-              if (up) L.planes[base + nup + __popcll(mu & below)] = wp;
-              nup += __popcll(mu);
-            }
-            if (lane == 0) L.reg[4 * b + 1] = base + nup;   // end of the up-facing planes
-          }
-        } else {
-          const int eo = L.ehdr[2 * b + 0], ne = L.ehdr[2 * b + 1];
-          const int cap = nt + 2;
-          // world xy of the vertices, one (two) per lane; end points are then cross-lane reads
-          float wx0 = 0.0f, wy0 = 0.0f, wx1 = 0.0f, wy1 = 0.0f;
-          for (int v = lane; v < nv; v += 64) {
-            const float4 lv = P.mv[vo + v];
-            const v3 a = mmul_add(R, V(lv.x, lv.y, lv.z), xb);
-            if (v < 64) { wx0 = a.x; wy0 = a.y; } else { wx1 = a.x; wy1 = a.y; }
-          }
-          int nsil = 0;
-          for (int c = 0; c < ne; c += 64) {
-            const bool act = c + lane < ne;
-            uchar4 ed = make_uchar4(0, 0, 0, 0);
-            if (act) ed = P.me[eo + c + lane];
-            const float4 na = P.mp[to + ed.z], nb_ = P.mp[to + ed.w];
-            const bool da = !(mmul(R, V(na.x, na.y, na.z)).z >= 0.0f), db = !(mmul(R, V(nb_.x, nb_.y, nb_.z)).z >= 0.0f);
-            const bool sil = act && (da != db);
-            const unsigned long long ms = __ballot(sil);
-            float Ax = __shfl(wx0, ed.x & 63), Ay = __shfl(wy0, ed.x & 63), Bx = __shfl(wx0, ed.y & 63), By = __shfl(wy0, ed.y & 63);
-            if (nv > 64) {
-              const float ax1 = __shfl(wx1, ed.x & 63), ay1 = __shfl(wy1, ed.x & 63), bx1 = __shfl(wx1, ed.y & 63), by1 = __shfl(wy1, ed.y & 63);
-              if (ed.x >= 64) { Ax = ax1; Ay = ay1; }
-              if (ed.y >= 64) { Bx = bx1; By = by1; }
-            }
-            if (sil) {
-              float ea = Ay - By, eb = Bx - Ax;
-              float ec = -fmaf(ea, Ax, eb * Ay);
-              if (fmaf(ea, xb.x, fmaf(eb, xb.y, ec)) < 0.0f) { ea = -ea; eb = -eb; ec = -ec; }
-              const int r = nsil + __popcll(ms & below);
-              if (r < cap) L.planes[base + cap - 1 - r] = make_float4(ea, eb, ec, 0.0f);
-            }
-            nsil += __popcll(ms);
-          }
-          if (nsil > cap) nsil = cap;   // (a closed convex mesh has nup + nsil <= nt + 2, see the prologue)
-          if (lane == 0) L.reg[4 * b + 2] = base + cap - nsil;   // start of the outline sides
-        }
-      }
-    }
-    __syncthreads();
+    if (lane < pcnt) pv = srec[(size_t)pb * SRL_STAGE_STRIDE + SRL_STAGE_HDR + lane];
     RSTAMP(1);
     // (d) first trip: rows no rock reaches hold the empty-pixel constants; their H / observation bytes leave
     //     now, so that HBM drains them while the ray cast computes.  cov bit k: this thread's k-th pixel group
@@ -545,6 +622,19 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       }
       RSTAMP(2);
     }
+    // the group's slots into their regions
+#ifdef SRL_ABL_NOSTAGE
+    if (P.px == 12345.0f)
+#endif
+    {
+      if (lane < pcnt) L.planes[pbase + lane] = pv;
+      for (int b = pb; b < be; b += SRL_RENDER_THREADS / 64) {
+        const int base = L.reg[4 * b + 0], cnt = L.reg[4 * b + 1] + L.reg[4 * b + 2];
+        const float4* src = srec + (size_t)b * SRL_STAGE_STRIDE + SRL_STAGE_HDR;
+        for (int k = (b == pb ? 64 : 0) + lane; k < cnt; k += 64) L.planes[base + k] = src[k];
+      }
+    }
+    __syncthreads();
     // (e) ray cast: lanes over the flattened (rock, item of SRL_ITEM_ROWS x 2 pixels) list; when the list is short each item
     //     is shared by S adjacent lanes that split the planes and combine with shuffles
 #ifdef SRL_ABL_NOCAST
@@ -580,13 +670,30 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
           b = wb; is = wis;
         }
         const int4 pr = ((const int4*)L.prange)[b], rg = ((const int4*)L.reg)[b];
-        const int w2 = pr.z, jj = pr.y, ii = pr.x;
+        const int nir = pr.z, jj = pr.y, ii = pr.x;
         const int j0 = jj & 0xffff, j1 = jj >> 16, i1 = ii >> 16;
         const int p = it - is;
-        // p / w2 without the integer-division sequence: (p + 0.5) / w2 stays at least 0.5 / w2 >= 1 / 256 away from
-        // an integer, far more than the error of the reciprocal (p < 2^14, w2 <= 128)
-        const int di = (int)(((float)p + 0.5f) * __builtin_amdgcn_rcpf((float)w2));
-        const int i = (ii & 0xffff) + SRL_ITEM_ROWS * di, j = j0 + 2 * (p - di * w2);
+        int di, j;
+        if (nir > 0) {
+          // item row = the last one whose first item is <= p (rows the outline does not reach share their successor's first
+          // item, rows past the last start at the rock's item count); the row's first column is in the low byte
+          const int4* sp = (const int4*)(L.span + SRL_STAGE_SPANS * b);
+          const int4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+          const int sv[SRL_STAGE_SPANS] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w};
+          const int key = (p << 8) | 0xff;
+          int w = sv[0];
+          di = 0;
+#pragma unroll
+          for (int r = 1; r < SRL_STAGE_SPANS; ++r) if (key >= sv[r]) { w = sv[r]; di = r; }
+          j = (w & 0xff) + 2 * (p - (w >> 8));
+        } else {
+          // items fill the bounding box.  p / w2 without the integer-division sequence: (p + 0.5) / w2 stays at least
+          // 0.5 / w2 >= 1 / 256 away from an integer, far more than the error of the reciprocal (p < 2^14, w2 <= 128)
+          const int w2 = (j1 - j0 + 2) >> 1;
+          di = (int)(((float)p + 0.5f) * __builtin_amdgcn_rcpf((float)w2));
+          j = j0 + 2 * (p - di * w2);
+        }
+        const int i = (ii & 0xffff) + SRL_ITEM_ROWS * di;
         const bool col2 = j + 1 <= j1;
         const f32x2 py = {((float)j + 0.5f) * P.px, ((float)(j + 1) + 0.5f) * P.px};
         f32x2 vx[SRL_ITEM_ROWS], hh[SRL_ITEM_ROWS], ll[SRL_ITEM_ROWS];
@@ -596,7 +703,7 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
           vx[r].x = x; vx[r].y = x; hh[r].x = 1e30f; hh[r].y = 1e30f; ll[r].x = 1e30f; ll[r].y = 1e30f;
         }
         // z_hi = min over the up-facing planes; inside the outline iff the smallest side function is >= 0
-        const int base = rg.x, nup = rg.y - base, e0 = rg.z, nsil = base + L.mhdr[4 * b + 3] + 2 - e0;
+        const int base = rg.x, nup = rg.y, e0 = base + nup, nsil = rg.z;
         plane_sweep<true>(L.planes + base, nup, s, S, py, vx, hh);
         plane_sweep<true>(L.planes + e0, nsil, s, S, py, vx, ll);
         // the S lanes of an item (adjacent, aligned) combine their partial minima with DPP moves folded into the min:
@@ -641,11 +748,9 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
     bs = be;
     if (bs < nb) {   // next group: its extent, then its region cursors
       const int p0 = L.reg[4 * bs + 3];
-      while (be < nb && L.reg[4 * be + 3] + L.mhdr[4 * be + 3] + 2 - p0 <= SRL_PLANE_CAP) ++be;
-      if (tid >= bs && tid < be) {
-        const int base = L.reg[4 * tid + 3] - p0;
-        L.reg[4 * tid + 0] = base; L.reg[4 * tid + 1] = base;
-      }
+      while (be < nb && L.reg[4 * be + 3] + L.reg[4 * be + 1] + L.reg[4 * be + 2] - p0 <= SRL_PLANE_CAP) ++be;
+      __syncthreads();                               // (every thread has read the old cursors)
+      if (tid >= bs && tid < be) L.reg[4 * tid + 0] = L.reg[4 * tid + 3] - p0;
       __syncthreads();
     }
   } while (bs < nb);
@@ -733,21 +838,6 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
   }
   RSTAMP(5);
   if (ext) return;
-  // ---- object observation (O2 from the per-mesh cache, requested at kernel start; empty map when nothing is pending)
-#ifndef SRL_ABL_NOOBJ
-  {
-    // the pending rock's maps, or with ordering freedom (observer.py:310-327) those of the rocks still unplaced, in list
-    // order, then empty maps; bytes from the per-mesh cache, four pixels per lane (the map size is a multiple of 4)
-    const int shown = P.c.ordering_freedom ? P.c.episode_length : 1, left = h->list_pos;
-    uint32_t* oo = (uint32_t*)(obs_obj + (size_t)e * rr * shown);
-    const uint32_t eb4 = P.obj_empty_byte * 0x01010101u;
-    for (int k = 0; k < shown; ++k) {
-      const int m = P.c.ordering_freedom ? (k < left ? h->ids[k] : -1) : pending;
-      const uint32_t* src = (const uint32_t*)(P.objmap_u8 + (size_t)(m < 0 ? 0 : m) * rr);
-      for (int idx = tid; idx < rr / 4; idx += SRL_RENDER_THREADS) oo[(size_t)k * (rr / 4) + idx] = m >= 0 ? src[idx] : eb4;
-    }
-  }
-#endif
   // ---- halving tree over the 512 partials: cross-wave stages through LDS, in-wave stages by shuffles
 #ifdef SRL_ABL_NOTAIL
   if (P.px != 12345.0f) return;
@@ -775,17 +865,20 @@ srl_k_render(DevParams P, uint8_t* __restrict__ obs_map, uint8_t* __restrict__ o
       if (P.c.metric == SRL_METRIC_ALL) {
         const float mv[4] = {iou, orr, discounted_metric(P, h, gb, SRL_METRIC_DIOU), discounted_metric(P, h, gb, SRL_METRIC_DOR)};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { rw[m] = (mv[m] - h->prev_metric[m]) * P.scale; h->prev_metric[m] = mv[m]; }
+        for (int m = 0; m < 4; ++m) { rw[m] = (mv[m] - prev_m[m]) * P.scale; h->prev_metric[m] = mv[m]; }
       } else if (P.c.metric == SRL_METRIC_EVAL) {
-        rw[0] = (iou - h->prev_metric[0]) * P.scale; h->prev_metric[0] = iou;
+        rw[0] = (iou - prev_m[0]) * P.scale; h->prev_metric[0] = iou;
         const float ad = average_discount(P, h, gb);
-        rw[1] = ad - h->prev_metric[3]; h->prev_metric[3] = ad;
+        rw[1] = ad - prev_m[3]; h->prev_metric[3] = ad;
       } else {
         float mv;
         if (P.c.metric == SRL_METRIC_IOU) mv = iou;
         else if (P.c.metric == SRL_METRIC_OR) mv = orr;
         else mv = discounted_metric(P, h, gb, P.c.metric);
-        rw[0] = (mv - h->prev_metric[P.c.metric]) * P.scale;
+        float pm = prev_m[0];                        // (requested in the prologue; a constant index keeps it in registers)
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (P.c.metric == k) pm = prev_m[k];
+        rw[0] = (mv - pm) * P.scale;
         h->prev_metric[P.c.metric] = mv;
       }
       done[e] = (uint8_t)hdone;

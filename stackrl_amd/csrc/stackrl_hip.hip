@@ -60,6 +60,10 @@ struct srl_env {
   int order_mode = -1;
   unsigned long long* d_order_keys = nullptr;
   int32_t* d_order = nullptr;
+  // staged rock records (render.hip, srl_k_stage -> srl_k_render): [n_envs][episode_length][SRL_STAGE_STRIDE] float4;
+  // the explicit-pose hook (srl_render_heightmap) has its own, SRL_MAX_BODIES slots per env, allocated at its first use
+  float4* d_stage = nullptr;
+  float4* d_stage_ext = nullptr;
   size_t step_lds = 0, render_lds = 0, objmap_lds = 0;
   bool profiling = false;
   std::vector<EventPair> pending;
@@ -235,8 +239,11 @@ int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void*
     HIP_TRY(hipGetLastError());
     return SRL_OK;
   }
-  SRL_LAUNCH(env, 1, srl_k_render, dim3(n), dim3(SRL_RENDER_THREADS), env->render_lds, st, P, (uint8_t*)obs_map, (uint8_t*)obs_obj,
-             reward, done, (const float*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (float*)nullptr);
+  const int L = P.c.episode_length;
+  SRL_LAUNCH(env, 2, srl_k_stage, dim3(n, (L + 3) / 4), dim3(256), 0, st, P, env->d_stage, L, (const float*)nullptr,
+             (const int32_t*)nullptr, (const int32_t*)nullptr);
+  SRL_LAUNCH(env, 1, srl_k_render, dim3(n), dim3(SRL_RENDER_THREADS), env->render_lds, st, P, (const float4*)env->d_stage, L,
+             (uint8_t*)obs_map, (uint8_t*)obs_obj, reward, done, (const int32_t*)nullptr, (float*)nullptr);
   HIP_TRY(hipGetLastError());
   return SRL_OK;
 }
@@ -290,6 +297,7 @@ int srl_create(const srl_config* cfg, srl_env** out) {
   HIP_TRY(hipMalloc((void**)&P.flags, sizeof(int32_t)));
   HIP_TRY(hipMalloc((void**)&env->d_P, sizeof(DevParams)));
   HIP_TRY(hipMalloc((void**)&env->d_reset_r, sizeof(float) * 4 * (size_t)n));   // up to 4 rewards per env (metric 'all')
+  HIP_TRY(hipMalloc((void**)&env->d_stage, sizeof(float4) * (size_t)n * P.c.episode_length * SRL_STAGE_STRIDE));
   if (n <= SRL_ORDER_MAX_ENVS) {   // launch order of the settle kernel (srl_k_order_*): keys + permutation, owned by the handle
     HIP_TRY(hipMalloc((void**)&env->d_order_keys, sizeof(unsigned long long) * (size_t)n));
     HIP_TRY(hipMalloc((void**)&env->d_order, sizeof(int32_t) * (size_t)n));
@@ -341,6 +349,7 @@ void srl_destroy(srl_env* env) {
   (void)hipFree(env->d_codec); (void)hipFree(env->d_me);
   (void)hipFree(env->d_reset_r); (void)hipFree(env->d_reset_d);
   (void)hipFree(env->d_order_keys); (void)hipFree(env->d_order);
+  (void)hipFree(env->d_stage); (void)hipFree(env->d_stage_ext);
   delete env;
 }
 
@@ -706,8 +715,13 @@ int srl_render_heightmap(srl_env* env, const float* poses, const int32_t* mesh_i
   if (!env || !poses || !mesh_ids || !n_bodies || !height) return fail(SRL_EINVAL, "null argument");
   if (!env->d_mh) return fail(SRL_ENOMESH, "srl_load_meshes must be called first");
   hipStream_t st = (hipStream_t)stream;
-  SRL_LAUNCH(env, 1, srl_k_render, dim3(env->P.c.n_envs), dim3(SRL_RENDER_THREADS), env->render_lds, st, env->P, (uint8_t*)nullptr,
-             (uint8_t*)nullptr, (float*)nullptr, (uint8_t*)nullptr, poses, mesh_ids, n_bodies, height);
+  const int n = env->P.c.n_envs;
+  if (!env->d_stage_ext)
+    HIP_TRY(hipMalloc((void**)&env->d_stage_ext, sizeof(float4) * (size_t)n * SRL_MAX_BODIES * SRL_STAGE_STRIDE));
+  SRL_LAUNCH(env, 2, srl_k_stage, dim3(n, SRL_MAX_BODIES / 4), dim3(256), 0, st, env->P, env->d_stage_ext, SRL_MAX_BODIES, poses,
+             mesh_ids, n_bodies);
+  SRL_LAUNCH(env, 1, srl_k_render, dim3(n), dim3(SRL_RENDER_THREADS), env->render_lds, st, env->P, (const float4*)env->d_stage_ext,
+             SRL_MAX_BODIES, (uint8_t*)nullptr, (uint8_t*)nullptr, (float*)nullptr, (uint8_t*)nullptr, n_bodies, height);
   HIP_TRY(hipGetLastError());
   return SRL_OK;
 }
