@@ -140,6 +140,13 @@ int srl_set_concurrent_envs(srl_env* env, int32_t n_envs_on_device);
 int srl_set_launch_order(srl_env* env, int32_t mode);
 int srl_get_kernel_times(srl_env* env, float* ms3, int32_t* launches3);
 
+/* Test hook: the staged rock records of the latest step (csrc/render.hip: srl_k_stage -> srl_k_render), host array
+ * float[n_envs][episode_length][srl_stage_record_stride()][4]: per rock its pixel bounding box, up-facing planes, outline
+ * sides and, per row of ray-cast items, the columns and the ranges of the two lists that row sweeps (layout: render.hip).
+ * Synchronises the device. */
+int srl_get_stage_records(srl_env* env, float* records, int64_t n_floats);
+int32_t srl_stage_record_stride(void);
+
 /* How this library was built: "SRL_BUILD_INFO<variant|hash>" — variant "vectorised+rewritten" (clang's SLP vectoriser on and
  * the pass of stackrl_amd/isa_fix.py over the compiled assembly) or "safe" (built in one go without the vectoriser), hash =
  * sha256 prefix of the sources and flags (stackrl_amd/build.py; bench.py prints both). */

@@ -503,6 +503,60 @@ static inline int pixel_range(float lo, float hi, float inv_px, int res, int* i0
   return 1;
 }
 
+/* Which faces and outline sides a pixel consults (round 4; the kernels' ray cast visits a rock in items of ITEM_ROWS pixel
+ * rows x 2 columns, csrc/render.hip srl_k_stage).  Along the vertical line through a pixel inside the outline the hull's top
+ * is the face the line pierces, so the minimum over ALL up-facing planes equals the minimum over any subset that holds that
+ * face — up to the last bit where two faces are coplanar within rounding, which is why the subset is part of the definition
+ * and not an optimisation behind it:
+ *   item row r of a rock = pixel rows i0 + ITEM_ROWS r .. (i0 the first row of its bounding box); with more than ROW_SPANS
+ *   item rows every pixel consults every face and side (as before round 4);
+ *   a face reaches the item rows [r0, r1] that its x extent, a pixel wider on either side, overlaps (slab_rows); so does an
+ *   outline side with the x extent of its edge;
+ *   a pixel of item row r consults the faces whose first row r0 lies in [R(r), r], R(r) = the smallest r0 among the faces
+ *   that reach r (r1 >= r) — a superset of those that reach r, and one contiguous range of the faces ordered by r0, whatever
+ *   the order inside one r0 (the kernel fills its lists with LDS counters); the sides likewise;
+ *   and within item row r only the columns between the bounds the outline can reach there are visited at all (span_columns:
+ *   over the rows' x range [xa, xb] a side with eb > 0 bounds y from below by the smaller of its line's values at xa, xb,
+ *   one with eb < 0 from above by the larger; widened by 1e-4 m and to the column pairs the items cover). */
+enum { ITEM_ROWS = 4, ROW_SPANS = 16 };
+
+static void slab_rows(float x0, float x1, float inv_px, int i0, int nirows, int* r0, int* r1) {
+  float f0 = floorf(x0 * inv_px - 0.5f) - 1.0f - (float)i0, f1 = ceilf(x1 * inv_px - 0.5f) + 1.0f - (float)i0;
+  int a = f0 > 0.0f ? (int)(f0 * (1.0f / ITEM_ROWS)) : 0, z = f1 > 0.0f ? (int)(f1 * (1.0f / ITEM_ROWS)) : 0;
+  if (a > nirows - 1) a = nirows - 1;
+  if (z > nirows - 1) z = nirows - 1;
+  *r0 = a; *r1 = z;
+}
+
+/* R[r] = the smallest first row among the entries that reach item row r (last row >= r); ROW_SPANS + 1 if none does */
+static void first_rows(int n, const int* r0, const int* r1, int* R) {
+  for (int r = 0; r < ROW_SPANS; ++r) R[r] = ROW_SPANS + 1;
+  for (int k = 0; k < n; ++k)
+    for (int r = 0; r <= r1[k]; ++r) if (r0[k] < R[r]) R[r] = r0[k];
+}
+
+/* columns [*ja, *jz] of the bounding box [j0, j1] visited in the item row whose pixel rows are ia .. ib; returns 0 if none */
+static int span_columns(const struct srlo_env* e, int ns, const float* ea, const float* eb, const float* ec, int ia, int ib,
+                        int j0, int j1, int* ja, int* jz) {
+  float xa = ((float)ia + 0.5f) * e->px, xe = ((float)ib + 0.5f) * e->px;
+  float ylo = -1e30f, yhi = 1e30f;
+  int empty = 0;
+  for (int k = 0; k < ns; ++k) {
+    float fa = fmaf(ea[k], xa, ec[k]), fe = fmaf(ea[k], xe, ec[k]);
+    if (fabsf(eb[k]) < 1e-12f) { empty = empty || (fa < 0.0f && fe < 0.0f); continue; }
+    float rcp = -1.0f / eb[k];
+    float la = fa * rcp, le = fe * rcp;
+    if (eb[k] > 0.0f) ylo = fmaxf(ylo, fminf(la, le)); else yhi = fminf(yhi, fmaxf(la, le));
+  }
+  float fl = ceilf((ylo - 1e-4f) * e->inv_px - 0.5f), fh = floorf((yhi + 1e-4f) * e->inv_px - 0.5f);
+  int a = fl > (float)j0 ? (fl < (float)(j1 + 1) ? (int)fl : j1 + 1) : j0;
+  int z = fh < (float)j1 ? (fh > (float)(j0 - 1) ? (int)fh : j0 - 1) : j1;
+  if (empty || a > z) return 0;
+  int cnt = (z - a + 2) >> 1;                         /* items of two columns from column a */
+  *ja = a; *jz = a + 2 * cnt - 1 < j1 ? a + 2 * cnt - 1 : j1;
+  return 1;
+}
+
 /* O1: overhead height map of the placed bodies (observer.py:252-260; row <-> +x, col <-> +y) */
 static void render_heightmap(const struct srlo_env* e, int nb, const int* mesh, const v3* x,
                              const q4* q, float* H) {
@@ -512,38 +566,70 @@ static void render_heightmap(const struct srlo_env* e, int nb, const int* mesh, 
   for (int b = 0; b < nb; ++b) {
     const mesh_t* M = &e->mesh[mesh[b]];
     m3 R = quat_to_mat(q[b]);
+    float wx[MAXV], wy[MAXV];
     float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
     for (int k = 0; k < M->nv; ++k) {
       v3 a = mmul_add(&R, M->v[k], x[b]);
+      wx[k] = a.x; wy[k] = a.y;
       xmin = fminf(xmin, a.x); xmax = fmaxf(xmax, a.x);
       ymin = fminf(ymin, a.y); ymax = fmaxf(ymax, a.y);
     }
     int i0, i1, j0, j1;
     if (!pixel_range(xmin, xmax, e->inv_px, res, &i0, &i1)) continue;
     if (!pixel_range(ymin, ymax, e->inv_px, res, &j0, &j1)) continue;
+    const int nirows = (i1 - i0 + ITEM_ROWS) / ITEM_ROWS;
+    const int nir = nirows <= ROW_SPANS ? nirows : 0;
     rplane_t pl[MAXT];
     int np = make_rplanes(M, &R, x[b], pl);
-    float ea[3 * MAXT / 2], eb[3 * MAXT / 2], ec[3 * MAXT / 2];
-    int ns = 0;
+    /* up-facing faces in face order, with the item rows they reach */
+    rplane_t up[MAXT];
+    int ur0[MAXT], ur1[MAXT], nup = 0;
+    for (int t = 0; t < np; ++t) {
+      if (pl[t].type != 0) continue;
+      const uint8_t* tv = M->tri[t];
+      float fa = wx[tv[0]], fb = wx[tv[1]], fc = wx[tv[2]];
+      ur0[nup] = 0; ur1[nup] = 0;
+      if (nir) slab_rows(fminf(fa, fminf(fb, fc)), fmaxf(fa, fmaxf(fb, fc)), e->inv_px, i0, nirows, &ur0[nup], &ur1[nup]);
+      up[nup++] = pl[t];
+    }
+    /* outline sides in edge order (at most nt + 2 - nup of them: a closed triangulated cap with an s-edge rim has >= s - 2
+     * triangles) */
+    float ea[MAXT + 2], eb[MAXT + 2], ec[MAXT + 2];
+    int sr0[MAXT + 2], sr1[MAXT + 2], ns = 0;
+    const int cap = M->nt + 2 - nup;
     for (int k = 0; k < M->ne; ++k) {
       const uint8_t* e4 = M->edge[k];
       if (pl[e4[2]].type == pl[e4[3]].type) continue;       /* not on the outline */
-      v3 A = mmul_add(&R, M->v[e4[0]], x[b]), B = mmul_add(&R, M->v[e4[1]], x[b]);
-      float a = A.y - B.y, bb = B.x - A.x;
-      float cc = -fmaf(a, A.x, bb * A.y);
+      if (ns >= cap) continue;
+      float Ax = wx[e4[0]], Ay = wy[e4[0]], Bx = wx[e4[1]], By = wy[e4[1]];
+      float a = Ay - By, bb = Bx - Ax;
+      float cc = -fmaf(a, Ax, bb * Ay);
       float s = fmaf(a, x[b].x, fmaf(bb, x[b].y, cc));      /* the centre of mass is inside */
       if (s < 0.0f) { a = -a; bb = -bb; cc = -cc; }
+      sr0[ns] = 0; sr1[ns] = 0;
+      if (nir) slab_rows(fminf(Ax, Bx), fmaxf(Ax, Bx), e->inv_px, i0, nirows, &sr0[ns], &sr1[ns]);
       ea[ns] = a; eb[ns] = bb; ec[ns] = cc; ++ns;
     }
-    for (int i = i0; i <= i1; ++i) {
-      float px = ((float)i + 0.5f) * e->px;
-      for (int j = j0; j <= j1; ++j) {
-        float py = ((float)j + 0.5f) * e->px;
-        float hi = 1e30f, lo = 1e30f;
-        for (int t = 0; t < np; ++t)
-          if (pl[t].type == 0) hi = fminf(hi, fmaf(pl[t].a, px, fmaf(pl[t].b, py, pl[t].c)));
-        for (int t = 0; t < ns; ++t) lo = fminf(lo, fmaf(ea[t], px, fmaf(eb[t], py, ec[t])));
-        if (lo >= 0.0f && hi > H[i * res + j]) H[i * res + j] = hi;
+    int Rp[ROW_SPANS], Rs[ROW_SPANS];
+    first_rows(nup, ur0, ur1, Rp);
+    first_rows(ns, sr0, sr1, Rs);
+    for (int r = 0; r < nirows; ++r) {
+      const int ia = i0 + ITEM_ROWS * r, ib = ia + ITEM_ROWS - 1 < i1 ? ia + ITEM_ROWS - 1 : i1;
+      int ja = j0, jz = j1;
+      const int pr0 = nir ? Rp[r] : 0, sr0_ = nir ? Rs[r] : 0, rr = nir ? r : 0;   /* consulted: first row in [.., rr] */
+      if (nir && !span_columns(e, ns, ea, eb, ec, ia, ib, j0, j1, &ja, &jz)) continue;
+      if (pr0 > rr || sr0_ > rr || nup == 0 || ns == 0) continue;   /* a row the lists do not reach holds no rock pixel */
+      for (int i = ia; i <= ib; ++i) {
+        float px = ((float)i + 0.5f) * e->px;
+        for (int j = ja; j <= jz; ++j) {
+          float py = ((float)j + 0.5f) * e->px;
+          float hi = 1e30f, lo = 1e30f;
+          for (int t = 0; t < nup; ++t)
+            if (ur0[t] >= pr0 && ur0[t] <= rr) hi = fminf(hi, fmaf(up[t].a, px, fmaf(up[t].b, py, up[t].c)));
+          for (int t = 0; t < ns; ++t)
+            if (sr0[t] >= sr0_ && sr0[t] <= rr) lo = fminf(lo, fmaf(ea[t], px, fmaf(eb[t], py, ec[t])));
+          if (lo >= 0.0f && hi > H[i * res + j]) H[i * res + j] = hi;
+        }
       }
     }
   }

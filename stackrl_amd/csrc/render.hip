@@ -168,27 +168,33 @@ __device__ __forceinline__ uint32_t goal_pair(uint32_t m, uint32_t gdiff) {
 }
 
 #ifndef SRL_PLANE_CAP
-#define SRL_PLANE_CAP 768    // planes staged in LDS per group of rocks (12 KB): 8 rocks of the default pool in one group
+#define SRL_PLANE_CAP 640    // plane / side slots staged in LDS per group of rocks (10 KB; a rock holds ~60): 8 - 10 rocks per group
 #endif
 #define SRL_PLANE_ROUNDS ((SRL_PLANE_CAP + SRL_RENDER_THREADS - 1) / SRL_RENDER_THREADS)
 
 // ---- the staged record of one rock (srl_k_stage -> srl_k_render), SRL_STAGE_STRIDE float4s per (env, body slot) in HBM:
 //   [0] ints  i0 | i1 << 16, j0 | j1 << 16 (pixel bounding box), nup (up-facing planes), nsil (outline sides)
-//   [1] ints  items (of SRL_ITEM_ROWS x 2 pixels), nir (item rows with a span below; 0: items fill the bounding box), 0, 0
+//   [1] ints  items (of SRL_ITEM_ROWS x 2 pixels), nir (item rows with an entry below; 0: items fill the bounding box and
+//             every item sweeps the whole lists), 0, 0
 //   [2..5]    16 ints, one per item row r: first item of the row << 8 | first column — the columns of the bounding box
 //             the outline can reach in the row's SRL_ITEM_ROWS pixel rows (a superset: the ray cast still tests every pixel)
-//   [6..]     the nup up-facing world-frame planes (a, b, c, -), then the nsil outline sides (ea, eb, ec, -)
-#define SRL_STAGE_HDR 6
+//   [6..9]    16 ints, one per item row: the ranges of the two lists an item of the row sweeps, as bytes
+//             plane_lo | plane_hi << 8 | side_lo << 16 | side_hi << 24 (a superset of the faces / outline edges whose
+//             x extent reaches the row, see srl_k_stage)
+//   [10..]    the nup up-facing world-frame planes (a, b, c, -), then the nsil outline sides (ea, eb, ec, -), each list
+//             ordered by the first item row its face / edge reaches
+#define SRL_STAGE_HDR 10
 #define SRL_STAGE_SPANS 16
 #define SRL_STAGE_STRIDE (SRL_STAGE_HDR + SRL_MAX_TRIS + 2)
 
-// LDS carve of srl_k_render (64 KB tile + 12 KB planes + 3.5 KB per-rock records at 128^2: two workgroups per CU)
+// LDS carve of srl_k_render (64 KB tile + 10 KB planes + 5 KB per-rock records at 128^2: two workgroups per CU)
 struct RenderLds {
   float* tile;      // [res*res]
   float4* planes;   // [SRL_PLANE_CAP] per rock region: its up-facing planes, then its outline sides
   int* prange;      // [32][4] i0|i1<<16, j0|j1<<16, nir (item rows with spans; 0 = bounding-box items), items
   int* reg;         // [32][4] region base in its group, nup, nsil, slots before this rock (over all rocks)
   int* span;        // [32][16] per item row: first item << 8 | first column
+  int* range;       // [32][16] per item row: plane_lo | plane_hi << 8 | side_lo << 16 | side_hi << 24
   uint32_t* rowmask;   // [8] bit i set: tile row i may hold a rock pixel (union of the rocks' row ranges)
   int* misc;        // [4] rocks in the first group
   float* pi;        // [512]  (pi and pu alias the plane staging area: used after the ray cast)
@@ -197,7 +203,7 @@ struct RenderLds {
 
 __host__ __device__ inline size_t render_lds_bytes(int res) {
   return sizeof(float) * (size_t)res * res + sizeof(float4) * SRL_PLANE_CAP +
-         sizeof(int) * (4 + 4 + SRL_STAGE_SPANS) * SRL_MAX_BODIES + sizeof(uint32_t) * (8 + 4);
+         sizeof(int) * (4 + 4 + 2 * SRL_STAGE_SPANS) * SRL_MAX_BODIES + sizeof(uint32_t) * (8 + 4);
 }
 
 // one min / max sweep over planes [0, n) of a region for a lane's item of SRL_ITEM_ROWS x 2 pixels, this lane taking
@@ -282,32 +288,51 @@ __device__ __forceinline__ float wave_minmax(float v) {
 
 // ------------------------------------------------------------------ staging: one wave per (env, rock)
 // What the ray cast needs of a rock — its pixel bounding box, its up-facing face planes in the world frame, the sides of
-// its outline, and per item row the columns the outline can reach — depends on the rock's pose and mesh alone.  Until
-// round 4 srl_k_render did this itself, two wave tasks per rock between two block barriers, with a 64 KB tile per workgroup
-// limiting a CU to 16 waves: four dependent memory round trips (pose -> mesh header -> vertices / planes / edges -> the two
-// faces of every edge) that two workgroups per CU could not hide (7 us of a 43 us launch).  Here the same arithmetic runs
-// with one wave per rock and no tile, so a CU holds as many waves as it has slots, and srl_k_render starts from
-// finished records (one contiguous read per rock).
+// its outline, and per item row the columns the outline can reach and the faces / sides that matter there — depends on the
+// rock's pose and mesh alone.  Until round 4 srl_k_render did this itself, two wave tasks per rock between two block
+// barriers, with a 64 KB tile per workgroup limiting a CU to 16 waves: four dependent memory round trips that two
+// workgroups per CU could not hide (7 us of a 43 us launch).  Here the same arithmetic runs with one wave per rock and no
+// tile, and srl_k_render starts from finished records (one contiguous read per rock).
 //   xy bounds: vertices over the lanes, DPP min / max -> pixel range (pixel_range)
-//   planes:    world-frame plane of every face (make_rplane); the up-facing ones packed by ballot ranks
-//   outline:   lanes over the mesh's edge list (edge -> its two faces, built at srl_load_meshes); facing of the two faces
-//              from their normals (the very expression make_rplane classifies by); side through the projected end points
-//              A, B (A the lower vertex index): E(p) = fma(ea, p.x, fma(eb, p.y, ec)) >= 0 inside, oriented by the centre
-//              of mass
+//   planes:    world-frame plane of every face (make_rplane), the up-facing ones kept
+//   outline:   lanes over the mesh's edge list (edge -> its two faces, built at srl_load_meshes); an edge between an up- and
+//              a down-facing face (facing = the bit make_rplane classifies by, looked up in the ballot masks of the face
+//              pass) is a side of the outline: through the projected end points A, B (A the lower vertex index)
+//              E(p) = fma(ea, p.x, fma(eb, p.y, ec)) >= 0 inside, oriented by the centre of mass
 //   spans:     lane r = item row r (SRL_ITEM_ROWS pixel rows, x in [xa, xb]): a side with eb > 0 bounds y from below by
 //              its line, one with eb < 0 from above; over the slab a line is at least / at most its value at one of the
 //              two ends, so max_k min(L_k(xa), L_k(xb)) <= y <= min_k max(L_k(xa), L_k(xb)) holds for every inside
-//              point — widened by a pixel on either side against rounding.  A superset is all that is needed: the ray
-//              cast evaluates the definition's side functions at every pixel it visits.
+//              point (widened by 1e-4 m against rounding).  A superset is all that is needed: the ray cast evaluates the
+//              definition's side functions at every pixel it visits.
+//   ranges:    along the vertical line through a pixel inside the outline the hull's top is the face the line pierces, so
+//              min over ALL up-facing planes = min over any subset that holds that face: an item row needs the faces whose
+//              x extent reaches its rows (a pixel of margin: the neighbours a rounding could prefer are included).  The
+//              same holds for the outline: a point of the row outside it violates a side whose x extent contains the
+//              point's x, or one of the two sides at the outline's extreme vertex.  Both lists are ordered by the first
+//              item row their face / edge reaches (LDS counters), so a row's subset is one range [lo, hi) of each.
 // Lists are sets here: the ray cast takes minima over them, so their order does not enter any result.
+struct StageLds {
+  float4 slot[SRL_MAX_TRIS + 2];     // the rock's up-facing planes from the front, its outline sides from the back; .w = r0 | r1 << 8
+  int cnt[2][SRL_STAGE_SPANS], st[2][SRL_STAGE_SPANS], lo[2][SRL_STAGE_SPANS];   // entries per first row, their prefix, first row of the entries that reach a row
+};
+
+// item rows [r0, r1] (clamped to the rock's) that a face / edge with x extent [x0, x1] reaches, a pixel of margin either side
+__device__ __forceinline__ int slab_range(float x0, float x1, float inv_px, int i0, int nirows) {
+  const float f0 = floorf(x0 * inv_px - 0.5f) - 1.0f - (float)i0, f1 = ceilf(x1 * inv_px - 0.5f) + 1.0f - (float)i0;
+  int r0 = f0 > 0.0f ? (int)(f0 * (1.0f / SRL_ITEM_ROWS)) : 0, r1 = f1 > 0.0f ? (int)(f1 * (1.0f / SRL_ITEM_ROWS)) : 0;
+  r0 = min(r0, nirows - 1); r1 = min(r1, nirows - 1);
+  return r0 | (r1 << 8);
+}
+
 extern "C" __global__ void __launch_bounds__(256) srl_k_stage(DevParams P, float4* __restrict__ stage, int slots,
     const float* __restrict__ poses_ext, const int32_t* __restrict__ mesh_ext, const int32_t* __restrict__ nb_ext) {
-  __shared__ float4 sides[4][SRL_MAX_TRIS + 2];
+  __shared__ StageLds lds[4];
   const int e = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.y * 4 + wave;
+  if (b >= slots) return;                            // (wave-uniform; nothing below synchronises across waves)
+  StageLds& S = lds[wave];
   const bool ext = poses_ext != nullptr;
-  const int nb = ext ? nb_ext[e] : P.hdr[e].nb;
-  if (b >= nb || b >= slots) return;                 // (wave-uniform; nothing below synchronises across waves)
+  // pose and mesh id of the slot are requested together with the rock count (slots past it hold stale or no data)
   q4 q; v3 xb; int m;
   if (ext) {
     const float* p = poses_ext + ((size_t)e * SRL_MAX_BODIES + b) * 7;
@@ -320,17 +345,22 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_stage(DevParams P, float
     q.x = qq[0]; q.y = qq[1]; q.z = qq[2]; q.w = qq[3];
     m = ((const int*)gb)[P.OFF_MESH + b];
   }
+  const int nb = ext ? nb_ext[e] : P.hdr[e].nb;
+  if (b >= nb) return;
   m = min(max(m, 0), P.n_mesh - 1);
   const MeshHdr mh = P.mh[m];
   const int vo = mh.vo, nv = mh.nv, to = mh.to, nt = mh.nt, eo = mh.eo, ne = mh.ne;
   const int res = P.c.overhead_res;
   float4* rec = stage + ((size_t)e * slots + b) * SRL_STAGE_STRIDE;
-  // the first two chunks of faces and the first chunk of edges are requested before the vertex pass
+  // everything the mesh header points at is requested now: the first two chunks of faces (planes + vertex ids), the first
+  // chunk of edges, the vertices
   float4 pl0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pl1 = pl0;
-  if (lane < nt) pl0 = P.mp[to + lane];
-  if (64 + lane < nt) pl1 = P.mp[to + 64 + lane];
+  uchar4 tr0 = make_uchar4(0, 0, 0, 0), tr1 = tr0, ed0 = tr0;
+  if (lane < nt) { pl0 = P.mp[to + lane]; tr0 = P.mt[to + lane]; }
+  if (64 + lane < nt) { pl1 = P.mp[to + 64 + lane]; tr1 = P.mt[to + 64 + lane]; }
+  if (lane < ne) ed0 = P.me[eo + lane];
   const m3 R = quat_to_mat(q);
-  // world xy of the vertices, one (two) per lane; the outline's end points are cross-lane reads of these
+  // world xy of the vertices, one (two) per lane; faces and edges read their end points from these lanes
   float wx0 = 0.0f, wy0 = 0.0f, wx1 = 0.0f, wy1 = 0.0f;
   float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
   for (int v = lane; v < nv; v += 64) {
@@ -351,29 +381,54 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_stage(DevParams P, float
     }
     return;
   }
+  const int nirows = (i1 - i0 + SRL_ITEM_ROWS) / SRL_ITEM_ROWS;
+  const int nir = nirows <= SRL_STAGE_SPANS ? nirows : 0;   // more item rows than the tables hold: one row for the lists
   const unsigned long long below = (1ull << lane) - 1ull;
-  // ---- up-facing planes
+  if (lane < SRL_STAGE_SPANS) { S.cnt[0][lane] = 0; S.cnt[1][lane] = 0; S.lo[0][lane] = 0x7fffffff; S.lo[1][lane] = 0x7fffffff; }
+  // ---- up-facing planes -> S.slot[0 .. nup), their facing kept as ballot masks for the outline pass
+  unsigned long long upm0 = 0ull, upm1 = 0ull, upm2 = 0ull, upm3 = 0ull;
   int nup = 0;
-  for (int c = 0; c < nt; c += 64) {
-    const bool act = c + lane < nt;
-    float4 pl = c == 0 ? pl0 : pl1;
-    if (c >= 128 && act) pl = P.mp[to + c + lane];
-    const float4 wp = make_rplane(pl, R, xb);
-    const bool up = act && __float_as_int(wp.w) == 0;
-    const unsigned long long mu = __ballot(up);
-    if (up) rec[SRL_STAGE_HDR + nup + __popcll(mu & below)] = wp;
-    nup += __popcll(mu);
+#pragma unroll
+  for (int ch = 0; ch < (SRL_MAX_TRIS + 63) / 64; ++ch) {
+    const int c = 64 * ch;
+    if (c < nt) {
+      const bool act = c + lane < nt;
+      float4 pl = ch == 0 ? pl0 : pl1;
+      uchar4 tr = ch == 0 ? tr0 : tr1;
+      if (ch >= 2 && act) { pl = P.mp[to + c + lane]; tr = P.mt[to + c + lane]; }
+      const float4 wp = make_rplane(pl, R, xb);
+      const bool up = act && __float_as_int(wp.w) == 0;
+      const unsigned long long mu = __ballot(up);
+      if (ch == 0) upm0 = mu; else if (ch == 1) upm1 = mu; else if (ch == 2) upm2 = mu; else upm3 = mu;
+      // world x of the face's three vertices (every lane takes part in every shuffle: no shuffle under a lane-dependent branch)
+      float fa = __shfl(wx0, tr.x & 63), fb = __shfl(wx0, tr.y & 63), fc = __shfl(wx0, tr.z & 63);
+      if (nv > 64) {
+        const float ga = __shfl(wx1, tr.x & 63), gb_ = __shfl(wx1, tr.y & 63), gc = __shfl(wx1, tr.z & 63);
+        if (tr.x >= 64) fa = ga;
+        if (tr.y >= 64) fb = gb_;
+        if (tr.z >= 64) fc = gc;
+      }
+      if (up) {
+        const int rr = nir ? slab_range(fminf(fa, fminf(fb, fc)), fmaxf(fa, fmaxf(fb, fc)), P.inv_px, i0, nirows) : 0;
+        S.slot[nup + __popcll(mu & below)] = make_float4(wp.x, wp.y, wp.z, __int_as_float(rr));
+        atomicAdd(&S.cnt[0][rr & 0xff], 1);
+        atomicMin(&S.lo[0][rr >> 8], rr & 0xff);
+      }
+      nup += __popcll(mu);
+    }
   }
-  // ---- outline sides (at most nt + 2 - nup: a closed triangulated cap with an s-edge rim has >= s - 2 triangles)
+  // ---- outline sides -> S.slot[nt + 1 - k] (from the back; at most nt + 2 - nup: a closed triangulated cap with an
+  //      s-edge rim has >= s - 2 triangles)
   const int cap = nt + 2 - nup;
   int nsil = 0;
   for (int c = 0; c < ne; c += 64) {
     const bool act = c + lane < ne;
-    uchar4 ed = make_uchar4(0, 0, 0, 0);
-    if (act) ed = P.me[eo + c + lane];
-    const float4 na = P.mp[to + ed.z], nb_ = P.mp[to + ed.w];
-    const bool da = !(mmul(R, V(na.x, na.y, na.z)).z >= 0.0f), db = !(mmul(R, V(nb_.x, nb_.y, nb_.z)).z >= 0.0f);
-    const bool sil = act && (da != db);
+    uchar4 ed = ed0;
+    if (c > 0) { ed = make_uchar4(0, 0, 0, 0); if (act) ed = P.me[eo + c + lane]; }
+    const unsigned long long ma = ed.z < 128 ? (ed.z < 64 ? upm0 : upm1) : (ed.z < 192 ? upm2 : upm3);
+    const unsigned long long mb = ed.w < 128 ? (ed.w < 64 ? upm0 : upm1) : (ed.w < 192 ? upm2 : upm3);
+    const bool ua = (ma >> (ed.z & 63)) & 1ull, ub = (mb >> (ed.w & 63)) & 1ull;
+    const bool sil = act && (ua != ub);
     const unsigned long long ms = __ballot(sil);
     float Ax = __shfl(wx0, ed.x & 63), Ay = __shfl(wy0, ed.x & 63), Bx = __shfl(wx0, ed.y & 63), By = __shfl(wy0, ed.y & 63);
     if (nv > 64) {
@@ -381,56 +436,89 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_stage(DevParams P, float
       if (ed.x >= 64) { Ax = ax1; Ay = ay1; }
       if (ed.y >= 64) { Bx = bx1; By = by1; }
     }
-    if (sil) {
+    const int sidx = nsil + __popcll(ms & below);
+    if (sil && sidx < cap) {
       float ea = Ay - By, eb = Bx - Ax;
       float ec = -fmaf(ea, Ax, eb * Ay);
       if (fmaf(ea, xb.x, fmaf(eb, xb.y, ec)) < 0.0f) { ea = -ea; eb = -eb; ec = -ec; }
-      const int r = nsil + __popcll(ms & below);
-      if (r < cap) {
-        const float4 sd = make_float4(ea, eb, ec, 0.0f);
-        rec[SRL_STAGE_HDR + nup + r] = sd;
-        sides[wave][r] = sd;
-      }
+      const int rr = nir ? slab_range(fminf(Ax, Bx), fmaxf(Ax, Bx), P.inv_px, i0, nirows) : 0;
+      S.slot[nt + 1 - sidx] = make_float4(ea, eb, ec, __int_as_float(rr));
+      atomicAdd(&S.cnt[1][rr & 0xff], 1);
+      atomicMin(&S.lo[1][rr >> 8], rr & 0xff);
     }
     nsil += __popcll(ms);
   }
   if (nsil > cap) nsil = cap;
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the wave's own LDS writes have landed
+  __builtin_amdgcn_wave_barrier();                   // (one wave: LDS keeps its order; the compiler must too)
   // ---- items: SRL_ITEM_ROWS x 2 pixels; per item row the columns the outline can reach
-  const int nirows = (i1 - i0 + SRL_ITEM_ROWS) / SRL_ITEM_ROWS;
-  int items, nir;
-  if (nirows <= SRL_STAGE_SPANS) {
-    nir = nirows;
+  int items;
+  if (nir) {
+    // lane = 4 (item row) + (quarter of the sides); the quarters combine by DPP within the quad (max / min / or)
+    const int row = lane >> 2, sq = lane & 3;
+    const int ia = i0 + SRL_ITEM_ROWS * row, ib = min(ia + SRL_ITEM_ROWS - 1, i1);
+    const float xa = ((float)ia + 0.5f) * P.px, xe = ((float)ib + 0.5f) * P.px;
+    float ylo = -1e30f, yhi = 1e30f;
+    int empty = 0;
+    for (int k = sq; k < nsil; k += 4) {
+      const float4 sd = S.slot[nt + 1 - k];
+      const float fa = fmaf(sd.x, xa, sd.z), fe = fmaf(sd.x, xe, sd.z);   // E = f + eb y
+      if (fabsf(sd.y) < 1e-12f) { empty |= (fa < 0.0f && fe < 0.0f) ? 1 : 0; continue; }
+      const float rcp = -1.0f / sd.y;                                        // (IEEE division: the oracle states the same bounds)
+      const float la = fa * rcp, le = fe * rcp;                              // the side's line at the two ends of the slab
+      if (sd.y > 0.0f) ylo = fmaxf(ylo, fminf(la, le)); else yhi = fminf(yhi, fmaxf(la, le));
+    }
+#define SRL_QUAD(ctrl)                                                                                                     \
+    ylo = fmaxf(ylo, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ylo), __float_as_int(ylo), ctrl, 0xf, 0xf, false))); \
+    yhi = fminf(yhi, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(yhi), __float_as_int(yhi), ctrl, 0xf, 0xf, false))); \
+    empty |= __builtin_amdgcn_update_dpp(empty, empty, ctrl, 0xf, 0xf, false);
+    SRL_QUAD(0xB1) SRL_QUAD(0x4E)                    // quad_perm [1,0,3,2], [2,3,0,1]
+#undef SRL_QUAD
     int cnt = 0, jlo = j0;
-    if (lane < nirows) {
-      const int ia = i0 + SRL_ITEM_ROWS * lane, ib = min(ia + SRL_ITEM_ROWS - 1, i1);
-      const float xa = ((float)ia + 0.5f) * P.px, xe = ((float)ib + 0.5f) * P.px;
-      float ylo = -1e30f, yhi = 1e30f;
-      bool empty = false;
-      for (int k = 0; k < nsil; ++k) {
-        const float4 sd = sides[wave][k];
-        const float fa = fmaf(sd.x, xa, sd.z), fe = fmaf(sd.x, xe, sd.z);   // E = f + eb y
-        if (fabsf(sd.y) < 1e-12f) { empty = empty || (fa < 0.0f && fe < 0.0f); continue; }
-        const float rcp = -__builtin_amdgcn_rcpf(sd.y);                        // (1 ulp: the spans carry a pixel of margin)
-        const float la = fa * rcp, le = fe * rcp;                              // the side's line at the two ends of the slab
-        if (sd.y > 0.0f) ylo = fmaxf(ylo, fminf(la, le)); else yhi = fminf(yhi, fmaxf(la, le));
-      }
-      // pixel centres ((j + 0.5) px) between the bounds, one pixel of margin on either side, inside the bounding box
-      const float fl = floorf(ylo * P.inv_px - 0.5f) - 1.0f, fh = ceilf(yhi * P.inv_px - 0.5f) + 1.0f;
+    if (row < nirows) {
+      // pixel centres ((j + 0.5) px) between the bounds widened by 1e-4 m, inside the bounding box
+      const float fl = ceilf((ylo - 1e-4f) * P.inv_px - 0.5f), fh = floorf((yhi + 1e-4f) * P.inv_px - 0.5f);
       const int a = fl > (float)j0 ? (fl < (float)(j1 + 1) ? (int)fl : j1 + 1) : j0;
       const int z = fh < (float)j1 ? (fh > (float)(j0 - 1) ? (int)fh : j0 - 1) : j1;
       if (!empty && a <= z) { jlo = a; cnt = (z - a + 2) >> 1; }
     }
-    int pre = cnt;                                   // inclusive prefix over the item rows (lanes 0 .. 15)
+    int pre = cnt;                                   // inclusive prefix over the item rows (every lane of a row's quad holds it)
 #pragma unroll
-    for (int d = 1; d < SRL_STAGE_SPANS; d <<= 1) { const int v = __shfl_up(pre, d); if (lane >= d) pre += v; }
-    items = __shfl(pre, SRL_STAGE_SPANS - 1);
-    if (lane < SRL_STAGE_SPANS) ((int*)(rec + 2))[lane] = ((pre - cnt) << 8) | jlo;
-  } else {                                           // more item rows than the table holds: items fill the bounding box
-    nir = 0;
+    for (int d = 4; d < 64; d <<= 1) { const int v = __shfl_up(pre, d); if (lane >= d) pre += v; }
+    items = __shfl(pre, 63);
+    if (sq == 0) ((int*)(rec + 2))[row] = ((pre - cnt) << 8) | jlo;
+  } else {                                           // items fill the bounding box
     items = nirows * ((j1 - j0 + 2) >> 1);
   }
+  // ---- the two lists into the record, ordered by first item row (within one first row in no particular order); an item row
+  //      r consults the entries whose first row lies in [R(r), r], R(r) = the smallest first row among the entries that reach
+  //      r — a set that does not depend on the order inside the buckets, stated the same way by the oracle
+  int hi0 = 0, hi1 = 0, lo0 = 0, lo1 = 0;
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    int c = 0, incl = 0, rmin = 0x7fffffff;
+    if (lane < SRL_STAGE_SPANS) {
+      c = S.cnt[w][lane]; incl = c; rmin = S.lo[w][lane];
+#pragma unroll
+      for (int d = 1; d < SRL_STAGE_SPANS; d <<= 1) {
+        const int v = __shfl_up(incl, d), u = __shfl_down(rmin, d);
+        if (lane >= d) incl += v;
+        if (lane + d < SRL_STAGE_SPANS) rmin = min(rmin, u);
+      }
+      S.st[w][lane] = incl - c; S.cnt[w][lane] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    int lo = incl;                                   // (no entry reaches the row: an empty range)
+    if (lane < SRL_STAGE_SPANS && rmin <= lane) lo = S.st[w][rmin];
+    if (w == 0) { hi0 = incl; lo0 = lo; } else { hi1 = incl; lo1 = lo; }
+    const int n = w == 0 ? nup : nsil;
+    for (int k = lane; k < n; k += 64) {
+      const float4 v = S.slot[w == 0 ? k : nt + 1 - k];
+      const int r0 = __float_as_int(v.w) & 0xff;
+      const int pos = S.st[w][r0] + atomicAdd(&S.cnt[w][r0], 1);
+      rec[SRL_STAGE_HDR + (w == 0 ? 0 : nup) + pos] = make_float4(v.x, v.y, v.z, 0.0f);
+    }
+  }
+  if (lane < SRL_STAGE_SPANS) ((int*)(rec + 6))[lane] = lo0 | (hi0 << 8) | (lo1 << 16) | (hi1 << 24);
   if (lane == 0) {
     if (items == 0) { nup = 0; nsil = 0; }
     rec[0] = make_float4(__int_as_float(i0 | (i1 << 16)), __int_as_float(j0 | (j1 << 16)), __int_as_float(nup), __int_as_float(nsil));
@@ -455,7 +543,8 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
   L.prange = (int*)(L.planes + SRL_PLANE_CAP);
   L.reg = L.prange + 4 * SRL_MAX_BODIES;
   L.span = L.reg + 4 * SRL_MAX_BODIES;
-  L.rowmask = (uint32_t*)(L.span + SRL_STAGE_SPANS * SRL_MAX_BODIES);
+  L.range = L.span + SRL_STAGE_SPANS * SRL_MAX_BODIES;
+  L.rowmask = (uint32_t*)(L.range + SRL_STAGE_SPANS * SRL_MAX_BODIES);
   L.misc = (int*)(L.rowmask + 8);
   L.pi = (float*)L.planes;
   L.pu = L.pi + SRL_RENDER_THREADS;
@@ -511,10 +600,11 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
       }
     }
   }
-  // the span tables of the rocks: four 16-byte words each, one per thread
-  if (tid < 4 * nb) {
-    const int b = tid >> 2, k = tid & 3;
-    ((float4*)L.span)[4 * b + k] = srec[(size_t)b * SRL_STAGE_STRIDE + 2 + k];
+  // the span and range tables of the rocks: eight 16-byte words each, one per thread
+  if (tid < 8 * nb) {
+    const int b = tid >> 3, k = tid & 7;
+    const float4 v = srec[(size_t)b * SRL_STAGE_STRIDE + 2 + k];
+    if (k < 4) ((float4*)L.span)[4 * b + k] = v; else ((float4*)L.range)[4 * b + k - 4] = v;
   }
   // epilogue constants
   const float nearp = SRL_FAR - P.c.max_z;
@@ -703,9 +793,12 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
           vx[r].x = x; vx[r].y = x; hh[r].x = 1e30f; hh[r].y = 1e30f; ll[r].x = 1e30f; ll[r].y = 1e30f;
         }
         // z_hi = min over the up-facing planes; inside the outline iff the smallest side function is >= 0
-        const int base = rg.x, nup = rg.y, e0 = base + nup, nsil = rg.z;
-        plane_sweep<true>(L.planes + base, nup, s, S, py, vx, hh);
-        plane_sweep<true>(L.planes + e0, nsil, s, S, py, vx, ll);
+        // the item row's ranges of the two lists (srl_k_stage): the faces / outline edges whose x extent reaches the row
+        const uint32_t rw = nir > 0 ? (uint32_t)L.range[SRL_STAGE_SPANS * b + di] : ((uint32_t)rg.y << 8) | ((uint32_t)rg.z << 24);
+        const int plo = rw & 0xff, pn = ((rw >> 8) & 0xff) - plo, slo = (rw >> 16) & 0xff, sn = (int)(rw >> 24) - slo;
+        plane_sweep<true>(L.planes + rg.x + plo, pn, s, S, py, vx, hh);
+        plane_sweep<true>(L.planes + rg.x + rg.y + slo, sn, s, S, py, vx, ll);
+        const bool lists = pn > 0 && sn > 0;           // (a row the lists do not reach holds no rock pixel)
         // the S lanes of an item (adjacent, aligned) combine their partial minima with DPP moves folded into the min:
         // within quads (lanes ^ 1, ^ 2), then across the two quads of a half row (mirror) — no LDS traffic
         if (S >= 2) {
@@ -736,8 +829,8 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
 #pragma unroll
           for (int r = 0; r < SRL_ITEM_ROWS; ++r) {
             const bool rowok = i + r <= i1;
-            if (rowok && ll[r].x >= 0.0f && hh[r].x > 0.0f) atomicMax(t0p + r * res, codec_row(hh[r].x, nearp, P.codec_n));
-            if (rowok && col2 && ll[r].y >= 0.0f && hh[r].y > 0.0f) atomicMax(t0p + r * res + 1, codec_row(hh[r].y, nearp, P.codec_n));
+            if (lists && rowok && ll[r].x >= 0.0f && hh[r].x > 0.0f) atomicMax(t0p + r * res, codec_row(hh[r].x, nearp, P.codec_n));
+            if (lists && rowok && col2 && ll[r].y >= 0.0f && hh[r].y > 0.0f) atomicMax(t0p + r * res + 1, codec_row(hh[r].y, nearp, P.codec_n));
           }
         }
       }

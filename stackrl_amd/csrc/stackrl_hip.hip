@@ -710,6 +710,17 @@ int srl_get_object_map(srl_env* env, int32_t mesh_id, float* object_map) {
   return SRL_OK;
 }
 
+int srl_get_stage_records(srl_env* env, float* records, int64_t n_floats) {
+  if (!env || !records) return fail(SRL_EINVAL, "null argument");
+  const int64_t need = (int64_t)env->P.c.n_envs * env->P.c.episode_length * SRL_STAGE_STRIDE * 4;
+  if (n_floats != need) return fail(SRL_EINVAL, "records must hold n_envs x episode_length x SRL_STAGE_STRIDE x 4 floats");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(records, env->d_stage, sizeof(float) * (size_t)need, hipMemcpyDeviceToHost));
+  return SRL_OK;
+}
+
+int32_t srl_stage_record_stride(void) { return SRL_STAGE_STRIDE; }
+
 int srl_render_heightmap(srl_env* env, const float* poses, const int32_t* mesh_ids, const int32_t* n_bodies,
                          float* height, void* stream) {
   if (!env || !poses || !mesh_ids || !n_bodies || !height) return fail(SRL_EINVAL, "null argument");

@@ -307,6 +307,13 @@ class VecStackEnv(object):
   def set_profiling(self, enable=True):
     _check(self._lib.srl_set_profiling(self._h, int(bool(enable))))
 
+  def stage_records(self):
+    """Test hook (`srl_get_stage_records`): int32 view [B, L, stride, 4] of the rocks' staged render records."""
+    stride = int(self._lib.srl_stage_record_stride())
+    out = np.zeros((self._B, self.config.episode_length, stride, 4), np.float32)
+    _check(self._lib.srl_get_stage_records(self._h, _np_ptr(out), out.size))
+    return out
+
   def kernel_times(self):
     ms = np.zeros(3, np.float32)
     n = np.zeros(3, np.int32)

@@ -35,6 +35,8 @@ _SIGS = {
   'srl_set_concurrent_envs': (ctypes.c_int, [_VP, ctypes.c_int32]),
   'srl_set_launch_order': (ctypes.c_int, [_VP, ctypes.c_int32]),
   'srl_build_info': (ctypes.c_char_p, []),
+  'srl_get_stage_records': (ctypes.c_int, [_VP, _VP, ctypes.c_int64]),
+  'srl_stage_record_stride': (ctypes.c_int32, []),
 }
 EXPORTS = tuple(sorted(_SIGS))
 

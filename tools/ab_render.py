@@ -42,17 +42,17 @@ def run(so):
   torch.cuda.synchronize()
   ms, n = g.kernel_times()
   g.set_profiling(False)
-  res.append('step-path %.2f us' % (ms[1] / max(n[1], 1) * 1e3))
+  res.append('step-path %.2f us (+ stage %.2f us)' % (ms[1] / max(n[1], 1) * 1e3, ms[2] / max(n[2], 1) * 1e3))
   print('  '.join(res), flush=True)
 
 if __name__ == '__main__':
-  if sys.argv[1] == '--run':
+  if len(sys.argv) > 1 and sys.argv[1] == '--run':
     run(sys.argv[2]); sys.exit(0)
   variants = sys.argv[1:]
   sos = []
   if variants and variants[0] == '--libs':
     import glob
-    sos = sorted(glob.glob(os.path.join(os.path.abspath(variants[1]), 'lib*.so')))
+    sos = sorted(x for x in glob.glob(os.path.join(os.path.abspath(variants[1]), 'lib*.so')) if 'qnet' not in x)
     variants = [os.path.basename(x) for x in sos]
   for k, v in enumerate([] if sos else variants):
     so = os.path.join(ROOT, 'gpurun_out', 'libstackrl_ab%d.so' % k)
@@ -61,5 +61,5 @@ if __name__ == '__main__':
     sos.append(so)
   for rep in range(2):
     for k, so in enumerate(sos):
-      print('[%d] %-40s' % (k, variants[k] or '(default)'), end=' ', flush=True)
-      subprocess.check_call([sys.executable, os.path.abspath(__file__), '--run', so])
+      out = subprocess.run([sys.executable, os.path.abspath(__file__), '--run', so], check=True, stdout=subprocess.PIPE, universal_newlines=True).stdout
+      print('[%d] %-40s %s' % (k, variants[k] or '(default)', out.strip().splitlines()[-1]), flush=True)
