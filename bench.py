@@ -186,12 +186,24 @@ def cpu_baseline(L, seed, kw, budget_envs=48, episodes=20):
   wall = time.perf_counter() - t0
   placed = sum(r[0] for r in res)
   busy = max(r[1] for r in res)
+  model = None
+  try:
+    with open('/proc/cpuinfo') as f:
+      model = next((l.split(':', 1)[1].strip() for l in f if l.startswith('model name')), None)
+  except OSError:
+    pass
   return {
-    'value': placed / busy, 'unit': 'env_steps/s', 'cores': cores, 'kind': 'port',
+    'value': placed / busy, 'unit': 'env_steps/s', 'cores': cores, 'kind': 'port', 'nproc': os.cpu_count(), 'cpu_model': model,
     'sample': '{} procs x {} envs x {} episode(s) of {} placements (oracle/srl_oracle.c -O3 x86-64-v3, same pool, '
               'RNG keys and solver definition); wall incl. process start {:.1f}s'.format(cores, budget_envs, episodes, L, wall),
     'single_thread_value': n1 / t1,
   }
+
+
+def build_info():
+  from stackrl_amd import build as _b
+  i = _b.info(_b.LIB) or {}
+  return {'variant': i.get('variant'), 'source_hash': i.get('hash')}
 
 
 def aggregate(dt, placed, world, device):
@@ -297,6 +309,21 @@ def env_leg(args, rank, world, pool, barrier, solver_kw):
   last()     # raises if any env diverged / action invalid
   ms, nl = env.kernel_times()
   env.set_profiling(False)
+  # the same loop over a window of 54 calls (six whole episodes: every fill level of the scene weighs the same), reported
+  # beside the contract's K-step figure as value_long
+  long_steps, long_value = 54, None
+  if args.steps != long_steps and world == 1:
+    while phase['k'] != 0:
+      do_step()[0]()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    lp = 0
+    for _ in range(long_steps):
+      last, p, _nb = do_step()
+      lp += p
+    last()
+    torch.cuda.synchronize()
+    long_value = lp / (time.perf_counter() - t1)
   # statistics of one further (untimed) episode: what the stop criterion and the residual threshold asked of the kernel
   subs, sweeps = [], []
   while phase['k'] != 0:
@@ -307,7 +334,8 @@ def env_leg(args, rank, world, pool, barrier, solver_kw):
     sweeps.append(env.sweeps())
   do_step()[0]()
   sub, sw = np.stack(subs), np.stack(sweeps)
-  out = dict(B=B, L=L, res=res, r=r, dt=dt, placed=placed, alg=alg, ms=ms, nl=nl, sub=sub, sw=sw, config=env.config)
+  out = dict(B=B, L=L, res=res, r=r, dt=dt, placed=placed, alg=alg, ms=ms, nl=nl, sub=sub, sw=sw, config=env.config,
+             long_value=long_value, long_steps=long_steps)
   env.close()
   torch.cuda.synchronize()
   return out
@@ -419,6 +447,23 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
       if self.on:
         self.pairs[-1][1].record()
 
+  # the policy evaluation of the whole batch ALONE on the device (nothing else in flight): the kernel-level figure beside the
+  # in-loop one, where the forward shares the CUs with the other group's settle kernel and the update's gradient half
+  step = env.reset()
+  step = step() if callable(step) else step
+  getattr(env, 'drain', lambda: None)()
+  torch.cuda.synchronize()
+  draws = agent.policy_draws(B)
+  fa, fb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  with torch.no_grad():
+    agent._policy(step[0], True, False, draws)
+    torch.cuda.synchronize()
+    fa.record()
+    for _ in range(3):
+      agent._policy(step[0], True, False, draws)
+    fb.record()
+  torch.cuda.synchronize()
+  fwd_alone_ms = fa.elapsed_time(fb) / 3
   agent.policy_timer = ptimer = PolicyTimer()
   step = env.reset()
   agent.acknowledge_reset()
@@ -479,13 +524,16 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
     # nothing); step_calls_per_s counts every vectorised step() call
     'env_steps_per_s': steps_all / dt_max, 'step_calls_per_s': steps_all / dt_max * iters / max(placed_calls, 1),
     'placement_calls': placed_calls, 'iters_per_s': iters / dt_max, 'ms_per_iter': 1e3 * dt_max / iters,
-    'rollout_forward_ms': fwd_ms, 'update_ms': upd_ms, 'allreduce_ms': ar_ms,
+    'rollout_forward_ms': fwd_ms, 'rollout_forward_alone_ms': fwd_alone_ms, 'update_ms': upd_ms, 'allreduce_ms': ar_ms,
     'grad_bucket_bytes': int(agent._flat_grad.numel() * 4), 'update_graphed': agent._train_graph is not None or agent._grad_graph is not None,
     'roofline': {
       'kernel': 'Q-net rollout forward (DeepQSiamFCN, {} samples)'.format(B), 'bound': 'mfma',
       'achieved': flops_fwd / (fwd_ms * 1e-3) / 1e12, 'peak': PEAK_TFLOPS[dtype], 'unit': 'TFLOP/s',
       'frac': flops_fwd / (fwd_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 'traffic': None, **mfma_counters(dtype),
       'alg_flops_per_launch': flops_fwd, 'avg_launch_ms': fwd_ms,
+      # the same forward with nothing else on the device (three evaluations of the batch before the loop)
+      'alone': {'avg_launch_ms': fwd_alone_ms, 'achieved': flops_fwd / (fwd_alone_ms * 1e-3) / 1e12,
+                'frac': flops_fwd / (fwd_alone_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype]},
       'note': 'model-level: 2 x {:.1f} M MAC per sample (SURVEY.md N1) x samples / HIP-event time of the policy evaluations of an '
               'iteration in the timed region (with env_groups > 1 they run beside the other group\'s settle kernel); peak = {}'.format(macs / 1e6, 'dense bf16 MFMA' if dtype == 'bf16' else
                                                    'dense bf16 MFMA / 3 (fp32-class products = three bf16 MFMAs; the fp32 MFMA peak '
@@ -584,6 +632,11 @@ def worker(args):
         'mesh_pool': '{} synthetic rocks (generator seed 11)'.format(len(pool)),
       },
       'step_calls_per_s': args.steps * B * args.gpus / dt_max,
+      # the same loop over 54 calls = six whole episodes (the K-step window above starts mid-episode and weighs the fuller scenes more)
+      'value_long': None if a.get('long_value') is None else {'value': a['long_value'], 'steps': a['long_steps'], 'unit': 'env_steps/s'},
+      # which build of the env library was timed (stackrl_amd/build.py: 'vectorised+rewritten' = SLP vectoriser + the pass of
+      # isa_fix.py over the assembly; 'safe' = the fall-back without the vectoriser) and the hash of the sources it carries
+      'env_library': build_info(),
       'roofline': {
         'kernel': 'srl_k_render', 'bound': 'hbm', 'achieved': a['alg'] / render_s / 1e9 if render_s > 0 else None,
         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -591,6 +644,9 @@ def worker(args):
         'traffic_source': traffic_source,
         'avg_launch_us': 1e3 * float(ms[1]) / max(int(nl[1]), 1), 'launches': int(nl[1]),
         'alg_bytes_per_launch': a['alg'] / max(int(nl[1]), 1),
+        # since round 4 the rocks' planes / outlines are prepared by their own kernel (one wave per rock, no tile: csrc/render.hip
+        # srl_k_stage) and srl_k_render reads the finished records; its time is NOT part of `achieved` and is stated here
+        'stage_kernel': {'kernel': 'srl_k_stage', 'avg_launch_us': 1e3 * float(ms[2]) / max(int(nl[2]), 1), 'launches': int(nl[2])},
       },
       'settle': {
         'kernel': 'srl_k_step', 'avg_launch_ms': float(ms[0]) / max(int(nl[0]), 1), 'launches': int(nl[0]),

@@ -510,8 +510,8 @@ static inline int pixel_range(float lo, float hi, float inv_px, int res, int* i0
  * and not an optimisation behind it:
  *   item row r of a rock = pixel rows i0 + ITEM_ROWS r .. (i0 the first row of its bounding box); with more than ROW_SPANS
  *   item rows every pixel consults every face and side (as before round 4);
- *   a face reaches the item rows [r0, r1] that its x extent, a pixel wider on either side, overlaps (slab_rows); so does an
- *   outline side with the x extent of its edge;
+ *   a face reaches the item rows [r0, r1] of the pixel rows from the last one whose centre is at or below its x extent to the
+ *   first one at or above it (slab_rows); so does an outline side with the x extent of its edge;
  *   a pixel of item row r consults the faces whose first row r0 lies in [R(r), r], R(r) = the smallest r0 among the faces
  *   that reach r (r1 >= r) — a superset of those that reach r, and one contiguous range of the faces ordered by r0, whatever
  *   the order inside one r0 (the kernel fills its lists with LDS counters); the sides likewise;
@@ -521,7 +521,7 @@ static inline int pixel_range(float lo, float hi, float inv_px, int res, int* i0
 enum { ITEM_ROWS = 4, ROW_SPANS = 16 };
 
 static void slab_rows(float x0, float x1, float inv_px, int i0, int nirows, int* r0, int* r1) {
-  float f0 = floorf(x0 * inv_px - 0.5f) - 1.0f - (float)i0, f1 = ceilf(x1 * inv_px - 0.5f) + 1.0f - (float)i0;
+  float f0 = floorf(x0 * inv_px - 0.5f) - (float)i0, f1 = ceilf(x1 * inv_px - 0.5f) - (float)i0;
   int a = f0 > 0.0f ? (int)(f0 * (1.0f / ITEM_ROWS)) : 0, z = f1 > 0.0f ? (int)(f1 * (1.0f / ITEM_ROWS)) : 0;
   if (a > nirows - 1) a = nirows - 1;
   if (z > nirows - 1) z = nirows - 1;

@@ -249,10 +249,13 @@ __device__ __forceinline__ void plane_sweep(const float4* pl, int n, int s, int 
       float4 r0 = pl[ob], r1 = pl[ob + 1], r2 = pl[ob + 2], r3 = pl[ob + 3];
 #ifndef SRL_ABL_NOPLANEREAD
       asm volatile("" : "+v"(q0.w), "+v"(q1.w), "+v"(q2.w), "+v"(q3.w));   // keeps each fetch one 16-byte read
-      asm volatile("" : "+v"(r0.w), "+v"(r1.w), "+v"(r2.w), "+v"(r3.w));
 #endif
       plane_eval<UP>(q0, py, vx, acc); plane_eval<UP>(q1, py, vx, acc);
       plane_eval<UP>(q2, py, vx, acc); plane_eval<UP>(q3, py, vx, acc);
+#ifndef SRL_ABL_NOPLANEREAD
+      __builtin_amdgcn_sched_barrier(0);             // (the second batch arrives under the first one's arithmetic)
+      asm volatile("" : "+v"(r0.w), "+v"(r1.w), "+v"(r2.w), "+v"(r3.w));
+#endif
       plane_eval<UP>(r0, py, vx, acc); plane_eval<UP>(r1, py, vx, acc);
       plane_eval<UP>(r2, py, vx, acc); plane_eval<UP>(r3, py, vx, acc);
     }
@@ -306,7 +309,8 @@ __device__ __forceinline__ float wave_minmax(float v) {
 //              definition's side functions at every pixel it visits.
 //   ranges:    along the vertical line through a pixel inside the outline the hull's top is the face the line pierces, so
 //              min over ALL up-facing planes = min over any subset that holds that face: an item row needs the faces whose
-//              x extent reaches its rows (a pixel of margin: the neighbours a rounding could prefer are included).  The
+//              x extent reaches its rows (rounded outwards to whole pixel rows: a neighbour that a rounding could prefer at
+//              the face's rim is included).  The
 //              same holds for the outline: a point of the row outside it violates a side whose x extent contains the
 //              point's x, or one of the two sides at the outline's extreme vertex.  Both lists are ordered by the first
 //              item row their face / edge reaches (LDS counters), so a row's subset is one range [lo, hi) of each.
@@ -316,9 +320,10 @@ struct StageLds {
   int cnt[2][SRL_STAGE_SPANS], st[2][SRL_STAGE_SPANS], lo[2][SRL_STAGE_SPANS];   // entries per first row, their prefix, first row of the entries that reach a row
 };
 
-// item rows [r0, r1] (clamped to the rock's) that a face / edge with x extent [x0, x1] reaches, a pixel of margin either side
+// item rows [r0, r1] (clamped to the rock's) that a face / edge with x extent [x0, x1] reaches: those of the pixel rows from
+// the last one whose centre is at or below x0 to the first one at or above x1 (so up to a pixel of slack on either side)
 __device__ __forceinline__ int slab_range(float x0, float x1, float inv_px, int i0, int nirows) {
-  const float f0 = floorf(x0 * inv_px - 0.5f) - 1.0f - (float)i0, f1 = ceilf(x1 * inv_px - 0.5f) + 1.0f - (float)i0;
+  const float f0 = floorf(x0 * inv_px - 0.5f) - (float)i0, f1 = ceilf(x1 * inv_px - 0.5f) - (float)i0;
   int r0 = f0 > 0.0f ? (int)(f0 * (1.0f / SRL_ITEM_ROWS)) : 0, r1 = f1 > 0.0f ? (int)(f1 * (1.0f / SRL_ITEM_ROWS)) : 0;
   r0 = min(r0, nirows - 1); r1 = min(r1, nirows - 1);
   return r0 | (r1 << 8);
@@ -355,10 +360,12 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_stage(DevParams P, float
   // everything the mesh header points at is requested now: the first two chunks of faces (planes + vertex ids), the first
   // chunk of edges, the vertices
   float4 pl0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pl1 = pl0;
-  uchar4 tr0 = make_uchar4(0, 0, 0, 0), tr1 = tr0, ed0 = tr0;
+  uchar4 tr0 = make_uchar4(0, 0, 0, 0), tr1 = tr0, ed0 = tr0, ed1 = tr0, ed2 = tr0;
   if (lane < nt) { pl0 = P.mp[to + lane]; tr0 = P.mt[to + lane]; }
   if (64 + lane < nt) { pl1 = P.mp[to + 64 + lane]; tr1 = P.mt[to + 64 + lane]; }
   if (lane < ne) ed0 = P.me[eo + lane];
+  if (64 + lane < ne) ed1 = P.me[eo + 64 + lane];
+  if (128 + lane < ne) ed2 = P.me[eo + 128 + lane];
   const m3 R = quat_to_mat(q);
   // world xy of the vertices, one (two) per lane; faces and edges read their end points from these lanes
   float wx0 = 0.0f, wy0 = 0.0f, wx1 = 0.0f, wy1 = 0.0f;
@@ -423,8 +430,8 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_stage(DevParams P, float
   int nsil = 0;
   for (int c = 0; c < ne; c += 64) {
     const bool act = c + lane < ne;
-    uchar4 ed = ed0;
-    if (c > 0) { ed = make_uchar4(0, 0, 0, 0); if (act) ed = P.me[eo + c + lane]; }
+    uchar4 ed = c == 0 ? ed0 : c == 64 ? ed1 : ed2;
+    if (c >= 192) { ed = make_uchar4(0, 0, 0, 0); if (act) ed = P.me[eo + c + lane]; }
     const unsigned long long ma = ed.z < 128 ? (ed.z < 64 ? upm0 : upm1) : (ed.z < 192 ? upm2 : upm3);
     const unsigned long long mb = ed.w < 128 ? (ed.w < 64 ? upm0 : upm1) : (ed.w < 192 ? upm2 : upm3);
     const bool ua = (ma >> (ed.z & 63)) & 1ull, ub = (mb >> (ed.w & 63)) & 1ull;
@@ -564,6 +571,18 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
     hd1 = make_int4(__float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
   }
   const int nb = ext ? nb_ext[e] : h->nb;
+  // every wave also reads the header of the first rock it will copy (rock `wave`: the rocks of a group go to the waves round
+  // robin) and requests that rock's first 64 slots at once, two barriers before they are needed
+  float4 pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  {
+    int c0 = 0;
+    if (wave < slots) { const float4 a = srec[(size_t)wave * SRL_STAGE_STRIDE]; c0 = __float_as_int(a.z) + __float_as_int(a.w); }
+    c0 = __builtin_amdgcn_readfirstlane(c0);
+#ifdef SRL_ABL_NOSTAGE
+    if (P.px == 12345.0f)
+#endif
+    if (wave < nb && lane < c0) pv = srec[(size_t)wave * SRL_STAGE_STRIDE + SRL_STAGE_HDR + lane];
+  }
   int g0 = 0, g1 = 0, g2 = 0, g3 = 0, pending = -1, mode = 0, hdone = 0, left = 0;
   float prev_m[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if (!ext) {
@@ -657,11 +676,10 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
     const int pb = bs + wave;
     int pbase = 0, pcnt = 0;
     if (pb < be) { pbase = L.reg[4 * pb + 0]; pcnt = L.reg[4 * pb + 1] + L.reg[4 * pb + 2]; }
-    float4 pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #ifdef SRL_ABL_NOSTAGE
     if (P.px == 12345.0f)
 #endif
-    if (lane < pcnt) pv = srec[(size_t)pb * SRL_STAGE_STRIDE + SRL_STAGE_HDR + lane];
+    if (!first && lane < pcnt) pv = srec[(size_t)pb * SRL_STAGE_STRIDE + SRL_STAGE_HDR + lane];   // (first group: requested in the prologue)
     RSTAMP(1);
     // (d) first trip: rows no rock reaches hold the empty-pixel constants; their H / observation bytes leave
     //     now, so that HBM drains them while the ray cast computes.  cov bit k: this thread's k-th pixel group
@@ -935,15 +953,18 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
 #ifdef SRL_ABL_NOTAIL
   if (P.px != 12345.0f) return;
 #endif
+  //      (p[t] += p[t + 256], t < 256; p[t] += p[t + 128], t < 128; p[t] += p[t + 64], t < 64; then shuffles): the three
+  //      cross-wave stages only ever combine lane t of the eight waves, so wave 0 reads the eight partials after ONE barrier
+  //      and adds them in the tree's order — the same sums, bit for bit, with two barriers fewer
   L.pi[tid] = spi; L.pu[tid] = spu;
-  __syncthreads();
-  if (tid < 256) { L.pi[tid] += L.pi[tid + 256]; L.pu[tid] += L.pu[tid + 256]; }
-  __syncthreads();
-  if (tid < 128) { L.pi[tid] += L.pi[tid + 128]; L.pu[tid] += L.pu[tid + 128]; }
   __syncthreads();
   float sum_i = 0.0f, sum_u = 0.0f;
   if (tid < 64) {
-    sum_i = L.pi[tid] + L.pi[tid + 64]; sum_u = L.pu[tid] + L.pu[tid + 64];
+    float qi[8], qu[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { qi[k] = L.pi[tid + 64 * k]; qu[k] = L.pu[tid + 64 * k]; }
+    sum_i = ((qi[0] + qi[4]) + (qi[2] + qi[6])) + ((qi[1] + qi[5]) + (qi[3] + qi[7]));
+    sum_u = ((qu[0] + qu[4]) + (qu[2] + qu[6])) + ((qu[1] + qu[5]) + (qu[3] + qu[7]));
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) { sum_i = sum_i + __shfl_down(sum_i, s); sum_u = sum_u + __shfl_down(sum_u, s); }   // p[t] += p[t+s], t < s
   }
