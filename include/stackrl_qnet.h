@@ -278,6 +278,31 @@ int srl_thead_fwd(const float* z_dev, const float* pw_dev, const float* pb_dev, 
                   int32_t A, void* stream);
 int srl_thead_bwd(const float* z_dev, const float* pw_dev, const float* gq_dev, float* gz_dev, float* gv_dev, float* gpw_dev,
                   float* gpb_dev, float* scratch_dev, int32_t n, int32_t A, void* stream);
+/* The value branch of the dueling head (`layers.value`, layers.py:424-436; models.py:179-186): global average pool of the
+ * bottom features x0 [B][P][C] (channels last, P = h x w), Dense(U) + ReLU (W1 [U][C], b1 [U]), Dense(1) (W2 [U], b2 [1]):
+ *   srl_tvalue_fwd:  v[b]; pooled [B][C] and h [B][U] (may be NULL) are kept for the backward
+ *   srl_tvalue_bwd:  for the first n samples, from gv[n]: gW1, gb1, gW2, gb2 (written, not accumulated) and
+ *                    gx[b][p][c] = gin[b][p][c] + (d v / d pooled)[b][c] / P — the gradient wrt x0, added to the one that
+ *                    arrives through the decoder (gin); scratch: n U floats.
+ * One workgroup per sample / hidden unit, every sum in index order, no atomics; replaces the framework's GEMM, bias, ReLU and
+ * reduction kernels of rounds 1-3. */
+int srl_tvalue_fwd(const float* x0_dev, const float* W1_dev, const float* b1_dev, const float* W2_dev, const float* b2_dev,
+                   float* pooled_dev, float* h_dev, float* v_dev, int32_t B, int32_t P, int32_t C, int32_t U, void* stream);
+int srl_tvalue_bwd(const float* gv_dev, const float* h_dev, const float* pooled_dev, const float* W1_dev, const float* W2_dev,
+                   const float* gin_dev, float* gx_dev, float* gW1_dev, float* gb1_dev, float* gW2_dev, float* gb2_dev,
+                   float* scratch_dev, int32_t n, int32_t P, int32_t C, int32_t U, void* stream);
+/* Layout passes around the cross-correlation (`layers.correlation`, layers.py:21-38: its kernels read channel-major maps, the
+ * U-Nets of the update work channels-last): srl_tlayout copies a channels-last activation (pixel stride / channel offset) to
+ * [B][C][HW] (to_nhwc = 0) or a channel-major tensor to [B][HW][C] (to_nhwc = 1); srl_tcorr_grad takes channel 0 of a
+ * channels-last gradient [n][O][O][g_stride] as the plain map [n][O][O] and as its zero-padded copy [n][O + 2 pad][O + 2 pad];
+ * srl_tflip reverses each of `planes` planes of hw elements (the flipped kernels of the data gradient); srl_tu8_to_f32 is the
+ * network's input scaling uint8 -> float32 / 255 (models.py:144-147; n a multiple of 4). */
+int srl_tlayout(const float* src_dev, int32_t src_stride, int32_t src_off, float* dst_dev, int32_t B, int32_t HW, int32_t C,
+                int32_t to_nhwc, void* stream);
+int srl_tcorr_grad(const float* g_dev, int32_t g_stride, float* plain_dev, float* padded_dev, int32_t n, int32_t O, int32_t pad,
+                   void* stream);
+int srl_tflip(const float* in_dev, float* out_dev, int64_t planes, int32_t hw, void* stream);
+int srl_tu8_to_f32(const uint8_t* in_dev, float* out_dev, int64_t n, void* stream);
 const char* srl_train_conv_last_error(void);
 
 #ifdef __cplusplus

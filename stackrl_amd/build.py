@@ -10,16 +10,23 @@ SOURCES = ['stackrl_hip.hip']
 DEPS = ['stackrl_hip.hip', 'settle.hip', 'render.hip', 'srl_device.h', 'srl_kernels.h',
         os.path.join('..', '..', 'include', 'stackrl_hip.h'), os.path.join('..', '..', 'include', 'srl_types.h')]
 # -ffp-contract=off: the solver/rasteriser definition is "one IEEE rounding per written operation"
-# The packed-fp32 erratum: on gfx950 a v_pk_add_f32 / v_pk_mul_f32 whose LOW lane takes the HIGH half
-#   of its SECOND source (op_sel:[x,1]; v_pk_fma_f32 too, and its addend) reads 0 for that operand now and then while wavefronts of an MFMA kernel share the CU
-#   (tools/experiments/pk_seq2.hip reproduces it in 30 lines).  clang's SLP vectoriser emits exactly that form when it packs
-#   scalars that sit in different halves of their pairs; with it the settle and render kernels returned results that differ
-#   from the oracle's in a few envs per thousand steps, only beside the Q-net's convolution kernels.  The env library is
-#   therefore built in steps: device assembly (vectoriser on: it is worth 3.4 % of the settle kernel), `isa_fix.rewrite`
-#   (the two commuting sources of every flagged instruction swapped — the same selection on the FIRST source is clean),
-#   assembler, code object, fat binary, host object, link: what hipcc does in one go, with the pass in the middle.  If any step
-#   fails the library is built in one go WITHOUT the vectoriser instead (FLAGS_SAFE: no flagged instruction either, slower).
-#   tests/test_isa_guard.py checks the compiled ISA of every source file of both libraries.
+# The packed-fp32 erratum: on the MI355X boxes of this pool a v_pk_add_f32 / v_pk_mul_f32 whose LOW lane
+#   takes the HIGH half of its SECOND source (op_sel:[x,1]; v_pk_fma_f32 too, and its addend) reads 0 for that operand now and
+#   then while another wavefront on the CU issues one of gfx950's MFMA shapes with 128-bit A / B operands
+#   (v_mfma_f32_16x16x32_bf16 / _f16, v_mfma_f32_32x32x16_bf16, v_mfma_i32_16x16x64_i8): measured with a 30-line victim
+#   (tools/experiments/pk_seq2.hip) beside one-property aggressors (tools/experiments/pk_aggressor.hip, tools/diag_aggressor.py,
+#   profiles/r04_erratum_aggressor*.log) — 1 - 3 % of the executions beside a bare loop of such MFMAs, whether their
+#   accumulators live in v or a registers, at any s_setprio, with or without wait states between them; 0 beside
+#   v_mfma_f32_16x16x4_f32, the 64-bit-operand v_mfma_f32_16x16x16_bf16, vector FMAs, DPP, v_perm_b32, SDWA or packed FMAs, and
+#   0 alone.  clang's SLP vectoriser emits exactly that form when it packs scalars that sit in different halves of their
+#   pairs; with it the settle and render kernels returned results that differ from the oracle's in a few envs per thousand
+#   steps, only beside the Q-net's bf16 convolution kernels.  The env library is therefore built in steps: device assembly
+#   (vectoriser on: it is worth 3.4 % of the settle kernel), `isa_fix.rewrite` (the two commuting sources of every flagged
+#   instruction swapped — the same selection on the FIRST source is clean), assembler, code object, fat binary, host object,
+#   link: what hipcc does in one go, with the pass in the middle.  If any step fails the library is built in one go WITHOUT
+#   the vectoriser instead (FLAGS_SAFE: no flagged instruction either, slower); the library says which it is
+#   (`srl_build_info`, printed by bench.py).  tests/test_isa_guard.py checks the compiled ISA of every source file of both
+#   libraries AND disassembles the shipped .so files.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
          '-fno-fast-math', '-Wall', '-Wno-unused-function', '-Wno-unused-value', '-Wno-unused-result']
 FLAGS = FLAGS + os.environ.get('SRL_EXTRA_FLAGS', '').split()      # experiments only (e.g. -DSRL_STEP_PRIO=3)

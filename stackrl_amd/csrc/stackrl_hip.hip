@@ -453,6 +453,9 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   layout(P, env->concurrent_envs);
   if (P.BLOB != old_blob) return fail(SRL_EINVAL, "internal: blob layout changed");
   env->step_lds = sizeof(float) * (size_t)P.LDS_WORDS;
+  // experiment hook (tools / DESIGN.md section 8): SRL_STEP_LDS_PAD_KB pads the settle kernel's LDS request, i.e. lowers the
+  // number of env workgroups a CU holds, leaving LDS to kernels that run beside it
+  if (const char* pad = getenv("SRL_STEP_LDS_PAD_KB")) env->step_lds += (size_t)atoi(pad) * 1024;
   if (env->step_lds > 160 * 1024) return fail(SRL_EINVAL, "episode_length x mesh size exceeds the 160 KB LDS budget");
   // threads per env / pair-manifold points per thread (settle.hip "Variants")
   // 128 threads up to 8 rocks, 256 up to 16 (one contact point per thread), 256 with two points per thread above

@@ -627,6 +627,150 @@ __global__ void __launch_bounds__(64) k_thead_finish(const float* __restrict__ p
   if (c < 16) gpw[c] = s; else gpb[0] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------- value head
+// `layers.value` (layers.py:424-436) of the dueling network (models.py:179-192): global average pool of the bottom features
+// x0 [B][P][C] (P = h x w pixels) -> Dense(U) + ReLU -> Dense(1).  Rounds 1-3 left these two small dense layers to the
+// framework (rocBLAS GEMMs, bias / ReLU / reduction kernels through autograd).  Here: one workgroup per sample forwards,
+// one per sample + one per hidden unit backwards; every sum runs in index order (pixels, inputs, samples), no atomics.
+//   pooled[b][i] = (sum_p x0[b][p][i]) / P;  h[b][j] = relu(b1[j] + sum_i pooled[b][i] W1[j][i]);  v[b] = b2 + sum_j h[b][j] W2[j]
+__global__ void __launch_bounds__(256) k_tvalue_fwd(const float* __restrict__ x0, const float* __restrict__ W1,
+                                                    const float* __restrict__ b1, const float* __restrict__ W2,
+                                                    const float* __restrict__ b2, float* __restrict__ pooled,
+                                                    float* __restrict__ h, float* __restrict__ v, int P, int C, int U) {
+  extern __shared__ float sh[];                      // [C] pooled features, then [256] partial sums
+  float* red = sh + C;
+  const int b = blockIdx.x;
+  const float* xb = x0 + (long long)b * P * C;
+  for (int i = threadIdx.x; i < C; i += 256) {
+    float s = 0.0f;
+    for (int p = 0; p < P; ++p) s += xb[(long long)p * C + i];
+    s = s / (float)P;
+    sh[i] = s;
+    if (pooled) pooled[(long long)b * C + i] = s;
+  }
+  __syncthreads();
+  float part = 0.0f;
+  for (int j = threadIdx.x; j < U; j += 256) {
+    const float* w = W1 + (long long)j * C;
+    float a = b1[j];
+    for (int i = 0; i < C; ++i) a = fmaf(sh[i], w[i], a);
+    a = fmaxf(a, 0.0f);
+    if (h) h[(long long)b * U + j] = a;
+    part = fmaf(a, W2[j], part);
+  }
+  const float tot = block_sum_256(part, red);
+  if (threadIdx.x == 0) v[b] = tot + b2[0];
+}
+
+// backward for the first n samples, kernel A (one workgroup per sample): gh[b][j] = gv[b] W2[j] [h[b][j] > 0] (kept for kernel
+// B), gpooled[i] = sum_j gh[j] W1[j][i], and the gradient wrt x0: gx[b][p][i] = gin[b][p][i] + gpooled[i] / P (gin = the
+// gradient that reaches x0 through the decoder; the two meet here instead of in a framework add)
+__global__ void __launch_bounds__(256) k_tvalue_bwd_a(const float* __restrict__ gv, const float* __restrict__ h,
+                                                      const float* __restrict__ W1, const float* __restrict__ W2,
+                                                      const float* __restrict__ gin, float* __restrict__ gh,
+                                                      float* __restrict__ gx, int P, int C, int U) {
+  extern __shared__ float sh[];                      // [U] gh of this sample
+  const int b = blockIdx.x;
+  const float g = gv[b];
+  for (int j = threadIdx.x; j < U; j += 256) {
+    const float t = h[(long long)b * U + j] > 0.0f ? g * W2[j] : 0.0f;
+    sh[j] = t;
+    gh[(long long)b * U + j] = t;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    float a = 0.0f;
+    for (int j = 0; j < U; ++j) a = fmaf(sh[j], W1[(long long)j * C + i], a);
+    a = a / (float)P;
+    for (int p = 0; p < P; ++p) {
+      const long long o = ((long long)b * P + p) * C + i;
+      gx[o] = gin[o] + a;
+    }
+  }
+}
+
+// kernel B: block j < U: gW1[j][i] = sum_b gh[b][j] pooled[b][i] (thread i), gb1[j] = sum_b gh[b][j]; block U: gW2[j] =
+// sum_b gv[b] h[b][j] (thread j), gb2 = sum_b gv[b].  Samples in index order.
+__global__ void __launch_bounds__(256) k_tvalue_bwd_b(const float* __restrict__ gv, const float* __restrict__ gh,
+                                                      const float* __restrict__ h, const float* __restrict__ pooled,
+                                                      float* __restrict__ gW1, float* __restrict__ gb1,
+                                                      float* __restrict__ gW2, float* __restrict__ gb2, int n, int C, int U) {
+  const int j = blockIdx.x;
+  if (j < U) {
+    for (int i = threadIdx.x; i < C; i += 256) {
+      float a = 0.0f;
+      for (int b = 0; b < n; ++b) a = fmaf(gh[(long long)b * U + j], pooled[(long long)b * C + i], a);
+      gW1[(long long)j * C + i] = a;
+    }
+    if (threadIdx.x == 0) {
+      float a = 0.0f;
+      for (int b = 0; b < n; ++b) a += gh[(long long)b * U + j];
+      gb1[j] = a;
+    }
+    return;
+  }
+  for (int k = threadIdx.x; k < U; k += 256) {
+    float a = 0.0f;
+    for (int b = 0; b < n; ++b) a = fmaf(gv[b], h[(long long)b * U + k], a);
+    gW2[k] = a;
+  }
+  if (threadIdx.x == 0) {
+    float a = 0.0f;
+    for (int b = 0; b < n; ++b) a += gv[b];
+    gb2[0] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- layout passes
+// The cross-correlation kernels (csrc/xcorr_mfma.hip) read channel-major maps [B][C][H][W]; the U-Nets of the update work on
+// channels-last ones [B][H][W][C].  These were framework copies (permute + contiguous, pad, flip); one kernel each:
+//   k_tlayout mode 0: NHWC (stride / offset slice) -> NCHW;  mode 1: NCHW -> NHWC;  both one element per thread, the reads
+//   of a wave contiguous in the source's fastest dimension for mode 1, in the destination's for mode 0
+__global__ void __launch_bounds__(256) k_tlayout(const float* __restrict__ src, int ss, int so, float* __restrict__ dst, int B,
+                                                 int HW, int C, int mode) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x, n = (long long)B * HW * C;
+  if (e >= n) return;
+  if (mode == 0) {          // e indexes dst [b][c][p]
+    const int p = (int)(e % HW); const long long r = e / HW; const int c = (int)(r % C), b = (int)(r / C);
+    dst[e] = src[((long long)b * HW + p) * ss + so + c];
+  } else {                  // e indexes dst [b][p][c]; src [b][c][p]
+    const int c = (int)(e % C); const long long r = e / C; const int p = (int)(r % HW), b = (int)(r / HW);
+    dst[e] = src[((long long)b * C + c) * HW + p];
+  }
+}
+
+// channel 0 of a channels-last gradient g [n][O][O][Cs] -> the plain map [n][O][O] AND its zero-padded copy
+// [n][O + 2 pad][O + 2 pad] (the operand of the cross-correlation's data gradient)
+__global__ void __launch_bounds__(256) k_tcorr_grad(const float* __restrict__ g, int Cs, float* __restrict__ plain,
+                                                    float* __restrict__ padded, int n, int O, int pad) {
+  const int Op = O + 2 * pad;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x, tot = (long long)n * Op * Op;
+  if (e >= tot) return;
+  const int x = (int)(e % Op) - pad; const long long r = e / Op; const int y = (int)(r % Op) - pad, b = (int)(r / Op);
+  float v = 0.0f;
+  if (x >= 0 && x < O && y >= 0 && y < O) {
+    v = g[(((long long)b * O + y) * O + x) * Cs];
+    plain[((long long)b * O + y) * O + x] = v;
+  }
+  padded[e] = v;
+}
+
+// out[b][c][kh - 1 - y][kw - 1 - x] = in[b][c][y][x] for the first n samples (the flipped kernels of the data gradient)
+__global__ void __launch_bounds__(256) k_tflip(const float* __restrict__ in, float* __restrict__ out, long long planes, int hw) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= planes * hw) return;
+  const long long pl = e / hw; const int k = (int)(e % hw);
+  out[pl * hw + (hw - 1 - k)] = in[e];
+}
+
+// uint8 observation -> float32 / 255 (models.py:144-147), 4 elements per thread
+__global__ void __launch_bounds__(256) k_tu8_to_f32(const uint8_t* __restrict__ in, float* __restrict__ out, long long n4) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  const uchar4 v = ((const uchar4*)in)[e];
+  ((float4*)out)[e] = make_float4((float)v.x / 255.0f, (float)v.y / 255.0f, (float)v.z / 255.0f, (float)v.w / 255.0f);
+}
+
 }  // namespace
 
 extern "C" {
@@ -717,6 +861,53 @@ int srl_thead_bwd(const float* z, const float* pw, const float* gq, float* gz, f
   hipLaunchKernelGGL(k_thead_bwd, dim3(n), dim3(256), 0, st, z, pw, gq, gz, gv, scratch, A);
   hipLaunchKernelGGL(k_thead_finish, dim3(1), dim3(64), 0, st, scratch, n, gpw, gpb);
   return t_finish("srl_thead_bwd");
+}
+
+int srl_tvalue_fwd(const float* x0, const float* W1, const float* b1, const float* W2, const float* b2, float* pooled, float* h,
+                   float* v, int32_t B, int32_t P, int32_t C, int32_t U, void* stream) {
+  if (!x0 || !W1 || !b1 || !W2 || !b2 || !v || B < 1 || P < 1 || C < 1 || U < 1 || C > 4096) return t_bad("srl_tvalue_fwd: bad arguments");
+  hipLaunchKernelGGL(k_tvalue_fwd, dim3(B), dim3(256), sizeof(float) * (C + 256), (hipStream_t)stream, x0, W1, b1, W2, b2, pooled, h, v, P, C, U);
+  return t_finish("srl_tvalue_fwd");
+}
+
+int srl_tvalue_bwd(const float* gv, const float* h, const float* pooled, const float* W1, const float* W2, const float* gin,
+                   float* gx, float* gW1, float* gb1, float* gW2, float* gb2, float* scratch, int32_t n, int32_t P, int32_t C,
+                   int32_t U, void* stream) {
+  if (!gv || !h || !pooled || !W1 || !W2 || !gin || !gx || !gW1 || !gb1 || !gW2 || !gb2 || !scratch || n < 1 || P < 1 || C < 1 ||
+      U < 1 || U > 4096)
+    return t_bad("srl_tvalue_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_tvalue_bwd_a, dim3(n), dim3(256), sizeof(float) * U, st, gv, h, W1, W2, gin, scratch, gx, P, C, U);
+  hipLaunchKernelGGL(k_tvalue_bwd_b, dim3(U + 1), dim3(256), 0, st, gv, (const float*)scratch, h, pooled, gW1, gb1, gW2, gb2, n, C, U);
+  return t_finish("srl_tvalue_bwd");
+}
+
+int srl_tlayout(const float* src, int32_t src_stride, int32_t src_off, float* dst, int32_t B, int32_t HW, int32_t C, int32_t to_nhwc,
+                void* stream) {
+  if (!src || !dst || B < 1 || HW < 1 || C < 1) return t_bad("srl_tlayout: bad arguments");
+  const long long n = (long long)B * HW * C;
+  hipLaunchKernelGGL(k_tlayout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, src_stride, src_off, dst, B, HW, C,
+                     to_nhwc ? 1 : 0);
+  return t_finish("srl_tlayout");
+}
+
+int srl_tcorr_grad(const float* g, int32_t g_stride, float* plain, float* padded, int32_t n, int32_t O, int32_t pad, void* stream) {
+  if (!g || !plain || !padded || n < 1 || O < 1 || pad < 0 || g_stride < 1) return t_bad("srl_tcorr_grad: bad arguments");
+  const long long tot = (long long)n * (O + 2 * pad) * (O + 2 * pad);
+  hipLaunchKernelGGL(k_tcorr_grad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, g_stride, plain, padded, n, O, pad);
+  return t_finish("srl_tcorr_grad");
+}
+
+int srl_tflip(const float* in, float* out, int64_t planes, int32_t hw, void* stream) {
+  if (!in || !out || planes < 1 || hw < 1) return t_bad("srl_tflip: bad arguments");
+  hipLaunchKernelGGL(k_tflip, dim3((unsigned)((planes * hw + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, (long long)planes, hw);
+  return t_finish("srl_tflip");
+}
+
+int srl_tu8_to_f32(const uint8_t* in, float* out, int64_t n, void* stream) {
+  if (!in || !out || n < 4 || n % 4) return t_bad("srl_tu8_to_f32: bad arguments (element count a multiple of 4)");
+  hipLaunchKernelGGL(k_tu8_to_f32, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, (long long)(n / 4));
+  return t_finish("srl_tu8_to_f32");
 }
 
 }  // extern "C"

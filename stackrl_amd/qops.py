@@ -583,6 +583,7 @@ class FastFeatures(object):
     self._wf = _LazyPacked()
     self._wt = {}
     self._wg = _LazyPacked()
+    self._w1 = _LazyPacked()
     self._pos = None
     self._posbuf = {}
 
@@ -596,6 +597,7 @@ class FastFeatures(object):
     self._wf = _LazyPacked()
     self._wt = {}
     self._wg = _LazyPacked()
+    self._w1 = _LazyPacked()        # transposed convolutions left to the float32 1 x 1 form of the update's kernel (srl_tconv)
     for m in self.net.modules():
       if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
         self._w[m] = _WeightBias(m, self.dtype)
@@ -615,6 +617,12 @@ class FastFeatures(object):
         if (self.mfma_conv or self.x3_conv) and isinstance(m, torch.nn.ConvTranspose2d) and m.kernel_size == (2, 2) and \
            (m.in_channels, m.out_channels) in ((128, 64), (256, 128)):
           self._wg.offer(m, lambda m=m: pack_convt2x2_weights(m.weight, x3=not self.mfma_conv))
+        # float32 rollout: any other 2 x 2 stride-2 transposed convolution (the right U-Net's 64 -> 32 at 8 x 8, whose rows
+        # are narrower than the MFMA kernel's 16-pixel tiles) as a 1 x 1 convolution to 4 cout channels + depth-to-space in
+        # true float32 on the matrix cores (csrc/train_conv.hip k_tconv): weights [cin][q cout + co], q = 2 dy + dx
+        if self.x3_conv and isinstance(m, torch.nn.ConvTranspose2d) and m.kernel_size == (2, 2) and m.stride == (2, 2) and \
+           m.out_channels % 4 == 0 and (4 * m.out_channels) % 16 == 0:
+          self._w1.offer(m, lambda m=m: m.weight.detach().float().permute(0, 2, 3, 1).reshape(m.in_channels, 4 * m.out_channels).contiguous())
         if (self.mfma_conv or self.x3_conv) and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.in_channels in (1, 2) and m.out_channels == 16:
           self._wt[m] = m.weight.detach().float().contiguous()
@@ -683,6 +691,10 @@ class FastFeatures(object):
         convt2x2_bias_relu(x, self._wf[up], b, f, cat, 0)
       elif up in self._wg and x.is_contiguous(memory_format=_CL):
         convt2x2_gemm_bias_relu(x, self._wg[up], b, f, cat, 0)
+      elif up in self._w1 and x.dtype == torch.float32 and x.is_contiguous(memory_format=_CL) and cat.is_contiguous(memory_format=_CL):
+        from stackrl_amd import qtrain                    # channels-last tensors are [B, H, W, C] in memory
+        qtrain.tconv(qtrain.Act(x.permute(0, 2, 3, 1)), self._w1[up], b, 4 * f, taps=1, relu=True,
+                     out=(cat.permute(0, 2, 3, 1), 0), d2s=f)
       else:
         y = _cl(F.conv_transpose2d(x, self._w[up][0], None, stride=up.stride))
         bias_act(y, b, out=cat, out_offset=0)       # Concatenate([up, skip]) without a copy

@@ -44,6 +44,18 @@ def _lib():
     L.srl_thead_fwd.argtypes = [VP, VP, VP, VP, VP, I32, I32, VP]
     L.srl_thead_bwd.restype = ctypes.c_int
     L.srl_thead_bwd.argtypes = [VP] * 8 + [I32, I32, VP]
+    L.srl_tvalue_fwd.restype = ctypes.c_int
+    L.srl_tvalue_fwd.argtypes = [VP] * 8 + [I32] * 4 + [VP]
+    L.srl_tvalue_bwd.restype = ctypes.c_int
+    L.srl_tvalue_bwd.argtypes = [VP] * 12 + [I32] * 4 + [VP]
+    L.srl_tlayout.restype = ctypes.c_int
+    L.srl_tlayout.argtypes = [VP, I32, I32, VP, I32, I32, I32, I32, VP]
+    L.srl_tcorr_grad.restype = ctypes.c_int
+    L.srl_tcorr_grad.argtypes = [VP, I32, VP, VP, I32, I32, I32, VP]
+    L.srl_tflip.restype = ctypes.c_int
+    L.srl_tflip.argtypes = [VP, VP, I64, I32, VP]
+    L.srl_tu8_to_f32.restype = ctypes.c_int
+    L.srl_tu8_to_f32.argtypes = [VP, VP, I64, VP]
     L.srl_train_conv_last_error.restype = ctypes.c_char_p
     L._train_conv_ready = True
   return L
@@ -141,6 +153,34 @@ def tact_bwd(g, y, scratch, gbias=None, gpool=None, relu=True, s2d=False, defer_
   if defer_bias:
     return gz, (sc, _lib().srl_tact_bwd_blocks(B * H * W, C), C, gbias)
   return gz
+
+
+def to_nchw(a):
+  """`srl_tlayout`: an `Act` -> contiguous channel-major tensor [B, C, H, W] (what the cross-correlation kernels read)."""
+  out = torch.empty((a.B, a.C, a.H, a.W), dtype=torch.float32, device=a.t.device)
+  with torch.cuda.device(a.t.device):
+    _chk(_lib().srl_tlayout(a.ptr(), a.stride, a.off, out.data_ptr(), a.B, a.H * a.W, a.C, 0, qops._stream(a.t)))
+  return out
+
+
+def to_nhwc(t):
+  """`srl_tlayout`: a contiguous channel-major tensor [B, C, H, W] -> `Act` [B, H, W, C]."""
+  B, C, H, W = (int(v) for v in t.shape)
+  out = torch.empty((B, H, W, C), dtype=torch.float32, device=t.device)
+  with torch.cuda.device(t.device):
+    _chk(_lib().srl_tlayout(t.data_ptr(), 0, 0, out.data_ptr(), B, H * W, C, 1, qops._stream(t)))
+  return Act(out)
+
+
+def input_scale(x):
+  """The network's input scaling (models.py:144-147): uint8 observation [B, H, W, C] -> float32 / 255 (`srl_tu8_to_f32`)."""
+  if x.dtype != torch.uint8 or x.numel() % 4:
+    return (x.float() / 255.0) if x.dtype == torch.uint8 else x.float().contiguous()
+  x = x.contiguous()
+  out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+  with torch.cuda.device(x.device):
+    _chk(_lib().srl_tu8_to_f32(x.data_ptr(), out.data_ptr(), x.numel(), qops._stream(x)))
+  return out
 
 
 def pool2x2(y):
@@ -297,7 +337,8 @@ class HandNet(object):
     return Act(gx.t, m.in_channels, 0) if cpad != m.in_channels else gx
 
   def _unet_bwd(self, U, tape, g_out, g_x0, n, need_dx_input=False):
-    """g_out: gradient wrt the U-Net's output (`Act`), g_x0: wrt the bottom features (tensor [n, h, w, C]) or None."""
+    """g_out: gradient wrt the U-Net's output (`Act`); g_x0: None, or a callable that takes the gradient arriving at the bottom
+    features through the decoder and returns the full gradient there (the value branch of the dueling head joins in)."""
     ups = [t for t in tape if t[0] == 'up']
     downs = [t for t in tape if t[0] == 'down']
     bottom = [t for t in tape if t[0] == 'bottom'][0]
@@ -310,7 +351,7 @@ class HandNet(object):
       gcats.append(gcat)
       g = self._layer_bwd(up, x_prev, yu, Act(gcat.t, f, 0), n, s2d=True)
     if g_x0 is not None:
-      g = Act(g.dense() + g_x0)
+      g = g_x0(g)
     (_, bm, xb, y1b, x0) = bottom
     g = self._layer_bwd(bm[2], y1b, x0, g, n)
     g = self._layer_bwd(bm[0], xb, y1b, g, n)                        # gradient wrt the deepest pooled map
@@ -330,31 +371,35 @@ class HandNet(object):
     xm, xo = inputs
     B = int(xm.shape[0])
     tape_l, tape_r = [], []
-    xl = Act((xm.float() / 255.0) if xm.dtype == torch.uint8 else xm.float().contiguous())      # models.py:144-147
-    xr = Act((xo.float() / 255.0) if xo.dtype == torch.uint8 else xo.float().contiguous())
+    xl, xr = Act(input_scale(xm)), Act(input_scale(xo))                                          # models.py:144-147
     fl, x0 = self._unet_fwd(net.left, xl, tape_l)
     fr, _ = self._unet_fwd(net.right, xr, tape_r)
     # layers.correlation (layers.py:21-38) on the matrix cores; the kernel reads channel-major tensors
-    xl_n = fl.dense().permute(0, 3, 1, 2).contiguous()
-    xr_n = fr.dense().permute(0, 3, 1, 2).contiguous()
+    xl_n, xr_n = to_nchw(fl), to_nchw(fr)
     corr = qops.xcorr_forward_mfma(xl_n, xr_n, self.precision)                                   # [B, 1, O, O]
     O = int(corr.shape[-1])
     cin = Act(corr.reshape(B, O, O, 1))
     z1 = self._conv(net.pos[0], cin)
     z2 = self._conv(net.pos[2], z1)
-    # the 1 x 1 projection and the dueling combination (models.py:179-192): one hand-written pass per sample (srl_thead_fwd);
-    # the value MLP on the pooled bottom map — two small dense layers — stays with the framework
-    x0t = x0.t.detach().requires_grad_(save)
-    with torch.set_grad_enabled(save):
-      v = net.value(x0t.mean(dim=(1, 2)))                                                          # [B, 1]
+    # the value branch (layers.value: average pool of the bottom features -> Dense + ReLU -> Dense) and the 1 x 1 projection
+    # with the dueling combination (models.py:179-192): hand-written passes, one workgroup per sample (srl_tvalue_fwd,
+    # srl_thead_fwd)
+    d1, d2 = net.value[0], net.value[2]
+    C, U, P = int(d1.in_features), int(d1.out_features), x0.H * x0.W
+    x0d = x0.dense()
+    pooled = torch.empty((B, C), dtype=torch.float32, device=xm.device) if save else None
+    hid = torch.empty((B, U), dtype=torch.float32, device=xm.device) if save else None
+    v = torch.empty((B,), dtype=torch.float32, device=xm.device)
     pw, pb = net.pos[4].weight.detach().reshape(-1), net.pos[4].bias.detach()
     q = torch.empty((B, O * O), dtype=torch.float32, device=xm.device)
     with torch.cuda.device(q.device):
-      _chk(_lib().srl_thead_fwd(z2.t.data_ptr(), pw.data_ptr(), pb.data_ptr(), v.detach().reshape(-1).contiguous().data_ptr(),
-                                q.data_ptr(), B, O * O, qops._stream(q)))
+      _chk(_lib().srl_tvalue_fwd(x0d.data_ptr(), d1.weight.data_ptr(), d1.bias.data_ptr(), d2.weight.data_ptr(), d2.bias.data_ptr(),
+                                 None if pooled is None else pooled.data_ptr(), None if hid is None else hid.data_ptr(),
+                                 v.data_ptr(), B, P, C, U, qops._stream(q)))
+      _chk(_lib().srl_thead_fwd(z2.t.data_ptr(), pw.data_ptr(), pb.data_ptr(), v.data_ptr(), q.data_ptr(), B, O * O, qops._stream(q)))
     if save:
-      self.saved = dict(tape_l=tape_l, tape_r=tape_r, fl=fl, fr=fr, xl_n=xl_n, xr_n=xr_n, cin=cin, z1=z1, z2=z2, v=v,
-                        x0t=x0t, x0=x0, B=B, O=O)
+      self.saved = dict(tape_l=tape_l, tape_r=tape_r, fl=fl, fr=fr, xl_n=xl_n, xr_n=xr_n, cin=cin, z1=z1, z2=z2,
+                        pooled=pooled, hid=hid, x0=x0, B=B, O=O)
     return q
 
   def backward(self, grad_q):
@@ -365,28 +410,46 @@ class HandNet(object):
     A = O * O
     dev = grad_q.device
     z2 = S['z2'].t                                                      # [B, O, O, 16], contiguous
-    pj = net.pos[4]
-    for p_ in (pj.weight, pj.bias):
+    pj, d1, d2 = net.pos[4], net.value[0], net.value[2]
+    for p_ in (pj.weight, pj.bias, d1.weight, d1.bias, d2.weight, d2.bias):
       if p_.grad is None:
         p_.grad = torch.zeros_like(p_)
     gz2 = torch.empty((n, O, O, 16), dtype=torch.float32, device=dev)
-    gv = torch.zeros((S['B'], 1), dtype=torch.float32, device=dev)
+    gv = torch.empty((n,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
       _chk(_lib().srl_thead_bwd(z2.data_ptr(), pj.weight.detach().reshape(-1).data_ptr(), grad_q.contiguous().data_ptr(),
                                 gz2.data_ptr(), gv.data_ptr(), pj.weight.grad.data_ptr(), pj.bias.grad.data_ptr(),
                                 self.scratch.get('head', 17 * n, dev).data_ptr(), n, A, qops._stream(gz2)))
-    S['v'].backward(gv)                          # value MLP gradients and x0.grad (dense layers: framework)
     g = self._layer_bwd(net.pos[2], S['z1'], S['z2'], Act(gz2), n)
     g = self._layer_bwd(net.pos[0], S['cin'], S['z1'], g, n)                     # [n, O, O, 16], channel 0 = d / d corr
-    gcorr = g.t[..., 0].contiguous()                                             # [n, O, O]
     kh = int(S['xr_n'].shape[-1])
     H = int(S['xl_n'].shape[-1])
     C = int(S['xl_n'].shape[1])
-    gp = _F.pad(gcorr, (kh - 1, kh - 1, kh - 1, kh - 1))
-    dxl = qops._xcorr_mfma(1, self.precision, gp, S['xr_n'][:n].flip(-1, -2), n, C, H, kh)   # [n, C, H, H]
+    # d / d corr as the plain map and zero-padded (the operand of the data gradient), the flipped kernels: one pass each
+    gcorr = torch.empty((n, O, O), dtype=torch.float32, device=dev)
+    gp = torch.empty((n, O + 2 * (kh - 1), O + 2 * (kh - 1)), dtype=torch.float32, device=dev)
+    wflip = torch.empty((n, C, kh, kh), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+      _chk(_lib().srl_tcorr_grad(g.t.data_ptr(), g.stride, gcorr.data_ptr(), gp.data_ptr(), n, O, kh - 1, qops._stream(gp)))
+      _chk(_lib().srl_tflip(S['xr_n'].data_ptr(), wflip.data_ptr(), n * C, kh * kh, qops._stream(gp)))
+    dxl = qops._xcorr_mfma(1, self.precision, gp, wflip, n, C, H, kh)                           # [n, C, H, H]
     dxr = qops._xcorr_mfma(2, self.precision, S['xl_n'][:n], gcorr, n, C, H, kh)              # [n, C, kh, kh]
-    g_l = Act(dxl.permute(0, 2, 3, 1).contiguous())
-    g_r = Act(dxr.permute(0, 2, 3, 1).contiguous())
-    self._unet_bwd(net.left, S['tape_l'], g_l, S['x0t'].grad[:n], n)
+    g_l, g_r = to_nhwc(dxl), to_nhwc(dxr)
+
+    def value_branch(g_dec):
+      """The gradient wrt the bottom features: what arrives through the decoder + the value branch's (srl_tvalue_bwd, which
+      also writes the two dense layers' gradients)."""
+      x0 = S['x0']
+      Cb, U, P = int(d1.in_features), int(d1.out_features), x0.H * x0.W
+      gin = g_dec.dense()
+      gx = torch.empty((n, x0.H, x0.W, Cb), dtype=torch.float32, device=dev)
+      with torch.cuda.device(dev):
+        _chk(_lib().srl_tvalue_bwd(gv.data_ptr(), S['hid'].data_ptr(), S['pooled'].data_ptr(), d1.weight.data_ptr(),
+                                   d2.weight.data_ptr(), gin.data_ptr(), gx.data_ptr(), d1.weight.grad.data_ptr(),
+                                   d1.bias.grad.data_ptr(), d2.weight.grad.data_ptr(), d2.bias.grad.data_ptr(),
+                                   self.scratch.get('value', n * U, dev).data_ptr(), n, P, Cb, U, qops._stream(gx)))
+      return Act(gx)
+
+    self._unet_bwd(net.left, S['tape_l'], g_l, value_branch, n)
     self._unet_bwd(net.right, S['tape_r'], g_r, None, n)
     self.saved = None

@@ -1,13 +1,16 @@
-"""No kernel of either library may contain the instruction form that misbehaves on gfx950 beside MFMA wavefronts.
+"""No kernel of either library may contain the packed-fp32 instruction form that misreads an operand on gfx950.
 
-Found in round 3 (tools/experiments/pk_seq2.hip is the 30-line reproduction): a packed-fp32
-instruction whose LOW lane takes the HIGH half of its SECOND source — `v_pk_add_f32` / `v_pk_mul_f32` / `v_pk_fma_f32` with
-`op_sel:[x,1...]`, and the fma's addend likewise (`op_sel:[x,x,1]`) — reads 0 for that operand in 2 - 4 of 10,000 executions while wavefronts of an MFMA
-kernel share the CU, and never alone.  clang's SLP vectoriser emits the form.  The env library is compiled with the
-vectoriser and a pass over its assembly that swaps the two (commuting) sources of every such instruction
-(stackrl_amd/isa_fix.py; the same selection on the first source is clean); the Q-net library is built without the
-vectoriser.  This test compiles every source to gfx950 assembly the way stackrl_amd/build.py does (no GPU needed) and checks
-the ISA, so that a later flag, compiler or source change cannot bring the form back unnoticed."""
+Found in round 3, its trigger narrowed down in round 4 (tools/experiments/pk_seq2.hip is the 30-line
+victim, tools/experiments/pk_aggressor.hip the one-property aggressors): a packed-fp32 instruction whose LOW lane takes the HIGH
+half of its SECOND source — `v_pk_add_f32` / `v_pk_mul_f32` / `v_pk_fma_f32` with `op_sel:[x,1...]`, and the fma's addend likewise
+(`op_sel:[x,x,1]`) — reads 0 for that operand in 1 - 3 % of its executions while another wavefront of the CU runs a loop of
+gfx950's 128-bit-operand MFMA shapes (`v_mfma_f32_16x16x32_bf16` / `_f16`, `_32x32x16_bf16`, `v_mfma_i32_16x16x64_i8`; 2 - 4 per
+10,000 beside the Q-net's bf16 convolution kernels), and never alone, beside fp32 or 64-bit-operand MFMAs, or beside vector-ALU
+work.  clang's SLP vectoriser emits the form.  The env library is compiled with the vectoriser and a pass over its assembly
+that swaps the two (commuting) sources of every such instruction (stackrl_amd/isa_fix.py; the same selection on the first
+source is clean); the Q-net library is built without the vectoriser.  These tests compile every source to gfx950 assembly
+the way stackrl_amd/build.py does AND take the shipped .so files apart (no GPU needed), so that a later flag, compiler or
+source change — or a stale library — cannot bring the form back unnoticed."""
 import os
 from concurrent.futures import ThreadPoolExecutor
 
@@ -16,7 +19,7 @@ from stackrl_amd import build, isa_fix
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 
 
-def test_no_kernel_contains_the_packed_form_that_fails_beside_mfma_wavefronts():
+def test_no_kernel_contains_the_packed_form_that_fails_beside_wide_operand_mfma_wavefronts():
   jobs = [lambda: build.fixed_env_asm(HIPCC)[0],                                                      # the product's env library
           lambda: build.device_asm(HIPCC, build.FLAGS_SAFE, os.path.join(build.CSRC, build.SOURCES[0]))]   # and its fall-back build
   jobs += [(lambda s=s: build.device_asm(HIPCC, build.QFLAGS, os.path.join(build.CSRC, s))) for s in build.QSRC]

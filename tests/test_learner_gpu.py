@@ -662,13 +662,18 @@ def test_bias_act_autograd_matches_torch(C, shape, relu):
 
 def test_fused_epilogue_net_matches_the_module_graph():
   """`DeepQSiamFCN.set_fused_epilogues` (the library update path, `DQN(hand_convs=False)`) against the plain module graph:
-  the fused path changes no arithmetic, only the order of the bias-gradient sums.  Both run the library's atomically
-  accumulating weight-gradient kernels, so they are not compared with each other but EACH with the module graph in float64
-  on the host, parameter by parameter, at 1e-3 of the parameter's gradient scale (re-association noise of float32 sums is
-  1e-6 ... 1e-5).  Round 3 saw 1.33e-3 between the two paths once on `left.down.3.0.weight` and widened the tolerance; the
-  record could not tell which side had moved or where.  A failure here now names the side, the elements, and how close to
-  zero the reference's pre-activations come (a ReLU mask that flips between two roundings of the same forward moves a
-  deep layer's gradient by x . g of one pixel — 1e-3 ... 1e-2 of its scale, confined to one output channel)."""
+  the fused path changes no arithmetic, only the order of the bias-gradient sums.  Round 3 compared the two paths with
+  each other at 1e-3 of a parameter's gradient scale, saw 1.33e-3 once on `left.down.3.0.weight` and widened the bound to 3e-3
+  without knowing which side had moved.  Round 4 put a float64 evaluation on the host beside both and found the answer in the
+  first run: the LIBRARY's float32 convolution gradients of the deep levels (64 ... 256 channels) sit 1.0 ... 1.4e-3 from
+  float64 on BOTH paths, the same figure to two digits (`left.down.3.0.weight`: 1.33e-3 on either side, thousands of
+  elements, every output channel) — the accuracy of the library's algorithm for those shapes, not noise and not corruption.
+  The two paths normally share it (same kernels: their mutual difference is an order below); when the library picks a
+  different algorithm for one of them the whole 1.3e-3 shows between them, which is what round 3 saw.  (The hand-written
+  update path, the default, is held to float64 at 2e-3 and observed at 5e-5: tests/test_train_conv_gpu.py.)
+  So each path is compared with float64, parameter by parameter, at 3e-3 — the library's measured accuracy class with a
+  factor of two — and a larger deviation is accepted only in the shape a flipped ReLU mask gives it (below); the record of
+  a failure names the side, the elements and the reference's smallest pre-activations."""
   import copy
   from stackrl_amd import nets
   net = nets.DeepQSiamFCN(seed=3).cuda()
@@ -695,7 +700,7 @@ def test_fused_epilogue_net_matches_the_module_graph():
   fused = {n: p.grad.clone() for n, p in net.named_parameters()}
   assert float((q1 - q0).abs().max()) <= 1e-5 * float(q0.abs().max())
   assert float((q0.double() - qd.cuda()).abs().max()) <= 1e-4 * float(qd.abs().max())
-  # A deviation above 1e-3 is accepted only in the shape a flipped ReLU mask gives it (the float64 forward's smallest
+  # A deviation above 3e-3 is accepted only in the shape a flipped ReLU mask gives it (the float64 forward's smallest
   # |pre-activation| is 1e-8 ... 1e-7 with these inputs — below the rounding of a float32 convolution, whose library kernels
   # split the reduction and add atomically for some shapes, so the mask of such a pixel can differ between roundings of the
   # same forward): below 5e-2 of the scale and confined to at most two output channels of the layer.  Anything else — a
@@ -708,7 +713,7 @@ def test_fused_epilogue_net_matches_the_module_graph():
     for side, got in (('plain', plain[n]), ('fused', fused[n])):
       diff = (got.double() - want[n]).abs()
       e = float(diff.max()) / scale
-      if e <= 1e-3:
+      if e <= 3e-3:
         continue
       d = (diff > 1e-4 * scale).nonzero()
       rng = [(int(d[:, k].min()), int(d[:, k].max())) for k in range(d.shape[1])]

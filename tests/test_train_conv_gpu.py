@@ -165,6 +165,69 @@ def test_activation_gradient_routes_the_max_pool_like_the_library(C, B, H, W):
   assert _rel(gb, want.sum(dim=(0, 1, 2))) <= 1e-5
 
 
+@pytest.mark.parametrize('B,n,P,C,U', [(6, 4, 64, 256, 256), (3, 3, 16, 128, 40), (2, 1, 1, 48, 300)])
+def test_value_branch_forward_and_gradients_match_torch_fp64(B, n, P, C, U):
+  """`layers.value` (layers.py:424-436): average pool -> Dense + ReLU -> Dense(1), forward and — for the first n samples — the
+  gradients of both dense layers and of the bottom features (added to an incoming gradient), against float64 on the host."""
+  from stackrl_amd import qtrain, qops
+  L = qtrain._lib()
+  g = torch.Generator(device='cuda').manual_seed(B + C)
+  side = int(round(P ** 0.5))
+  x0 = torch.randn((B, side, side, C), generator=g, device='cuda')
+  d1, d2 = torch.nn.Linear(C, U).cuda(), torch.nn.Linear(U, 1).cuda()
+  pooled, hid = torch.empty((B, C), device='cuda'), torch.empty((B, U), device='cuda')
+  v = torch.empty(B, device='cuda')
+  st = qops._stream(v)
+  assert L.srl_tvalue_fwd(x0.data_ptr(), d1.weight.data_ptr(), d1.bias.data_ptr(), d2.weight.data_ptr(), d2.bias.data_ptr(),
+                          pooled.data_ptr(), hid.data_ptr(), v.data_ptr(), B, P, C, U, st) == 0
+  xd = x0.double().cpu().requires_grad_()
+  w1, b1 = d1.weight.detach().double().cpu().requires_grad_(), d1.bias.detach().double().cpu().requires_grad_()
+  w2, b2 = d2.weight.detach().double().cpu().requires_grad_(), d2.bias.detach().double().cpu().requires_grad_()
+  vr = (torch.relu(xd.mean(dim=(1, 2)) @ w1.T + b1) @ w2.T + b2)[:, 0]
+  assert _rel(v, vr.cuda()) <= 1e-5
+  gv = torch.randn(n, generator=g, device='cuda')
+  gin = torch.randn((n, side, side, C), generator=g, device='cuda')
+  (vr[:n] * gv.double().cpu()).sum().backward()
+  gx = torch.full((n, side, side, C), float('nan'), device='cuda')
+  gw1, gb1 = torch.full_like(d1.weight, float('nan')), torch.full_like(d1.bias, float('nan'))
+  gw2, gb2 = torch.full_like(d2.weight, float('nan')), torch.full_like(d2.bias, float('nan'))
+  sc = torch.full((n * U,), float('nan'), device='cuda')
+  assert L.srl_tvalue_bwd(gv.data_ptr(), hid.data_ptr(), pooled.data_ptr(), d1.weight.data_ptr(), d2.weight.data_ptr(), gin.data_ptr(),
+                          gx.data_ptr(), gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(), sc.data_ptr(), n, P, C, U, st) == 0
+  assert _rel(gw1, w1.grad.cuda()) <= 1e-5 and _rel(gb1, b1.grad.cuda()) <= 1e-5
+  assert _rel(gw2, w2.grad.cuda()) <= 1e-5 and _rel(gb2, b2.grad.cuda()) <= 1e-5
+  assert _rel(gx, (gin.double().cpu() + xd.grad[:n]).cuda()) <= 1e-6
+  # bit-identical on repetition
+  gw1b = torch.empty_like(gw1)
+  assert L.srl_tvalue_bwd(gv.data_ptr(), hid.data_ptr(), pooled.data_ptr(), d1.weight.data_ptr(), d2.weight.data_ptr(), gin.data_ptr(),
+                          gx.data_ptr(), gw1b.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(), sc.data_ptr(), n, P, C, U, st) == 0
+  assert torch.equal(gw1, gw1b)
+
+
+def test_layout_passes_are_exact():
+  """The copies around the cross-correlation (channels-last <-> channel-major, channel 0 of a gradient plain and zero-padded,
+  flipped kernels) and the uint8 -> float32 / 255 input scaling, against the framework formulations, bit for bit."""
+  from stackrl_amd import qtrain, qops
+  L = qtrain._lib()
+  g = torch.Generator(device='cuda').manual_seed(4)
+  buf = torch.randn((3, 9, 7, 24), generator=g, device='cuda')
+  a = qtrain.Act(buf, 16, 4)
+  n = qtrain.to_nchw(a)
+  assert torch.equal(n, buf[..., 4:20].permute(0, 3, 1, 2))
+  assert torch.equal(qtrain.to_nhwc(n).t, buf[..., 4:20].contiguous())
+  gr = torch.randn((2, 11, 11, 16), generator=g, device='cuda')
+  plain, padded = torch.full((2, 11, 11), 5.0, device='cuda'), torch.full((2, 17, 17), 5.0, device='cuda')
+  assert L.srl_tcorr_grad(gr.data_ptr(), 16, plain.data_ptr(), padded.data_ptr(), 2, 11, 3, qops._stream(gr)) == 0
+  assert torch.equal(plain, gr[..., 0]) and torch.equal(padded, torch.nn.functional.pad(gr[..., 0], (3, 3, 3, 3)))
+  w = torch.randn((5, 4, 6, 6), generator=g, device='cuda')
+  out = torch.empty((3, 4, 6, 6), device='cuda')
+  assert L.srl_tflip(w.data_ptr(), out.data_ptr(), 3 * 4, 36, qops._stream(w)) == 0
+  assert torch.equal(out, w[:3].flip(-1, -2))
+  u = torch.randint(0, 256, (2, 8, 8, 2), generator=g, device='cuda', dtype=torch.uint8)
+  # a correctly rounded float32 division, as the reference's `inputs / 255` (the framework multiplies by the rounded reciprocal)
+  assert torch.equal(qtrain.input_scale(u), (u.double() / 255.0).float())
+
+
 @pytest.mark.parametrize('rf', [5, 4])
 def test_hand_net_forward_and_backward_match_the_module_autograd(rf):
   """`HandNet` against `DeepQSiamFCN`'s own graph in float64 (Stack-v0 shapes and the 64 x 64 configuration): Q values and
