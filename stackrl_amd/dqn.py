@@ -463,7 +463,8 @@ class DQN(object):
         loss, mtd, td_abs, new_logits, grad_q = qops.td_epilogue(
           q_all.detach(), qo, tq, actions, rewards, terminal, weights, self._gamma, self._huber_delta, self._reward_scale,
           self._double, self._replay_memory.epsilon, self._ws)
-        self._flat_grad.zero_()
+        # no zero-fill of the gradient bucket: the hand-written backward writes every element of every parameter's gradient
+        # (tests/test_train_conv_gpu.py starts it from NaN); the alignment padding between parameters keeps its initial zeros
         self._hand.backward(grad_q)
         return loss, mtd, indexes, td_abs, new_logits
       with torch.no_grad():

@@ -251,8 +251,8 @@ def test_hand_net_forward_and_backward_match_the_module_autograd(rf):
   qd[:n].backward(gq.double().cpu())
   qd = qd.cuda()
   for p in net.parameters():
-    p.grad = torch.zeros_like(p)
-  hn = qtrain.HandNet(net)
+    p.grad = torch.full_like(p, float('nan'))      # the backward WRITES every element of every gradient (nothing accumulates,
+  hn = qtrain.HandNet(net)                         # nothing needs a zero-fill first): a NaN left behind fails below
   hn.refresh()
   q = hn.forward((xm, xo), save=True)
   assert _rel(q.detach(), qd.detach()) <= 2e-4

@@ -41,8 +41,11 @@ def parse(d):
     c = agg.setdefault(n, [0, 0]); c[0] += dt; c[1] += 1
   tot = sum(v[0] for v in agg.values())
   print('steady state: %.2f ms per forward in kernels, %d launches per forward' % (tot / ITERS / 1e6, (b - a - 1) / ITERS))
-  for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:30]:
-    print('%6.2f%%  %9.1f us avg  %4d calls/fwd  %s' % (100 * t / tot, t / c / 1e3, c / ITERS, n[:120]))
+  for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):          # every kernel of the window, not a top list
+    print('%6.2f%%  %9.1f us avg  %6.1f calls/fwd  %s' % (100 * t / tot, t / c / 1e3, c / ITERS, n[:140]))
+  mine = sum(v[0] for n, v in agg.items() if 'k_' in n or 'srl_' in n)
+  print('kernels of this repo (k_* / srl_*): %.2f %% of the kernel time, %d of %d launches per forward' % (
+    100.0 * mine / tot, sum(v[1] for n, v in agg.items() if 'k_' in n or 'srl_' in n) / ITERS, (b - a - 1) / ITERS))
 
 
 if __name__ == '__main__':

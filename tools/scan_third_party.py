@@ -103,8 +103,9 @@ def main(argv):
     else:
       hits, kernels = scan_library(path)
     print('{}: {} {} kernels, {} contain the form ({} instructions)'.format(path, len(kernels), ARCH, len(hits), sum(len(v) for v in hits.values())))
-    for k in sorted(hits, key=lambda k: -len(hits[k]))[:40]:
-      print('   {:5d}  {}'.format(len(hits[k]), (k or '?')[:160]))
+    top = int(os.environ.get('SCAN_TOP', 40))
+    for k in sorted(hits, key=lambda k: -len(hits[k]))[:top]:
+      print('   {:5d}  {}'.format(len(hits[k]), (k or '?')[:int(os.environ.get('SCAN_WIDTH', 160))]))
     if names:
       for n in names:
         aff = [k for k in hits if k and n in k]
