@@ -5,8 +5,9 @@ TensorFlow's float32 convolutions.  Rounds 1-2 ran the update's convolutions thr
 weight-gradient kernels, ~940 launches per update).  `HandNet` runs every convolution of the update — forward with saved
 activations, data gradient, weight gradient, for the 3 x 3 layers, the 2 x 2 transposed ones and the thin first layers — on
 the kernels of csrc/train_conv.hip (true float32 on the matrix cores, fixed-order reductions), the cross-correlation and its
-two gradients on csrc/xcorr_mfma.hip, and leaves to the framework only the dueling head's two small dense layers and the
-1 x 1 projection (plain library GEMMs / element-wise ops, through autograd).
+two gradients on csrc/xcorr_mfma.hip, the dueling head (1 x 1 projection + combination, `srl_thead_*`) and — since round 4 — its
+value branch (average pool, two dense layers, `srl_tvalue_*`), the layout passes around the cross-correlation and the input
+scaling on fixed-order kernels of the same file: no library or framework kernel runs inside forward() / backward().
 
 Activations are float32 NHWC tensors ([B, H, W, C] contiguous); the decoder's concatenation buffers are written in place by
 the producing kernels (channel slices), the max-pool gradient is routed inside the activation-gradient pass.  Weight
