@@ -268,6 +268,25 @@ __device__ __forceinline__ void plane_sweep(const float4* pl, int n, int s, int 
   }
 }
 
+// the kernel's output stores (H float4, packed observation uint2) are non-temporal: the 100 MB a launch writes pass through a
+// 4 MB L2 per XCD once and are read by later kernels only in part (36.0 -> 34.95 us per launch; SRL_PLAIN_STORES: plain ones)
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int nt_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void out_f4(float* base, int g, float4 v) {
+#ifndef SRL_PLAIN_STORES
+  __builtin_nontemporal_store((nt_f4){v.x, v.y, v.z, v.w}, (nt_f4*)base + g);
+#else
+  ((float4*)base)[g] = v;
+#endif
+}
+__device__ __forceinline__ void out_u2(uint8_t* base, int g, uint2 v) {
+#ifndef SRL_PLAIN_STORES
+  __builtin_nontemporal_store((nt_u2){v.x, v.y}, (nt_u2*)base + g);
+#else
+  ((uint2*)base)[g] = v;
+#endif
+}
+
 // min with the lane a DPP control selects (0xB1: lane ^ 1, 0x4E: lane ^ 2 within quads; 0x141: mirror within half rows)
 template <int CTRL>
 __device__ __forceinline__ float dpp_min(float v) {
@@ -571,18 +590,6 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
     hd1 = make_int4(__float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
   }
   const int nb = ext ? nb_ext[e] : h->nb;
-  // every wave also reads the header of the first rock it will copy (rock `wave`: the rocks of a group go to the waves round
-  // robin) and requests that rock's first 64 slots at once, two barriers before they are needed
-  float4 pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  {
-    int c0 = 0;
-    if (wave < slots) { const float4 a = srec[(size_t)wave * SRL_STAGE_STRIDE]; c0 = __float_as_int(a.z) + __float_as_int(a.w); }
-    c0 = __builtin_amdgcn_readfirstlane(c0);
-#ifdef SRL_ABL_NOSTAGE
-    if (P.px == 12345.0f)
-#endif
-    if (wave < nb && lane < c0) pv = srec[(size_t)wave * SRL_STAGE_STRIDE + SRL_STAGE_HDR + lane];
-  }
   int g0 = 0, g1 = 0, g2 = 0, g3 = 0, pending = -1, mode = 0, hdone = 0, left = 0;
   float prev_m[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if (!ext) {
@@ -592,11 +599,8 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
     for (int k = 0; k < 4; ++k) prev_m[k] = h->prev_metric[k];
   }
   const int rr = P.c.object_res * P.c.object_res * P.n_orient;   // all observable orientations of the pending rock
-  {
-    float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float4* t4 = (float4*)L.tile;
-    for (int k = tid; k < npx / 4; k += SRL_RENDER_THREADS) t4[k] = z4;
-  }
+  // (the tile is zeroed where a rock may write — the groups of the rows some bounding box reaches — in the early-store loop
+  //  below, whose thread-to-group map the epilogue shares; a block barrier lies between that loop and the ray cast)
   if (tid < 8) L.rowmask[tid] = 0u;                  // (wave 0, like the atomicOr below: LDS keeps a wave's order)
   if (tid < SRL_MAX_BODIES) {
     // a rock's region holds its up-facing planes and the sides of its outline (a rock outside the window has neither)
@@ -672,14 +676,16 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
   do {
     // (a) the group's planes and outline sides from their records (srl_k_stage) into the regions, the rocks handed to the
     //     8 waves round robin, lanes over a rock's slots: the first 64 slots of a wave's first rock are requested now and
-    //     written to LDS after the early stores below (their latency hides under those), the rest follows there
+    //     written to LDS after the early stores below (their latency hides under those), the rest follows there.
+    //     (Requesting them two barriers earlier, from the prologue, was measured: no gain.)
     const int pb = bs + wave;
     int pbase = 0, pcnt = 0;
     if (pb < be) { pbase = L.reg[4 * pb + 0]; pcnt = L.reg[4 * pb + 1] + L.reg[4 * pb + 2]; }
+    float4 pv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #ifdef SRL_ABL_NOSTAGE
     if (P.px == 12345.0f)
 #endif
-    if (!first && lane < pcnt) pv = srec[(size_t)pb * SRL_STAGE_STRIDE + SRL_STAGE_HDR + lane];   // (first group: requested in the prologue)
+    if (lane < pcnt) pv = srec[(size_t)pb * SRL_STAGE_STRIDE + SRL_STAGE_HDR + lane];
     RSTAMP(1);
     // (d) first trip: rows no rock reaches hold the empty-pixel constants; their H / observation bytes leave
     //     now, so that HBM drains them while the ray cast computes.  cov bit k: this thread's k-th pixel group
@@ -689,7 +695,10 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
       const uint32_t epair = b_empty | (b_empty << 16);
       if (aligned) {
         // every round keeps the thread's four columns and moves walk_di rows down: the column part of the goal test
-        // and the two possible observation words are fixed, a round costs a row test and a row-mask bit
+        // and the two possible observation words are fixed, a round costs a row test and a row-mask bit (the mask's four
+        // words — res <= 128 on this path — are read once)
+        const uint4 rm4 = *(const uint4*)L.rowmask;
+        const unsigned long long rlo = rm4.x | ((unsigned long long)rm4.y << 32), rhi = rm4.z | ((unsigned long long)rm4.w << 32);
         const uint32_t w_out = epair | zpair, w_in_lo = w_out ^ goal_pair(colmask, gdiff), w_in_hi = w_out ^ goal_pair(colmask >> 2, gdiff);
         for (int k = 0; k < nrounds; ++k) {
           const int g = tid + k * SRL_RENDER_THREADS, i = walk_i0 + k * walk_di;
@@ -697,11 +706,11 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
 #ifndef SRL_ABL_NOGOAL
           if (rowin && colmask) goalm |= 1u << k;
 #endif
-          if ((L.rowmask[i >> 5] >> (i & 31)) & 1u) cov |= 1u << k;
+          if (((i < 64 ? rlo : rhi) >> (i & 63)) & 1ull) { cov |= 1u << k; ((float4*)L.tile)[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
           else {
 #ifndef SRL_ABL_NOSTORE
-            ((float4*)Hout)[g] = he4;
-            if (om) ((uint2*)om)[g] = make_uint2(rowin ? w_in_lo : w_out, rowin ? w_in_hi : w_out);
+            out_f4(Hout, g, he4);
+            if (om) out_u2(om, g, make_uint2(rowin ? w_in_lo : w_out, rowin ? w_in_hi : w_out));
 #endif
           }
         }
@@ -717,11 +726,11 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
         const uint32_t inm = 0u;
 #endif
         if (inm) goalm |= 1u << k;
-        if ((L.rowmask[i >> 5] >> (i & 31)) & 1u) cov |= 1u << k;
+        if ((L.rowmask[i >> 5] >> (i & 31)) & 1u) { cov |= 1u << k; ((float4*)L.tile)[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
         else {
 #ifndef SRL_ABL_NOSTORE
-          ((float4*)Hout)[g] = he4;
-          if (om) ((uint2*)om)[g] = make_uint2((epair | zpair) ^ goal_pair(inm, gdiff), (epair | zpair) ^ goal_pair(inm >> 2, gdiff));
+          out_f4(Hout, g, he4);
+          if (om) out_u2(om, g, make_uint2((epair | zpair) ^ goal_pair(inm, gdiff), (epair | zpair) ^ goal_pair(inm >> 2, gdiff)));
 #endif
         }
         jb += walk_dj; i += walk_di;
@@ -936,8 +945,8 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
         }
 #ifndef SRL_ABL_NOSTORE
         if (covg) {
-          ((float4*)Hout)[g] = make_float4(hv[0], hv[1], hv[2], hv[3]);
-          if (om) ((uint2*)om)[g] = make_uint2((hb[0] | (hb[1] << 16) | zpair) ^ glo, (hb[2] | (hb[3] << 16) | zpair) ^ ghi);
+          out_f4(Hout, g, make_float4(hv[0], hv[1], hv[2], hv[3]));
+          if (om) out_u2(om, g, make_uint2((hb[0] | (hb[1] << 16) | zpair) ^ glo, (hb[2] | (hb[3] << 16) | zpair) ^ ghi));
         }
 #else
         if (covg && hv[0] == 12345.0f && hb[0] == 77u) ((float4*)Hout)[g] = make_float4(hv[0], hv[1], hv[2], hv[3]);
