@@ -663,6 +663,10 @@ class DQN(object):
          'optimizer': self._optimizer.state_dict(), 'iterations': int(self._iterations), 'gen': self._gen.get_state()}
     if memory:
       d['replay_memory'] = self._replay_memory.state_dict()
+      # the minibatches already drawn and waiting (`dataset.prefetch`, dqn.py:247-252): part of the state, or a resumed run
+      # would train on freshly drawn ones where the uninterrupted run trains on these
+      if self._fifo is not None:
+        d['prefetched'] = [tuple(None if t is None else t.clone() for t in slot) for slot in self._fifo]
     return d
 
   def load_state_dict(self, d):
@@ -676,11 +680,27 @@ class DQN(object):
       self._q_net._weights_epoch = getattr(self._q_net, '_weights_epoch', 0) + 1   # restored weights: a new epoch, never an earlier one's
       if self._hand_t is not None:
         self._hand_t.refresh()
+    if self._pending is not None:
+      # a gradient half computed from the weights / minibatch being replaced is in flight on the update stream: wait for
+      # it and drop it (the next train() starts over from the restored state)
+      torch.cuda.current_stream(self.device).wait_stream(self._upd_stream)
+      self._pending = None
     if 'gen' in d:
       self._gen.set_state(d['gen'].cpu())
     if 'replay_memory' in d:
       self._replay_memory.load_state_dict(d['replay_memory'])
-      if self._fifo is not None and self._train_graph is None and self._grad_graph is None:
+      saved = d.get('prefetched')
+      graphed = self._train_graph is not None or self._grad_graph is not None
+      if saved is not None and len(saved) == self._prefetch:
+        # the waiting minibatches of the saved run, into the slots a captured update reads at their addresses (or new ones)
+        if self._fifo is None:
+          self._fifo = [tuple(None if t is None else t.clone().to(self.device) for t in slot) for slot in saved]
+        else:
+          for slot, src in zip(self._fifo, saved):
+            for dst, t in zip(slot, src):
+              if dst is not None:
+                dst.copy_(t)
+      elif self._fifo is not None and not graphed:
         self._fifo = None                      # minibatches drawn from the memory that was just replaced
       elif self._fifo is not None:             # (a captured update reads the slots at their addresses: refill in place)
         for slot in self._fifo:

@@ -399,6 +399,8 @@ class Trainer(object):
     if mine is not None:
       self._agent.load_state_dict(mine['agent'])
       self._reward.load_state_dict(mine['reward'])
+    elif 'gen' in d['agent'] and self._rank == 0:
+      pass    # a file written before the per-rank split: the streams and the memory it carried are (rank 0's) own, loaded above
     else:
       # no state of this rank's own (e.g. resumed on more GPUs than the run was saved on): its generators restart from
       # rank-specific seeds and `initialize` collects its replay shard afresh

@@ -465,6 +465,37 @@ def test_prefetch_restates_the_staleness_of_the_reference_pipeline():
       assert any(not (used[u] <= old) for u in range(1, 8)), used
 
 
+def test_resume_continues_the_uninterrupted_run_with_prefetched_minibatches():
+  """`DQN.state_dict` carries the minibatches already drawn and waiting (`dataset.prefetch`, dqn.py:247-252): an agent restored
+  from it trains on the very minibatches the uninterrupted run trains on — same losses, same weights, bit for bit."""
+  spec = ((16, 16, 2), (4, 4, 1))
+  B = 3
+
+  def make(seed):
+    net = nets.DeepQSiamFCN(spec, left_filters=4, left_depth=2, pos_filters=4, dueling_units=8, seed=seed)
+    return DQN(net, learning_rate=1e-3, minibatch_size=4, replay_memory_size=B * 8, discount_factor=.9, collect_batch_size=B,
+               exploration=0.5, prioritization=0.6, priority_bias_compensation=0.5, double=True, seed=seed,
+               target_update_period=3, prefetch=2)
+  g = torch.Generator().manual_seed(0)
+  a = make(3)
+  for t in range(8):
+    obs = (torch.randint(0, 256, (B, 16, 16, 2), generator=g, dtype=torch.uint8), torch.randint(0, 256, (B, 4, 4, 1), generator=g, dtype=torch.uint8))
+    a.observe(obs, torch.rand(B, generator=g), torch.zeros(B, dtype=torch.bool), torch.randint(0, 169, (B,), generator=g))
+  for _ in range(3):
+    a.train()
+  d = a.state_dict()
+  assert 'prefetched' in d and len(d['prefetched']) == 2
+  import copy
+  d = copy.deepcopy(d)                # (the nets' state dicts are views of the live parameters)
+  want = [float(a.train()[0]) for _ in range(4)]
+  b = make(99)                        # other weights, other streams: everything comes from the state
+  b.load_state_dict(d)
+  got = [float(b.train()[0]) for _ in range(4)]
+  assert got == want
+  for p, q in zip(a._q_net.parameters(), b._q_net.parameters()):
+    assert torch.equal(p, q)
+
+
 def _ckpt_rank(rank, world, port, d, out):
   import torch.distributed as dist
   from stackrl_amd.training import Trainer
