@@ -114,7 +114,8 @@ int srl_convt2x2_gemm_bias_relu(const void* in_dev, const void* wfrag_dev, const
                                 int32_t f32, void* stream);
 /* The thin first layers (1 or 2 input channels -> 16) on the vector ALU: in uint8 (in_dtype 0: the env's observation
  * bytes, scaled by 1/255 as in models.py:144-147) or float32 (in_dtype 1) channels-last [B][H][W][cin]; w float32
- * [16][cin][3][3], bias float32 [16]; out bfloat16 channels-last [B][Hp][Wp][16] with Hp >= H, Wp >= W (only the H x W
+ * [16][3][3][cin] (the Conv2d weight with the input channel innermost: a pixel's channels pair up with adjacent weights),
+ * bias float32 [16]; out bfloat16 channels-last [B][Hp][Wp][16] with Hp >= H, Wp >= W (only the H x W
  * region is written: a zero-initialised margin stays zero). */
 int srl_conv3x3_thin(const void* in_dev, int32_t in_dtype, const float* w_dev, const float* bias_dev, void* out_dev,
                      int32_t B, int32_t H, int32_t W, int32_t cin, int32_t Hp, int32_t Wp, void* stream);
@@ -130,6 +131,20 @@ int srl_conv3x3_relu_project(const void* in_dev, const void* wfrag_dev, const fl
 int srl_conv3x3_relu_project_f32(const float* in_dev, const void* wfrag_dev, const float* bias_dev, const float* proj_w_dev,
                                  float proj_b, float* out_dev, int32_t B, int32_t H, int32_t W, int32_t Hv, int32_t Wv,
                                  void* stream);
+/* The thin layer and the 16 -> 16 layer behind it in one kernel, fp32-class (`convdw00`, `convdw01` [+ `down0`] of layers.unet,
+ * layers.py:196-209: Conv2D(16, 3, relu) twice [+ MaxPool2D]): srl_conv3x3_thin_f32 followed by srl_conv3x3_bias_relu_f32 without the
+ * 16-channel intermediate's round trip through HBM; results equal the two calls' bit for bit.  in [B][H][W][cin] uint8
+ * (in_dtype 0, scaled by 1/255) or float32 (1), cin in {1, 2}, H and W multiples of 16; w1 [16][3][3][cin] (as for srl_conv3x3_thin), b1 [16] float32;
+ * wfrag / bias / out / pooled / out_stride / out_offset / nchw as for srl_conv3x3_bias_relu_f32 with cin = cout = 16. */
+int srl_thin_conv3x3_bias_relu_f32(const void* in_dev, int32_t in_dtype, int32_t cin, const float* w1_dev, const float* b1_dev,
+                                   const void* wfrag_dev, const float* bias_dev, float* out_dev, float* pooled_dev, int32_t B,
+                                   int32_t H, int32_t W, int32_t out_stride, int32_t out_offset, int32_t nchw, void* stream);
+/* `pos_layers` whole (layers.py:439-472: Conv2D(16, 3, relu) twice, Conv2D(1, 1)) in one kernel, fp32-class:
+ * srl_conv3x3_thin_f32 into a zero-margined map followed by srl_conv3x3_relu_project_f32, bit for bit.
+ * in float32 [B][H][W] (any H, W >= 1), out float32 [B][H][W]. */
+int srl_thin_conv3x3_relu_project_f32(const float* in_dev, const float* w1_dev, const float* b1_dev, const void* wfrag_dev,
+                                      const float* bias_dev, const float* proj_w_dev, float proj_b, float* out_dev, int32_t B,
+                                      int32_t H, int32_t W, void* stream);
 /* Transposed convolution 2 x 2, stride 2 + bias + ReLU on the matrix cores (`up{i}` of layers.unet, layers.py:222-229),
  * (cin, cout) in {(32, 16), (64, 32)}: in bfloat16 [B][H][W][cin] (W a multiple of 16) -> the channel slice
  * [out_offset, out_offset + cout) of a channels-last buffer [B][2H][2W][out_stride].  wfrag: the ConvTranspose2d weight

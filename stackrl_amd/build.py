@@ -123,7 +123,7 @@ def stale():
 QLIB = os.path.join(HERE, 'libstackrl_qnet.so')
 QSRC = ['qnet.hip', 'heuristics.hip', 'xcorr_mfma.hip', 'epilogue.hip', 'conv_mfma.hip', 'conv_gemm.hip', 'learner.hip',
         'train_conv.hip']
-QDEPS = QSRC + [ os.path.join('..', '..', 'include', 'stackrl_qnet.h')]
+QDEPS = QSRC + ['srl_bf16.h', os.path.join('..', '..', 'include', 'stackrl_qnet.h')]
 # the Q-net ops are ordinary fp32 kernels compared against a torch fp32 reference with a stated tolerance
 # (-fno-slp-vectorize: see above; it costs the Q-net's kernels nothing measurable — 20.6 against 20.8 ms per 2,048-sample forward)
 QFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-slp-vectorize', '-Wall', '-Wno-unused-function',

@@ -22,16 +22,13 @@
 #include <stdio.h>
 
 #include "../../include/stackrl_qnet.h"
+#include "srl_bf16.h"
 
 namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ uint32_t g_bf16_rne(float f) {
-  const uint32_t u = __float_as_uint(f);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
 
 template <int COUT, int W>
 struct GemmCfg {
@@ -102,11 +99,7 @@ k_conv3x3_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag,
           const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
           uint32_t hi[4], lo[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t h0 = g_bf16_rne(v[2 * j]), h1 = g_bf16_rne(v[2 * j + 1]);
-            const uint32_t l0 = g_bf16_rne(v[2 * j] - __uint_as_float(h0 << 16)), l1 = g_bf16_rne(v[2 * j + 1] - __uint_as_float(h1 << 16));
-            hi[j] = h0 | (h1 << 16); lo[j] = l0 | (l1 << 16);
-          }
+          for (int j = 0; j < 4; ++j) srl_split_bf16(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
           *(uint4*)(tile + p * G::PS + ch * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
           *(uint4*)(tile + G::TILE + p * G::PS + ch * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         } else {
@@ -164,7 +157,7 @@ k_conv3x3_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag,
       const float v2 = fmaxf(acc[mt][t][2] + bz.z, 0.0f), v3 = fmaxf(acc[mt][t][3] + bz.w, 0.0f);
       if (X3) *(float4*)((float*)out_ + pix * ostride + ooff + co) = make_float4(v0, v1, v2, v3);
       else *(uint2*)((uint16_t*)out_ + pix * ostride + ooff + co) =
-             make_uint2(g_bf16_rne(v0) | (g_bf16_rne(v1) << 16), g_bf16_rne(v2) | (g_bf16_rne(v3) << 16));
+             make_uint2(srl_pk_bf16(v0, v1), srl_pk_bf16(v2, v3));
     }
   }
 }
@@ -209,12 +202,11 @@ k_convt2x2_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag
         const float* s = (const float*)in_ + p * CIN + 32 * ks + 8 * g;
         const float4 a = *(const float4*)s, c = *(const float4*)(s + 4);
         const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        uint32_t ph[4], pl[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const uint32_t h = g_bf16_rne(v[j]);
-          xh[j] = (short)h;
-          xl[j] = (short)g_bf16_rne(v[j] - __uint_as_float(h << 16));
-        }
+        for (int j = 0; j < 4; ++j) srl_split_bf16(v[2 * j], v[2 * j + 1], ph[j], pl[j]);
+        xh = __builtin_bit_cast(bf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+        xl = __builtin_bit_cast(bf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
       } else {
         xh = *(const bf16x8*)((const uint16_t*)in_ + p * CIN + 32 * ks + 8 * g);
       }
@@ -244,7 +236,7 @@ k_convt2x2_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag
       const float v2 = fmaxf(acc[mt][t][2] + bz.z, 0.0f), v3 = fmaxf(acc[mt][t][3] + bz.w, 0.0f);
       const size_t o = (((size_t)b * 2 * H + 2 * y + dy) * 2 * W + 2 * x + dx) * ostride + ooff + co;
       if (X3) *(float4*)((float*)out_ + o) = make_float4(v0, v1, v2, v3);
-      else *(uint2*)((uint16_t*)out_ + o) = make_uint2(g_bf16_rne(v0) | (g_bf16_rne(v1) << 16), g_bf16_rne(v2) | (g_bf16_rne(v3) << 16));
+      else *(uint2*)((uint16_t*)out_ + o) = make_uint2(srl_pk_bf16(v0, v1), srl_pk_bf16(v2, v3));
     }
   }
 }

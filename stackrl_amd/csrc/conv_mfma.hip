@@ -20,17 +20,13 @@
 #include <stdio.h>
 
 #include "../../include/stackrl_qnet.h"
+#include "srl_bf16.h"
 
 namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t c_bf16_rne(float f) {
-  const uint32_t u = __float_as_uint(f);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
 
 template <int CIN>
 struct ConvCfg {
@@ -139,7 +135,7 @@ k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, c
     for (int r = 0; r < RW; ++r) {
       const float v0 = fmaxf(acc[r][mt][0] + bz.x, 0.0f), v1 = fmaxf(acc[r][mt][1] + bz.y, 0.0f);
       const float v2 = fmaxf(acc[r][mt][2] + bz.z, 0.0f), v3 = fmaxf(acc[r][mt][3] + bz.w, 0.0f);
-      lo[r] = c_bf16_rne(v0) | (c_bf16_rne(v1) << 16); hi[r] = c_bf16_rne(v2) | (c_bf16_rne(v3) << 16);
+      lo[r] = srl_pk_bf16(v0, v1); hi[r] = srl_pk_bf16(v2, v3);
       const int y = y0 + row0 + r, x = x0 + n;
       if (nchw) {
         uint16_t* o = out + ((size_t)b * COUT + co) * H * W + (size_t)y * W + x;
@@ -168,6 +164,74 @@ k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, c
         if (!(n & 1)) {
           const int y2 = (y0 + row0) / 2 + rp, x2 = (x0 + n) / 2;
           *(uint2*)(pooled + (((size_t)b * (H / 2) + y2) * (W / 2) + x2) * COUT + co) = make_uint2(m[0], m[1]);
+        }
+      }
+    }
+  }
+}
+
+// Epilogue of the fp32-class kernels (k_conv3x3_x3, k_thin_conv3x3_x3).  D: lane holds column lane & 15 = pixel n, rows
+// 4 g .. 4 g + 3 = output channels of tile mt.  Bias + ReLU, then 16-byte stores into a channel slice of a channels-last
+// buffer, or channel-major output, optionally the 2 x 2 max-pooled tensor too; PROJ: the 1 x 1 projection instead.
+template <int COUT, int MT_W, int RW, bool PROJ>
+__device__ __forceinline__ void x3_epilogue(const f32x4 (&acc)[RW][MT_W], const float* __restrict__ bias, float* __restrict__ out,
+                                            float* __restrict__ pooled, int H, int W, int ostride, int ooff, int nchw,
+                                            const float* __restrict__ pw, float pb, float* __restrict__ proj_out, int Hv, int Wv,
+                                            int b, int x0, int y0, int mt0, int row0, int n, int g) {
+  constexpr int MT = COUT / 16;
+  if (PROJ) {
+    static_assert(!PROJ || MT_W == MT, "the projection epilogue needs all channels in one wave");
+    float part[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) part[r] = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < MT_W; ++mt) {
+      const int co = 16 * mt + 4 * g;
+      const float4 bz = *(const float4*)(bias + co), wz = *(const float4*)(pw + co);
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+        part[r] += (wz.x * fmaxf(acc[r][mt][0] + bz.x, 0.0f) + wz.y * fmaxf(acc[r][mt][1] + bz.y, 0.0f)) +
+                   (wz.z * fmaxf(acc[r][mt][2] + bz.z, 0.0f) + wz.w * fmaxf(acc[r][mt][3] + bz.w, 0.0f));
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      part[r] += __shfl_xor(part[r], 16);
+      part[r] += __shfl_xor(part[r], 32);
+      const int y = y0 + row0 + r, x = x0 + n;
+      if (g == 0 && y < Hv && x < Wv) proj_out[((size_t)b * Hv + y) * Wv + x] = part[r] + pb;
+    }
+    return;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT_W; ++mt) {
+    const int co = 16 * (mt0 + mt) + 4 * g;
+    const float4 bz = *(const float4*)(bias + co);
+    float4 val[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      val[r] = make_float4(fmaxf(acc[r][mt][0] + bz.x, 0.0f), fmaxf(acc[r][mt][1] + bz.y, 0.0f),
+                           fmaxf(acc[r][mt][2] + bz.z, 0.0f), fmaxf(acc[r][mt][3] + bz.w, 0.0f));
+      const int y = y0 + row0 + r, x = x0 + n;
+      if (nchw) {
+        float* o = out + ((size_t)b * COUT + co) * H * W + (size_t)y * W + x;
+        o[0] = val[r].x; o[(size_t)H * W] = val[r].y; o[(size_t)2 * H * W] = val[r].z; o[(size_t)3 * H * W] = val[r].w;
+      } else {
+        *(float4*)(out + (((size_t)b * H + y) * W + x) * ostride + ooff + co) = val[r];
+      }
+    }
+    if (pooled) {   // 2 x 2 max: rows in registers, the neighbouring column (lane n ^ 1) by a DPP quad permute
+#pragma unroll
+      for (int rp = 0; rp < RW / 2; ++rp) {
+        float m[4] = {fmaxf(val[2 * rp].x, val[2 * rp + 1].x), fmaxf(val[2 * rp].y, val[2 * rp + 1].y),
+                      fmaxf(val[2 * rp].z, val[2 * rp + 1].z), fmaxf(val[2 * rp].w, val[2 * rp + 1].w)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float other = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m[q]), __float_as_int(m[q]), 0xb1, 0xf, 0xf, false));
+          m[q] = fmaxf(m[q], other);
+        }
+        if (!(n & 1)) {
+          const int y2 = (y0 + row0) / 2 + rp, x2 = (x0 + n) / 2;
+          *(float4*)(pooled + (((size_t)b * (H / 2) + y2) * (W / 2) + x2) * COUT + co) = make_float4(m[0], m[1], m[2], m[3]);
         }
       }
     }
@@ -235,11 +299,7 @@ k_conv3x3_x3(const float* __restrict__ in, const uint16_t* __restrict__ wfrag, c
         }
         uint32_t hi[4], lo[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t h0 = c_bf16_rne(v[2 * j]), h1 = c_bf16_rne(v[2 * j + 1]);
-          const uint32_t l0 = c_bf16_rne(v[2 * j] - __uint_as_float(h0 << 16)), l1 = c_bf16_rne(v[2 * j + 1] - __uint_as_float(h1 << 16));
-          hi[j] = h0 | (h1 << 16); lo[j] = l0 | (l1 << 16);
-        }
+        for (int j = 0; j < 4; ++j) srl_split_bf16(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
         *(uint4*)(tile + p * G::PS + ch * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         *(uint4*)(tile + PLANE + p * G::PS + ch * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
       }
@@ -265,63 +325,7 @@ k_conv3x3_x3(const float* __restrict__ in, const uint16_t* __restrict__ wfrag, c
       }
     }
   }
-  if (PROJ) {
-    static_assert(!PROJ || MT_W == MT, "the projection epilogue needs all channels in one wave");
-    float part[RW];
-#pragma unroll
-    for (int r = 0; r < RW; ++r) part[r] = 0.0f;
-#pragma unroll
-    for (int mt = 0; mt < MT_W; ++mt) {
-      const int co = 16 * mt + 4 * g;
-      const float4 bz = *(const float4*)(bias + co), wz = *(const float4*)(pw + co);
-#pragma unroll
-      for (int r = 0; r < RW; ++r)
-        part[r] += (wz.x * fmaxf(acc[r][mt][0] + bz.x, 0.0f) + wz.y * fmaxf(acc[r][mt][1] + bz.y, 0.0f)) +
-                   (wz.z * fmaxf(acc[r][mt][2] + bz.z, 0.0f) + wz.w * fmaxf(acc[r][mt][3] + bz.w, 0.0f));
-    }
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-      part[r] += __shfl_xor(part[r], 16);
-      part[r] += __shfl_xor(part[r], 32);
-      const int y = y0 + row0 + r, x = x0 + n;
-      if (g == 0 && y < Hv && x < Wv) proj_out[((size_t)b * Hv + y) * Wv + x] = part[r] + pb;
-    }
-    return;
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT_W; ++mt) {
-    const int co = 16 * (mt0 + mt) + 4 * g;
-    const float4 bz = *(const float4*)(bias + co);
-    float4 val[RW];
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-      val[r] = make_float4(fmaxf(acc[r][mt][0] + bz.x, 0.0f), fmaxf(acc[r][mt][1] + bz.y, 0.0f),
-                           fmaxf(acc[r][mt][2] + bz.z, 0.0f), fmaxf(acc[r][mt][3] + bz.w, 0.0f));
-      const int y = y0 + row0 + r, x = x0 + n;
-      if (nchw) {
-        float* o = out + ((size_t)b * COUT + co) * H * W + (size_t)y * W + x;
-        o[0] = val[r].x; o[(size_t)H * W] = val[r].y; o[(size_t)2 * H * W] = val[r].z; o[(size_t)3 * H * W] = val[r].w;
-      } else {
-        *(float4*)(out + (((size_t)b * H + y) * W + x) * ostride + ooff + co) = val[r];
-      }
-    }
-    if (pooled) {   // 2 x 2 max: rows in registers, the neighbouring column (lane n ^ 1) by a DPP quad permute
-#pragma unroll
-      for (int rp = 0; rp < RW / 2; ++rp) {
-        float m[4] = {fmaxf(val[2 * rp].x, val[2 * rp + 1].x), fmaxf(val[2 * rp].y, val[2 * rp + 1].y),
-                      fmaxf(val[2 * rp].z, val[2 * rp + 1].z), fmaxf(val[2 * rp].w, val[2 * rp + 1].w)};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float other = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m[q]), __float_as_int(m[q]), 0xb1, 0xf, 0xf, false));
-          m[q] = fmaxf(m[q], other);
-        }
-        if (!(n & 1)) {
-          const int y2 = (y0 + row0) / 2 + rp, x2 = (x0 + n) / 2;
-          *(float4*)(pooled + (((size_t)b * (H / 2) + y2) * (W / 2) + x2) * COUT + co) = make_float4(m[0], m[1], m[2], m[3]);
-        }
-      }
-    }
-  }
+  x3_epilogue<COUT, MT_W, RW, PROJ>(acc, bias, out, pooled, H, W, ostride, ooff, nchw, pw, pb, proj_out, Hv, Wv, b, x0, y0, mt0, row0, n, g);
 }
 
 // what one tap of the thin convolution loads: the pixel's CIN values in one register (pair)
@@ -346,6 +350,30 @@ template <> struct ThinRaw<2, float> {
   static __device__ __forceinline__ type load(const float* p) { return *(const uint64_t*)p; }
   static __device__ __forceinline__ float get(type r, int c) { return __uint_as_float((uint32_t)(r >> (32 * c))); }
 };
+
+// NCO outputs of the thin layer for one pixel from its nine taps: relu(bias + sum_k w[k] v[k]), k = CIN tap + channel (the
+// weights arrive packed [co][tap][channel]: a two-channel pixel is one 8-byte operand pair as it lies in memory).
+// Uniform addresses: the weights and biases arrive by scalar loads and are SGPR operands of the FMAs; two partial sums over
+// alternate k so that the FMAs pair up as v_pk_fma_f32 (weights w[k], w[k + 1] are adjacent SGPRs).  One statement of
+// the arithmetic for k_conv3x3_thin and the fused k_thin_conv3x3_x3: their values are equal bit for bit.
+template <int CIN, int NCO>
+__device__ __forceinline__ void thin_outputs(const float (&v)[9 * CIN], const float* __restrict__ w, const float* __restrict__ bias,
+                                             float (&r)[NCO]) {
+#pragma unroll
+  for (int co = 0; co < NCO; ++co) {
+    const float* wk = w + co * CIN * 9;
+    f32x2 a = {bias[co], 0.0f};
+#pragma unroll
+    for (int k = 0; k + 1 < 9 * CIN; k += 2) {
+      const f32x2 wv = {wk[k], wk[k + 1]};
+      const f32x2 xv = {v[k], v[k + 1]};
+      a = __builtin_elementwise_fma(wv, xv, a);
+    }
+    float sum = a[0] + a[1];
+    if ((9 * CIN) & 1) sum = fmaf(wk[9 * CIN - 1], v[9 * CIN - 1], sum);
+    r[co] = fmaxf(sum, 0.0f);
+  }
+}
 
 // 3 x 3 convolution + bias + ReLU from 1 or 2 input channels to 16 (the first layer of each U-Net and of
 // `pos_layers`): K = 9 or 18 is too thin for the matrix cores, the layer is bound by its 32-byte-per-pixel output.
@@ -380,28 +408,13 @@ k_conv3x3_thin(const TIN* __restrict__ in, const float* __restrict__ w, const fl
   // one fence for the nine values: keeps the loads out of the selects' branches without serialising them
   asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]),
                "+v"(raw[7]), "+v"(raw[8]));
-  float v[9][CIN];
+  float v[9 * CIN];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) v[t][c] = ok[t] ? ThinRaw<CIN, TIN>::get(raw[t], c) * scale : 0.0f;
+    for (int c = 0; c < CIN; ++c) v[CIN * t + c] = ok[t] ? ThinRaw<CIN, TIN>::get(raw[t], c) * scale : 0.0f;
   float r[16];
-#pragma unroll
-  for (int co = 0; co < 16; ++co) {
-    // uniform addresses: the weights and biases arrive by scalar loads and are SGPR operands of the FMAs; two partial
-    // sums over alternate k so that the FMAs pair up as v_pk_fma_f32 (weights w[k], w[k + 1] are adjacent SGPRs)
-    const float* wk = w + co * CIN * 9;
-    f32x2 a = {bias[co], 0.0f};
-#pragma unroll
-    for (int k = 0; k + 1 < 9 * CIN; k += 2) {
-      const f32x2 wv = {wk[k], wk[k + 1]};
-      const f32x2 xv = {v[k % 9][k / 9], v[(k + 1) % 9][(k + 1) / 9]};
-      a = __builtin_elementwise_fma(wv, xv, a);
-    }
-    float sum = a[0] + a[1];
-    if ((9 * CIN) & 1) sum = fmaf(wk[9 * CIN - 1], v[8][CIN - 1], sum);
-    r[co] = fmaxf(sum, 0.0f);
-  }
+  thin_outputs<CIN, 16>(v, w, bias, r);
   // a thread's pixel is 32 or 64 contiguous bytes: exchanged through LDS so that every store instruction of a wave
   // writes one contiguous kilobyte (NQ adjacent lanes = the quads of one pixel)
   uint32_t* mine = xch + threadIdx.x * LS;
@@ -411,7 +424,7 @@ k_conv3x3_thin(const TIN* __restrict__ in, const float* __restrict__ w, const fl
   } else {
     uint32_t pk[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) pk[q] = c_bf16_rne(r[2 * q]) | (c_bf16_rne(r[2 * q + 1]) << 16);
+    for (int q = 0; q < 8; ++q) pk[q] = srl_pk_bf16(r[2 * q], r[2 * q + 1]);
     *(uint4*)mine = make_uint4(pk[0], pk[1], pk[2], pk[3]); *(uint4*)(mine + 4) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
   }
   __syncthreads();
@@ -425,6 +438,117 @@ k_conv3x3_thin(const TIN* __restrict__ in, const float* __restrict__ w, const fl
       *(uint4*)((uint32_t*)(out + (((size_t)b * Hp + py) * Wp + px) * 16) + 4 * q) = *(const uint4*)(xch + t * LS + 4 * q);
     }
   }
+}
+
+// The thin layer and the 16 -> 16 layer behind it as ONE kernel, fp32-class (float32 rollout): the first two layers of each
+// U-Net's encoder (uint8 observation -> 16 -> 16 [+ pooled]) and the whole of `pos_layers` (correlation map -> 16 -> 16 -> 1,
+// layers.py:439-472).  As two kernels the 16-channel intermediate went out to HBM and came back (64 bytes per pixel each
+// way against 1 - 8 bytes of input); here a workgroup keeps it in LDS: it stages the raw 20 x 20 input tile, evaluates the
+// thin layer on the vector ALU for the 18 x 18 pixels the 3 x 3 taps of its 16 x 16 outputs reach (zero outside the
+// H x W image: the second layer's SAME padding, and the zero margin of the padded map the two-kernel path used), splits
+// the values into the hi / lo bf16 planes and runs k_conv3x3_x3<16, 16>'s MFMA loop and epilogue on them.  Same
+// arithmetic per value as k_conv3x3_thin followed by k_conv3x3_x3: the outputs are equal bit for bit (GPU test).
+// Thin-layer work items are (pixel, half of the 16 channels), dealt out wave by wave so that a wave's weights stay uniform
+// (SGPR operands): five full waves of pixels per half, 8 outputs per thread and round; the four pixels left over (324 =
+// 5 x 64 + 4) go to one more wave as (pixel, channel) per lane.
+template <int CT, typename TIN, bool PROJ>
+__global__ void __launch_bounds__(256, 2)
+k_thin_conv3x3_x3(const TIN* __restrict__ in, const float* __restrict__ w1, const float* __restrict__ b1,
+                  const uint16_t* __restrict__ wfrag, const float* __restrict__ bias, float* __restrict__ out,
+                  float* __restrict__ pooled, int H, int W, int ostride, int ooff, int nchw, const float* __restrict__ pw, float pb,
+                  float* __restrict__ proj_out) {
+  typedef ConvCfg<16> G;
+  constexpr int RT = G::TW + 2;                     // raw tile width: the halo of the halo
+  constexpr int PLANE = G::TW * G::TW * G::PS;
+  constexpr int RW = 4;
+  extern __shared__ uint16_t tile[];                // [2][18][18][PS]: hi plane, lo plane
+  __shared__ float rawt[RT * RT * CT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = (W + 15) / 16;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  const int x0 = 16 * tx, y0 = 16 * ty;
+  const int row0 = wave * RW;
+  const int n = lane & 15, g = lane >> 4;
+  bf16x8 wh[G::KS], wl[G::KS];
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks) {
+    wh[ks] = ((const bf16x8*)wfrag)[ks * 64 + lane];
+    wl[ks] = ((const bf16x8*)wfrag)[(G::KS + ks) * 64 + lane];
+  }
+  {
+    const float scale = sizeof(TIN) == 1 ? 1.0f / 255.0f : 1.0f;
+    const TIN* src = in + (size_t)b * H * W * CT;
+    for (int k = tid; k < RT * RT; k += 256) {
+      const int ry = k / RT, rx = k - ry * RT;
+      const int y = y0 + ry - 2, x = x0 + rx - 2;
+      const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+      const typename ThinRaw<CT, TIN>::type raw = ThinRaw<CT, TIN>::load(src + (size_t)(ok ? y * W + x : 0) * CT);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) rawt[k * CT + c] = ok ? ThinRaw<CT, TIN>::get(raw, c) * scale : 0.0f;
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int j = 0; j < 3; ++j) {
+    const int wid = __builtin_amdgcn_readfirstlane(4 * j + wave);   // 0 .. 11
+    if (wid < 10) {        // five full waves of pixels (0 .. 319) per channel half
+      const int half = wid >= 5 ? 1 : 0;
+      const int q = (wid - 5 * half) * 64 + lane;
+      const int py = q / G::TW, px = q - py * G::TW;
+      const int y = y0 + py - 1, x = x0 + px - 1;
+      float v[9 * CT];
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) v[CT * t + c] = rawt[((py + t / 3) * RT + px + t % 3) * CT + c];
+      float r[8];
+      thin_outputs<CT, 8>(v, w1 + half * 8 * CT * 9, b1 + half * 8, r);
+      const bool inside = y >= 0 && y < H && x >= 0 && x < W;
+      uint32_t hi[4], lo[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) srl_split_bf16(inside ? r[2 * i] : 0.0f, inside ? r[2 * i + 1] : 0.0f, hi[i], lo[i]);
+      *(uint4*)(tile + q * G::PS + 8 * half) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      *(uint4*)(tile + PLANE + q * G::PS + 8 * half) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    } else if (wid == 10) {   // the last four pixels (320 .. 323): one lane per (pixel, channel), weights per lane — the same
+      const int q = 320 + (lane >> 4), co = lane & 15;   // two sums, term by term, as thin_outputs' packed FMAs
+      const int py = q / G::TW, px = q - py * G::TW;
+      const int y = y0 + py - 1, x = x0 + px - 1;
+      const float* wk = w1 + co * CT * 9;
+      float a0 = b1[co], a1 = 0.0f;
+#pragma unroll
+      for (int k = 0; k + 1 < 9 * CT; k += 2) {
+        a0 = fmaf(wk[k], rawt[((py + (k / CT) / 3) * RT + px + (k / CT) % 3) * CT + k % CT], a0);
+        a1 = fmaf(wk[k + 1], rawt[((py + ((k + 1) / CT) / 3) * RT + px + ((k + 1) / CT) % 3) * CT + (k + 1) % CT], a1);
+      }
+      float sum = a0 + a1;
+      if ((9 * CT) & 1) sum = fmaf(wk[9 * CT - 1], rawt[((py + 2) * RT + px + 2) * CT + CT - 1], sum);
+      const bool inside = y >= 0 && y < H && x >= 0 && x < W;
+      uint32_t hi, lo;
+      srl_split_bf16(inside ? fmaxf(sum, 0.0f) : 0.0f, 0.0f, hi, lo);
+      tile[q * G::PS + co] = (uint16_t)hi;
+      tile[PLANE + q * G::PS + co] = (uint16_t)lo;
+    }
+  }
+  __syncthreads();
+  f32x4 acc[RW][1];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) acc[r][0] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks) {
+    int tap, ci0;
+    k_of<16>(ks, g, tap, ci0);
+    if (tap > 8) tap = 8;
+    const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int off = ((row0 + r + dy) * G::TW + n + dx) * G::PS + ci0;
+      const bf16x8 xh = *(const bf16x8*)(tile + off), xl = *(const bf16x8*)(tile + PLANE + off);
+      acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], xh, acc[r][0], 0, 0, 0);
+      acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], xl, acc[r][0], 0, 0, 0);
+      acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], xh, acc[r][0], 0, 0, 0);
+    }
+  }
+  x3_epilogue<16, 1, RW, PROJ>(acc, bias, out, pooled, H, W, ostride, ooff, nchw, pw, pb, proj_out, H, W, b, x0, y0, 0, row0, n, g);
 }
 
 // Transposed convolution 2 x 2, stride 2 (`up{i}` of layers.unet, layers.py:222-229) + bias + ReLU: every input pixel
@@ -465,8 +589,8 @@ k_convt2x2(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, 
     const int m = 16 * mt + 4 * g;     // row of the GEMM = (dy, dx, co)
     const int q = m / COUT, co = m - q * COUT, dy = q >> 1, dx = q & 1;
     const float4 bz = *(const float4*)(bias + co);
-    const uint32_t lo = c_bf16_rne(fmaxf(acc[mt][0] + bz.x, 0.0f)) | (c_bf16_rne(fmaxf(acc[mt][1] + bz.y, 0.0f)) << 16);
-    const uint32_t hi = c_bf16_rne(fmaxf(acc[mt][2] + bz.z, 0.0f)) | (c_bf16_rne(fmaxf(acc[mt][3] + bz.w, 0.0f)) << 16);
+    const uint32_t lo = srl_pk_bf16(fmaxf(acc[mt][0] + bz.x, 0.0f), fmaxf(acc[mt][1] + bz.y, 0.0f));
+    const uint32_t hi = srl_pk_bf16(fmaxf(acc[mt][2] + bz.z, 0.0f), fmaxf(acc[mt][3] + bz.w, 0.0f));
     *(uint2*)(out + (((b * 2 * H + 2 * y + dy) * 2 * W) + 2 * x + dx) * ostride + ooff + co) = make_uint2(lo, hi);
   }
 }
@@ -499,13 +623,11 @@ k_convt2x2_x3(const float* __restrict__ in, const uint16_t* __restrict__ wfrag, 
     const float* src = in + (pix0 + n) * CIN + 32 * ks + 8 * g;
     const float4 a = *(const float4*)src, c = *(const float4*)(src + 4);
     const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-    bf16x8 xh, xl;
+    uint32_t ph[4], pl[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t h = c_bf16_rne(v[j]);
-      xh[j] = (short)h;
-      xl[j] = (short)c_bf16_rne(v[j] - __uint_as_float(h << 16));
-    }
+    for (int j = 0; j < 4; ++j) srl_split_bf16(v[2 * j], v[2 * j + 1], ph[j], pl[j]);
+    const bf16x8 xh = __builtin_bit_cast(bf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+    const bf16x8 xl = __builtin_bit_cast(bf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks][mt], xh, acc[mt], 0, 0, 0);
@@ -569,6 +691,26 @@ int launch_thin(const char* what, const void* in, int32_t in_dtype, const float*
   else if (cin == 1) hipLaunchKernelGGL((k_conv3x3_thin<1, float, TOUT>), grid, blk, 0, st, (const float*)in, w, bias, o, H, W, Hp, Wp);
   else if (in_dtype == 0) hipLaunchKernelGGL((k_conv3x3_thin<2, uint8_t, TOUT>), grid, blk, 0, st, (const uint8_t*)in, w, bias, o, H, W, Hp, Wp);
   else hipLaunchKernelGGL((k_conv3x3_thin<2, float, TOUT>), grid, blk, 0, st, (const float*)in, w, bias, o, H, W, Hp, Wp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "%s: %s", what, hipGetErrorString(e)); return 2; }
+  return 0;
+}
+
+template <bool PROJ>
+int launch_thin_conv(const char* what, const void* in, int32_t in_dtype, int32_t cin, const float* w1, const float* b1, const void* wfrag,
+                     const float* bias, float* out, float* pooled, int B, int H, int W, int ostride, int ooff, int nchw,
+                     const float* pw, float pb, float* proj_out, hipStream_t st) {
+  const size_t lds = 2 * sizeof(uint16_t) * ConvCfg<16>::TW * ConvCfg<16>::TW * ConvCfg<16>::PS;
+  const dim3 grid(((W + 15) / 16) * ((H + 15) / 16), B), blk(256);
+  const uint16_t* wf = (const uint16_t*)wfrag;
+  if (cin == 1 && in_dtype == 0)
+    hipLaunchKernelGGL((k_thin_conv3x3_x3<1, uint8_t, PROJ>), grid, blk, lds, st, (const uint8_t*)in, w1, b1, wf, bias, out, pooled, H, W, ostride, ooff, nchw, pw, pb, proj_out);
+  else if (cin == 1)
+    hipLaunchKernelGGL((k_thin_conv3x3_x3<1, float, PROJ>), grid, blk, lds, st, (const float*)in, w1, b1, wf, bias, out, pooled, H, W, ostride, ooff, nchw, pw, pb, proj_out);
+  else if (in_dtype == 0)
+    hipLaunchKernelGGL((k_thin_conv3x3_x3<2, uint8_t, PROJ>), grid, blk, lds, st, (const uint8_t*)in, w1, b1, wf, bias, out, pooled, H, W, ostride, ooff, nchw, pw, pb, proj_out);
+  else
+    hipLaunchKernelGGL((k_thin_conv3x3_x3<2, float, PROJ>), grid, blk, lds, st, (const float*)in, w1, b1, wf, bias, out, pooled, H, W, ostride, ooff, nchw, pw, pb, proj_out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "%s: %s", what, hipGetErrorString(e)); return 2; }
   return 0;
@@ -682,6 +824,28 @@ int srl_conv3x3_relu_project_f32(const float* in, const void* wfrag, const float
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { snprintf(c_err, sizeof c_err, "srl_conv3x3_relu_project_f32: %s", hipGetErrorString(e)); return 2; }
   return 0;
+}
+
+int srl_thin_conv3x3_bias_relu_f32(const void* in, int32_t in_dtype, int32_t cin, const float* w1, const float* b1, const void* wfrag,
+                                   const float* bias, float* out, float* pooled, int32_t B, int32_t H, int32_t W,
+                                   int32_t out_stride, int32_t out_offset, int32_t nchw, void* stream) {
+  if (!in || !w1 || !b1 || !wfrag || !bias || !out || B < 1 || H < 16 || W < 16 || H % 16 || W % 16 || out_stride % 4 ||
+      out_offset % 4 || (cin != 1 && cin != 2) || (in_dtype != 0 && in_dtype != 1) || (pooled && nchw)) {
+    snprintf(c_err, sizeof c_err, "srl_thin_conv3x3_bias_relu_f32: bad arguments (H, W multiples of 16; cin in {1, 2}; in_dtype 0 = uint8 / 255, 1 = float32)");
+    return 1;
+  }
+  return launch_thin_conv<false>("srl_thin_conv3x3_bias_relu_f32", in, in_dtype, cin, w1, b1, wfrag, bias, out, pooled, B, H, W,
+                                 out_stride, out_offset, nchw, nullptr, 0.0f, nullptr, (hipStream_t)stream);
+}
+
+int srl_thin_conv3x3_relu_project_f32(const float* in, const float* w1, const float* b1, const void* wfrag, const float* bias,
+                                      const float* proj_w, float proj_b, float* out, int32_t B, int32_t H, int32_t W, void* stream) {
+  if (!in || !w1 || !b1 || !wfrag || !bias || !proj_w || !out || B < 1 || H < 1 || W < 1) {
+    snprintf(c_err, sizeof c_err, "srl_thin_conv3x3_relu_project_f32: bad arguments");
+    return 1;
+  }
+  return launch_thin_conv<true>("srl_thin_conv3x3_relu_project_f32", in, 1, 1, w1, b1, wfrag, bias, nullptr, nullptr, B, H, W, 16, 0, 0,
+                                proj_w, proj_b, out, (hipStream_t)stream);
 }
 
 int srl_conv3x3_relu_project(const void* in, const void* wfrag, const float* bias, const float* proj_w, float proj_b,

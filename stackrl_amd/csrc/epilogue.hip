@@ -17,13 +17,11 @@
 #include <stdio.h>
 
 #include "../../include/stackrl_qnet.h"
+#include "srl_bf16.h"
 
 namespace {
 
-__device__ __forceinline__ uint32_t e_bf16_rne(float f) {
-  const uint32_t u = __float_as_uint(f);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
+__device__ __forceinline__ uint32_t e_bf16_rne(float f) { return srl_bf16(f); }
 __device__ __forceinline__ void unpack8(const uint4 q, float* v) {
   const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
@@ -32,7 +30,7 @@ __device__ __forceinline__ void unpack8(const uint4 q, float* v) {
 __device__ __forceinline__ uint4 pack8(const float* v) {
   uint32_t w[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) w[k] = e_bf16_rne(v[2 * k]) | (e_bf16_rne(v[2 * k + 1]) << 16);
+  for (int k = 0; k < 4; ++k) w[k] = srl_pk_bf16(v[2 * k], v[2 * k + 1]);
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 

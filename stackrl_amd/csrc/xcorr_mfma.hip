@@ -36,6 +36,7 @@
 #include <stdio.h>
 
 #include "../../include/stackrl_qnet.h"
+#include "srl_bf16.h"
 
 namespace {
 
@@ -58,10 +59,7 @@ struct XcorrCfg {
   static constexpr int KR = 16 + 32 * KB + 16;       // elements per row (even: rows are 4-byte aligned)
 };
 
-__device__ __forceinline__ uint32_t bf16_rne(float f) {   // round to nearest even (finite inputs)
-  const uint32_t u = __float_as_uint(f);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
+__device__ __forceinline__ uint32_t bf16_rne(float f) { return srl_bf16(f); }   // round to nearest even
 __device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
 
 template <bool F32>
@@ -134,14 +132,14 @@ k_xcorr_mfma(const void* __restrict__ in, const void* __restrict__ kern, float* 
             v[0] = bf16_to_f32(q.x & 0xffffu); v[1] = bf16_to_f32(q.x >> 16);
             v[2] = bf16_to_f32(q.y & 0xffffu); v[3] = bf16_to_f32(q.y >> 16);
           }
-          uint32_t hi[4], lo[4];
+          uint32_t hi[2], lo[2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            hi[e] = bf16_rne(v[e]);
-            lo[e] = SPLIT ? bf16_rne(v[e] - bf16_to_f32(hi[e])) : 0u;
+          for (int e = 0; e < 2; ++e) {
+            if (SPLIT) srl_split_bf16(v[2 * e], v[2 * e + 1], hi[e], lo[e]);
+            else hi[e] = srl_pk_bf16(v[2 * e], v[2 * e + 1]);
           }
-          *(uint2*)(xs + r * G::RS + cc) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-          if (SPLIT) *(uint2*)(xs + TILE + r * G::RS + cc) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+          *(uint2*)(xs + r * G::RS + cc) = make_uint2(hi[0], hi[1]);
+          if (SPLIT) *(uint2*)(xs + TILE + r * G::RS + cc) = make_uint2(lo[0], lo[1]);
         }
       } else {   // odd sides (the padded gradient map): element by element
         const int nrow = min(ROWS_L, HIN - row0);

@@ -72,6 +72,10 @@ def load():
     L.srl_convt2x2_bias_relu_f32.argtypes = L.srl_convt2x2_bias_relu.argtypes
     L.srl_conv3x3_relu_project_f32.restype = ctypes.c_int
     L.srl_conv3x3_relu_project_f32.argtypes = [VP, VP, VP, VP, ctypes.c_float, VP] + [ctypes.c_int32] * 5 + [VP]
+    L.srl_thin_conv3x3_bias_relu_f32.restype = ctypes.c_int
+    L.srl_thin_conv3x3_bias_relu_f32.argtypes = [VP, ctypes.c_int32, ctypes.c_int32] + [VP] * 6 + [ctypes.c_int32] * 6 + [VP]
+    L.srl_thin_conv3x3_relu_project_f32.restype = ctypes.c_int
+    L.srl_thin_conv3x3_relu_project_f32.argtypes = [VP] * 6 + [ctypes.c_float, VP] + [ctypes.c_int32] * 3 + [VP]
     L.srl_conv3x3_relu_project.restype = ctypes.c_int
     L.srl_conv3x3_relu_project.argtypes = [VP, VP, VP, VP, ctypes.c_float, VP] + [ctypes.c_int32] * 5 + [VP]
     L.srl_policy_head.restype = ctypes.c_int
@@ -489,9 +493,14 @@ def convt2x2_bias_relu(x, wfrag, bias, cout, out, out_offset=0):
   return out
 
 
+def pack_thin_weights(w):
+  """Conv2d weight [16, cin, 3, 3] (cin 1 or 2) -> float32 [16, 3, 3, cin], the order the thin-layer kernels read."""
+  return w.detach().float().permute(0, 2, 3, 1).contiguous()
+
+
 def conv3x3_thin(x, w, bias, out=None, dtype=torch.bfloat16):
   """relu(conv3x3(x) + bias) for 1 or 2 input channels -> 16 (csrc/conv_mfma.hip, vector ALU).  x: uint8 (scaled by
-  1/255) or float32, channels-last memory [B,H,W,cin].  Returns bf16 (or float32, per `dtype` / `out`) [B,16,Hp,Wp]
+  1/255) or float32, channels-last memory [B,H,W,cin]; w from `pack_thin_weights`.  Returns bf16 (or float32, per `dtype` / `out`) [B,16,Hp,Wp]
   channels-last; `out` (optional) is a larger zero-margined buffer of that kind whose top-left H x W region is written."""
   B, H, W, cin = x.shape
   if out is None:
@@ -513,6 +522,41 @@ def conv3x3_relu_project(x, wfrag, bias, proj_w, proj_b, hv, wv):
   with torch.cuda.device(x.device):
     rc = fn(x.data_ptr(), wfrag.data_ptr(), bias.data_ptr(), proj_w.data_ptr(), float(proj_b),
                                          out.data_ptr(), B, H, W, hv, wv, _stream(x))
+  if rc:
+    raise RuntimeError(load().srl_conv_last_error().decode())
+  return out
+
+
+def thin_conv3x3_bias_relu(x, w1, b1, wfrag, bias, out=None, out_offset=0, pool=False, nchw=False):
+  """`conv3x3_thin` (float32 output) followed by `conv3x3_bias_relu` (16 -> 16, fp32-class) as one kernel: the 16-channel
+  intermediate stays in LDS.  x: uint8 or float32 [B,H,W,cin] (cin 1 or 2; H, W multiples of 16), w1 from
+  `pack_thin_weights`; returns what
+  `conv3x3_bias_relu` returns, equal bit for bit."""
+  B, H, W, cin = x.shape
+  if nchw:
+    dst = torch.empty((B, 16, H, W), dtype=torch.float32, device=x.device)
+    stride = 16
+  else:
+    dst = out if out is not None else torch.empty((B, 16, H, W), dtype=torch.float32, device=x.device, memory_format=_CL)
+    stride = dst.shape[1]
+  pooled = torch.empty((B, 16, H // 2, W // 2), dtype=torch.float32, device=x.device, memory_format=_CL) if pool else None
+  with torch.cuda.device(x.device):
+    rc = load().srl_thin_conv3x3_bias_relu_f32(x.data_ptr(), int(x.dtype != torch.uint8), cin, w1.data_ptr(), b1.data_ptr(),
+                                               wfrag.data_ptr(), bias.data_ptr(), dst.data_ptr(), pooled.data_ptr() if pool else None,
+                                               B, H, W, stride, out_offset, int(nchw), _stream(x))
+  if rc:
+    raise RuntimeError(load().srl_conv_last_error().decode())
+  return (dst, pooled) if pool else dst
+
+
+def thin_conv3x3_relu_project(x, w1, b1, wfrag, bias, proj_w, proj_b):
+  """`pos_layers` whole as one kernel (fp32-class): x float32 [B,H,W] -> float32 [B,H,W]; equal bit for bit to
+  `conv3x3_thin` into a zero-margined map followed by `conv3x3_relu_project`."""
+  B, H, W = x.shape
+  out = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
+  with torch.cuda.device(x.device):
+    rc = load().srl_thin_conv3x3_relu_project_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), wfrag.data_ptr(), bias.data_ptr(),
+                                                  proj_w.data_ptr(), float(proj_b), out.data_ptr(), B, H, W, _stream(x))
   if rc:
     raise RuntimeError(load().srl_conv_last_error().decode())
   return out
@@ -568,8 +612,9 @@ class FastFeatures(object):
   csrc/epilogue.hip instead of separate bias / ReLU / max-pool / concatenate / layout kernels.  Returns the left and
   right feature maps NCHW-contiguous, ready for the MFMA cross-correlation."""
 
-  def __init__(self, net, mfma_conv=True, dtype=torch.bfloat16, x3_conv=True):
+  def __init__(self, net, mfma_conv=True, dtype=torch.bfloat16, x3_conv=True, fuse_thin=True):
     self.net = net
+    self.fuse_thin = bool(fuse_thin)   # fp32-class: thin layer + the 16 -> 16 layer behind it as one kernel (False: two, same values)
     # dtype float32 = the reference's dtype: (x3_conv) the same hand-written layers as the bf16 mode, in fp32-class
     # precision — the 16- / 32-output-channel 3 x 3 layers, the 32 -> 16 / 64 -> 32 transposed convolutions and the
     # position head with bf16x3 products on the matrix cores (csrc/conv_mfma.hip k_conv3x3_x3, k_convt2x2_x3), the thin
@@ -625,7 +670,7 @@ class FastFeatures(object):
           self._w1.offer(m, lambda m=m: m.weight.detach().float().permute(0, 2, 3, 1).reshape(m.in_channels, 4 * m.out_channels).contiguous())
         if (self.mfma_conv or self.x3_conv) and isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and \
            m.in_channels in (1, 2) and m.out_channels == 16:
-          self._wt[m] = m.weight.detach().float().contiguous()
+          self._wt[m] = pack_thin_weights(m.weight)
     pos = getattr(self.net, 'pos', None)
     self._pos = None
     if (self.mfma_conv or self.x3_conv) and pos is not None and len(pos) == 5 and pos[0] in self._wt and pos[2] in self._wf and \
@@ -652,6 +697,13 @@ class FastFeatures(object):
     x = None
     for blk in U.down:
       f = blk[0].out_channels
+      if x is None and self.fuse_thin and self.x3_conv and blk[0] in self._wt and blk[2] in self._wf and f == 16 and \
+         blk[2].in_channels == 16 and obs.shape[1] % 16 == 0 and obs.shape[2] % 16 == 0:
+        cat = torch.empty((B, 2 * f, obs.shape[1], obs.shape[2]), dtype=self.dtype, device=obs.device, memory_format=_CL)
+        _, x = thin_conv3x3_bias_relu(obs, self._wt[blk[0]], self._w[blk[0]][1], self._wf[blk[2]], self._w[blk[2]][1],
+                                      out=cat, out_offset=f, pool=True)
+        cats.append(cat)
+        continue
       if x is None and blk[0] in self._wt:
         y = conv3x3_thin(obs, self._wt[blk[0]], self._w[blk[0]][1], dtype=self.dtype)   # /255 and the cast happen in the kernel
       elif x is None:
@@ -732,6 +784,10 @@ class FastFeatures(object):
       return self.net.pos(corr).flatten(1)
     pos = self.net.pos
     B, _, oh, ow = corr.shape
+    pw, pb = self._pos
+    if self.fuse_thin and self.x3_conv:       # fp32-class: the three layers as one kernel, the 16-channel maps never leave LDS
+      return thin_conv3x3_relu_project(corr.reshape(B, oh, ow).contiguous(), self._wt[pos[0]], self._w[pos[0]][1], self._wf[pos[2]],
+                                       self._w[pos[2]][1], pw, pb).flatten(1)
     hp, wp = (oh + 15) // 16 * 16, (ow + 15) // 16 * 16
     key = (B, hp, wp, corr.device.index)
     buf = self._posbuf.get(key)
@@ -739,7 +795,6 @@ class FastFeatures(object):
       buf = torch.zeros((B, 16, hp, wp), dtype=self.dtype, device=corr.device).contiguous(memory_format=_CL)
       self._posbuf = {key: buf}
     conv3x3_thin(corr.reshape(B, oh, ow, 1).contiguous(), self._wt[pos[0]], self._w[pos[0]][1], out=buf)
-    pw, pb = self._pos
     return conv3x3_relu_project(buf, self._wf[pos[2]], self._w[pos[2]][1], pw, pb, oh, ow).flatten(1)
 
 

@@ -36,7 +36,7 @@ def test_qnet_library_exports_every_declared_symbol():
                    'srl_conv_last_error', 'srl_convt2x2_bias_relu', 'srl_convt2x2_bias_relu_f32', 'srl_convt2x2_gemm_bias_relu', 'srl_convt2x2_gemm_supported', 'srl_convt2x2_wfrag_elems', 'srl_epilogue_last_error', 'srl_gumbel_topk',
                    'srl_gumbel_topk_scratch_bytes', 'srl_heuristic', 'srl_learner_last_error', 'srl_logit_extrema', 'srl_logit_extrema_scratch_bytes',
                    'srl_policy_head', 'srl_pool2x2', 'srl_qnet_build_info', 'srl_qnet_last_error', 'srl_replay_gather', 'srl_replay_scatter', 'srl_tact_bwd', 'srl_tact_bwd_blocks',
-                   'srl_tact_bwd_scratch_floats', 'srl_tconv', 'srl_tcorr_grad', 'srl_td_epilogue', 'srl_tflip', 'srl_thead_bwd', 'srl_thead_fwd', 'srl_tlayout', 'srl_train_conv_last_error', 'srl_trepack', 'srl_tu8_to_f32', 'srl_tvalue_bwd', 'srl_tvalue_fwd', 'srl_twrw', 'srl_twrw_scratch_floats', 'srl_xcorr_forward',
+                   'srl_tact_bwd_scratch_floats', 'srl_tconv', 'srl_tcorr_grad', 'srl_td_epilogue', 'srl_tflip', 'srl_thead_bwd', 'srl_thead_fwd', 'srl_thin_conv3x3_bias_relu_f32', 'srl_thin_conv3x3_relu_project_f32', 'srl_tlayout', 'srl_train_conv_last_error', 'srl_trepack', 'srl_tu8_to_f32', 'srl_tvalue_bwd', 'srl_tvalue_fwd', 'srl_twrw', 'srl_twrw_scratch_floats', 'srl_xcorr_forward',
                    'srl_xcorr_mfma', 'srl_xcorr_mfma_last_error', 'srl_xcorr_mfma_scratch_bytes']
   L = ctypes.CDLL(build.QLIB)
   for n in names:

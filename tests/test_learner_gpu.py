@@ -125,12 +125,12 @@ def test_thin_conv_and_projection_head_match_torch():
     b = torch.rand(16, generator=g, device='cuda') - 0.5
     xf = x.float() / 255.0 if dt == torch.uint8 else x
     ref = F.relu(F.conv2d(xf.permute(0, 3, 1, 2), w, b, padding=1))
-    y = qops.conv3x3_thin(x, w, b)
+    y = qops.conv3x3_thin(x, qops.pack_thin_weights(w), b)
     assert y.shape == ref.shape and y.dtype == torch.bfloat16
     assert bool(((y.float() - ref).abs() <= 2.0 ** -8 * ref.abs().clamp(min=1e-2)).all())   # fp32 math, one bf16 rounding
   # padded, zero-margined buffer: only the H x W region is written
   buf = torch.zeros((B, 16, 48, 64), dtype=torch.bfloat16, device='cuda').contiguous(memory_format=torch.channels_last)
-  qops.conv3x3_thin(x, w, b, out=buf)
+  qops.conv3x3_thin(x, qops.pack_thin_weights(w), b, out=buf)
   assert torch.equal(buf[:, :, :H, :W], y) and float(buf[:, :, H:].abs().sum()) == 0 and float(buf[:, :, :, W:].abs().sum()) == 0
   # projection tail on the padded buffer
   w2 = (torch.rand((16, 16, 3, 3), generator=g, device='cuda') - 0.5) * 0.2
@@ -569,11 +569,11 @@ def test_thin_conv_and_projection_head_fp32():
     b = torch.rand(16, generator=g, device='cuda') - 0.5
     xf = x.float() / 255.0 if dt == torch.uint8 else x
     ref = F.relu(F.conv2d(xf.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1))
-    y = qops.conv3x3_thin(x, w, b, dtype=torch.float32)
+    y = qops.conv3x3_thin(x, qops.pack_thin_weights(w), b, dtype=torch.float32)
     assert y.shape == ref.shape and y.dtype == torch.float32 and y.is_contiguous(memory_format=torch.channels_last)
     assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
   buf = torch.zeros((B, 16, 48, 64), device='cuda').contiguous(memory_format=torch.channels_last)
-  qops.conv3x3_thin(x, w, b, out=buf)
+  qops.conv3x3_thin(x, qops.pack_thin_weights(w), b, out=buf)
   assert torch.equal(buf[:, :, :H, :W], y) and float(buf[:, :, H:].abs().sum()) == 0 and float(buf[:, :, :, W:].abs().sum()) == 0
   w2 = (torch.rand((16, 16, 3, 3), generator=g, device='cuda') - 0.5) * 0.2
   b2 = torch.rand(16, generator=g, device='cuda') - 0.5
@@ -583,6 +583,76 @@ def test_thin_conv_and_projection_head_fp32():
   ref = (act * pw.double()[None, :, None, None]).sum(1) + 0.25
   assert got.shape == (B, H, W) and got.dtype == torch.float32
   assert float((got.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('cin,dt,H,W', [(2, torch.uint8, 128, 128), (1, torch.uint8, 32, 32), (2, torch.float32, 48, 16), (1, torch.float32, 16, 64)])
+def test_fused_thin_and_second_layer_equal_the_two_kernels(cin, dt, H, W):
+  """`thin_conv3x3_bias_relu` (one kernel, the 16-channel intermediate in LDS) against `conv3x3_thin` followed by
+  `conv3x3_bias_relu` — each held to float64 by the tests above: the same arithmetic per value, so equal BIT FOR BIT, in every
+  output form (new tensor; channel slice of a concat buffer + pooled tensor, the rest of the buffer untouched; channel-major)."""
+  from stackrl_amd import qops
+  g = torch.Generator(device='cuda').manual_seed(31 + cin)
+  B = 3
+  x = torch.randint(0, 256, (B, H, W, cin), generator=g, device='cuda', dtype=torch.uint8) if dt == torch.uint8 else \
+      torch.randn((B, H, W, cin), generator=g, device='cuda') * 3.0
+  w1 = qops.pack_thin_weights((torch.rand((16, cin, 3, 3), generator=g, device='cuda') - 0.5) * 0.5)
+  b1 = torch.rand(16, generator=g, device='cuda') - 0.5
+  w2 = (torch.rand((16, 16, 3, 3), generator=g, device='cuda') - 0.5) * 0.2
+  b2 = torch.rand(16, generator=g, device='cuda') - 0.5
+  wf = qops.pack_conv3x3_weights_x3(w2)
+  y = qops.conv3x3_thin(x, w1, b1, dtype=torch.float32)
+  assert float(y.abs().max()) > 0
+  ref = qops.conv3x3_bias_relu(y, wf, b2, 16)
+  got = qops.thin_conv3x3_bias_relu(x, w1, b1, wf, b2)
+  assert got.shape == ref.shape and got.dtype == torch.float32 and got.is_contiguous(memory_format=torch.channels_last)
+  assert torch.equal(got, ref)
+  cat_r = torch.full((B, 32, H, W), 7.0, device='cuda').contiguous(memory_format=torch.channels_last)
+  cat_g = cat_r.clone(memory_format=torch.preserve_format)
+  _, pr = qops.conv3x3_bias_relu(y, wf, b2, 16, out=cat_r, out_offset=16, pool=True)
+  _, pg = qops.thin_conv3x3_bias_relu(x, w1, b1, wf, b2, out=cat_g, out_offset=16, pool=True)
+  assert torch.equal(cat_g, cat_r) and torch.equal(pg, pr) and bool((cat_g[:, :16] == 7.0).all())
+  assert torch.equal(pg, torch.nn.functional.max_pool2d(ref, 2))
+  nr = qops.conv3x3_bias_relu(y, wf, b2, 16, nchw=True)
+  ng = qops.thin_conv3x3_bias_relu(x, w1, b1, wf, b2, nchw=True)
+  assert ng.is_contiguous() and torch.equal(ng, nr)
+
+
+@pytest.mark.parametrize('H,W', [(97, 97), (40, 56), (5, 130), (16, 16)])
+def test_fused_position_head_equals_the_two_kernels(H, W):
+  """`pos_layers` as one kernel against the thin layer into a zero-margined map + the 16 -> 16 -> 1 tail: bit for bit, for
+  maps that are not multiples of the 16 x 16 tile (the kernel's own border handling replaces the padded map)."""
+  from stackrl_amd import qops
+  g = torch.Generator(device='cuda').manual_seed(41)
+  B = 3
+  x = torch.randn((B, H, W), generator=g, device='cuda') * 30.0
+  w1 = qops.pack_thin_weights((torch.rand((16, 1, 3, 3), generator=g, device='cuda') - 0.5) * 0.5)
+  b1 = torch.rand(16, generator=g, device='cuda') - 0.5
+  w2 = (torch.rand((16, 16, 3, 3), generator=g, device='cuda') - 0.5) * 0.2
+  b2 = torch.rand(16, generator=g, device='cuda') - 0.5
+  pw = torch.rand(16, generator=g, device='cuda') - 0.5
+  wf = qops.pack_conv3x3_weights_x3(w2)
+  hp, wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+  buf = torch.zeros((B, 16, hp, wp), device='cuda').contiguous(memory_format=torch.channels_last)
+  qops.conv3x3_thin(x.reshape(B, H, W, 1), w1, b1, out=buf)
+  ref = qops.conv3x3_relu_project(buf, wf, b2, pw, -0.75, H, W)
+  got = qops.thin_conv3x3_relu_project(x, w1, b1, wf, b2, pw, -0.75)
+  assert got.shape == (B, H, W) and torch.equal(got, ref)
+
+
+def test_fast_rollout_with_and_without_the_fused_first_level():
+  """The fp32-class rollout forward with the fused kernels (default) and with the two-kernel forms: features and advantages
+  equal bit for bit.  (Eight samples: a batch the deep levels' kernels take — with an odd batch those layers fall to the library's
+  fp32 convolutions, whose results move by ~1e-5 of the scale from run to run.)"""
+  from stackrl_amd import nets, qops
+  net = nets.DeepQSiamFCN(seed=7).cuda().eval()
+  g = torch.Generator(device='cuda').manual_seed(8)
+  xm = torch.randint(0, 256, (8, 128, 128, 2), generator=g, device='cuda', dtype=torch.uint8)
+  xo = torch.randint(0, 256, (8, 32, 32, 1), generator=g, device='cuda', dtype=torch.uint8)
+  fa, fb = qops.FastFeatures(net, dtype=torch.float32), qops.FastFeatures(net, dtype=torch.float32, fuse_thin=False)
+  (ax, aw), (bx, bw) = fa((xm, xo)), fb((xm, xo))
+  assert torch.equal(ax, bx) and torch.equal(aw, bw)
+  corr = torch.randn((8, 1, 97, 97), generator=g, device='cuda') * 20.0
+  assert fa._pos is not None and torch.equal(fa.pos(corr), fb.pos(corr))
 
 
 def test_fast_position_head_fp32_tracks_the_module():
