@@ -170,6 +170,14 @@ k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, c
   }
 }
 
+// 16-byte store of a finished float32 activation, non-temporal: at rollout batch sizes these tensors (0.25 - 2 GB per layer at
+// 2,048 samples) are larger than the last-level cache, the lines only pass through on their way to HBM, and streaming them
+// leaves the L2 to the loads (the fused first level at 2,048 x 128^2: 1,345 -> 1,102 us per launch, tools/ab_fused.py).
+__device__ __forceinline__ void store_f4(float* p, float a, float b, float c, float d) {
+  const f32x4 v = {a, b, c, d};
+  __builtin_nontemporal_store(v, (f32x4*)p);
+}
+
 // Epilogue of the fp32-class kernels (k_conv3x3_x3, k_thin_conv3x3_x3).  D: lane holds column lane & 15 = pixel n, rows
 // 4 g .. 4 g + 3 = output channels of tile mt.  Bias + ReLU, then 16-byte stores into a channel slice of a channels-last
 // buffer, or channel-major output, optionally the 2 x 2 max-pooled tensor too; PROJ: the 1 x 1 projection instead.
@@ -216,7 +224,7 @@ __device__ __forceinline__ void x3_epilogue(const f32x4 (&acc)[RW][MT_W], const 
         float* o = out + ((size_t)b * COUT + co) * H * W + (size_t)y * W + x;
         o[0] = val[r].x; o[(size_t)H * W] = val[r].y; o[(size_t)2 * H * W] = val[r].z; o[(size_t)3 * H * W] = val[r].w;
       } else {
-        *(float4*)(out + (((size_t)b * H + y) * W + x) * ostride + ooff + co) = val[r];
+        store_f4(out + (((size_t)b * H + y) * W + x) * ostride + ooff + co, val[r].x, val[r].y, val[r].z, val[r].w);
       }
     }
     if (pooled) {   // 2 x 2 max: rows in registers, the neighbouring column (lane n ^ 1) by a DPP quad permute
@@ -231,7 +239,7 @@ __device__ __forceinline__ void x3_epilogue(const f32x4 (&acc)[RW][MT_W], const 
         }
         if (!(n & 1)) {
           const int y2 = (y0 + row0) / 2 + rp, x2 = (x0 + n) / 2;
-          *(float4*)(pooled + (((size_t)b * (H / 2) + y2) * (W / 2) + x2) * COUT + co) = make_float4(m[0], m[1], m[2], m[3]);
+          store_f4(pooled + (((size_t)b * (H / 2) + y2) * (W / 2) + x2) * COUT + co, m[0], m[1], m[2], m[3]);
         }
       }
     }
@@ -452,7 +460,7 @@ k_conv3x3_thin(const TIN* __restrict__ in, const float* __restrict__ w, const fl
 // (SGPR operands): five full waves of pixels per half, 8 outputs per thread and round; the four pixels left over (324 =
 // 5 x 64 + 4) go to one more wave as (pixel, channel) per lane.
 template <int CT, typename TIN, bool PROJ>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 4)
 k_thin_conv3x3_x3(const TIN* __restrict__ in, const float* __restrict__ w1, const float* __restrict__ b1,
                   const uint16_t* __restrict__ wfrag, const float* __restrict__ bias, float* __restrict__ out,
                   float* __restrict__ pooled, int H, int W, int ostride, int ooff, int nchw, const float* __restrict__ pw, float pb,
@@ -644,9 +652,8 @@ k_convt2x2_x3(const float* __restrict__ in, const uint16_t* __restrict__ wfrag, 
     const int m = 16 * mt + 4 * g;     // row of the GEMM = (dy, dx, co)
     const int q = m / COUT, co = m - q * COUT, dy = q >> 1, dx = q & 1;
     const float4 bz = *(const float4*)(bias + co);
-    *(float4*)(out + (((b * 2 * H + 2 * y + dy) * 2 * W) + 2 * x + dx) * ostride + ooff + co) =
-        make_float4(fmaxf(acc[mt][0] + bz.x, 0.0f), fmaxf(acc[mt][1] + bz.y, 0.0f), fmaxf(acc[mt][2] + bz.z, 0.0f),
-                    fmaxf(acc[mt][3] + bz.w, 0.0f));
+    store_f4(out + (((b * 2 * H + 2 * y + dy) * 2 * W) + 2 * x + dx) * ostride + ooff + co, fmaxf(acc[mt][0] + bz.x, 0.0f),
+             fmaxf(acc[mt][1] + bz.y, 0.0f), fmaxf(acc[mt][2] + bz.z, 0.0f), fmaxf(acc[mt][3] + bz.w, 0.0f));
   }
 }
 
