@@ -407,6 +407,15 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
   if os.environ.get('SRL_BENCH_FAIL_LEG_B') == str(rank):     # test hook: this rank is lost in leg B
     raise RuntimeError('injected leg-B failure on rank {}'.format(rank))
   B, L, res, name = dqn_shape(args)
+  if os.environ.get('SRL_FWD_CU_MASK'):        # experiment hook: the current stream (forward, update) on a subset of the CUs
+    import ctypes                              # eight 32-bit hex words, comma separated, bit i = CU i
+    words = [int(w, 16) for w in os.environ['SRL_FWD_CU_MASK'].split(',')]
+    hip = ctypes.CDLL('libamdhip64.so')
+    hs = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(hs), len(words), (ctypes.c_uint32 * len(words))(*words))
+    if rc:
+      raise RuntimeError('hipExtStreamCreateWithCUMask: {}'.format(rc))
+    torch.cuda.set_stream(torch.cuda.ExternalStream(hs.value))
   # as the headline (--config 2|3|4) the leg follows the contract's K timed / W warm-up steps; the three eager updates
   # and the graph capture of the update (DQN._GRAPH_WARMUP) then run before those, as part of the setup
   # (default: one whole episode of L placements + the auto-reset call, so that every fill level of the scene is in the window)
@@ -416,6 +425,8 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
     kw['resolution_factor'] = 4
   if args.launch_order != 'auto':
     kw['launch_order'] = args.launch_order == 'ordered'
+  if os.environ.get('SRL_ENV_STREAM_PRIORITY'):        # experiment hook: HIP priority of the env groups' streams (-1 = high)
+    kw['stream_priority'] = int(os.environ['SRL_ENV_STREAM_PRIORITY'])
   groups = args.dqn_groups if args.dqn_groups else 2
   if groups > 1:
     kw['groups'] = groups
@@ -426,7 +437,7 @@ def dqn_leg(args, rank, world, pool, barrier, solver_kw, dtype):
               replay_memory_size=B * args.dqn_slots, discount_factor=.966667, collect_batch_size=B,
               exploration=PolynomialDecay(1.0, 400000, .1), prioritization=0.6,
               priority_bias_compensation=PolynomialDecay(0.4, 400000, 1.0), double=True, seed=7 + rank,
-              policy_op=qops.FusedPolicy(autocast=torch.bfloat16 if dtype == 'bf16' else None, fast=True),
+              policy_op=qops.FusedPolicy(chunk=int(os.environ.get('SRL_POLICY_CHUNK', 2048)), autocast=torch.bfloat16 if dtype == 'bf16' else None, fast=True),
               xcorr='bf16x3', graphs=True, process_group=rccl_group(args, world), prefetch=3,   # config.gin:55-112 (prefetch :104)
               early_gradient=not os.environ.get('SRL_NO_EARLY_GRADIENT'))
   tr = Trainer(env, agent)

@@ -30,7 +30,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
-template <int COUT, int W>
+template <int COUT, int W, bool X3 = false>
 struct GemmCfg {
   static constexpr int WM = COUT / 64;             // waves along the output channels
   static constexpr int WN = 4 / WM;                // waves along the pixels
@@ -38,7 +38,13 @@ struct GemmCfg {
   static constexpr int NI = PXT >= W * W ? PXT / (W * W) : 1;   // whole maps per workgroup (8^2: two)
   static constexpr int RT = NI > 1 ? W : PXT / W;  // rows of a map per workgroup
   static constexpr int TH = RT + 2, TWD = W + 2;   // tile incl. halo, per map
-  static constexpr int PS = 40;                    // LDS pixel stride in bf16 elements (80 B)
+  // LDS pixel stride in bf16 elements: 40 (80 B for the 64 B of a pixel's 32 channels: the sixteen lanes of a 16-byte read land
+  // in sixteen different bank quads), or — SWZ: the fp32-class 64-channel layers at 32^2, whose two planes of 18 x 34 pixels
+  // would be 98 KB and leave a CU to ONE workgroup, i.e. one wave per SIMD with nothing to run under its staging — 32 with the
+  // pixel's four 16-byte chunks permuted by its column, slot = chunk ^ ((column >> 2) & 3): columns c, c + 4, c + 8, c + 12
+  // share their sixteen banks and now use different quads of them.  78 KB, two workgroups per CU.
+  static constexpr bool SWZ = X3 && COUT == 64 && W == 32;
+  static constexpr int PS = SWZ ? 32 : 40;
   static constexpr int TILE = NI * TH * TWD * PS;  // elements per plane
   static_assert(COUT == 64 || COUT == 128 || COUT == 256, "COUT");
   static_assert(PXT % W == 0 && (NI == 1 || PXT == NI * W * W), "pixel tile");
@@ -49,7 +55,7 @@ template <int CIN, int COUT, int W, bool X3>
 __global__ void __launch_bounds__(256, 2)
 k_conv3x3_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag, const float* __restrict__ bias,
                void* __restrict__ out_, int ostride, int ooff) {
-  typedef GemmCfg<COUT, W> G;
+  typedef GemmCfg<COUT, W, X3> G;
   constexpr int NCB = CIN / 32, MT = COUT / 16;
   extern __shared__ uint16_t tile[];               // [1 or (X3) 2 planes: hi, lo][NI][TH][TWD][PS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -66,8 +72,13 @@ k_conv3x3_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag,
   for (int t = 0; t < 8; ++t) {
     const int p = wn * 128 + t * 16 + n;           // pixel within the workgroup tile
     const int im = p / (G::RT * W), r = (p / W) % G::RT, c = p % W;
-    poff[t] = ((im * G::TH + r) * G::TWD + c) * G::PS + 8 * g;
+    poff[t] = ((im * G::TH + r) * G::TWD + c) * G::PS + (G::SWZ ? 0 : 8 * g);
   }
+  // SWZ: the lane's chunk slot for a tap in tile column c + dx; c = n + 16 (t & 1), so the key ((c + dx) >> 2) & 3 depends on
+  // n and dx alone
+  int sw[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) sw[dx] = G::SWZ ? 8 * (g ^ (((n + dx) >> 2) & 3)) : 0;
   f32x4 acc[4][8];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
@@ -100,8 +111,9 @@ k_conv3x3_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag,
           uint32_t hi[4], lo[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) srl_split_bf16(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
-          *(uint4*)(tile + p * G::PS + ch * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-          *(uint4*)(tile + G::TILE + p * G::PS + ch * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+          const int slot = G::SWZ ? (ch ^ ((cc >> 2) & 3)) : ch;
+          *(uint4*)(tile + p * G::PS + slot * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+          *(uint4*)(tile + G::TILE + p * G::PS + slot * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         } else {
           uint4 v = *(const uint4*)((const uint16_t*)in_ + src);
           if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
@@ -123,9 +135,10 @@ k_conv3x3_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag,
       const int toff = ((tap / 3) * G::TWD + tap % 3) * G::PS;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const bf16x8 xh = *(const bf16x8*)(tile + poff[t] + toff);
+        const int xoff = poff[t] + toff + (G::SWZ ? sw[tap % 3] : 0);
+        const bf16x8 xh = *(const bf16x8*)(tile + xoff);
         if (X3) {
-          const bf16x8 xl = *(const bf16x8*)(tile + G::TILE + poff[t] + toff);
+          const bf16x8 xl = *(const bf16x8*)(tile + G::TILE + xoff);
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
             acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], xh, acc[mt][t], 0, 0, 0);
@@ -245,7 +258,7 @@ thread_local char gm_err[256] = "";
 
 template <int CIN, int COUT, int W, bool X3>
 int launch_gemm(const void* in, const void* wfrag, const float* bias, void* out, int B, int ostride, int ooff, hipStream_t st) {
-  typedef GemmCfg<COUT, W> G;
+  typedef GemmCfg<COUT, W, X3> G;
   const size_t lds = sizeof(uint16_t) * G::TILE * (X3 ? 2 : 1);
   const int nwg = G::NI > 1 || G::PXT == W * W ? B / G::NI : B * ((W * W) / G::PXT);
   static bool attr = false;
