@@ -46,6 +46,10 @@ struct GemmCfg {
   static constexpr bool SWZ = X3 && COUT == 64 && W == 32;
   static constexpr int PS = SWZ ? 32 : 40;
   static constexpr int TILE = NI * TH * TWD * PS;  // elements per plane
+  // element offset of N tile t's pixel relative to N tile 0's, the same for every lane
+  static constexpr int tile_delta(int t) {
+    return (((16 * t) / (RT * W) * TH + ((16 * t) / W) % RT) * TWD + (16 * t) % W) * PS;
+  }
   static_assert(COUT == 64 || COUT == 128 || COUT == 256, "COUT");
   static_assert(PXT % W == 0 && (NI == 1 || PXT == NI * W * W), "pixel tile");
 };
@@ -65,14 +69,15 @@ k_conv3x3_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag,
   constexpr int PARTS = (W * W + G::PXT - 1) / G::PXT;   // workgroups per map (when NI == 1)
   const int img0 = G::NI > 1 ? blockIdx.x * G::NI : blockIdx.x / PARTS;
   const int row0 = G::NI > 1 ? 0 : (blockIdx.x % PARTS) * G::RT;
-  // LDS offset (elements) of the top-left tap of each of the lane's 8 pixels: N tile t = 16 consecutive pixels of the
-  // wave's 128 (row-major over the workgroup's pixel tile)
-  int poff[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int p = wn * 128 + t * 16 + n;           // pixel within the workgroup tile
+  // LDS offset (elements) of the top-left tap of the lane's pixel in N tile 0 (N tile t = 16 consecutive pixels of the wave's
+  // 128, row-major over the workgroup's pixel tile).  Tile t lies a whole number of images / rows / 16-column halves further
+  // on for every lane (16 divides the row length or is a multiple of it), so its offset is this one plus a constant,
+  // G::tile_delta(t): an immediate of the LDS read instead of a register per tile.
+  int poff0;
+  {
+    const int p = wn * 128 + n;                    // pixel within the workgroup tile
     const int im = p / (G::RT * W), r = (p / W) % G::RT, c = p % W;
-    poff[t] = ((im * G::TH + r) * G::TWD + c) * G::PS + (G::SWZ ? 0 : 8 * g);
+    poff0 = ((im * G::TH + r) * G::TWD + c) * G::PS + (G::SWZ ? 0 : 8 * g);
   }
   // SWZ: the lane's chunk slot for a tap in tile column c + dx; c = n + 16 (t & 1), so the key ((c + dx) >> 2) & 3 depends on
   // n and dx alone
@@ -122,6 +127,7 @@ k_conv3x3_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag,
       }
     }
     __syncthreads();
+    bf16x8 pxh = {0, 0, 0, 0, 0, 0, 0, 0}, pxl = pxh;   // the fragments read ahead for the next tap's first tile
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       bf16x8 nh[4], nl[4];
@@ -132,13 +138,28 @@ k_conv3x3_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag,
           if (X3) nl[mt] = wf[LO + ((size_t)(cb * 9 + tap + 1) * MT + mt) * 64];
         }
       }
-      const int toff = ((tap / 3) * G::TWD + tap % 3) * G::PS;
+      // B fragments one step ahead: tile t + 1's (or the next tap's first) LDS reads are in flight during tile t's MFMAs
+      bf16x8 xh, xl;
+      if (tap == 0) {
+        const int xoff = poff0 + (G::SWZ ? sw[0] : 0);
+        xh = *(const bf16x8*)(tile + xoff);
+        if (X3) xl = *(const bf16x8*)(tile + G::TILE + xoff);
+      } else {
+        xh = pxh; xl = pxl;
+      }
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const int xoff = poff[t] + toff + (G::SWZ ? sw[tap % 3] : 0);
-        const bf16x8 xh = *(const bf16x8*)(tile + xoff);
+        bf16x8 yh = xh, yl = xl;
+        if (t < 7 || tap < 8) {
+          const int tn = t < 7 ? t + 1 : 0, tp = t < 7 ? tap : tap + 1;
+          const int xoff = poff0 + G::tile_delta(tn) + ((tp / 3) * G::TWD + tp % 3) * G::PS + (G::SWZ ? sw[tp % 3] : 0);
+          yh = *(const bf16x8*)(tile + xoff);
+          if (X3) yl = *(const bf16x8*)(tile + G::TILE + xoff);
+        }
+        // the reads stay here: issued before this tile's MFMAs (left alone the scheduler sinks them to their first use, one
+        // LDS latency exposed per tile) and not earlier than the previous tile's (hoisted further they spill)
+        __builtin_amdgcn_sched_barrier(0);
         if (X3) {
-          const bf16x8 xl = *(const bf16x8*)(tile + G::TILE + xoff);
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
             acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], xh, acc[mt][t], 0, 0, 0);
@@ -149,7 +170,9 @@ k_conv3x3_gemm(const void* __restrict__ in_, const uint16_t* __restrict__ wfrag,
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], xh, acc[mt][t], 0, 0, 0);
         }
+        xh = yh; xl = yl;
       }
+      pxh = xh; pxl = xl;
       if (tap < 8) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) { ah[mt] = nh[mt]; if (X3) al[mt] = nl[mt]; }
