@@ -246,6 +246,50 @@ __device__ __forceinline__ void x3_epilogue(const f32x4 (&acc)[RW][MT_W], const 
   }
 }
 
+// The MFMA loop of the fp32-class kernels over one staged pass (CB channels: hi plane at `tile`, lo plane PLANE elements on):
+// acc[r][mt] += W x X over the KS K-steps, three products per fragment pair (small terms first: lo hi + hi lo, then the leading
+// one).  The B fragments (16-byte LDS reads) are read ONE step (ks, r) ahead of their MFMAs and pinned there with
+// sched_barrier: left alone the scheduler sinks every read to its first use and a step pays one LDS latency for its 3 MT_W
+// MFMAs (the read-ahead form of k_conv3x3_gemm, csrc/conv_gemm.hip, where it was measured first).
+template <int CB, int RW, int MT_W>
+__device__ __forceinline__ void x3_mfma_pass(const uint16_t* tile, int plane, int row0, int n, int g,
+                                             const bf16x8 (&wh)[ConvCfg<CB>::KS][MT_W], const bf16x8 (&wl)[ConvCfg<CB>::KS][MT_W],
+                                             f32x4 (&acc)[RW][MT_W]) {
+  typedef ConvCfg<CB> G;
+  // element offset of the lane's fragment for K-step ks in tile row row0: the tap may depend on the lane (CB = 16: two taps
+  // per step), the row r then adds a constant
+  auto koff = [&](int ks) {
+    int tap, ci0;
+    k_of<CB>(ks, g, tap, ci0);
+    if (tap > 8) tap = 8;   // the padded tenth tap: its weights are zero, any valid address will do
+    const int dy = tap / 3, dx = tap - 3 * dy;
+    return ((row0 + dy) * G::TW + n + dx) * G::PS + ci0;
+  };
+  int off = koff(0);
+  bf16x8 xh = *(const bf16x8*)(tile + off), xl = *(const bf16x8*)(tile + plane + off);
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks) {
+    const int offn = ks + 1 < G::KS ? koff(ks + 1) : off;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      bf16x8 yh = xh, yl = xl;
+      if (r + 1 < RW || ks + 1 < G::KS) {
+        const int o = r + 1 < RW ? off + (r + 1) * G::TW * G::PS : offn;
+        yh = *(const bf16x8*)(tile + o); yl = *(const bf16x8*)(tile + plane + o);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT_W; ++mt) {
+        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks][mt], xh, acc[r][mt], 0, 0, 0);
+        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][mt], xl, acc[r][mt], 0, 0, 0);
+        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][mt], xh, acc[r][mt], 0, 0, 0);
+      }
+      xh = yh; xl = yl;
+    }
+    off = offn;
+  }
+}
+
 // The same convolution in fp32-class precision for the fp32 rollout (the reference's dtype): float32 channels-last in and
 // out, every operand split into a high and a low bfloat16 part (x = hi + lo up to 2^-17 |x|) and the product taken as
 // hi hi + hi lo + lo hi on the matrix cores with fp32 accumulation ("bf16x3": relative error ~2^-16 per product, the
@@ -313,25 +357,7 @@ k_conv3x3_x3(const float* __restrict__ in, const uint16_t* __restrict__ wfrag, c
       }
     }
     __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < G::KS; ++ks) {
-      int tap, ci0;
-      k_of<CB>(ks, g, tap, ci0);
-      if (tap > 8) tap = 8;
-      const int dy = tap / 3, dx = tap - 3 * dy;
-#pragma unroll
-      for (int r = 0; r < RW; ++r) {
-        const int off = ((row0 + r + dy) * G::TW + n + dx) * G::PS + ci0;
-        const bf16x8 xh = *(const bf16x8*)(tile + off), xl = *(const bf16x8*)(tile + PLANE + off);
-#pragma unroll
-        for (int mt = 0; mt < MT_W; ++mt) {
-          // small terms first: lo hi + hi lo, then the leading product
-          acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks][mt], xh, acc[r][mt], 0, 0, 0);
-          acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][mt], xl, acc[r][mt], 0, 0, 0);
-          acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][mt], xh, acc[r][mt], 0, 0, 0);
-        }
-      }
-    }
+    x3_mfma_pass<CB, RW, MT_W>(tile, PLANE, row0, n, g, wh, wl, acc);
   }
   x3_epilogue<COUT, MT_W, RW, PROJ>(acc, bias, out, pooled, H, W, ostride, ooff, nchw, pw, pb, proj_out, Hv, Wv, b, x0, y0, mt0, row0, n, g);
 }
@@ -477,11 +503,11 @@ k_thin_conv3x3_x3(const TIN* __restrict__ in, const float* __restrict__ w1, cons
   const int x0 = 16 * tx, y0 = 16 * ty;
   const int row0 = wave * RW;
   const int n = lane & 15, g = lane >> 4;
-  bf16x8 wh[G::KS], wl[G::KS];
+  bf16x8 wh[G::KS][1], wl[G::KS][1];
 #pragma unroll
   for (int ks = 0; ks < G::KS; ++ks) {
-    wh[ks] = ((const bf16x8*)wfrag)[ks * 64 + lane];
-    wl[ks] = ((const bf16x8*)wfrag)[(G::KS + ks) * 64 + lane];
+    wh[ks][0] = ((const bf16x8*)wfrag)[ks * 64 + lane];
+    wl[ks][0] = ((const bf16x8*)wfrag)[(G::KS + ks) * 64 + lane];
   }
   {
     const float scale = sizeof(TIN) == 1 ? 1.0f / 255.0f : 1.0f;
@@ -541,21 +567,7 @@ k_thin_conv3x3_x3(const TIN* __restrict__ in, const float* __restrict__ w1, cons
   f32x4 acc[RW][1];
 #pragma unroll
   for (int r = 0; r < RW; ++r) acc[r][0] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int ks = 0; ks < G::KS; ++ks) {
-    int tap, ci0;
-    k_of<16>(ks, g, tap, ci0);
-    if (tap > 8) tap = 8;
-    const int dy = tap / 3, dx = tap - 3 * dy;
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-      const int off = ((row0 + r + dy) * G::TW + n + dx) * G::PS + ci0;
-      const bf16x8 xh = *(const bf16x8*)(tile + off), xl = *(const bf16x8*)(tile + PLANE + off);
-      acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], xh, acc[r][0], 0, 0, 0);
-      acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], xl, acc[r][0], 0, 0, 0);
-      acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], xh, acc[r][0], 0, 0, 0);
-    }
-  }
+  x3_mfma_pass<16, RW, 1>(tile, PLANE, row0, n, g, wh, wl, acc);
   x3_epilogue<16, 1, RW, PROJ>(acc, bias, out, pooled, H, W, ostride, ooff, nchw, pw, pb, proj_out, H, W, b, x0, y0, 0, row0, n, g);
 }
 
