@@ -246,6 +246,50 @@ __device__ __forceinline__ void x3_epilogue(const f32x4 (&acc)[RW][MT_W], const 
   }
 }
 
+// Stage one pass of an fp32-class kernel: the 18 x 18 pixel window (halo included, zero outside the H x W image) of CB float32
+// channels at `src` (pixel stride `cstride` floats) into the hi / lo bf16 planes of the LDS tile.  The loads of BATCH
+// thread-items are issued together — unconditionally, from clamped addresses, selected to zero afterwards — before the first
+// is converted: written as a plain loop the compiler waited for each item's two loads before issuing the next's (six HBM
+// round trips in a row per pass at CB = 32).
+template <int CB, int BATCH>
+__device__ __forceinline__ void stage_tile_x3(const float* __restrict__ src, int cstride, int H, int W, int x0, int y0,
+                                              uint16_t* tile, int plane, int tid) {
+  typedef ConvCfg<CB> G;
+  constexpr int CPP = CB / 8;                       // 8-channel chunks per pixel
+  constexpr int N = G::TW * G::TW * CPP, NIT = (N + 255) / 256;
+#pragma unroll
+  for (int i0 = 0; i0 < NIT; i0 += BATCH) {
+    float4 a[BATCH], c[BATCH];
+    bool ok[BATCH];
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      if (i0 + i >= NIT) continue;
+      const int k = tid + 256 * (i0 + i), kk = k < N ? k : N - 1;
+      const int p = kk / CPP, ch = kk - p * CPP;
+      const int py = p / G::TW, px = p - py * G::TW;
+      const int y = y0 + py - 1, x = x0 + px - 1;
+      ok[i] = k < N && y >= 0 && y < H && x >= 0 && x < W;
+      const float* q = src + ((size_t)(ok[i] ? y : 0) * W + (ok[i] ? x : 0)) * cstride + ch * 8;
+      a[i] = *(const float4*)q; c[i] = *(const float4*)(q + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      if (i0 + i >= NIT) continue;
+      const int k = tid + 256 * (i0 + i);
+      if (k < N) {
+        const int p = k / CPP, ch = k - p * CPP;
+        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float4 va = ok[i] ? a[i] : z, vc = ok[i] ? c[i] : z;
+        uint32_t hi[4], lo[4];
+        srl_split_bf16(va.x, va.y, hi[0], lo[0]); srl_split_bf16(va.z, va.w, hi[1], lo[1]);
+        srl_split_bf16(vc.x, vc.y, hi[2], lo[2]); srl_split_bf16(vc.z, vc.w, hi[3], lo[3]);
+        *(uint4*)(tile + p * G::PS + ch * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *(uint4*)(tile + plane + p * G::PS + ch * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+      }
+    }
+  }
+}
+
 // The MFMA loop of the fp32-class kernels over one staged pass (CB channels: hi plane at `tile`, lo plane PLANE elements on):
 // acc[r][mt] += W x X over the KS K-steps, three products per fragment pair (small terms first: lo hi + hi lo, then the leading
 // one).  The B fragments (16-byte LDS reads) are read ONE step (ks, r) ahead of their MFMAs and pinned there with
@@ -337,24 +381,10 @@ k_conv3x3_x3(const float* __restrict__ in, const uint16_t* __restrict__ wfrag, c
       }
     if (ps) __syncthreads();   // the previous pass has read its tile
     {
-      constexpr int CPP = CB / 8;   // 8-channel chunks per pixel
-      const float* src = in + (size_t)b * H * W * CIN + ps * CB;
-      for (int k = tid; k < G::TW * G::TW * CPP; k += 256) {
-        const int p = k / CPP, ch = k - p * CPP;
-        const int py = p / G::TW, px = p - py * G::TW;
-        const int y = y0 + py - 1, x = x0 + px - 1;
-        float v[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        if (y >= 0 && y < H && x >= 0 && x < W) {
-          const float4 a = *(const float4*)(src + ((size_t)y * W + x) * CIN + ch * 8);
-          const float4 c = *(const float4*)(src + ((size_t)y * W + x) * CIN + ch * 8 + 4);
-          v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
-        }
-        uint32_t hi[4], lo[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) srl_split_bf16(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
-        *(uint4*)(tile + p * G::PS + ch * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-        *(uint4*)(tile + PLANE + p * G::PS + ch * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-      }
+      // (the weights above hold 8 KS MT_W registers: with 144 of them the window's loads go in two batches)
+      constexpr int NIT = (G::TW * G::TW * (CB / 8) + 255) / 256;
+      // (16-channel passes, three items per thread: batching measured 8 % slower at 16 -> 16, 128^2 — left item by item)
+      stage_tile_x3<CB, (CB == 16 ? 1 : G::KS * MT_W >= 18 ? (NIT + 1) / 2 : NIT)>(in + (size_t)b * H * W * CIN + ps * CB, CIN, H, W, x0, y0, tile, PLANE, tid);
     }
     __syncthreads();
     x3_mfma_pass<CB, RW, MT_W>(tile, PLANE, row0, n, g, wh, wl, acc);
