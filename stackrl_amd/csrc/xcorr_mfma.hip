@@ -114,8 +114,58 @@ k_xcorr_mfma(const void* __restrict__ in, const void* __restrict__ kern, float* 
   // blockIdx.y takes channels [c0, c1): with few samples the channels are spread over workgroups (summed outputs
   // then land in per-workgroup partials, reduced by k_sum_partials in a fixed order)
   const int c0 = blockIdx.y * cper, c1 = min(C, c0 + cper);
+  // PF (the forward with float32 operands per channel — the rollout and the update's forward): a channel's map rows and
+  // kernel rows are requested as whole batches of 16-byte loads into registers while the PREVIOUS channel's matrix products
+  // run, and converted into LDS after them.  As a plain loop per channel the compiler waited for every load before
+  // issuing the next: twelve + four HBM round trips in a row per channel, ~19 us against 9 us of MFMAs (MFMA pipes busy
+  // 57 % of the kernel's time with two workgroups per CU).
+  constexpr bool PF = IN_PER_C && K_PER_C && F32 && KF32 && HIN % 4 == 0 && (KH * KH) % (4 * NT) == 0;
+  constexpr int MAP_IT = PF ? (ROWS_L * (HIN / 4) + NT - 1) / NT : 1, K_IT = PF ? KH * KH / (4 * NT) : 1;
+  float4 mreg[MAP_IT], kreg[K_IT];
+  const int nrow_pf = min(ROWS_L, HIN - row0);
+  auto fetch = [&](int c) {
+    const float4* mp = (const float4*)((const float*)in + ((size_t)b * C + c) * HIN * HIN) + row0 * (HIN / 4);
+    const float4* kp = (const float4*)((const float*)kern + ((size_t)b * C + c) * KH * KH);
+#pragma unroll
+    for (int i = 0; i < MAP_IT; ++i) {
+      const int k = tid + NT * i;
+      mreg[i] = mp[k < nrow_pf * (HIN / 4) ? k : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < K_IT; ++i) kreg[i] = kp[tid + NT * i];
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < MAP_IT; ++i) {
+      const int k = tid + NT * i;
+      if (k < nrow_pf * (HIN / 4)) {
+        const int r = k / (HIN / 4), cc = (k - r * (HIN / 4)) * 4;
+        uint32_t h0, l0, h1, l1;
+        if (SPLIT) { srl_split_bf16(mreg[i].x, mreg[i].y, h0, l0); srl_split_bf16(mreg[i].z, mreg[i].w, h1, l1); }
+        else { h0 = srl_pk_bf16(mreg[i].x, mreg[i].y); h1 = srl_pk_bf16(mreg[i].z, mreg[i].w); l0 = l1 = 0u; }
+        *(uint2*)(xs + r * G::RS + cc) = make_uint2(h0, h1);
+        if (SPLIT) *(uint2*)(xs + TILE + r * G::RS + cc) = make_uint2(l0, l1);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < K_IT; ++i) {
+      const int k4 = 4 * (tid + NT * i), r = k4 / KH, t = k4 - r * KH;   // four consecutive elements of one kernel row
+      uint32_t h0, l0, h1, l1;
+      if (SPLIT) { srl_split_bf16(kreg[i].x, kreg[i].y, h0, l0); srl_split_bf16(kreg[i].z, kreg[i].w, h1, l1); }
+      else { h0 = srl_pk_bf16(kreg[i].x, kreg[i].y); h1 = srl_pk_bf16(kreg[i].z, kreg[i].w); l0 = l1 = 0u; }
+      *(uint2*)(ks + r * G::KR + 16 + t) = make_uint2(h0, h1);
+      if (SPLIT) *(uint2*)(ks + KTILE + r * G::KR + 16 + t) = make_uint2(l0, l1);
+    }
+  };
+  if (PF && c0 < c1) fetch(c0);
   for (int c = c0; c < c1; ++c) {
-    if (IN_PER_C || c == c0) {
+    if (PF) {
+      __syncthreads();   // the previous channel's reads are done (first trip: the zero fill is complete)
+      store();
+      __syncthreads();
+      if (c + 1 < c1) fetch(c + 1);
+    }
+    if (!PF && (IN_PER_C || c == c0)) {
       __syncthreads();   // the previous channel's reads are done (first trip: the zero fill is complete)
       const size_t base = (IN_PER_C ? (size_t)b * C + c : (size_t)b) * HIN * HIN;
       if (HIN % 4 == 0) {   // 4 elements per thread and step
@@ -153,7 +203,7 @@ k_xcorr_mfma(const void* __restrict__ in, const void* __restrict__ kern, float* 
       }
       __syncthreads();
     }
-    if (K_PER_C || c == c0) {   // this channel's (or the sample's) kernel rows into LDS, behind 16 zeros each
+    if (!PF && (K_PER_C || c == c0)) {   // this channel's (or the sample's) kernel rows into LDS, behind 16 zeros each
       if (IN_PER_C || c == c0) {} else __syncthreads();   // (the previous channel's fragment reads are done)
       const size_t kbase = (K_PER_C ? (size_t)b * C + c : (size_t)b) * KH * KH;
       for (int k = tid; k < KH * KH; k += NT) {
