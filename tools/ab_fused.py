@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Which phase bounds the fused thin + 16 -> 16 kernel (csrc/conv_mfma.hip k_thin_conv3x3_x3)?  Ablation by source edit:
 
-  ab_fused.py build     (here, CPU: hipcc cross-compiles)  variants of conv_mfma.hip with one phase removed -> ab_libs/fused_*.so
+  ab_fused.py build     (here, CPU: hipcc cross-compiles)  variants of conv_mfma.hip with one phase removed (or, the last two,
+                        with plain stores / the compiler's two workgroups per CU: what the kernel had before) -> ab_libs/fused_*.so
   ab_fused.py run [B]   (GPU box)  times srl_thin_conv3x3_bias_relu_f32 (uint8 128 x 128 x 2 -> skip slice + pooled) per variant
 
 The variants' outputs are wrong by construction; only their durations mean anything."""
@@ -9,27 +10,20 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 AB = os.path.join(ROOT, 'ab_libs')
 SRC = os.path.join(ROOT, 'stackrl_amd', 'csrc', 'conv_mfma.hip')
-LB4 = ('template <int CT, typename TIN, bool PROJ>\n__global__ void __launch_bounds__(256, 2)', 'template <int CT, typename TIN, bool PROJ>\n__global__ void __launch_bounds__(256, 4)')
-NT_SKIP = ('        *(float4*)(out + (((size_t)b * H + y) * W + x) * ostride + ooff + co) = val[r];',
-           '        __builtin_nontemporal_store(*(const f32x4*)&val[r], (f32x4*)(out + (((size_t)b * H + y) * W + x) * ostride + ooff + co));')
-NT_POOL = ('          *(float4*)(pooled + (((size_t)b * (H / 2) + y2) * (W / 2) + x2) * COUT + co) = make_float4(m[0], m[1], m[2], m[3]);',
-           '          __builtin_nontemporal_store((f32x4){m[0], m[1], m[2], m[3]}, (f32x4*)(pooled + (((size_t)b * (H / 2) + y2) * (W / 2) + x2) * COUT + co));')
+LB2 = ('template <int CT, typename TIN, bool PROJ>\n__global__ void __launch_bounds__(256, 4)', 'template <int CT, typename TIN, bool PROJ>\n__global__ void __launch_bounds__(256, 2)')
+NT_OFF = ('  __builtin_nontemporal_store(v, (f32x4*)p);', '  *(f32x4*)p = v;')
 VARIANTS = {
   'default': [],
   'no_thin_fma': [('      thin_outputs<CT, 8>(v, w1 + half * 8 * CT * 9, b1 + half * 8, r);',
                    '      for (int i = 0; i < 8; ++i) r[i] = v[i % (9 * CT)] + b1[half];')],
-  'no_mfma': [('      acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], xh, acc[r][0], 0, 0, 0);\n'
-               '      acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], xl, acc[r][0], 0, 0, 0);\n'
-               '      acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], xh, acc[r][0], 0, 0, 0);\n    }\n  }\n  x3_epilogue<16, 1, RW, PROJ>',
-               '      acc[r][0][0] += (float)xh[0] + (float)xl[1] + (float)wl[ks][0] + (float)wh[ks][1];\n    }\n  }\n  x3_epilogue<16, 1, RW, PROJ>')],
+  'no_mfma': [('  x3_mfma_pass<16, RW, 1>(tile, PLANE, row0, n, g, wh, wl, acc);\n',
+               '  for (int r = 0; r < RW; ++r) acc[r][0][0] += (float)tile[(row0 + r) * G::TW * G::PS + n] + (float)wh[r][0][0] + (float)wl[r][0][1];\n')],
   'one_round': [('  for (int j = 0; j < 3; ++j) {\n    const int wid = __builtin_amdgcn_readfirstlane(4 * j + wave);   // 0 .. 11',
                  '  for (int j = 0; j < 1; ++j) {\n    const int wid = __builtin_amdgcn_readfirstlane(4 * j + wave);   // 0 .. 11')],
   'no_store': [('  x3_epilogue<16, 1, RW, PROJ>(acc, bias, out, pooled, H, W, ostride, ooff, nchw, pw, pb, proj_out, H, W, b, x0, y0, 0, row0, n, g);\n}',
                 '  if (acc[0][0][0] == 12345.678f) x3_epilogue<16, 1, RW, PROJ>(acc, bias, out, pooled, H, W, ostride, ooff, nchw, pw, pb, proj_out, H, W, b, x0, y0, 0, row0, n, g);\n}')],
-  'nt': [NT_SKIP, NT_POOL],
-  'lb4_nt': [LB4, NT_SKIP, NT_POOL],
-  'lb3': [(LB4[0], LB4[1].replace('(256, 4)', '(256, 3)'))],
-  'lb4': [LB4],
+  'plain_stores': [NT_OFF],
+  'lb2': [LB2],
 }
 
 
