@@ -297,12 +297,13 @@ def env_leg(args, rank, world, pool, barrier, solver_kw):
   env.set_profiling(True)
   barrier()
   t0 = time.perf_counter()
-  placed, alg = 0, 0
+  placed, alg, rocks = 0, 0, 0
   res, r = env.config.overhead_res, env.config.object_res
   last = None
   for _ in range(args.steps):
     last, p, nb = do_step()
     placed += p
+    rocks += nb
     alg += B * alg_bytes_per_env(res, r, nb)
   barrier()
   dt = time.perf_counter() - t0
@@ -334,7 +335,7 @@ def env_leg(args, rank, world, pool, barrier, solver_kw):
     sweeps.append(env.sweeps())
   do_step()[0]()
   sub, sw = np.stack(subs), np.stack(sweeps)
-  out = dict(B=B, L=L, res=res, r=r, dt=dt, placed=placed, alg=alg, ms=ms, nl=nl, sub=sub, sw=sw, config=env.config,
+  out = dict(B=B, L=L, res=res, r=r, dt=dt, placed=placed, alg=alg, rocks=rocks, ms=ms, nl=nl, sub=sub, sw=sw, config=env.config,
              long_value=long_value, long_steps=long_steps)
   env.close()
   torch.cuda.synchronize()
@@ -655,6 +656,8 @@ def worker(args):
         'traffic_source': traffic_source,
         'avg_launch_us': 1e3 * float(ms[1]) / max(int(nl[1]), 1), 'launches': int(nl[1]),
         'alg_bytes_per_launch': a['alg'] / max(int(nl[1]), 1),
+        # rocks in the scene, averaged over the timed launches (a whole episode cycle: L / 2; the kernel's time grows with it)
+        'scene_rocks_mean': a['rocks'] / max(int(nl[1]), 1),
         # since round 4 the rocks' planes / outlines are prepared by their own kernel (one wave per rock, no tile: csrc/render.hip
         # srl_k_stage) and srl_k_render reads the finished records; its time is NOT part of `achieved` and is stated here
         'stage_kernel': {'kernel': 'srl_k_stage', 'avg_launch_us': 1e3 * float(ms[2]) / max(int(nl[2]), 1), 'launches': int(nl[2])},
