@@ -293,6 +293,36 @@ __device__ __forceinline__ float dpp_min(float v) {
   return fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)));
 }
 
+// The in-wave stages of the halving tree (p[t] += p[t + s] for t < s, s = 32, 16, 8, 4, 2, 1; lane 0 ends with the sum): the
+// partner's value comes by v_permlane32_swap / v_permlane16_swap (halves, rows of 16 lanes) and DPP row shifts instead of six
+// ds_bpermute round trips (`__shfl_down`) — the same pairs added in the same order, so the same bits.
+__device__ __forceinline__ float halving_sum(float v) {
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = v + __uint_as_float(r[1]);   // r[1] lanes 0..31 = lanes 32..63 of v
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = v + __uint_as_float(r[1]);   // r[1] row 0 = row 1 of v (lanes 16..31)
+  }
+  v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x108, 0xf, 0xf, true));   // row_shl:8
+  v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0xf, true));   // row_shl:4
+  v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x102, 0xf, 0xf, true));   // row_shl:2
+  v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true));   // row_shl:1
+  return v;
+}
+
+// inclusive prefix sum over lanes 0 .. 31 (integers): four DPP row shifts within the rows of 16 lanes (zero shifted in) and one
+// row broadcast that adds lane 15 to row 1 — no ds_bpermute round trips in the prologue's chain
+__device__ __forceinline__ int prefix32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+  return v;
+}
+
 // min / max over the 64 lanes of a wave by DPP row shifts and row broadcasts (no LDS traffic); the result is
 // returned to every lane through an SGPR.  min / max are idempotent, so lanes without a source keep their own value.
 template <bool MIN>
@@ -606,8 +636,7 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
     // a rock's region holds its up-facing planes and the sides of its outline (a rock outside the window has neither)
     const int nt = tid < nb ? hd0.z + hd0.w : 0;
     int pre = nt;   // inclusive prefix of the region sizes over the rocks (lanes 0..31 of wave 0)
-#pragma unroll
-    for (int d = 1; d < SRL_MAX_BODIES; d <<= 1) { const int v = __shfl_up(pre, d); if (lane >= d) pre += v; }
+    pre = prefix32(pre);
     const int be0 = __popcll(__ballot(tid < nb && pre <= SRL_PLANE_CAP));   // rocks whose planes fit the first group
     if (tid == 0) L.misc[0] = be0;
     if (tid < nb) {
@@ -974,8 +1003,7 @@ srl_k_render(DevParams P, const float4* __restrict__ stage, int slots, uint8_t* 
     for (int k = 0; k < 8; ++k) { qi[k] = L.pi[tid + 64 * k]; qu[k] = L.pu[tid + 64 * k]; }
     sum_i = ((qi[0] + qi[4]) + (qi[2] + qi[6])) + ((qi[1] + qi[5]) + (qi[3] + qi[7]));
     sum_u = ((qu[0] + qu[4]) + (qu[2] + qu[6])) + ((qu[1] + qu[5]) + (qu[3] + qu[7]));
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) { sum_i = sum_i + __shfl_down(sum_i, s); sum_u = sum_u + __shfl_down(sum_u, s); }   // p[t] += p[t+s], t < s
+    sum_i = halving_sum(sum_i); sum_u = halving_sum(sum_u);   // p[t] += p[t + s], t < s, s = 32 ... 1: lane 0 holds the sum
   }
   // ---- K5: reward = scale * (metric_t - metric_{t-1})  (rewarder.py:176-179)
   //      'all' (rewarder.py:157-158): the four metrics at once, reward[e][4]; 'eval' (rewarder.py:147-156): reward[e][2] = the
