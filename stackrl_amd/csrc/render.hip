@@ -554,12 +554,14 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_stage(DevParams P, float
     int c = 0, incl = 0, rmin = 0x7fffffff;
     if (lane < SRL_STAGE_SPANS) {
       c = S.cnt[w][lane]; incl = c; rmin = S.lo[w][lane];
-#pragma unroll
-      for (int d = 1; d < SRL_STAGE_SPANS; d <<= 1) {
-        const int v = __shfl_up(incl, d), u = __shfl_down(rmin, d);
-        if (lane >= d) incl += v;
-        if (lane + d < SRL_STAGE_SPANS) rmin = min(rmin, u);
-      }
+      // inclusive prefix of the counts and suffix minimum of the first rows over the 16 lanes = one DPP row: shifts by 1, 2, 4,
+      // 8 with zero / INT_MAX shifted in (no ds_bpermute)
+      static_assert(SRL_STAGE_SPANS == 16, "the scans below run over one DPP row");
+#define SRL_SCAN(ctrl_r, ctrl_l)                                                                 \
+      incl += __builtin_amdgcn_update_dpp(0, incl, ctrl_r, 0xf, 0xf, true);                      \
+      rmin = min(rmin, __builtin_amdgcn_update_dpp(0x7fffffff, rmin, ctrl_l, 0xf, 0xf, false));
+      SRL_SCAN(0x111, 0x101) SRL_SCAN(0x112, 0x102) SRL_SCAN(0x114, 0x104) SRL_SCAN(0x118, 0x108)
+#undef SRL_SCAN
       S.st[w][lane] = incl - c; S.cnt[w][lane] = 0;
     }
     __builtin_amdgcn_wave_barrier();
