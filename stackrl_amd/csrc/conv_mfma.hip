@@ -28,6 +28,21 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// The four lane groups of a wave hold the four channel quarters of one pixel: (q0 + q1) + (q2 + q3) into lane group 0 (the
+// other groups' results are not used), the partners' values by v_permlane16_swap / v_permlane32_swap instead of two
+// ds_bpermute round trips (`__shfl_xor` 16, 32) — the same sums in the same order.
+__device__ __forceinline__ float quarter_sum(float v) {
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = v + __uint_as_float(r[1]);   // rows 0 and 2 take rows 1 and 3
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = v + __uint_as_float(r[1]);   // lanes 0..31 take lanes 32..63
+  }
+  return v;
+}
+
 template <int CIN>
 struct ConvCfg {
   static constexpr int KS = CIN == 16 ? 5 : 9 * (CIN / 32);   // K = 32 steps: tap pairs (the 10th tap is zero) | taps x 32-channel blocks
@@ -119,8 +134,7 @@ k_conv3x3(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wfrag, c
     }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {   // the four lane groups hold the four channel quarters of one pixel
-      part[r] += __shfl_xor(part[r], 16);
-      part[r] += __shfl_xor(part[r], 32);
+      part[r] = quarter_sum(part[r]);
       const int y = y0 + row0 + r, x = x0 + n;
       if (g == 0 && y < Hv && x < Wv) proj_out[((size_t)b * Hv + y) * Wv + x] = part[r] + pb;
     }
@@ -203,8 +217,7 @@ __device__ __forceinline__ void x3_epilogue(const f32x4 (&acc)[RW][MT_W], const 
     }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-      part[r] += __shfl_xor(part[r], 16);
-      part[r] += __shfl_xor(part[r], 32);
+      part[r] = quarter_sum(part[r]);
       const int y = y0 + row0 + r, x = x0 + n;
       if (g == 0 && y < Hv && x < Wv) proj_out[((size_t)b * Hv + y) * Wv + x] = part[r] + pb;
     }
