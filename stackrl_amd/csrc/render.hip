@@ -367,6 +367,7 @@ __device__ __forceinline__ float wave_minmax(float v) {
 struct StageLds {
   float4 slot[SRL_MAX_TRIS + 2];     // the rock's up-facing planes from the front, its outline sides from the back; .w = r0 | r1 << 8
   int cnt[2][SRL_STAGE_SPANS], st[2][SRL_STAGE_SPANS], lo[2][SRL_STAGE_SPANS];   // entries per first row, their prefix, first row of the entries that reach a row
+  float2 wxy[128];                   // world xy of the vertices: faces and edges read their end points by vertex id
 };
 
 // item rows [r0, r1] (clamped to the rock's) that a face / edge with x extent [x0, x1] reaches: those of the pixel rows from
@@ -416,15 +417,16 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_stage(DevParams P, float
   if (64 + lane < ne) ed1 = P.me[eo + 64 + lane];
   if (128 + lane < ne) ed2 = P.me[eo + 128 + lane];
   const m3 R = quat_to_mat(q);
-  // world xy of the vertices, one (two) per lane; faces and edges read their end points from these lanes
-  float wx0 = 0.0f, wy0 = 0.0f, wx1 = 0.0f, wy1 = 0.0f;
+  // world xy of the vertices into LDS, one (two) per lane; faces and edges read their end points there by vertex id (one
+  // 8-byte LDS read per end point; as cross-lane reads of per-lane copies they were up to eight ds_bpermute per chunk)
   float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
   for (int v = lane; v < nv; v += 64) {
     const float4 lv = P.mv[vo + v];
     const v3 a = mmul_add(R, V(lv.x, lv.y, lv.z), xb);
-    if (v < 64) { wx0 = a.x; wy0 = a.y; } else { wx1 = a.x; wy1 = a.y; }
+    S.wxy[v] = make_float2(a.x, a.y);
     xmin = fminf(xmin, a.x); xmax = fmaxf(xmax, a.x); ymin = fminf(ymin, a.y); ymax = fmaxf(ymax, a.y);
   }
+  __builtin_amdgcn_wave_barrier();                   // (one wave: LDS keeps its order; the compiler must too)
   xmin = wave_minmax<true>(xmin); xmax = wave_minmax<false>(xmax);
   ymin = wave_minmax<true>(ymin); ymax = wave_minmax<false>(ymax);
   int i0 = 0, i1 = -1, j0 = 0, j1 = -1;
@@ -456,14 +458,8 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_stage(DevParams P, float
       const bool up = act && __float_as_int(wp.w) == 0;
       const unsigned long long mu = __ballot(up);
       if (ch == 0) upm0 = mu; else if (ch == 1) upm1 = mu; else if (ch == 2) upm2 = mu; else upm3 = mu;
-      // world x of the face's three vertices (every lane takes part in every shuffle: no shuffle under a lane-dependent branch)
-      float fa = __shfl(wx0, tr.x & 63), fb = __shfl(wx0, tr.y & 63), fc = __shfl(wx0, tr.z & 63);
-      if (nv > 64) {
-        const float ga = __shfl(wx1, tr.x & 63), gb_ = __shfl(wx1, tr.y & 63), gc = __shfl(wx1, tr.z & 63);
-        if (tr.x >= 64) fa = ga;
-        if (tr.y >= 64) fb = gb_;
-        if (tr.z >= 64) fc = gc;
-      }
+      // world x of the face's three vertices
+      const float fa = S.wxy[tr.x & 127].x, fb = S.wxy[tr.y & 127].x, fc = S.wxy[tr.z & 127].x;
       if (up) {
         const int rr = nir ? slab_range(fminf(fa, fminf(fb, fc)), fmaxf(fa, fmaxf(fb, fc)), P.inv_px, i0, nirows) : 0;
         S.slot[nup + __popcll(mu & below)] = make_float4(wp.x, wp.y, wp.z, __int_as_float(rr));
@@ -486,12 +482,8 @@ extern "C" __global__ void __launch_bounds__(256) srl_k_stage(DevParams P, float
     const bool ua = (ma >> (ed.z & 63)) & 1ull, ub = (mb >> (ed.w & 63)) & 1ull;
     const bool sil = act && (ua != ub);
     const unsigned long long ms = __ballot(sil);
-    float Ax = __shfl(wx0, ed.x & 63), Ay = __shfl(wy0, ed.x & 63), Bx = __shfl(wx0, ed.y & 63), By = __shfl(wy0, ed.y & 63);
-    if (nv > 64) {
-      const float ax1 = __shfl(wx1, ed.x & 63), ay1 = __shfl(wy1, ed.x & 63), bx1 = __shfl(wx1, ed.y & 63), by1 = __shfl(wy1, ed.y & 63);
-      if (ed.x >= 64) { Ax = ax1; Ay = ay1; }
-      if (ed.y >= 64) { Bx = bx1; By = by1; }
-    }
+    const float2 pa = S.wxy[ed.x & 127], pbv = S.wxy[ed.y & 127];
+    const float Ax = pa.x, Ay = pa.y, Bx = pbv.x, By = pbv.y;
     const int sidx = nsil + __popcll(ms & below);
     if (sil && sidx < cap) {
       float ea = Ay - By, eb = Bx - Ax;
