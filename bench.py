@@ -325,6 +325,47 @@ def env_leg(args, rank, world, pool, barrier, solver_kw):
     last()
     torch.cuda.synchronize()
     long_value = lp / (time.perf_counter() - t1)
+  # The same 1,024 envs held as G handles that are NOT kept in lock-step: with a policy that needs no observation (the random
+  # policy of this leg) a group's next step waits for nothing but its own previous one, so a group's launch lasts as long as
+  # the slowest of ITS envs, not of all of them.  Every handle on a stream of its own through the C-ABI (sample, step; output
+  # buffers reused); env i keeps its seed, so its trajectory is the one it has in the lock-step batch.  Reported beside the
+  # contract's figure, never as `value`: the reference's `ParallelEnv.step` waits for all its workers.
+  free_run = None
+  if world == 1 and not os.environ.get('SRL_NO_FREE_RUN'):
+    import ctypes
+    G = int(os.environ.get('SRL_FREE_RUN_GROUPS', 4))     # (2: +12 %, 4: +25 %, 8: -29 %, 32: -61 %: more streams than hardware queues queue behind one another)
+    if B % G == 0:
+      gs = [envs.VecStackEnv(n_parallel=B // G, seed=args.seed, pool=pool, block=False, episode_length=L,
+                             env_index_offset=rank * B + k * (B // G), concurrent_envs=B, **kw) for k in range(G)]
+      sts = [torch.cuda.Stream() for _ in range(G)]
+      bufs = []
+      for g_ in gs:
+        n_ = B // G
+        bufs.append((torch.empty(n_, dtype=torch.int64, device='cuda'), torch.empty((n_, res, res, 2), dtype=torch.uint8, device='cuda'),
+                     torch.empty((n_, r, r, 1), dtype=torch.uint8, device='cuda'), torch.empty(n_, dtype=torch.float32, device='cuda'),
+                     torch.empty(n_, dtype=torch.uint8, device='cuda')))
+        g_.reset()()
+      torch.cuda.synchronize()
+      VP = ctypes.c_void_p
+
+      def run(calls):
+        for _ in range(calls):
+          for g_, st_, (a_, om_, oo_, rw_, dn_) in zip(gs, sts, bufs):
+            sp = VP(st_.cuda_stream)
+            assert g_._lib.srl_sample(g_._h, VP(a_.data_ptr()), sp) == 0
+            assert g_._lib.srl_step(g_._h, VP(a_.data_ptr()), VP(om_.data_ptr()), VP(oo_.data_ptr()), VP(rw_.data_ptr()), VP(dn_.data_ptr()), sp) == 0
+      run(L + 1)                                   # one whole episode cycle: warm-up, and every handle back at an episode start
+      torch.cuda.synchronize()
+      t2 = time.perf_counter()
+      cycles = 6
+      run(cycles * (L + 1))
+      torch.cuda.synchronize()
+      free_run = {'groups': G, 'value': cycles * L * B / (time.perf_counter() - t2), 'steps': cycles * (L + 1), 'unit': 'env_steps/s',
+                  'note': 'the same envs as G handles on G streams, not in lock-step (random policy: no observation is waited for); '
+                          'placements per second over six whole episodes, comparable with value_long'}
+      for g_, st_ in zip(gs, sts):
+        envs._check(g_._lib.srl_sync_status(g_._h, VP(st_.cuda_stream)))     # raises if an env diverged / an action was invalid
+        g_.close()
   # statistics of one further (untimed) episode: what the stop criterion and the residual threshold asked of the kernel
   subs, sweeps = [], []
   while phase['k'] != 0:
@@ -336,7 +377,7 @@ def env_leg(args, rank, world, pool, barrier, solver_kw):
   do_step()[0]()
   sub, sw = np.stack(subs), np.stack(sweeps)
   out = dict(B=B, L=L, res=res, r=r, dt=dt, placed=placed, alg=alg, rocks=rocks, ms=ms, nl=nl, sub=sub, sw=sw, config=env.config,
-             long_value=long_value, long_steps=long_steps)
+             long_value=long_value, long_steps=long_steps, free_run=free_run)
   env.close()
   torch.cuda.synchronize()
   return out
@@ -646,6 +687,8 @@ def worker(args):
       'step_calls_per_s': args.steps * B * args.gpus / dt_max,
       # the same loop over 54 calls = six whole episodes (the K-step window above starts mid-episode and weighs the fuller scenes more)
       'value_long': None if a.get('long_value') is None else {'value': a['long_value'], 'steps': a['long_steps'], 'unit': 'env_steps/s'},
+      # the same envs as handles that are not kept in lock-step (see env_leg): a capability of the interface, not the contract's figure
+      'value_free_running': a.get('free_run'),
       # which build of the env library was timed (stackrl_amd/build.py: 'vectorised+rewritten' = SLP vectoriser + the pass of
       # isa_fix.py over the assembly; 'safe' = the fall-back without the vectoriser) and the hash of the sources it carries
       'env_library': build_info(),
