@@ -144,6 +144,19 @@ class OracleEnv(object):
       raise ValueError(self.L.srlo_last_error().decode())
     return out
 
+  def render_heightmap_all(self, poses, mesh_ids, form=1, raw=False):
+    """The plain statement of the overhead map (observer.py:252-260): form 1 = every pixel of a rock's bounding box against
+    all up-facing faces and all outline sides, form 2 = the hull interval over all planes, form 0 = the culled definition
+    `render_heightmap` runs; raw: heights before the depth codec."""
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
+    mesh_ids = np.ascontiguousarray(mesh_ids, np.int32)
+    out = np.zeros((self.H, self.H), np.float32)
+    rc = self.L.srlo_render_heightmap_all(self.h, _p(poses), _p(mesh_ids), ctypes.c_int32(len(mesh_ids)), ctypes.c_int32(form),
+                                          ctypes.c_int32(1 if raw else 0), _p(out))
+    if rc:
+      raise ValueError(self.L.srlo_last_error().decode())
+    return out
+
   def render_object(self, mesh_id):
     k = self.cfg.n_orientations
     out = np.zeros((self.h_, self.h_) if k == 1 else (k, self.h_, self.h_), np.float32)

@@ -558,8 +558,8 @@ static int span_columns(const struct srlo_env* e, int ns, const float* ea, const
 }
 
 /* O1: overhead height map of the placed bodies (observer.py:252-260; row <-> +x, col <-> +y) */
-static void render_heightmap(const struct srlo_env* e, int nb, const int* mesh, const v3* x,
-                             const q4* q, float* H) {
+static void render_heightmap_raw(const struct srlo_env* e, int nb, const int* mesh, const v3* x,
+                                 const q4* q, float* H) {
   const srl_config* c = &e->c;
   int res = c->overhead_res;
   for (int k = 0; k < res * res; ++k) H[k] = 0.0f;
@@ -633,11 +633,83 @@ static void render_heightmap(const struct srlo_env* e, int nb, const int* mesh, 
       }
     }
   }
+}
+
+/* heights above the ground -> what Observer.state[0] holds: TinyRenderer's depth encoding and the reference's decode */
+static void heightmap_codec(const struct srlo_env* e, float* H) {
+  const srl_config* c = &e->c;
+  const int res = c->overhead_res;
   float nearp = FAR_PLANE - c->max_z;
   for (int k = 0; k < res * res; ++k) {
     float d = depth_encode(FAR_PLANE - H[k], nearp, FAR_PLANE);
     H[k] = elev_overhead(c, d);
   }
+}
+
+static void render_heightmap(const struct srlo_env* e, int nb, const int* mesh, const v3* x, const q4* q, float* H) {
+  render_heightmap_raw(e, nb, mesh, x, q, H);
+  heightmap_codec(e, H);
+}
+
+/* O1, THE PLAIN STATEMENT (observer.py:252-260: one getCameraImage call of the overhead camera).  Kept apart from
+ * render_heightmap on purpose and never to be touched by a render optimisation: no item rows, no list ranges, no column
+ * spans — every pixel of a rock's bounding box consults every face / every outline side.  tests/test_render_plain.py holds
+ * render_heightmap (the culled definition above, which the kernels restate) to this function on random scenes, and the
+ * `-m gpu` tests hold srl_render_heightmap to it.
+ *   form 1: max over rocks of (min over ALL up-facing planes) where every outline side's E(p) >= 0   (round-3 definition)
+ *   form 2: max over rocks of z_hi where z_lo <= z_hi over ALL planes (no edge table at all)          (round-1 definition)
+ * raw != 0: heights before the depth codec (where the culled definition may differ in the last bit on coplanar faces);
+ * raw == 0: after the codec, as Observer.state[0] holds them. */
+static void render_heightmap_all(const struct srlo_env* e, int nb, const int* mesh, const v3* x, const q4* q, int form,
+                                 int raw, float* H) {
+  const srl_config* c = &e->c;
+  const int res = c->overhead_res;
+  for (int k = 0; k < res * res; ++k) H[k] = 0.0f;
+  for (int b = 0; b < nb; ++b) {
+    const mesh_t* M = &e->mesh[mesh[b]];
+    m3 R = quat_to_mat(q[b]);
+    float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+    for (int k = 0; k < M->nv; ++k) {
+      v3 a = mmul_add(&R, M->v[k], x[b]);
+      xmin = fminf(xmin, a.x); xmax = fmaxf(xmax, a.x);
+      ymin = fminf(ymin, a.y); ymax = fmaxf(ymax, a.y);
+    }
+    int i0, i1, j0, j1;
+    if (!pixel_range(xmin, xmax, e->inv_px, res, &i0, &i1)) continue;
+    if (!pixel_range(ymin, ymax, e->inv_px, res, &j0, &j1)) continue;
+    rplane_t pl[MAXT];
+    const int np = make_rplanes(M, &R, x[b], pl);
+    float ea[3 * MAXT / 2 + 3], eb[3 * MAXT / 2 + 3], ec[3 * MAXT / 2 + 3];
+    int ns = 0;
+    if (form == 1)
+      for (int k = 0; k < M->ne; ++k) {
+        const uint8_t* e4 = M->edge[k];
+        if (pl[e4[2]].type == pl[e4[3]].type) continue;       /* not on the outline */
+        v3 A = mmul_add(&R, M->v[e4[0]], x[b]), B = mmul_add(&R, M->v[e4[1]], x[b]);
+        float a = A.y - B.y, bb = B.x - A.x;
+        float cc = -fmaf(a, A.x, bb * A.y);
+        float s = fmaf(a, x[b].x, fmaf(bb, x[b].y, cc));      /* the centre of mass is inside */
+        if (s < 0.0f) { a = -a; bb = -bb; cc = -cc; }
+        ea[ns] = a; eb[ns] = bb; ec[ns] = cc; ++ns;
+      }
+    for (int i = i0; i <= i1; ++i) {
+      float px = ((float)i + 0.5f) * e->px;
+      for (int j = j0; j <= j1; ++j) {
+        float py = ((float)j + 0.5f) * e->px;
+        if (form == 1) {
+          float hi = 1e30f, lo = 1e30f;
+          for (int t = 0; t < np; ++t)
+            if (pl[t].type == 0) hi = fminf(hi, fmaf(pl[t].a, px, fmaf(pl[t].b, py, pl[t].c)));
+          for (int t = 0; t < ns; ++t) lo = fminf(lo, fmaf(ea[t], px, fmaf(eb[t], py, ec[t])));
+          if (ns > 0 && lo >= 0.0f && hi > H[i * res + j]) H[i * res + j] = hi;
+        } else {
+          float lo, hi;
+          if (ray_cast(pl, np, px, py, &lo, &hi) && hi > H[i * res + j]) H[i * res + j] = hi;
+        }
+      }
+    }
+  }
+  if (!raw) heightmap_codec(e, H);
 }
 
 /* O2: underside map of a mesh at the spawn pose (link frame at spawn, identity orientation;
@@ -1854,6 +1926,26 @@ int srlo_render_heightmap(srlo_env* e, const float* poses, const int32_t* mesh_i
     q[b].x = poses[7 * b + 3]; q[b].y = poses[7 * b + 4]; q[b].z = poses[7 * b + 5]; q[b].w = poses[7 * b + 6];
   }
   render_heightmap(e, nb, mesh, x, q, height);
+  return SRL_OK;
+}
+
+/* The plain statement of O1 (render_heightmap_all) and, for the comparison before the codec, the culled definition's raw
+ * heights.  form: 0 = the culled definition (item rows, ranges, spans), 1 = all faces / all outline sides / every pixel of
+ * the bounding box, 2 = z_lo <= z_hi over all planes.  raw != 0: heights before the depth codec. */
+int srlo_render_heightmap_all(srlo_env* e, const float* poses, const int32_t* mesh_ids, int32_t nb, int32_t form,
+                              int32_t raw, float* height) {
+  if (!e->mesh) return fail(SRL_ENOMESH, "load meshes first");
+  if (nb < 0 || nb > MAXB) return fail(SRL_EINVAL, "n_bodies out of range");
+  if (form < 0 || form > 2) return fail(SRL_EINVAL, "form is 0 (culled), 1 (plain outline) or 2 (hull interval)");
+  int mesh[MAXB]; v3 x[MAXB]; q4 q[MAXB];
+  for (int b = 0; b < nb; ++b) {
+    if (mesh_ids[b] < 0 || mesh_ids[b] >= e->n_mesh) return fail(SRL_EINVAL, "mesh id out of range");
+    mesh[b] = mesh_ids[b];
+    x[b] = V(poses[7 * b], poses[7 * b + 1], poses[7 * b + 2]);
+    q[b].x = poses[7 * b + 3]; q[b].y = poses[7 * b + 4]; q[b].z = poses[7 * b + 5]; q[b].w = poses[7 * b + 6];
+  }
+  if (form == 0) { render_heightmap_raw(e, nb, mesh, x, q, height); if (!raw) heightmap_codec(e, height); }
+  else render_heightmap_all(e, nb, mesh, x, q, form, raw, height);
   return SRL_OK;
 }
 

@@ -74,6 +74,10 @@ int srlo_get_sweeps(srlo_env* e, int32_t* sweeps);
  * mesh_ids [n_bodies]  ->  height f32 [H*W]. */
 int srlo_render_heightmap(srlo_env* e, const float* poses, const int32_t* mesh_ids,
                           int32_t n_bodies, float* height);
+/* the plain statement of the overhead map (form 1: all faces, all outline sides, every bounding-box pixel; form 2: the hull
+ * interval z_lo <= z_hi; form 0: the culled definition srlo_render_heightmap runs); raw: heights before the depth codec */
+int srlo_render_heightmap_all(srlo_env* e, const float* poses, const int32_t* mesh_ids, int32_t n_bodies, int32_t form,
+                              int32_t raw, float* height);
 int srlo_render_object(srlo_env* e, int32_t mesh_id, float* object_map);
 /* depth->elevation, observer.py:259-260 (which = 0) and :274-277 incl. flip (which = 1) */
 void srlo_depth_to_elevation(const srl_config* cfg, int which, const float* depth, float* elev);

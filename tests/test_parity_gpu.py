@@ -266,6 +266,7 @@ def test_full_size_batch_properties(ref_pool):
 
 @pytest.mark.parametrize('B,L,kw', [
   (4096, 16, {}),                                # BASELINE configs[2] per-GPU size
+  (2048, 16, {}),                                # BASELINE configs[3] per-GPU shard (8,192 envs over 4 GPUs): four-wave variant + ordered launch
   (2048, 32, dict(resolution_factor=4)),         # BASELINE configs[4] per-GPU size: 32 rocks, 64 x 64 maps
 ])
 def test_full_size_dqn_config_properties(B, L, kw):
