@@ -171,21 +171,72 @@ def _cpu_worker(a):
   return n * L * episodes, time.perf_counter() - t0
 
 
-def cpu_baseline(L, seed, kw, budget_envs=48, episodes=20):
-  """The oracle (oracle/srl_oracle.c, built -O3 at the x86-64-v3 level, oracle/Makefile) on this host's cores: `cores` processes x `budget_envs`
-  envs x `episodes` episodes of the same workload, forked before this process touches the GPU."""
+def host_cores():
+  """(physical cores this process may run on, logical CPUs it may run on, cgroup CPU quota in cores or None).  Physical cores =
+  distinct (physical id, core id) pairs of /proc/cpuinfo among the CPUs of the affinity mask; the quota is cpu.max (cgroup v2)
+  or cfs_quota / cfs_period (v1) when the container has one."""
+  try:
+    allowed = sorted(os.sched_getaffinity(0))
+  except AttributeError:
+    allowed = list(range(os.cpu_count() or 1))
+  phys, cur = set(), {}
+  try:
+    with open('/proc/cpuinfo') as f:
+      for line in f:
+        if ':' in line:
+          k, v = [t.strip() for t in line.split(':', 1)]
+          cur[k] = v
+        elif not line.strip() and cur:
+          if int(cur.get('processor', -1)) in allowed and 'core id' in cur:
+            phys.add((cur.get('physical id', '0'), cur['core id']))
+          cur = {}
+    if cur and int(cur.get('processor', -1)) in allowed and 'core id' in cur:
+      phys.add((cur.get('physical id', '0'), cur['core id']))
+  except (OSError, ValueError):
+    pass
+  quota = None
+  try:
+    with open('/sys/fs/cgroup/cpu.max') as f:
+      q, per = f.read().split()[:2]
+      if q != 'max':
+        quota = float(q) / float(per)
+  except (OSError, ValueError):
+    try:
+      with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as g:
+        q, per = float(f.read()), float(g.read())
+        if q > 0:
+          quota = q / per
+    except (OSError, ValueError):
+      pass
+  return (len(phys) or len(allowed)), len(allowed), quota
+
+
+def _cpu_pool_run(cores, budget_envs, L, seed, episodes, kw):
   import multiprocessing as mp
-  # sample: about 10 s of work per core (the contract asks for 10 - 30 s of CPU work): 48 envs x 20 episodes per process at
-  # ~1 k placements/s per core; the one-thread figure on a tenth of it
-  cores = min(os.cpu_count() or 1, 16)
-  n1, t1 = _cpu_worker((budget_envs, L, seed, 0, max(1, episodes // 10), kw))     # one-thread figure first
   ctx = mp.get_context('fork')
   t0 = time.perf_counter()
   with ctx.Pool(cores) as pool:
-    res = pool.map(_cpu_worker, [(budget_envs, L, seed, i * budget_envs, episodes, kw) for i in range(cores)])
+    res = pool.map(_cpu_worker, [(budget_envs, L, seed, i * budget_envs, episodes, kw) for i in range(cores)], chunksize=1)
   wall = time.perf_counter() - t0
-  placed = sum(r[0] for r in res)
-  busy = max(r[1] for r in res)
+  return sum(r[0] for r in res), max(r[1] for r in res), wall
+
+
+def cpu_baseline(L, seed, kw, budget_envs=48, episodes=20):
+  """The oracle (oracle/srl_oracle.c, built -O3 at the x86-64-v3 level, oracle/Makefile) on this host's cores, forked before
+  this process touches the GPU.  `value` / `cores`: one process per PHYSICAL core the process may use (the reference's own
+  default is every core, envs/utils.py:342 `n_parallel or mp.cpu_count()`; BASELINE.md section 3: "1 thread and all physical
+  cores"), each stepping `budget_envs` envs through `episodes` episodes of the same workload (about 10 s of work per core);
+  the 16-process figure of rounds 1 - 4 and the one-thread figure are kept beside it."""
+  phys, logical, quota = host_cores()
+  cores = phys
+  if os.environ.get('SRL_CPU_CORES'):                  # experiments / small boxes
+    cores = max(1, int(os.environ['SRL_CPU_CORES']))
+  n1, t1 = _cpu_worker((budget_envs, L, seed, 0, max(1, episodes // 10), kw))     # one-thread figure first
+  placed, busy, wall = _cpu_pool_run(cores, budget_envs, L, seed, episodes, kw)
+  sixteen = None
+  if cores > 16:
+    p16, b16, w16 = _cpu_pool_run(16, budget_envs, L, seed, episodes, kw)
+    sixteen = {'value': p16 / b16, 'cores': 16, 'wall_s': round(w16, 1)}
   model = None
   try:
     with open('/proc/cpuinfo') as f:
@@ -194,9 +245,14 @@ def cpu_baseline(L, seed, kw, budget_envs=48, episodes=20):
     pass
   return {
     'value': placed / busy, 'unit': 'env_steps/s', 'cores': cores, 'kind': 'port', 'nproc': os.cpu_count(), 'cpu_model': model,
-    'sample': '{} procs x {} envs x {} episode(s) of {} placements (oracle/srl_oracle.c -O3 x86-64-v3, same pool, '
+    'physical_cores': phys, 'logical_cpus_allowed': logical, 'cgroup_cpu_quota': quota,
+    # placements / the slowest process's busy time (every process does the same amount of work); by the wall clock of the
+    # whole pool, process start included, it is value_by_wall
+    'value_by_wall': placed / wall,
+    'sample': '{} procs (one per physical core) x {} envs x {} episode(s) of {} placements (oracle/srl_oracle.c -O3 x86-64-v3, same pool, '
               'RNG keys and solver definition); wall incl. process start {:.1f}s'.format(cores, budget_envs, episodes, L, wall),
     'single_thread_value': n1 / t1,
+    'sixteen_process_value': sixteen,
   }
 
 
@@ -235,26 +291,42 @@ def _latest_profile(pattern):
     return None, None
 
 
-def traffic_record(B, L, res):
-  """HBM bytes per render launch from the PMC counters (profiles/rNN_render_pmc.json, tools/pmc_summary.py)."""
+def traffic_record(B, L, res, alg_bytes_per_launch=None):
+  """HBM bytes per render launch from the PMC counters (profiles/rNN_render_pmc.json, tools/pmc_summary.py, launches of B
+  workgroups only).  A counter figure outside [0.8, 1.5] x the algorithmic bytes is not printed as traffic: every byte of H and
+  of the observation is compared in the parity tests, so less than the algorithmic stores is a summarising error (round 4: a
+  mean over launches of two batch sizes), and the note says so."""
   if not (B == 1024 and L == 8 and res == 128):
     return None, None
   rel, d = _latest_profile('render_pmc.json')
   if d is None:
     return None, None
-  return d.get('traffic_bytes_per_launch'), {'file': rel, 'commit': d.get('commit'),
-                                              'how': 'separate rocprofv3 --pmc passes of bench.py (FETCH_SIZE, WRITE_SIZE)'}
+  src = {'file': rel, 'commit': d.get('commit'), 'workgroups_per_launch': d.get('workgroups_per_launch'),
+         'how': 'separate rocprofv3 --pmc passes of bench.py (FETCH_SIZE, WRITE_SIZE)'}
+  t = d.get('traffic_bytes_per_launch')
+  alg = alg_bytes_per_launch or d.get('algorithmic_bytes_per_launch')
+  if t is None or d.get('workgroups_per_launch') not in (None, B) or (alg and not (0.8 <= t / alg <= 1.5)):
+    src['note'] = 'counter figure {} B per launch rejected (not of {}-workgroup launches, or outside [0.8, 1.5] x the algorithmic bytes)'.format(t, B)
+    return None, src
+  src['traffic_over_algorithmic'] = None if not alg else round(t / alg, 4)
+  return t, src
 
 
 def settle_counters(B, L, res):
-  """VALU utilisation and waiting share of srl_k_step from its PMC passes (profiles/rNN_settle_pmc.json, tools/pmc_insts.py)."""
+  """VALU utilisation and waiting share of srl_k_step from its PMC passes (profiles/rNN_settle_pmc.json, tools/pmc_insts.py).
+  Only a summary over launches of this batch (two waves per env at 8 rocks) is printed; a mean over launches of several batch
+  sizes (round 4's last file: 914.8 waves per launch) is rejected with a note."""
   if not (B == 1024 and L == 8 and res == 128):
     return {}
   rel, d = _latest_profile('settle_pmc.json')
   if d is None:
     return {}
-  return {'valu_util': d.get('valu_util'), 'wait_frac': d.get('wait_frac'),
-          'counters_source': {'file': rel, 'commit': d.get('commit'), 'how': d.get('how')}}
+  src = {'file': rel, 'commit': d.get('commit'), 'how': d.get('how'), 'workgroups_per_launch': d.get('workgroups_per_launch')}
+  waves = d.get('waves')
+  if waves is not None and abs(waves - 2 * B) > 0.5:
+    src['note'] = 'rejected: the summary averages launches of several batch sizes ({} waves per launch, this batch has {})'.format(waves, 2 * B)
+    return {'valu_util': None, 'wait_frac': None, 'counters_source': src}
+  return {'valu_util': d.get('valu_util'), 'wait_frac': d.get('wait_frac'), 'counters_source': src}
 
 
 def mfma_counters(dtype):
@@ -668,7 +740,7 @@ def worker(args):
 
   def make_line(dqn, mse):
     B, res, ms, nl, sub, sw = a['B'], a['res'], a['ms'], a['nl'], a['sub'], a['sw']
-    traffic, traffic_source = traffic_record(B, a['L'], res)
+    traffic, traffic_source = traffic_record(B, a['L'], res, a['alg'] / max(int(nl[1]), 1))
     render_s = float(ms[1]) / 1e3
     cfg = a['config']
     line = {
