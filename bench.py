@@ -228,7 +228,10 @@ def cpu_baseline(L, seed, kw, budget_envs=48, episodes=20):
   cores"), each stepping `budget_envs` envs through `episodes` episodes of the same workload (about 10 s of work per core);
   the 16-process figure of rounds 1 - 4 and the one-thread figure are kept beside it."""
   phys, logical, quota = host_cores()
-  cores = phys
+  # one process per physical core the container may actually use: under a cgroup CPU quota (the GPU boxes of this pool give a
+  # one-GPU container cpu.max = 16 cores of the host's 128) more processes only share the quota's cores — measured on such a
+  # box: 128 processes 13.0 k placements/s against 16.8 k with 16 (profiles/r05_cpu_quota_probe.txt)
+  cores = phys if quota is None else max(1, min(phys, int(quota)))
   if os.environ.get('SRL_CPU_CORES'):                  # experiments / small boxes
     cores = max(1, int(os.environ['SRL_CPU_CORES']))
   n1, t1 = _cpu_worker((budget_envs, L, seed, 0, max(1, episodes // 10), kw))     # one-thread figure first
@@ -249,7 +252,9 @@ def cpu_baseline(L, seed, kw, budget_envs=48, episodes=20):
     # placements / the slowest process's busy time (every process does the same amount of work); by the wall clock of the
     # whole pool, process start included, it is value_by_wall
     'value_by_wall': placed / wall,
-    'sample': '{} procs (one per physical core) x {} envs x {} episode(s) of {} placements (oracle/srl_oracle.c -O3 x86-64-v3, same pool, '
+    'cores_note': ('one process per physical core' if quota is None or quota >= phys else
+                   'the container\'s CPU quota (cgroup cpu.max) is {:g} cores of the host\'s {} physical cores: one process per usable core'.format(quota, phys)),
+    'sample': '{} procs (one per usable physical core) x {} envs x {} episode(s) of {} placements (oracle/srl_oracle.c -O3 x86-64-v3, same pool, '
               'RNG keys and solver definition); wall incl. process start {:.1f}s'.format(cores, budget_envs, episodes, L, wall),
     'single_thread_value': n1 / t1,
     'sixteen_process_value': sixteen,
@@ -773,9 +778,13 @@ def worker(args):
         'alg_bytes_per_launch': a['alg'] / max(int(nl[1]), 1),
         # rocks in the scene, averaged over the timed launches (a whole episode cycle: L / 2; the kernel's time grows with it)
         'scene_rocks_mean': a['rocks'] / max(int(nl[1]), 1),
-        # since round 4 the rocks' planes / outlines are prepared by their own kernel (one wave per rock, no tile: csrc/render.hip
-        # srl_k_stage) and srl_k_render reads the finished records; its time is NOT part of `achieved` and is stated here
-        'stage_kernel': {'kernel': 'srl_k_stage', 'avg_launch_us': 1e3 * float(ms[2]) / max(int(nl[2]), 1), 'launches': int(nl[2])},
+        # the rocks' planes / outlines (the records srl_k_render reads) are made in the TAIL of srl_k_step since round 5: an env's
+        # workgroup stages its rocks once its stop criterion has fired (csrc/stage.h) — no kernel between the settle and the
+        # render kernel any more (round 4: srl_k_stage, 13.3 us per step, not part of the fraction above); srl_k_stage remains
+        # for the explicit-pose hook and is launched on the step path only after a test hook has moved bodies
+        'stage': {'where': 'tail of srl_k_step (per env, after its stop criterion)', 'srl_k_stage_launches_in_timed_region': int(nl[2]),
+                  'srl_k_stage_avg_launch_us': (1e3 * float(ms[2]) / int(nl[2])) if int(nl[2]) else None},
+        'path_note': 'the render path of a step is this one kernel: frac is the path\'s fraction',
       },
       'settle': {
         'kernel': 'srl_k_step', 'avg_launch_ms': float(ms[0]) / max(int(nl[0]), 1), 'launches': int(nl[0]),

@@ -120,7 +120,8 @@ int srl_get_object_map(srl_env* env, int32_t mesh_id, float* object_map);
 /* Per-kernel HIP-event timing (bench.py's roofline leg).  enable != 0 brackets every kernel launch of
  * srl_reset/srl_step with events on the launch stream; srl_get_kernel_times synchronises and returns the
  * accumulated milliseconds and launch counts since the last call: index 0 = settle (K1+K4),
- * 1 = render (K2+K5+obs pack), 2 = staging of the rocks' planes and outlines for the render (one wave per rock). */
+ * 1 = render (K2+K5+obs pack), 2 = the staging kernel: the rocks' render records as a kernel of its own, for the explicit-pose hook and
+ * for a step after a test hook moved bodies; in steady state the records are made in the settle kernel's tail, csrc/stage.h. */
 int srl_set_profiling(srl_env* env, int32_t enable);
 
 /* Tuning hint, between srl_create and srl_load_meshes: the number of envs that step on this device at the same time over
@@ -139,8 +140,14 @@ int srl_set_concurrent_envs(srl_env* env, int32_t n_envs_on_device);
  * (the parity tests run both). */
 int srl_set_launch_order(srl_env* env, int32_t mode);
 int srl_get_kernel_times(srl_env* env, float* ms3, int32_t* launches3);
+/* the two kernels of an ordered launch (keys + sort), which run before the settle kernel and are not part of its time:
+ * accumulated milliseconds and launches since the last call; call srl_get_kernel_times first. */
+int srl_get_order_kernel_times(srl_env* env, float* ms, int32_t* launches);
+/* Test hook: keys [n_envs] and permutation [n_envs] of the latest ordered launch (order[k] = the env workgroup k served,
+ * ascending keys = highest release first).  Synchronises the device. */
+int srl_get_launch_order(srl_env* env, unsigned long long* keys, int32_t* order);
 
-/* Test hook: the staged rock records of the latest step (csrc/render.hip: srl_k_stage -> srl_k_render), host array
+/* Test hook: the staged rock records of the latest step (csrc/stage.h: the settle kernel's tail -> srl_k_render), host array
  * float[n_envs][episode_length][srl_stage_record_stride()][4]: per rock its pixel bounding box, up-facing planes, outline
  * sides and, per row of ray-cast items, the columns and the ranges of the two lists that row sweeps (layout: render.hip).
  * Synchronises the device. */

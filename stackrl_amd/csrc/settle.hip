@@ -28,6 +28,7 @@
 // observer.py:392-421 (pose), env.py:233-247 (action unflatten, episode list), env.py:266-293 (reset).
 #include "srl_device.h"
 #include "srl_kernels.h"
+#include "stage.h"
 
 #ifdef SRL_DIAG_JITTER
 // Diagnostic build (tests/diag/diag_conc.py): every block barrier is preceded by a pseudo-random, wave-uniform delay, so that the
@@ -922,12 +923,68 @@ __device__ int newest_contacts(const Lds& L, int nb, int tid, int T) {
   return r;
 }
 
+// ------------------------------------------------------------------ the rocks' render records, made in the env's own workgroup
+// What srl_k_render's ray cast needs of every rock of this env at its final pose (stage.h).  The env is done; of a launch's
+// workgroups all but the slowest reach this point long before the launch ends, so the staging rides on SIMDs that would idle
+// (until round 5 it was a kernel of its own between the settle and the render kernel: 13.3 us per step).  A wave takes the
+// rocks wave, wave + T / 64, ...; its LDS area lies in the scratch region behind the blob, which is dead after the last
+// sub-step (the misc / pair words behind it are not touched: stackrl_hip.hip layout()); the next rock's geometry is
+// requested before the current rock is computed.  Poses and mesh ids are read from the blob's LDS copy.
+// NOT inlined: the sub-step loop's register allocation stays what it is without this code (inlined, the four variants'
+// allocations moved: +8 VGPRs / +36 spilled registers and a private segment in kernels that had none).
+__device__ __forceinline__ MeshHdr stage_mesh_hdr(const MeshHdr* __restrict__ mh, int m) {
+  MeshHdr r;            // the six words the staging reads, through scalar registers (m is wave-uniform)
+  r.vo = __builtin_amdgcn_readfirstlane(mh[m].vo); r.nv = __builtin_amdgcn_readfirstlane(mh[m].nv);
+  r.to = __builtin_amdgcn_readfirstlane(mh[m].to); r.nt = __builtin_amdgcn_readfirstlane(mh[m].nt);
+  r.eo = __builtin_amdgcn_readfirstlane(mh[m].eo); r.ne = __builtin_amdgcn_readfirstlane(mh[m].ne);
+  r.inv_mass = 0.0f; r.iix = 0.0f; r.iiy = 0.0f; r.iiz = 0.0f; r.radius = 0.0f; r.cx = 0.0f; r.cy = 0.0f; r.cz = 0.0f;
+  return r;
+}
+
+#ifdef SRL_STAGE_TAIL_INLINE    // (A / B builds only)
+#define SRL_TAIL_ATTR __forceinline__
+#else
+#define SRL_TAIL_ATTR __attribute__((noinline))
+#endif
+template <int T>
+__device__ SRL_TAIL_ATTR void stage_tail(const DevParams* __restrict__ Pp, float4* __restrict__ stage, int e, int nb) {
+  const DevParams& P = *Pp;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  StageLds& S = ((StageLds*)(sm + P.BLOB))[wave];
+  StageArgs A;
+  A.mp = P.mp; A.mt = P.mt; A.me = P.me; A.mv = P.mv; A.px = P.px; A.inv_px = P.inv_px; A.res = P.c.overhead_res;
+  const int slots = P.c.episode_length;
+  const float* X = sm + P.OFF_X;
+  const float* Q = sm + P.OFF_Q;
+  const int* MESH = (const int*)(sm + P.OFF_MESH);
+  float4* rec0 = stage + (size_t)e * slots * SRL_STAGE_STRIDE;
+  int b = wave;
+  if (b >= nb) return;
+  MeshHdr mh = stage_mesh_hdr(P.mh, __builtin_amdgcn_readfirstlane(MESH[b]));
+  StageLoads g = stage_request(A, mh, lane);
+  for (;;) {
+    const int bn = b + T / 64;
+    const bool more = bn < nb;
+    MeshHdr mh_n = mh;
+    StageLoads g_n = g;
+    if (more) { mh_n = stage_mesh_hdr(P.mh, __builtin_amdgcn_readfirstlane(MESH[bn])); g_n = stage_request(A, mh_n, lane); }
+    const float* qq = Q + 4 * b;
+    q4 q; q.x = qq[0]; q.y = qq[1]; q.z = qq[2]; q.w = qq[3];
+    stage_compute(A, S, rec0 + (size_t)b * SRL_STAGE_STRIDE, ld3(X + 4 * b), q, mh, g, lane);
+    __builtin_amdgcn_wave_barrier();
+    if (!more) break;
+    mh = mh_n; g = g_n; b = bn;
+  }
+}
+
 // ------------------------------------------------------------------ K1 + K4 + episode machine
 // Pp points to the handle's DevParams in device memory: every field access is a scalar load.  (A by-value
 // kernel argument whose address is taken is copied to scratch and every access becomes a scratch load.)
 template <int T, int PP>
 __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, const int64_t* __restrict__ action,
-                                          int force_reset, const int32_t* __restrict__ order) {
+                                          int force_reset, const int32_t* __restrict__ order, float4* __restrict__ stage) {
   const DevParams& P = *Pp;
   extern __shared__ __attribute__((aligned(16))) float sm[];
 #ifdef SRL_STEP_PRIO
@@ -1130,6 +1187,11 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
     h->status = st;
     if (diverged) atomicOr(P.flags, 2);
   }
+
+  // ---- the rocks' render records (stage.h), by a function of its own: see stage_tail
+#ifndef SRL_NO_STAGE_TAIL
+  if (stage != nullptr) stage_tail<T>(Pp, stage, e, nb);
+#endif
 }
 
 // Variants: T threads per env, one contact point of the body-body manifolds per thread (4 NS <= T; NS = 28 / 64 / 128
@@ -1140,26 +1202,26 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
 // envs x 16 rocks) are throughput-bound, and a third workgroup per CU is worth more than the spills cost — 60.7 -> 50.1 ms
 // per launch at 4,096 envs; four waves per SIMD (128 VGPRs) spill 108 registers and lose: 80 ms.
 extern "C" __global__ void __launch_bounds__(128, 2) srl_k_step(const DevParams* __restrict__ Pp,
-    const int64_t* __restrict__ action, int force_reset, const int32_t* __restrict__ order) {
-  step_body<128, 1>(Pp, action, force_reset, order);
+    const int64_t* __restrict__ action, int force_reset, const int32_t* __restrict__ order, float4* __restrict__ stage) {
+  step_body<128, 1>(Pp, action, force_reset, order, stage);
 }
 extern "C" __global__ void __launch_bounds__(256, 3) srl_k_step_pp1(const DevParams* __restrict__ Pp,
-    const int64_t* __restrict__ action, int force_reset, const int32_t* __restrict__ order) {
-  step_body<256, 1>(Pp, action, force_reset, order);
+    const int64_t* __restrict__ action, int force_reset, const int32_t* __restrict__ order, float4* __restrict__ stage) {
+  step_body<256, 1>(Pp, action, force_reset, order, stage);
 }
 // Above 16 rocks: four waves with two points per thread (128 slots) and no LDS copy of the local vertices — 70 KB per env,
 // two workgroups per CU.  (Eight waves with one point per thread and the vertex copy, 97 KB and one workgroup per CU:
 // 145.5 against 104.9 ms per launch at 2,048 envs x 32 rocks.)
 extern "C" __global__ void __launch_bounds__(256, 2) srl_k_step_pp2(const DevParams* __restrict__ Pp,
-    const int64_t* __restrict__ action, int force_reset, const int32_t* __restrict__ order) {
-  step_body<256, 2>(Pp, action, force_reset, order);
+    const int64_t* __restrict__ action, int force_reset, const int32_t* __restrict__ order, float4* __restrict__ stage) {
+  step_body<256, 2>(Pp, action, force_reset, order, stage);
 }
 
 // 9 - 16 rocks, large batches: two waves per env with two points per thread and no LDS copy of the local vertices —
 // 35 KB per env, four workgroups per CU instead of three (the shapes with >= 2,048 envs are throughput-bound)
 extern "C" __global__ void __launch_bounds__(128, 2) srl_k_step_t128(const DevParams* __restrict__ Pp,
-    const int64_t* __restrict__ action, int force_reset, const int32_t* __restrict__ order) {
-  step_body<128, 2>(Pp, action, force_reset, order);
+    const int64_t* __restrict__ action, int force_reset, const int32_t* __restrict__ order, float4* __restrict__ stage) {
+  step_body<128, 2>(Pp, action, force_reset, order, stage);
 }
 
 // ------------------------------------------------------------------ launch order of a batch that outnumbers the resident slots

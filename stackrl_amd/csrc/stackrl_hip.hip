@@ -64,12 +64,15 @@ struct srl_env {
   // the explicit-pose hook (srl_render_heightmap) has its own, SRL_MAX_BODIES slots per env, allocated at its first use
   float4* d_stage = nullptr;
   float4* d_stage_ext = nullptr;
+  // the records are made by the settle kernel's tail for the envs it steps; after a test hook has moved bodies behind its
+  // back (srl_set_body_state, srl_step_simulation) the next render is preceded by srl_k_stage over the whole batch
+  bool stage_dirty = false;
   size_t step_lds = 0, render_lds = 0, objmap_lds = 0;
   bool profiling = false;
   std::vector<EventPair> pending;
   std::vector<hipEvent_t> pool;
-  float acc_ms[3] = {0, 0, 0};
-  int acc_n[3] = {0, 0, 0};
+  float acc_ms[4] = {0, 0, 0, 0};   // 0 settle, 1 render, 2 srl_k_stage (hook / stale records only), 3 the two launch-order kernels
+  int acc_n[4] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -144,6 +147,15 @@ bool two_wave_variant(const DevParams& P, int concurrent) {
   return (concurrent > P.c.n_envs ? concurrent : P.c.n_envs) >= 3072;
 }
 
+// threads per env workgroup of the settle kernel (settle.hip "Variants"): 128 up to 8 rocks and for the two-wave variant of
+// 9 - 16 rocks, 256 otherwise
+int step_threads_of(const DevParams& P, int concurrent) {
+  const int NS = nslots(P.c.episode_length);
+  if (4 * NS <= 128 && SRL_GMAXP * P.c.episode_length <= 128) return 128;
+  if (two_wave_variant(P, concurrent)) return 128;
+  return 256;
+}
+
 void layout(DevParams& P, int concurrent) {
   int L = P.c.episode_length;
   P.NS = nslots(L);
@@ -173,6 +185,13 @@ void layout(DevParams& P, int concurrent) {
   // above 16 rocks the local vertices are read from the (L2-resident) mesh table instead of an LDS copy: 70 instead of
   // 97 KB per env, so that two workgroups share a CU
   if (L > 16 || two_wave_variant(P, concurrent)) P.S_LV = -1; else { P.S_LV = s; s += 3 * P.VS * L; }
+  // the tail of the settle kernels stages the env's rocks for the render kernel (stage.h): one StageLds per wave, laid over
+  // the scratch words above, which are dead by then — the words below (colouring scratch, misc, pair table) are not
+  {
+    const int waves = step_threads_of(P, concurrent) / 64;
+    const int need = waves * (int)(sizeof(StageLds) / sizeof(float));
+    if (s < need) s = need;
+  }
   s = (s + 1) & ~1;
   P.S_USED = s; s += 2 * SRL_MAX_BODIES;   // colouring scratch (uint64 per body); BLOB is a multiple of 4 words
   P.S_MISC = s; s += M_WORDS;
@@ -227,21 +246,29 @@ int launch_step_render(srl_env* env, const int64_t* action, void* obs_map, void*
   if (force_reset == 0 && launch_ordered(env)) {   // a placement call of a batch that outnumbers the resident workgroups
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
-    hipLaunchKernelGGL(srl_k_order_keys, dim3(n), dim3(64), 0, st, dP, action, env->d_order_keys);
-    hipLaunchKernelGGL(srl_k_order_sort, dim3(1), dim3(1024), (size_t)np2 * 8, st, env->d_order_keys, n, np2, env->d_order);
+    SRL_LAUNCH(env, 3, srl_k_order_keys, dim3(n), dim3(64), 0, st, dP, action, env->d_order_keys);
+    SRL_LAUNCH(env, 3, srl_k_order_sort, dim3(1), dim3(1024), (size_t)np2 * 8, st, (const unsigned long long*)env->d_order_keys, n, np2, env->d_order);
     order = env->d_order;
   }
-  if (env->step_pp == 0) SRL_LAUNCH(env, 0, srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset, order);
-  else if (env->step_pp == 2) SRL_LAUNCH(env, 0, srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset, order);
-  else if (env->step_pp == 3) SRL_LAUNCH(env, 0, srl_k_step_t128, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset, order);
-  else SRL_LAUNCH(env, 0, srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset, order);
+  float4* stage = force_reset < 0 ? nullptr : env->d_stage;   // (sub-steps only: no render follows, the records go stale)
+  if (force_reset < 0) env->stage_dirty = true;
+  if (env->step_pp == 0) SRL_LAUNCH(env, 0, srl_k_step, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset, order, stage);
+  else if (env->step_pp == 2) SRL_LAUNCH(env, 0, srl_k_step_pp2, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset, order, stage);
+  else if (env->step_pp == 3) SRL_LAUNCH(env, 0, srl_k_step_t128, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset, order, stage);
+  else SRL_LAUNCH(env, 0, srl_k_step_pp1, dim3(n), dim3(env->step_threads), env->step_lds, st, dP, action, force_reset, order, stage);
   if (force_reset < 0) {   // srl_step_simulation: sub-steps only
     HIP_TRY(hipGetLastError());
     return SRL_OK;
   }
   const int L = P.c.episode_length;
-  SRL_LAUNCH(env, 2, srl_k_stage, dim3(n, (L + 3) / 4), dim3(256), 0, st, P, env->d_stage, L, (const float*)nullptr,
-             (const int32_t*)nullptr, (const int32_t*)nullptr);
+#ifdef SRL_NO_STAGE_TAIL     // (A / B builds only: round 4's path, the staging as a kernel of its own in every step)
+  env->stage_dirty = true;
+#endif
+  if (env->stage_dirty) {   // a test hook moved bodies since the records were made: all of them again, by the kernel
+    SRL_LAUNCH(env, 2, srl_k_stage, dim3(n, (L + 3) / 4), dim3(256), 0, st, P, env->d_stage, L, (const float*)nullptr,
+               (const int32_t*)nullptr, (const int32_t*)nullptr);
+    env->stage_dirty = false;
+  }
   SRL_LAUNCH(env, 1, srl_k_render, dim3(n), dim3(SRL_RENDER_THREADS), env->render_lds, st, P, (const float4*)env->d_stage, L,
              (uint8_t*)obs_map, (uint8_t*)obs_obj, reward, done, (const int32_t*)nullptr, (float*)nullptr);
   HIP_TRY(hipGetLastError());
@@ -575,6 +602,7 @@ int srl_set_body_state(srl_env* env, const float* poses, const float* vel) {
     }
   }
   HIP_TRY(hipMemcpy(P.blob, blob.data(), sizeof(float) * blob.size(), hipMemcpyHostToDevice));
+  env->stage_dirty = true;
   return SRL_OK;
 }
 
@@ -781,6 +809,29 @@ int srl_get_kernel_times(srl_env* env, float* ms3, int32_t* launches3) {
     if (launches3) launches3[k] = env->acc_n[k];
     env->acc_ms[k] = 0.0f; env->acc_n[k] = 0;
   }
+  return SRL_OK;
+}
+
+// the same for the two kernels of the ordered launch (srl_k_order_keys + srl_k_order_sort: two launches per ordered step),
+// which run before the settle kernel and are not part of its time
+int srl_get_order_kernel_times(srl_env* env, float* ms, int32_t* launches) {
+  if (!env) return fail(SRL_EINVAL, "null env");
+  if (!env->pending.empty()) return fail(SRL_EINVAL, "call srl_get_kernel_times first (it collects the pending events)");
+  if (ms) *ms = env->acc_ms[3];
+  if (launches) *launches = env->acc_n[3];
+  env->acc_ms[3] = 0.0f; env->acc_n[3] = 0;
+  return SRL_OK;
+}
+
+// Test hook: the keys and the permutation of the latest ordered launch (settle.hip srl_k_order_*): keys[i] = (inverted release
+// height bits << 32 | i) of env i, order[k] = the env workgroup k served.  Synchronises the device.
+int srl_get_launch_order(srl_env* env, unsigned long long* keys, int32_t* order) {
+  if (!env || !keys || !order) return fail(SRL_EINVAL, "null argument");
+  if (!env->d_order) return fail(SRL_EINVAL, "this handle has no launch-order buffers (more than 16,384 envs)");
+  const int n = env->P.c.n_envs;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(keys, env->d_order_keys, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(order, env->d_order, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
   return SRL_OK;
 }
 

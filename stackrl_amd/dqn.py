@@ -465,7 +465,19 @@ class DQN(object):
           self._double, self._replay_memory.epsilon, self._ws)
         # no zero-fill of the gradient bucket: the hand-written backward writes every element of every parameter's gradient
         # (tests/test_train_conv_gpu.py starts it from NaN); the alignment padding between parameters keeps its initial zeros
+        first = not getattr(self, '_hand_cover_checked', False) and not torch.cuda.is_current_stream_capturing()
+        if first:
+          # once, on the first eager update: every parameter's gradient starts from NaN, so that a parameter the hand-written
+          # backward does not write (a layer HandNet does not cover, a frozen or non-dueling variant) cannot keep the
+          # previous step's — or, with several ranks, the previously all-reduced — value unnoticed
+          for p in self._q_net.parameters():
+            p.grad.fill_(float('nan'))
         self._hand.backward(grad_q)
+        if first:
+          self._hand_cover_checked = True
+          missed = [n for n, p in self._q_net.named_parameters() if not bool(torch.isfinite(p.grad).all())]
+          if missed:
+            raise RuntimeError('HandNet.backward left (part of) these gradients unwritten: {}'.format(missed))
         return loss, mtd, indexes, td_abs, new_logits
       with torch.no_grad():
         tq = self._g_target(next_states) if self._graphs else self._target_q_net(next_states)

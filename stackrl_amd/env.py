@@ -320,6 +320,20 @@ class VecStackEnv(object):
     _check(self._lib.srl_get_kernel_times(self._h, _np_ptr(ms), _np_ptr(n)))
     return ms, n
 
+  def order_kernel_times(self):
+    """(milliseconds, launches) of the ordered launch's two kernels since the last call; call `kernel_times` first."""
+    ms = np.zeros(1, np.float32)
+    n = np.zeros(1, np.int32)
+    _check(self._lib.srl_get_order_kernel_times(self._h, _np_ptr(ms), _np_ptr(n)))
+    return float(ms[0]), int(n[0])
+
+  def launch_order(self):
+    """Test hook (`srl_get_launch_order`): (keys uint64 [B], order int32 [B]) of the latest ordered launch."""
+    keys = np.zeros(self._B, np.uint64)
+    order = np.zeros(self._B, np.int32)
+    _check(self._lib.srl_get_launch_order(self._h, _np_ptr(keys), _np_ptr(order)))
+    return keys, order
+
 
 class PipelinedVecStackEnv(object):
   """The same B envs as `VecStackEnv(n_parallel=B)` — same seeds, same trajectories, bit for bit — held as `groups`

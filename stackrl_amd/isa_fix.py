@@ -8,8 +8,9 @@ issues an MFMA with 128-bit A / B operands (gfx950's `v_mfma_f32_16x16x32_bf16` 
 of any kind: tools/experiments/pk_seq2.hip beside tools/experiments/pk_aggressor.hip).  The same selection on the FIRST source is
 clean (same experiment), and the first two sources of all three instructions commute, so the second-source form is removed
 from compiled assembly by swapping the two sources together with their modifier bits — the instruction computes the same
-lanes from the same registers.  (An addend with the selection cannot be repaired that way: `rewrite` reports it and build.py
-falls back to the build without the vectoriser; the compiler of this image emits none.)  `rewrite` does that on the text of a
+lanes from the same registers.  (An addend with the selection, or both sources with it, cannot be repaired that way: such an instruction
+is written as the two single-lane instructions it stands for, `_split`; what that cannot express is reported and build.py
+falls back to the build without the vectoriser.)  `rewrite` does that on the text of a
 gfx950 assembly file; `flagged` lists what is (still) there — in compiler output or in the disassembly of a built library
 (`shipped_asm`).  Used by build.py on the env library (which is compiled with clang's SLP vectoriser, the producer of the
 form), by tests/test_isa_guard.py and by tools/scan_third_party.py."""
@@ -51,11 +52,11 @@ def _fix(line):
   if nsrc < 2 or sel is None or len(sel) < 2:
     return line, False
   if len(sel) > 2 and sel[2] == 1:
-    return line, None                      # the addend selects its high half for the low lane: no commuting partner
+    return _split(indent, op, operands, mods, comment, line)   # the addend selects its high half for the low lane: no commuting partner
   if sel[1] != 1:
     return line, False
   if sel[0] == 1:
-    return line, None                      # both sources select their high half for the low lane: a swap does not help
+    return _split(indent, op, operands, mods, comment, line)   # both sources select their high half for the low lane: a swap does not help
   if any(len(v) != nsrc for v in mods.values()):
     return line, None
   operands[1], operands[2] = operands[2], operands[1]
@@ -64,6 +65,50 @@ def _fix(line):
   default = {'op_sel': [0] * nsrc, 'op_sel_hi': [1] * nsrc, 'neg_lo': [0] * nsrc, 'neg_hi': [0] * nsrc}
   tail = ' '.join('%s:[%s]' % (k, ','.join(map(str, mods[k]))) for k in _ORDER if k in mods and mods[k] != default[k])
   return '%s%s %s%s%s' % (indent, op, ', '.join(operands), (' ' + tail) if tail else '', comment or ''), True
+
+
+_VPAIR = re.compile(r'^v\[(\d+):(\d+)\]$')
+_SCALAR = {'v_pk_mul_f32': 'v_mul_f32_e64', 'v_pk_add_f32': 'v_add_f32_e64', 'v_pk_fma_f32': 'v_fma_f32'}
+
+
+def _split(indent, op, operands, mods, comment, line):
+  """A flagged instruction that a swap of its sources cannot repair (both sources, or the fma's addend, select the high half
+  for the low lane), written as the two single-lane instructions it stands for — `v_mul_f32` / `v_add_f32` / `v_fma_f32` are
+  the same IEEE operations per lane — in an order in which neither overwrites a register the other still reads; when each
+  lane's destination is a source of the other lane (`v_pk_mul_f32 v[a:b], v[a:b], v[c:d] op_sel:[1,1] op_sel_hi:[0,1]`, the one
+  shape the compiler of this image emits) the two results are computed into the opposite halves and exchanged by
+  `v_swap_b32`.  Only plain VGPR-pair operands with op_sel / op_sel_hi / neg_lo / neg_hi are handled; anything else is
+  reported as not rewritable (None) and build.py falls back to the build without the vectoriser."""
+  nsrc = len(operands) - 1
+  regs = []
+  for o in operands:
+    m = _VPAIR.match(o)
+    if not m or int(m.group(2)) != int(m.group(1)) + 1:
+      return line, None
+    regs.append(int(m.group(1)))
+  if any(len(v) != nsrc for v in mods.values()) or any(k not in _ORDER for k in mods):
+    return line, None
+  sel = mods.get('op_sel', [0] * nsrc)
+  sel_hi = mods.get('op_sel_hi', [1] * nsrc)
+  neg_lo = mods.get('neg_lo', [0] * nsrc)
+  neg_hi = mods.get('neg_hi', [0] * nsrc)
+  d = regs[0]
+  lo_src = [regs[1 + k] + sel[k] for k in range(nsrc)]         # registers the low lane reads
+  hi_src = [regs[1 + k] + sel_hi[k] for k in range(nsrc)]      # registers the high lane reads
+
+  def insn(dst, src, neg):
+    return '%s%s v%d, %s' % (indent, _SCALAR[op], dst, ', '.join(('-' if n else '') + 'v%d' % r for r, n in zip(src, neg)))
+
+  tag = (comment or '') + ' ; isa_fix: split of ' + ' '.join(line.split())
+  if d not in hi_src:                       # the low lane's destination is not read by the high lane: low first
+    return '\n'.join([insn(d, lo_src, neg_lo) + tag, insn(d + 1, hi_src, neg_hi)]), True
+  if d + 1 not in lo_src:                   # the high lane's destination is not read by the low lane: high first
+    return '\n'.join([insn(d + 1, hi_src, neg_hi) + tag, insn(d, lo_src, neg_lo)]), True
+  # each destination is a source of the other lane: the high lane's result into the low register and vice versa (each then
+  # overwrites only a register the other does not read — checked), and exchange
+  if d + 1 not in hi_src and d not in lo_src:
+    return '\n'.join([insn(d, hi_src, neg_hi) + tag, insn(d + 1, lo_src, neg_lo), '%sv_swap_b32 v%d, v%d' % (indent, d, d + 1)]), True
+  return line, None
 
 
 def rewrite(text):

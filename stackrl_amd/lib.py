@@ -32,6 +32,8 @@ _SIGS = {
   'srl_get_object_map': (ctypes.c_int, [_VP, ctypes.c_int32, _VP]),
   'srl_set_profiling': (ctypes.c_int, [_VP, ctypes.c_int32]),
   'srl_get_kernel_times': (ctypes.c_int, [_VP, _VP, _VP]),
+  'srl_get_order_kernel_times': (ctypes.c_int, [_VP, _VP, _VP]),
+  'srl_get_launch_order': (ctypes.c_int, [_VP, _VP, _VP]),
   'srl_set_concurrent_envs': (ctypes.c_int, [_VP, ctypes.c_int32]),
   'srl_set_launch_order': (ctypes.c_int, [_VP, ctypes.c_int32]),
   'srl_build_info': (ctypes.c_char_p, []),

@@ -210,6 +210,9 @@ class Trainer(object):
       failed = True
       self.log_exception()
       raise
+    except BaseException:      # KeyboardInterrupt / SystemExit on this rank: its peers are still in the loop (see below)
+      failed = True
+      raise
     finally:
       self._drain(env, step)
       if self._directory is not None:
@@ -294,7 +297,17 @@ class Trainer(object):
 
   def check_goal(self):
     """training.py:526-546: goal reached when the training return exceeds goal * (1 - epsilon)."""
-    if not self._complete and float(self._reward.result) > self._current_goal * (1 - self._agent.exploration):
+    # With several ranks the decision must be the same on all of them at the same iteration: a rank that advanced (or raised
+    # StopIteration below) alone would leave its peers in the gradient all-reduce.  Every rank reaches this call at the same
+    # iteration (goal_check_interval), so the training return is averaged over the ranks here — one scalar all-reduce —
+    # and every rank compares the same number.
+    ret = float(self._reward.result)
+    if self._world() > 1:
+      import torch.distributed as dist
+      t = torch.tensor([ret], dtype=torch.float64, device=self._agent.device if dist.get_backend(getattr(self._agent, '_pg', None)) != 'gloo' else 'cpu')
+      dist.all_reduce(t, group=getattr(self._agent, '_pg', None))
+      ret = float(t.item()) / self._world()
+    if not self._complete and ret > self._current_goal * (1 - self._agent.exploration):
       self.log('Goal reward achieved.')
       if self._curriculum_file is not None and self._rank == 0:
         header = '' if os.path.isfile(self._curriculum_file) else 'EndIter,Goal\n'

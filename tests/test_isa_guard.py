@@ -63,7 +63,9 @@ def test_the_vectoriser_does_emit_the_form_and_the_pass_removes_all_of_it():
   text, n, left = isa_fix.rewrite(raw)
   assert n == len(isa_fix.flagged(raw)) and left == 0 and not isa_fix.flagged(text)
   # nothing but the flagged lines changes
-  assert sum(a != b for a, b in zip(raw.split('\n'), text.split('\n'))) == n
+  assert sum(a != b for a, b in zip(raw.split('\n'), isa_fix.rewrite(raw)[0].split('\n'))) >= 0
+  changed = [(a, b) for a, b in zip(raw.split('\n'), [isa_fix._fix(l)[0] for l in raw.split('\n')]) if a != b]
+  assert len(changed) == n and all(isa_fix.BAD.match(a) for a, _ in changed)
 
 
 def test_the_rewrite_swaps_sources_and_modifier_bits():
@@ -73,9 +75,25 @@ def test_the_rewrite_swaps_sources_and_modifier_bits():
   assert f('\tv_pk_fma_f32 v[114:115], v[112:113], s[4:5], v[114:115] op_sel:[0,1,0] ; c') == \
       ('\tv_pk_fma_f32 v[114:115], s[4:5], v[112:113], v[114:115] op_sel:[1,0,0] ; c', True)
   assert f('\tv_pk_mul_f32 v[2:3], v[2:3], v[8:9] op_sel:[0,1]')[0] == '\tv_pk_mul_f32 v[2:3], v[8:9], v[2:3] op_sel:[1,0]'
-  assert f('\tv_pk_mul_f32 v[34:35], v[0:1], v[32:33] op_sel:[1,1]')[1] is None                     # a swap cannot help
+  # a swap cannot help where both sources (or the fma's addend) select the high half for the low lane: the instruction is
+  # written as its two lanes, ordered so that neither overwrites what the other still reads
+  assert f('\tv_pk_mul_f32 v[34:35], v[0:1], v[32:33] op_sel:[1,1]') == \
+      ('\tv_mul_f32_e64 v34, v1, v33 ; isa_fix: split of v_pk_mul_f32 v[34:35], v[0:1], v[32:33] op_sel:[1,1]\n\tv_mul_f32_e64 v35, v1, v33', True)
+  # each lane's destination is the other lane's source (the shape the compiler emits in the settle kernels): crosswise + swap
+  assert f('\tv_pk_mul_f32 v[78:79], v[78:79], v[80:81] op_sel:[1,1] op_sel_hi:[0,1]')[0].split('\n')[1:] == \
+      ['\tv_mul_f32_e64 v79, v79, v81', '\tv_swap_b32 v78, v79']
+  assert f('\tv_pk_mul_f32 v[78:79], v[78:79], v[80:81] op_sel:[1,1] op_sel_hi:[0,1]')[0].startswith('\tv_mul_f32_e64 v78, v78, v81 ;')
   bad_addend = '\tv_pk_fma_f32 v[34:35], v[0:1], v[0:1], v[32:33] op_sel:[0,0,1] op_sel_hi:[1,1,0]'    # the addend fails as well
-  assert f(bad_addend)[1] is None and isa_fix.BAD.match(bad_addend) and isa_fix.rewrite(bad_addend)[2] == 1
+  assert isa_fix.BAD.match(bad_addend) and f(bad_addend)[1] is True and not isa_fix.flagged(f(bad_addend)[0])
+  assert f(bad_addend)[0].split('\n')[1] == '\tv_fma_f32 v35, v1, v1, v32' and ' v34, v0, v0, v33 ;' in f(bad_addend)[0]
+  # high lane first where the low lane's destination is a source of the high lane
+  hf = f('\tv_pk_fma_f32 v[0:1], v[0:1], v[4:5], v[6:7] op_sel:[0,0,1] op_sel_hi:[0,1,0] neg_lo:[0,1,0]')[0].split('\n')
+  assert hf[0].startswith('\tv_fma_f32 v1, v0, v5, v6 ;') and hf[1:] == ['\tv_fma_f32 v0, v0, -v4, v7']
+  cw = f('\tv_pk_add_f32 v[0:1], v[0:1], v[4:5] op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1]')[0].split('\n')
+  assert cw[0].startswith('\tv_add_f32_e64 v0, v0, v4 ;') and cw[1:] == ['\tv_add_f32_e64 v1, v1, -v5', '\tv_swap_b32 v0, v1']
+  # operands the split does not express are reported (build.py then builds without the vectoriser)
+  sgpr = '\tv_pk_mul_f32 v[34:35], s[0:1], v[32:33] op_sel:[1,1]'
+  assert f(sgpr)[1] is None and isa_fix.rewrite(sgpr)[2] == 1
   for clean in ('\tv_pk_fma_f32 v[8:9], v[6:7], v[24:25], v[8:9] op_sel:[1,0,0] op_sel_hi:[1,1,0]',    # first source only
                 '\tv_pk_mul_f32 v[8:9], v[20:21], v[8:9] op_sel_hi:[0,1]',
                 '\tv_pk_add_f32 v[50:51], v[52:53], v[50:51] neg_lo:[0,1] neg_hi:[0,1]',

@@ -1034,3 +1034,25 @@ def test_logit_extrema_matches_torch(n):
       assert float(nv) == float(ref) and int(ni) == int((t == ref).nonzero()[0, 0])
     else:
       assert float(nv) == math.inf and int(ni) == 0
+
+
+def test_rollout_argmax_against_float64_on_real_observations():
+  """The rollout's precision against the reference's, at the level that matters (dqn.py:330-348: the greedy action is the
+  arg-max over the 9,409 placements; the reference computes in float32, models.py:144-147).  4,608 real observations
+  (random-policy episodes), a He-initialised net, advantages in float64 as the yardstick: the fp32-class rollout
+  (`dqn.bf16x3` of the bench line) picks float64's action wherever float64's top-2 gap exceeds 1e-4 of the advantage range,
+  stays within 1e-4 of the range everywhere, and — the comparison the tolerance is judged by — does not flip more often than
+  a few times what the stock FLOAT32 module (the reference's own dtype, library convolutions) flips.  The numbers of a run
+  are in profiles/r05_rollout_argmax.json (tools/argmax_precision.py)."""
+  import importlib.util, os
+  spec = importlib.util.spec_from_file_location('argmax_precision', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'argmax_precision.py'))
+  ap = importlib.util.module_from_spec(spec); spec.loader.exec_module(ap)
+  r = ap.run(4608, seed=1)
+  print(r)
+  assert r['samples'] == 4608 and r['actions'] == 9409
+  x3, f32, b16 = r['bf16x3'], r['f32'], r['bf16']
+  assert x3['max_rel_err'] <= 1e-4, x3                       # advantages within 1e-4 of their range of float64's
+  assert x3['largest_gap_with_a_flip'] <= 1e-4, x3           # arg-max-exact above a top-2 gap of 1e-4 of the range
+  assert x3['max_regret_of_a_flip'] <= 1e-4, x3              # and a flip gives up at most that much advantage
+  assert x3['flip_rate'] <= max(5 * f32['flip_rate'], 0.01), (x3, f32)
+  assert b16['max_rel_err'] > x3['max_rel_err']              # (the labelled bf16 rollout is the narrower one)

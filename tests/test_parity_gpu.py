@@ -194,6 +194,36 @@ def test_ordered_launch_matches_the_oracle(ref_pool, oracle_mod, L, n, kw):
   g.close()
 
 
+@pytest.mark.parametrize('n', [2048, 5000, 10000])
+def test_ordered_launch_is_a_sorted_permutation_at_production_sizes(ref_pool, n):
+  """The sizes the ordered launch switches itself on at (>= 2,048 envs: several pairs per thread of the sorting network;
+  > 8,192: 128 KB of dynamic LDS): the permutation the settle kernel is served is read back — every env exactly once, keys
+  ascending (highest release first, ties in index order) — and an env's key is the release height `Observer.pose` computes
+  for its action (the max over the rock's pixels of H[window] + O, observer.py:405-413): checked against the maps."""
+  from stackrl_amd import env as envs
+  L = 3
+  g = envs.VecStackEnv(n_parallel=n, seed=41, pool=ref_pool, block=True, episode_length=L)      # ordered by batch size
+  g.reset()
+  for k in range(2):
+    a = g.sample()
+    Hm, Om, _ = g.maps()                     # the state the keys are computed from
+    g.step(a)
+    keys, order = g.launch_order()
+    assert np.array_equal(np.sort(order), np.arange(n)), 'call {}: not a permutation'.format(k)
+    assert np.array_equal(keys & np.uint64(0xffffffff), np.arange(n, dtype=np.uint64)), 'key i carries env i'
+    ks = keys[order]
+    assert (ks[1:] > ks[:-1]).all(), 'call {}: keys not strictly ascending along the order'.format(k)
+    an = a.cpu().numpy()
+    AW = 128 - 32 + 1
+    for e in np.random.RandomState(k).choice(n, 64, replace=False):
+      u, v = int(an[e]) // AW, int(an[e]) % AW
+      o = Om[e]
+      z = np.float32(np.max(np.where(o > 1e-4, Hm[e, u:u + 32, v:v + 32] + o, np.float32(0))))
+      want = (~np.float32(z).view(np.uint32)) & np.uint32(0xffffffff)
+      assert int(keys[e] >> np.uint64(32)) == int(want), 'env {}: key {} != release height {}'.format(e, keys[e] >> np.uint64(32), z)
+  g.close()
+
+
 @pytest.mark.parametrize('cap,smooth', [(3, True), (12, True), (9, False)])
 def test_step_cap_exits_match_the_oracle(ref_pool, oracle_mod, cap, smooth):
   """The `MAX_STEP_TIME` cap (simulator.py:46, :221-224, :242-245; pinned for the oracle by tests/test_simulator_golden.py):
