@@ -15,7 +15,10 @@ a path is "arg-max-exact above gap g" when no sample with a float64 gap above g 
 usage: python tools/argmax_precision.py [N=4608] [seed=1]  ->  one JSON object on stdout"""
 import copy
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import numpy as np
 import torch

@@ -29,8 +29,15 @@ env)
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/pmc_s1 -- python3 bench.py --no-cpu --no-dqn --steps 20 --warmup 5 > $O/pmc_s1.log 2>&1 || exit 1
   rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_s2 -- python3 bench.py --no-cpu --no-dqn --steps 20 --warmup 5 > $O/pmc_s2.log 2>&1 || exit 1
   python tools/pmc_insts.py srl_k_step $O/pmc_s1 $O/pmc_s2 --wgs 1024 --json $O/settle_pmc.json > $O/settle_pmc.txt || exit 1
-  unset SRL_NO_FREE_RUN
   echo settle pmc done
+  # the settle kernel at a batch-bound shape (configs[2]'s 4,096 envs x 16 rocks: the two-wave variant srl_k_step_t128, ordered
+  # launch): the same counters
+  rm -rf $O/pmc_b1 $O/pmc_b2
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/pmc_b1 -- python3 bench.py --no-cpu --no-dqn --envs 4096 --rocks 16 --steps 17 --warmup 4 > $O/pmc_b1.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_b2 -- python3 bench.py --no-cpu --no-dqn --envs 4096 --rocks 16 --steps 17 --warmup 4 > $O/pmc_b2.log 2>&1 || exit 1
+  python tools/pmc_insts.py srl_k_step_t128 $O/pmc_b1 $O/pmc_b2 --wgs 4096 --json $O/settle_pmc_4096x16.json > $O/settle_pmc_4096x16.txt || exit 1
+  unset SRL_NO_FREE_RUN
+  python tools/argmax_precision.py 4608 1 > $O/rollout_argmax.json 2> $O/rollout_argmax.err
   ;;
 qnet)
   rm -rf $O/train $O/qprof_* $O/mfma_*
