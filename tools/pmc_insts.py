@@ -52,7 +52,7 @@ if js:
          'valu_util': None if (valu is None or d is None) else valu * 4.0 / (1024 * d * 2.4e9),
          'wait_frac': None if (mean('SQ_WAIT_ANY') is None or not mean('SQ_WAVE_CYCLES')) else mean('SQ_WAIT_ANY') / mean('SQ_WAVE_CYCLES'),
          'lds_insts_per_launch': mean('SQ_INSTS_LDS'), 'salu_insts_per_launch': mean('SQ_INSTS_SALU'), 'waves': mean('SQ_WAVES'),
-         'how': 'separate rocprofv3 --kernel-trace --pmc passes of bench.py (tools/refresh_profiles_r03.sh): valu_util = SQ_INSTS_VALU x 4 '
+         'how': 'separate rocprofv3 --kernel-trace --pmc passes of bench.py (tools/refresh_profiles_r05.sh): valu_util = SQ_INSTS_VALU x 4 '
                 '/ (1,024 SIMDs x launch duration x 2.4 GHz); wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES',
          'commit': os.environ.get('SRL_COMMIT')}
   json.dump(out, open(js, 'w'), indent=2)
