@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/stackrl_qnet.h"
 #include "srl_bf16.h"
@@ -349,6 +350,442 @@ bool shapes(int mode, int H, int kh, int* hin, int* ks) {
   return (H == 128 && kh == 32) || (H == 64 && kh == 16);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 5: the FORWARD of large batches (the rollout) as a product per MAP ROW instead of per kernel row — no banded operand.
+//
+//   out[y][x] = sum_c sum_i Z_c[y + i][x][i],      Z_c[rho][x][i] = sum_t X_c[rho][x + t] * W_c[i][t]
+//
+// For a fixed map row rho, Z_c[rho] is a plain matrix product: A[m = x][k = t] = X_c[rho][x + t] (a Hankel matrix of the row:
+// lane (m, g) holds the 8 consecutive elements from x0 + m + 8 g), B[k = t][n = i] = W_c[i][t] (8 consecutive elements of
+// kernel row i: one aligned 16-byte LDS read), K = 32 = the kernel's width: ONE v_mfma_f32_16x16x32_bf16 per (x tile, i tile)
+// with every MAC useful — the Toeplitz form above issues two K blocks of 32 for 32 taps (half of T is zero) and a 7 x 7 grid of
+// tiles; this form issues 7 x tiles x 2 i tiles per (rho, c) over 128 map rows: 0.57 x the MFMAs, and 32 LDS instructions per
+// 42 MFMAs where the Toeplitz form has 38 (of four times the bytes).
+// The sum over i runs along a DIAGONAL of (rho, i): a wave sweeps rho = 0 .. 127 and keeps, in registers laid out like the
+// accumulator tiles (lane n = i), the partial sums S[x][i] of output row y = rho - i; a step to the next map row moves every
+// partial one lane up (DPP row_shr:1 within the 16 lanes of a tile row; lane 15 of i-tile 0 carries into lane 0 of i-tile 1 by
+// row_ror:1) and adds the new row's products; what arrives at i = 31 is the finished output row y = rho - 31.  The order of
+// every sum is fixed (i ascending, channels in the wave's order, waves in index order): bit-identical on repetition.
+// One workgroup = one sample, eight waves; wave w takes the channels w, w + 8 and ALL x tiles; its channels' kernel fragments
+// stay in registers for the whole sweep; the map is streamed row by row (one float4 per thread per row, requested two rows
+// ahead, double-buffered in LDS as four copies shifted by 0 .. 3 elements, so that a Hankel fragment — 8 consecutive elements
+// from ANY start — is two 8-byte reads at their natural alignment: 28 ds_read_b64 of 2 LDS cycles per 42 MFMAs); the eight waves' partial output rows
+// meet in LDS and are added in wave order.  87 KB of LDS: one workgroup (two waves per SIMD) per CU.
+
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2 lds_u2;
+
+template <bool SPLIT, bool F32>
+__global__ void __launch_bounds__(512)
+k_xcorr_rows(const void* __restrict__ in, const void* __restrict__ kern, float* __restrict__ out, int C) {
+  constexpr int HIN = 128, KH = 32, O = HIN - KH + 1, T = 7, NW = 8;
+  constexpr int XS = 160;                     // staged map row stride in elements: 128 + zeros up to what the last window reads
+  constexpr int CMAX = 16, NCP = 4;           // NCP copies of every staged row, copy k shifted by k elements
+  constexpr int PL = (SPLIT ? 2 : 1);
+  constexpr int CPS = CMAX * XS + 32;         // elements per copy: 64 bytes of padding, so that the four copies a half-wave's
+                                              // 8-byte reads touch lie on different quarters of the 64 banks
+  constexpr int XPL = NCP * CPS;              // elements per plane (hi or lo) of one buffer
+  extern __shared__ uint16_t xs[];
+  uint16_t* xr = xs;                                            // [2 buffers][PL][NCP][CMAX][XS]
+  float* comb = (float*)(xr + 2 * PL * XPL);                    // [2][NW][16 T]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  {   // zero the staged-row buffers once: their tails (columns 128 ..) are never written again
+    uint32_t* z = (uint32_t*)xr;
+    for (int k = tid; k < 2 * PL * XPL / 2; k += 512) z[k] = 0u;
+  }
+  // B fragments of this wave's channels (c = wave, wave + 8), in registers for the whole sweep: lane (n, g) holds
+  // W_c[16 it + n][8 g .. 8 g + 7] — straight from global memory, once
+  bf16x8 bh[2][2], bl[SPLIT ? 2 : 1][2];
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    const int c = wave + NW * ci;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      union { uint32_t u[4]; bf16x8 v; } h, l;
+      h.u[0] = h.u[1] = h.u[2] = h.u[3] = 0u; l.u[0] = l.u[1] = l.u[2] = l.u[3] = 0u;
+      if (c < C) {
+        const size_t off = (((size_t)b * C + c) * KH + 16 * it + n) * KH + 8 * g;
+        if (F32) {
+          const float4 q0 = *(const float4*)((const float*)kern + off), q1 = *(const float4*)((const float*)kern + off + 4);
+          if (SPLIT) {
+            srl_split_bf16(q0.x, q0.y, h.u[0], l.u[0]); srl_split_bf16(q0.z, q0.w, h.u[1], l.u[1]);
+            srl_split_bf16(q1.x, q1.y, h.u[2], l.u[2]); srl_split_bf16(q1.z, q1.w, h.u[3], l.u[3]);
+          } else {
+            h.u[0] = srl_pk_bf16(q0.x, q0.y); h.u[1] = srl_pk_bf16(q0.z, q0.w);
+            h.u[2] = srl_pk_bf16(q1.x, q1.y); h.u[3] = srl_pk_bf16(q1.z, q1.w);
+          }
+        } else {
+          const uint4 q = *(const uint4*)((const uint16_t*)kern + off);
+          h.u[0] = q.x; h.u[1] = q.y; h.u[2] = q.z; h.u[3] = q.w;
+        }
+      }
+      bh[ci][it] = h.v;
+      if (SPLIT) bl[ci][it] = l.v;
+    }
+  }
+  // map rows: thread -> (channel tid / 32, columns 4 (tid % 32) .. + 3)
+  const int sc = tid >> 5, scol = (tid & 31) * 4;
+  const bool sact = sc < C;
+  float4 rowreg = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  auto fetch = [&](int rho) {
+    if (!sact) return;
+    if (F32) rowreg = *(const float4*)((const float*)in + (((size_t)b * C + sc) * HIN + rho) * HIN + scol);
+    else {
+      const uint2 q = *(const uint2*)((const uint16_t*)in + (((size_t)b * C + sc) * HIN + rho) * HIN + scol);
+      rowreg = make_float4(bf16_to_f32(q.x & 0xffffu), bf16_to_f32(q.x >> 16), bf16_to_f32(q.y & 0xffffu), bf16_to_f32(q.y >> 16));
+    }
+  };
+  // the row goes to LDS NCP times, copy k holding X[j + k] at element j: a fragment (8 consecutive elements from any start s)
+  // is then ONE 16-byte read at the 8-byte aligned element s & ~3 of copy s & 3.  A thread has the elements 4 q .. 4 q + 3
+  // and takes 4 q + 4 .. 4 q + 6 from the next lane (zeros behind the row's last thread).
+  auto stash = [&](int buf) {
+    float e[7] = {rowreg.x, rowreg.y, rowreg.z, rowreg.w, 0.0f, 0.0f, 0.0f};
+    const float nx = __shfl_down(rowreg.x, 1), ny = __shfl_down(rowreg.y, 1), nz = __shfl_down(rowreg.z, 1);
+    if ((tid & 31) != 31) { e[4] = nx; e[5] = ny; e[6] = nz; }
+    if (!sact) return;
+    uint32_t hi[7], lo[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      hi[k] = bf16_rne(e[k]);
+      lo[k] = SPLIT ? bf16_rne(e[k] - bf16_to_f32(hi[k])) : 0u;
+    }
+    uint16_t* d = xr + buf * PL * XPL + sc * XS + scol;
+#pragma unroll
+    for (int k = 0; k < NCP; ++k) {
+      *(uint2*)(d + k * CPS) = make_uint2(hi[k] | (hi[k + 1] << 16), hi[k + 2] | (hi[k + 3] << 16));
+      if (SPLIT) *(uint2*)(d + XPL + k * CPS) = make_uint2(lo[k] | (lo[k + 1] << 16), lo[k + 2] | (lo[k + 3] << 16));
+    }
+  };
+  fetch(0);
+  __syncthreads();            // the zero fill is complete
+  stash(0);
+  fetch(1);
+  // S[t][it]: accumulator tiles that ARE the diagonal sums: lane n of i-tile `it` holds the partial sum of output row
+  // y = rho - 16 it - n, columns 16 t + 4 g + r.  A step to the next map row moves every partial one lane up (row_shr:1, zero
+  // into lane 0: a fresh row) and the row's products are accumulated on top by the matrix cores themselves (the shifted
+  // registers are the MFMAs' C operand).  The two i-tiles run as two chains of 16: what leaves lane 15 of i-tile 0 at step rho is
+  // the first half (i < 16) of output row rho - 15, what leaves lane 15 of i-tile 1 the second half of row rho - 31.
+  f32x4 S[T][2];
+#pragma unroll
+  for (int t = 0; t < T; ++t) { S[t][0] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; S[t][1] = S[t][0]; }
+  // per-lane fragment offset (elements) inside a plane, without channel and tile: tile t starts at s = 16 t + n + 8 g, whose
+  // copy (s & 3) and aligned part (s & ~3) = 16 t + ((n + 8 g) & ~3) depend on the lane only up to the immediate 16 t
+  const int s_lane = n + 8 * g;
+  const int lane_off = (s_lane & 3) * CPS + (s_lane & ~3);
+  float* ring = comb + 2 * 2 * NW * (16 * T);          // [16][128]: first halves of the output rows waiting for their second
+  __syncthreads();
+  for (int rho = 0; rho < HIN; ++rho) {
+    const uint16_t* xb = xr + (rho & 1) * PL * XPL + lane_off;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          S[t][it][r] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(S[t][it][r]), 0x111, 0xf, 0xf, true));   // row_shr:1
+    // A fragments of the seven tiles of both channels: lane (m = n, g) holds X_c[rho][s .. s + 7] — two 8-byte reads each
+    // (ds_read_b64: 256 B per LDS clock; as one ds_read2_b64 the pair runs at half that, so every read goes through a 32-bit LDS
+    // address the compiler cannot see through and none is merged with a neighbour 8 or 32 bytes away).  All of a step's reads
+    // are requested first; the next row's conversion and LDS writes (the other buffer) run while they arrive.
+    bf16x8 ah[2][T], al[SPLIT ? 2 : 1][SPLIT ? T : 1];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+      const int c = min(wave + NW * ci, C - 1);
+      const uint16_t* pc = xb + c * XS;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        uint32_t pa = (uint32_t)(uintptr_t)(const lds_u16*)(pc + 16 * t);
+        asm volatile("" : "+v"(pa));
+        uint32_t pb = pa + 8u;
+        asm volatile("" : "+v"(pb));
+        union { u32x2 h[2]; bf16x8 v; } fh, fl;
+        fh.h[0] = *(const lds_u2*)(uintptr_t)pa; fh.h[1] = *(const lds_u2*)(uintptr_t)pb;
+        ah[ci][t] = fh.v;
+        if (SPLIT) {
+          fl.h[0] = *(const lds_u2*)(uintptr_t)(pa + 2u * XPL); fl.h[1] = *(const lds_u2*)(uintptr_t)(pb + 2u * XPL);
+          al[ci][t] = fl.v;
+        }
+      }
+    }
+    if (rho + 1 < HIN) stash((rho + 1) & 1);
+    if (rho + 2 < HIN) fetch(rho + 2);
+    // per channel three passes over the fourteen accumulator tiles (hi hi, hi lo, lo hi): an accumulator's next product is
+    // fourteen MFMAs away instead of next in line.  (A channel past the last one has zero kernel fragments: its products add 0.)
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+      if (wave + NW * ci < C) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int it = 0; it < 2; ++it) S[t][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ci][t], bh[ci][it], S[t][it], 0, 0, 0);
+        if (SPLIT) {
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) S[t][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ci][t], bl[ci][it], S[t][it], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) S[t][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ci][t], bh[ci][it], S[t][it], 0, 0, 0);
+        }
+      }
+    }
+    // this wave's parts of the two output rows that complete a chain at this step (lanes n = 15)
+    if (n == 15) {
+      float* cp = comb + ((rho & 1) * 2 * NW + wave) * (16 * T) + 4 * g;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        *(float4*)(cp + 16 * t) = make_float4(S[t][0][0], S[t][0][1], S[t][0][2], S[t][0][3]);
+        *(float4*)(cp + NW * 16 * T + 16 * t) = make_float4(S[t][1][0], S[t][1][1], S[t][1][2], S[t][1][3]);
+      }
+    }
+    // (interleaving the row parts' LDS writes and the lane shift with the last pass's matrix products, tile by tile and
+    // branch-free, was measured: 665 against 590 us per 512 samples)
+    __syncthreads();
+    if (tid < O) {      // the waves' parts added in wave order; column tid is always this thread's: the ring needs no barrier
+      const float* cp = comb + (rho & 1) * 2 * NW * (16 * T) + tid;
+      float p0 = cp[0], p1 = cp[NW * 16 * T];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) { p0 += cp[w * 16 * T]; p1 += cp[(NW + w) * 16 * T]; }
+      float* rp = ring + (rho & 15) * 128 + tid;
+      if (rho >= KH - 1) out[((size_t)b * O + (rho - (KH - 1))) * O + tid] = *rp + p1;   // row rho - 31: its first half left at step rho - 16
+      *rp = p0;                                                                            // first half of row rho - 15
+    }
+  }
+}
+
+// The same sweep with FOUR waves per sample and two samples per CU: a wave takes four channels (168 MFMAs per map row between
+// barriers instead of 84), the staged row is single-buffered (two barriers per row), and the two workgroups that share a CU's
+// SIMDs are not in step with one another — one's conversions, LDS traffic and barriers run under the other's matrix products
+// (with eight waves of ONE sample per CU every wave is in the same phase at the same time: MFMA pipes busy 43 % of the time).
+template <bool SPLIT, bool F32>
+__global__ void __launch_bounds__(256, 2)
+k_xcorr_rows4(const void* __restrict__ in, const void* __restrict__ kern, float* __restrict__ out, int C) {
+  constexpr int HIN = 128, KH = 32, O = HIN - KH + 1, T = 7, NW = 4, CPW = 4;
+  constexpr int XS = 160, CMAX = 16, NCP = 4;
+  constexpr int PL = (SPLIT ? 2 : 1);
+  constexpr int CPS = CMAX * XS + 32;
+  constexpr int XPL = NCP * CPS;
+  extern __shared__ uint16_t xs[];
+  uint16_t* xr = xs;                                            // [PL][NCP][CMAX][XS]
+  float* comb = (float*)(xr + PL * XPL);                        // [2 halves][NW][16 T]
+  float* ring = comb + 2 * NW * (16 * T);                       // [16][128]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  {
+    uint32_t* z = (uint32_t*)xr;
+    for (int k = tid; k < PL * XPL / 2; k += 256) z[k] = 0u;
+  }
+  bf16x8 bh[CPW][2], bl[SPLIT ? CPW : 1][2];
+#pragma unroll
+  for (int ci = 0; ci < CPW; ++ci) {
+    const int c = wave + NW * ci;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      union { uint32_t u[4]; bf16x8 v; } h, l;
+      h.u[0] = h.u[1] = h.u[2] = h.u[3] = 0u; l.u[0] = l.u[1] = l.u[2] = l.u[3] = 0u;
+      if (c < C) {
+        const size_t off = (((size_t)b * C + c) * KH + 16 * it + n) * KH + 8 * g;
+        if (F32) {
+          const float4 q0 = *(const float4*)((const float*)kern + off), q1 = *(const float4*)((const float*)kern + off + 4);
+          if (SPLIT) {
+            srl_split_bf16(q0.x, q0.y, h.u[0], l.u[0]); srl_split_bf16(q0.z, q0.w, h.u[1], l.u[1]);
+            srl_split_bf16(q1.x, q1.y, h.u[2], l.u[2]); srl_split_bf16(q1.z, q1.w, h.u[3], l.u[3]);
+          } else {
+            h.u[0] = srl_pk_bf16(q0.x, q0.y); h.u[1] = srl_pk_bf16(q0.z, q0.w);
+            h.u[2] = srl_pk_bf16(q1.x, q1.y); h.u[3] = srl_pk_bf16(q1.z, q1.w);
+          }
+        } else {
+          const uint4 q = *(const uint4*)((const uint16_t*)kern + off);
+          h.u[0] = q.x; h.u[1] = q.y; h.u[2] = q.z; h.u[3] = q.w;
+        }
+      }
+      bh[ci][it] = h.v;
+      if (SPLIT) bl[ci][it] = l.v;
+    }
+  }
+  // map rows: thread -> (channels tid / 32 and tid / 32 + 8, columns 4 (tid % 32) .. + 3)
+  const int sc = tid >> 5, scol = (tid & 31) * 4;
+  float4 rowreg[2];
+  auto fetch = [&](int rho) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = sc + 8 * h;
+      rowreg[h] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (c < C) {
+        if (F32) rowreg[h] = *(const float4*)((const float*)in + (((size_t)b * C + c) * HIN + rho) * HIN + scol);
+        else {
+          const uint2 q = *(const uint2*)((const uint16_t*)in + (((size_t)b * C + c) * HIN + rho) * HIN + scol);
+          rowreg[h] = make_float4(bf16_to_f32(q.x & 0xffffu), bf16_to_f32(q.x >> 16), bf16_to_f32(q.y & 0xffffu), bf16_to_f32(q.y >> 16));
+        }
+      }
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = sc + 8 * h;
+      float e[7] = {rowreg[h].x, rowreg[h].y, rowreg[h].z, rowreg[h].w, 0.0f, 0.0f, 0.0f};
+      const float nx = __shfl_down(rowreg[h].x, 1), ny = __shfl_down(rowreg[h].y, 1), nz = __shfl_down(rowreg[h].z, 1);
+      if ((tid & 31) != 31) { e[4] = nx; e[5] = ny; e[6] = nz; }
+      if (c < C) {
+        uint32_t hi[7], lo[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+          hi[k] = bf16_rne(e[k]);
+          lo[k] = SPLIT ? bf16_rne(e[k] - bf16_to_f32(hi[k])) : 0u;
+        }
+        uint16_t* d = xr + c * XS + scol;
+#pragma unroll
+        for (int k = 0; k < NCP; ++k) {
+          *(uint2*)(d + k * CPS) = make_uint2(hi[k] | (hi[k + 1] << 16), hi[k + 2] | (hi[k + 3] << 16));
+          if (SPLIT) *(uint2*)(d + XPL + k * CPS) = make_uint2(lo[k] | (lo[k + 1] << 16), lo[k + 2] | (lo[k + 3] << 16));
+        }
+      }
+    }
+  };
+  fetch(0);
+  __syncthreads();
+  stash();
+  fetch(1);
+  f32x4 S[T][2];
+#pragma unroll
+  for (int t = 0; t < T; ++t) { S[t][0] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; S[t][1] = S[t][0]; }
+  const int s_lane = n + 8 * g;
+  const uint16_t* xb = xr + (s_lane & 3) * CPS + (s_lane & ~3);
+  __syncthreads();
+  for (int rho = 0; rho < HIN; ++rho) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          S[t][it][r] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(S[t][it][r]), 0x111, 0xf, 0xf, true));   // row_shr:1
+#pragma unroll
+    for (int ci = 0; ci < CPW; ++ci) {
+      const int c = wave + NW * ci;
+      if (c < C) {
+        const uint16_t* pc = xb + c * XS;
+        bf16x8 ah[T], al[SPLIT ? T : 1];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          uint32_t pa = (uint32_t)(uintptr_t)(const lds_u16*)(pc + 16 * t);
+          asm volatile("" : "+v"(pa));
+          uint32_t pb = pa + 8u;
+          asm volatile("" : "+v"(pb));
+          union { u32x2 h[2]; bf16x8 v; } fh, fl;
+          fh.h[0] = *(const lds_u2*)(uintptr_t)pa; fh.h[1] = *(const lds_u2*)(uintptr_t)pb;
+          ah[t] = fh.v;
+          if (SPLIT) {
+            fl.h[0] = *(const lds_u2*)(uintptr_t)(pa + 2u * XPL); fl.h[1] = *(const lds_u2*)(uintptr_t)(pb + 2u * XPL);
+            al[t] = fl.v;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int it = 0; it < 2; ++it) S[t][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bh[ci][it], S[t][it], 0, 0, 0);
+        if (SPLIT) {
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) S[t][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bl[ci][it], S[t][it], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) S[t][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], bh[ci][it], S[t][it], 0, 0, 0);
+        }
+      }
+    }
+    if (n == 15) {
+      float* cp = comb + wave * (16 * T) + 4 * g;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        *(float4*)(cp + 16 * t) = make_float4(S[t][0][0], S[t][0][1], S[t][0][2], S[t][0][3]);
+        *(float4*)(cp + NW * 16 * T + 16 * t) = make_float4(S[t][1][0], S[t][1][1], S[t][1][2], S[t][1][3]);
+      }
+    }
+    __syncthreads();        // every wave has read row rho; the row parts are in LDS
+    if (tid < O) {
+      const float* cp = comb + tid;
+      float p0 = cp[0], p1 = cp[NW * 16 * T];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) { p0 += cp[w * 16 * T]; p1 += cp[(NW + w) * 16 * T]; }
+      float* rp = ring + (rho & 15) * 128 + tid;
+      if (rho >= KH - 1) out[((size_t)b * O + (rho - (KH - 1))) * O + tid] = *rp + p1;
+      *rp = p0;
+    }
+    if (rho + 1 < HIN) stash();
+    if (rho + 2 < HIN) fetch(rho + 2);
+    __syncthreads();        // row rho + 1 is in LDS; the row parts have been consumed
+  }
+}
+
+constexpr size_t rows4_lds_bytes(bool split) {
+  return sizeof(uint16_t) * ((split ? 2 : 1) * 4 * (16 * 160 + 32)) + sizeof(float) * (2 * 4 * 112 + 16 * 128);
+}
+
+constexpr size_t rows_lds_bytes(bool split) {
+  return sizeof(uint16_t) * (2 * (split ? 2 : 1) * 4 * (16 * 160 + 32)) + sizeof(float) * (2 * 2 * 8 * 112 + 16 * 128);
+}
+
+template <bool SPLIT, bool F32>
+int launch_rows(const void* in, const void* kern, float* out, int B, int C, hipStream_t st) {
+  const char* var = getenv("SRL_XCORR_ROWS_WAVES");      // (A / B: "8" = one eight-wave workgroup per CU)
+  if (!(var && var[0] == '8')) {
+    auto fn4 = k_xcorr_rows4<SPLIT, F32>;
+    const size_t lds4 = rows4_lds_bytes(SPLIT);
+    static bool opted4 = false;
+    if (!opted4) {
+      hipError_t e = hipFuncSetAttribute((const void*)fn4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+      if (e != hipSuccess) {
+        snprintf(x_err, sizeof x_err, "srl_xcorr_mfma: LDS opt-in of %zu bytes failed: %s", lds4, hipGetErrorString(e));
+        return 2;
+      }
+      opted4 = true;
+    }
+    hipLaunchKernelGGL(fn4, dim3(B), dim3(256), lds4, st, in, kern, out, C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      snprintf(x_err, sizeof x_err, "srl_xcorr_mfma: %s", hipGetErrorString(e));
+      return 2;
+    }
+    return 0;
+  }
+  auto fn = k_xcorr_rows<SPLIT, F32>;
+  const size_t lds = rows_lds_bytes(SPLIT);
+  static bool opted = false;   // per instantiation; set once, outside any later stream capture
+  if (!opted) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      snprintf(x_err, sizeof x_err, "srl_xcorr_mfma: LDS opt-in of %zu bytes failed: %s", lds, hipGetErrorString(e));
+      return 2;
+    }
+    opted = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(B), dim3(512), lds, st, in, kern, out, C);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(x_err, sizeof x_err, "srl_xcorr_mfma: %s", hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
+
+// the row-product forward serves batches that fill the chip with one workgroup per sample (the rollout); smaller batches (the
+// update's 32 / 64 samples) keep the Toeplitz kernel with its channel split.  SRL_XCORR_ROWS=0 / 1 forces either (tests, A / B).
+bool use_rows(int mode, int precision, int in_f32, int kern_f32, int B, int C, int H, int kh) {
+  if (mode != 0 || H != 128 || kh != 32 || C < 1 || C > 16 || in_f32 != kern_f32 || (precision == 1 && !in_f32)) return false;
+  const char* force = getenv("SRL_XCORR_ROWS");   // (read at every call: a test switches it)
+  if (force && force[0] == '0') return false;
+  if (force && force[0] == '1') return true;
+  return B >= 192;
+}
+
 }  // namespace
 
 extern "C" {
@@ -384,6 +821,11 @@ int srl_xcorr_mfma(int32_t mode, int32_t precision, const void* in, int32_t in_f
     return 1;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (use_rows(mode, precision, in_f32, kern_f32, B, C, H, kh)) {
+    if (precision == 1) return launch_rows<true, true>(in, kern, out, B, C, st);
+    if (in_f32) return launch_rows<false, true>(in, kern, out, B, C, st);
+    return launch_rows<false, false>(in, kern, out, B, C, st);
+  }
   if (H == 128) {
     // tile rows per workgroup: 4 of 7 (forward: 76 KB of LDS with the bf16x3 split, two workgroups per CU), 3 of 8 (d/dx:
     // 70 KB), both rows of the d/dw's 2 (its 97 kernel rows are the larger part of the 140 KB)

@@ -1056,3 +1056,32 @@ def test_rollout_argmax_against_float64_on_real_observations():
   assert x3['max_regret_of_a_flip'] <= 1e-4, x3              # and a flip gives up at most that much advantage
   assert x3['flip_rate'] <= max(5 * f32['flip_rate'], 0.01), (x3, f32)
   assert b16['max_rel_err'] > x3['max_rel_err']              # (the labelled bf16 rollout is the narrower one)
+
+
+@pytest.mark.parametrize('B,C,dt', [(3, 16, 'f32x3'), (2, 7, 'f32x3'), (2, 16, 'f32'), (3, 16, 'bf16'), (200, 16, 'f32x3')])
+def test_xcorr_row_product_forward(B, C, dt, monkeypatch):
+  """The rollout's cross-correlation forward as a product per map row (`k_xcorr_rows`, csrc/xcorr_mfma.hip: Hankel fragments of
+  the row x the kernel's rows, the sum over kernel rows along a diagonal by DPP lane shifts): against the library formulation
+  in float64 at the kernel family's stated tolerances, against the Toeplitz kernel it replaces for large batches, bit-identical
+  on repetition, and chosen by batch size (>= 192 samples) when nothing forces it."""
+  from stackrl_amd import nets, qops
+  g = torch.Generator(device='cuda').manual_seed(B * 17 + C)
+  x = torch.rand((B, C, 128, 128), generator=g, device='cuda')
+  w = torch.rand((B, C, 32, 32), generator=g, device='cuda') - 0.3
+  if dt == 'bf16':
+    x, w = x.to(torch.bfloat16), w.to(torch.bfloat16)
+  prec = {'f32x3': qops.BF16X3, 'f32': qops.BF16, 'bf16': qops.BF16}[dt]
+  def run():
+    return qops.xcorr_forward_mfma(x, w, prec)
+  if B < 192:
+    monkeypatch.setenv('SRL_XCORR_ROWS', '1')
+  rows = run()
+  assert torch.equal(rows, run())
+  ref = nets.correlation_reference(x.double(), w.double())
+  scale = float(ref.abs().max())
+  tol = 2e-5 if dt != 'f32' else 6e-3          # operands split (fp32-class) or exact bf16 operands / operands rounded to bf16
+  assert rows.shape == ref.shape and rows.dtype == torch.float32
+  assert float((rows.double() - ref).abs().max()) <= tol * scale
+  monkeypatch.setenv('SRL_XCORR_ROWS', '0')
+  toep = run()
+  assert float((rows - toep).abs().max()) <= 2e-5 * scale      # the same products, another order of the fp32 sums
