@@ -476,6 +476,7 @@ int srl_load_meshes(srl_env* env, const float* verts, const int32_t* vert_off, c
   P.n_mesh = n_mesh;
   P.VS = vs;
   env->P_dirty = true;
+  env->stage_dirty = true;     // (records made from another mesh table are stale)
   int old_blob = P.BLOB;
   layout(P, env->concurrent_envs);
   if (P.BLOB != old_blob) return fail(SRL_EINVAL, "internal: blob layout changed");
