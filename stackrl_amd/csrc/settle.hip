@@ -588,6 +588,90 @@ __device__ __forceinline__ void ground_turn(const Lds& L, GPoint& p, float& res)
   *(float4*)L.Vl(p.a) = make_float4(v.x, v.y, v.z, 0.0f); *(float4*)L.Wl(p.a) = make_float4(w.x, w.y, w.z, 0.0f);
 }
 
+// ---- the ground phase by BODY lanes (round 5).  The (up to 4) ground points of one body share that body's velocities and
+// nothing else, so a sweep's ground phase is, per body, a sequence of 4 x 3 rows on one pair (v, w).  As turns of point lanes
+// the pair went through LDS between the points (write, read, wait: ~100 cycles a turn, and a lone wave has nothing to hide
+// them under); here lane = body keeps (v, w) and the points' accumulated impulses in registers for the whole phase and reads
+// the rows' constants — made once per sub-step by the point lanes, as before — from LDS in the order it consumes them
+// (reads that depend on nothing the rows compute).  Same rows, same order per body, same expression trees: bit-identical.
+#define SRL_CG_WORDS 28      // per ground point: 7 float4 (layout: cg_store)
+struct GBody {
+  float acc[SRL_GMAXP][3];   // accumulated impulses (normal, tangent 1, tangent 2) of the body's ground points
+  float ima;
+  int np, b;                 // points in the body's ground manifold (0: none / not a body lane)
+  float4 *pv, *pw;           // the body's linear / angular velocity in LDS
+  const float4* rec;         // its points' row constants
+};
+
+__device__ __forceinline__ float4* cg_rec(const Lds& L, int b, int i) {   // aliases the world vertices, dead during the solve
+  return (float4*)L.WV(0) + (SRL_CG_WORDS / 4) * (SRL_GMAXP * b + i);
+}
+__device__ __forceinline__ void cg_store(const Lds& L, const GPoint& p) {
+  float4* r = cg_rec(L, p.a, p.idx);
+  r[0] = make_float4(p.n.ca.x, p.n.ca.y, p.n.ca.z, p.n.rk);
+  r[1] = make_float4(p.n.aa.x, p.n.aa.y, p.n.aa.z, p.target * p.n.rk);
+  r[2] = make_float4(p.t1.ca.x, p.t1.ca.y, p.t1.ca.z, p.t1.rk);
+  r[3] = make_float4(p.t1.aa.x, p.t1.aa.y, p.t1.aa.z, p.n.k);
+  r[4] = make_float4(p.t2.ca.x, p.t2.ca.y, p.t2.ca.z, p.t2.rk);
+  r[5] = make_float4(p.t2.aa.x, p.t2.aa.y, p.t2.aa.z, p.t1.k);
+  r[6] = make_float4(p.t2.k, p.mu, 0.0f * p.t1.rk, 0.0f * p.t2.rk);   // (a friction row's target is 0: `target * rk` as grow_solve forms it)
+}
+
+// grow_solve with the product target * rk handed in (trk): the same operations on the velocities' chain
+template <int AXIS, int SGN>
+__device__ __forceinline__ void grow_solve_t(v3 ca, v3 aa, float rk, float k, float ima, v3& v, v3& w, float trk, float& acc,
+                                             float lo, float hi, float& res) {
+  float& va = AXIS == 0 ? v.x : AXIS == 1 ? v.y : v.z;
+  const float vrel = fmaf(ca.x, w.x, fmaf(ca.y, w.y, fmaf(ca.z, w.z, SGN < 0 ? -va : va)));
+  float dl = fmaf(-vrel, rk, trk);
+  const float na = __builtin_amdgcn_fmed3f(acc + dl, lo, hi);
+  dl = na - acc;
+  acc = na;
+  res = fmaxf(res, fabsf(dl * k));
+  va = fmaf(SGN < 0 ? -ima : ima, dl, va);
+  w = madd(w, aa, dl);
+}
+
+template <bool WARM>
+__device__ __forceinline__ void ground_point(const float4* rec, GBody& gb, int i, float ws, v3& v, v3& w, float& res) {
+  const float4 q0 = rec[7 * i], q1 = rec[7 * i + 1], q2 = rec[7 * i + 2], q3 = rec[7 * i + 3], q4 = rec[7 * i + 4],
+               q5 = rec[7 * i + 5], q6 = rec[7 * i + 6];
+  if (WARM) {
+    gb.acc[i][0] = gb.acc[i][0] * ws; gb.acc[i][1] = gb.acc[i][1] * ws; gb.acc[i][2] = gb.acc[i][2] * ws;
+    GRow g; g.rk = 0.0f; g.k = 0.0f;
+    g.ca = V(q0.x, q0.y, q0.z); g.aa = V(q1.x, q1.y, q1.z); grow_apply<2, 1>(g, gb.ima, v, w, gb.acc[i][0]);
+    g.ca = V(q2.x, q2.y, q2.z); g.aa = V(q3.x, q3.y, q3.z); grow_apply<1, -1>(g, gb.ima, v, w, gb.acc[i][1]);
+    g.ca = V(q4.x, q4.y, q4.z); g.aa = V(q5.x, q5.y, q5.z); grow_apply<0, 1>(g, gb.ima, v, w, gb.acc[i][2]);
+  } else {
+    grow_solve_t<2, 1>(V(q0.x, q0.y, q0.z), V(q1.x, q1.y, q1.z), q0.w, q3.w, gb.ima, v, w, q1.w, gb.acc[i][0], 0.0f, 1e30f, res);
+    const float lim = q6.y * gb.acc[i][0];
+    grow_solve_t<1, -1>(V(q2.x, q2.y, q2.z), V(q3.x, q3.y, q3.z), q2.w, q5.w, gb.ima, v, w, q6.z, gb.acc[i][1], -lim, lim, res);
+    grow_solve_t<0, 1>(V(q4.x, q4.y, q4.z), V(q5.x, q5.y, q5.z), q4.w, q6.x, gb.ima, v, w, q6.w, gb.acc[i][2], -lim, lim, res);
+  }
+}
+
+template <bool WARM>
+__device__ __forceinline__ void ground_body(const Lds& L, GBody& gb, float& res) {
+  const float ws = L.P->c.warmstart;
+  const float4 a0 = *gb.pv, a1 = *gb.pw;
+  v3 v = V(a0.x, a0.y, a0.z), w = V(a1.x, a1.y, a1.z);
+  const float4* rec = gb.rec;
+  // The guards are nested: the points of a manifold are a prefix.  (Measured and dropped: the next point's record — or only its
+  // first row's constants — requested before the current point is computed, pinned by an empty asm because the compiler sinks a
+  // read that only the guarded block uses into that block: 28 registers more spill 20 - 366 in the four variants; 8 registers
+  // more gain less at the headline shape than this form, +2.1 against +4.2 %: profiles/r05_experiment_log.md.)
+  static_assert(SRL_GMAXP == 4, "four nested guards below");
+  ground_point<WARM>(rec, gb, 0, ws, v, w, res);        // (a body lane is called with np >= 1)
+  if (gb.np > 1) {
+    ground_point<WARM>(rec, gb, 1, ws, v, w, res);
+    if (gb.np > 2) {
+      ground_point<WARM>(rec, gb, 2, ws, v, w, res);
+      if (gb.np > 3) ground_point<WARM>(rec, gb, 3, ws, v, w, res);
+    }
+  }
+  *gb.pv = make_float4(v.x, v.y, v.z, 0.0f); *gb.pw = make_float4(w.x, w.y, w.z, 0.0f);
+}
+
 __device__ __forceinline__ Point make_pair_point(const Lds& L, int sl, int i) {
   const DevParams& P = *L.P;
   Point p;
@@ -661,16 +745,21 @@ __device__ __forceinline__ void point_turn(const Lds& L, Point& p, float& res) {
 // lanes, and manifold slots are handed out lowest first), so the sweep is wave 0's alone: the phases follow each other in
 // program order — the LDS serves one wave's accesses in order — without a single block barrier, and the residual is a
 // ballot.  The other waves skip the sweeps and wait at the barrier that ends the solve.
-template <bool WARM, int PP, bool SOLO>
-__device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, Point (&pp)[PP], int ncol, int gturns, int pturns,
+template <bool WARM, int PP, bool SOLO, bool GB>
+__device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, GBody& gb, Point (&pp)[PP], int ncol, int gturns, int pturns,
                                              int gslot, const int (&pslot)[PP], int gsweep) {
   // gslot / pslot: the turn a lane's point takes (ground: its index; colour phases: 4 * colour + index; -1: none), so
   // that a turn's guard is one compare
   // ground phase: the (up to 4) points of one body are consecutive lanes of one wave and take turns
   float res = 0.0f;
+  if (!GB) {     // the points of a body as turns of point lanes (round 1 - 4; kept for the variant that loses with body lanes)
 #pragma unroll 1
-  for (int i = 0; i < gturns; ++i) {
-    if (gslot == i) ground_turn<WARM>(L, gp, res);
+    for (int i = 0; i < gturns; ++i) {
+      if (gslot == i) ground_turn<WARM>(L, gp, res);
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+    if (gb.np > 0) ground_body<WARM>(L, gb, res);
     __builtin_amdgcn_wave_barrier();
   }
 #pragma unroll 1
@@ -810,6 +899,33 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
       if (tid >= 64 && __ballot(mine) != 0ull && (tid & 63) == 0) misc[M_SOLO] = 0;
     }
     __syncthreads();   // every lane has read the pre-solve velocities' companions (R, Iw, manifolds)
+    GBody gb;
+    gb.np = 0; gb.b = 0; gb.ima = 0.0f;
+    gb.pv = (float4*)L.Vl(0); gb.pw = (float4*)L.Wl(0); gb.rec = cg_rec(L, 0, 0);
+#pragma unroll
+    for (int i = 0; i < SRL_GMAXP; ++i) { gb.acc[i][0] = 0.0f; gb.acc[i][1] = 0.0f; gb.acc[i][2] = 0.0f; }
+    // The ground phase by body lanes (ground_body) in every variant but the four-wave one with one point per thread (9 - 16
+    // rocks, small batches): built for three waves per SIMD (168 VGPRs) it spills 185 registers with it against 113 and loses
+    // 9 % (1,024 / 2,048 envs x 16 rocks); the others gain 3 - 5 % (profiles/r05_ground_body_ab.txt).  SRL_GROUND_TURNS: A / B.
+#ifdef SRL_GROUND_TURNS
+    constexpr bool GB = false;
+#else
+    constexpr bool GB = !(T == 256 && PP == 1);
+#endif
+    if (GB) {
+    // the rows' constants of every ground point to LDS (over the world vertices, which nothing reads before the next
+    // sub-step rewrites them), for the body lanes (tid < nb: wave 0)
+    if (gp.valid) cg_store(L, gp);
+    if (tid < nb) {
+      const float* g = L.GM(tid);
+      gb.b = tid; gb.np = __float_as_int(g[0]); gb.ima = L.BC(tid)[0];
+      gb.pv = (float4*)L.Vl(tid); gb.pw = (float4*)L.Wl(tid); gb.rec = cg_rec(L, tid, 0);
+#pragma unroll
+      for (int i = 0; i < SRL_GMAXP; ++i)
+        if (i < gb.np) { gb.acc[i][0] = g[SRL_GM_IN + i]; gb.acc[i][1] = g[SRL_GM_T1 + i]; gb.acc[i][2] = g[SRL_GM_T2 + i]; }
+    }
+    __syncthreads();   // the records are in LDS
+    }
     STAMP(5);
 #ifdef SRL_DIAG_NOSOLO
     const bool solo = false;                           // diagnostic build: every sweep through the block-wide path
@@ -835,24 +951,31 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
     if (solo) {
       int done = 0;
       if (tid < 64) {
-        solver_sweep<true, PP, PP == 1>(L, gp, pp, ncol, gturns, pturns, gslot, pslot, 0);
+        solver_sweep<true, PP, PP == 1, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0);
         for (int it = 0; it < P.c.solver_iterations; ++it) {
           done++;
-          if (!solver_sweep<false, PP, PP == 1>(L, gp, pp, ncol, gturns, pturns, gslot, pslot, 0)) break;
+          if (!solver_sweep<false, PP, PP == 1, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0)) break;
         }
         if (tid == 0) misc[M_CNT] = done;   // (M_CNT is free between the calls of newest_contacts)
       }
       __syncthreads();
       gsweep += misc[M_CNT];
     } else {
-      solver_sweep<true, PP, false>(L, gp, pp, ncol, gturns, pturns, gslot, pslot, 0);
+      solver_sweep<true, PP, false, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0);
       for (int it = 0; it < P.c.solver_iterations; ++it) {
         gsweep++;
-        if (!solver_sweep<false, PP, false>(L, gp, pp, ncol, gturns, pturns, gslot, pslot, gsweep)) break;
+        if (!solver_sweep<false, PP, false, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, gsweep)) break;
       }
     }
     // accumulated impulses back to the manifolds (warm start of the next sub-step)
-    if (gp.valid) { float* g = L.GM(gp.a); g[SRL_GM_IN + gp.idx] = gp.in; g[SRL_GM_T1 + gp.idx] = gp.i1; g[SRL_GM_T2 + gp.idx] = gp.i2; }
+    if (!GB) {
+      if (gp.valid) { float* g = L.GM(gp.a); g[SRL_GM_IN + gp.idx] = gp.in; g[SRL_GM_T1 + gp.idx] = gp.i1; g[SRL_GM_T2 + gp.idx] = gp.i2; }
+    } else if (gb.np > 0) {
+      float* g = L.GM(gb.b);
+#pragma unroll
+      for (int i = 0; i < SRL_GMAXP; ++i)
+        if (i < gb.np) { g[SRL_GM_IN + i] = gb.acc[i][0]; g[SRL_GM_T1 + i] = gb.acc[i][1]; g[SRL_GM_T2 + i] = gb.acc[i][2]; }
+    }
 #pragma unroll
     for (int r = 0; r < PP; ++r)
       if (pp[r].valid) {
@@ -905,7 +1028,8 @@ __device__ __forceinline__ bool sim_stop(const Lds& L, int nb, int tid) {
 }
 
 // number of manifold points on the newest body (getContactPoints, simulator.py:340)
-__device__ int newest_contacts(const Lds& L, int nb, int tid, int T) {
+// (forced inline: called out of line, the Lds object — the layout offsets pinned in scalar registers — has to live in memory)
+__device__ __forceinline__ int newest_contacts(const Lds& L, int nb, int tid, int T) {
   int* misc = L.MISC();
   if (tid == 0) misc[M_CNT] = __float_as_int(L.GM(nb - 1)[0]);
   __syncthreads();

@@ -181,7 +181,8 @@ void layout(DevParams& P, int concurrent) {
   P.S_AMIN = s; s += 3 * L;
   P.S_AMAX = s; s += 3 * L;
   P.S_BC = s; s += 8 * L;
-  P.S_WV = s; s += 3 * P.VS * L;
+  // (during the solve the region holds the ground points' row constants instead: SRL_GMAXP x SRL_CG_WORDS words per body)
+  P.S_WV = s; s += (3 * P.VS > SRL_GMAXP * SRL_CG_WORDS ? 3 * P.VS : SRL_GMAXP * SRL_CG_WORDS) * L;
   // above 16 rocks the local vertices are read from the (L2-resident) mesh table instead of an LDS copy: 70 instead of
   // 97 KB per env, so that two workgroups share a CU
   if (L > 16 || two_wave_variant(P, concurrent)) P.S_LV = -1; else { P.S_LV = s; s += 3 * P.VS * L; }

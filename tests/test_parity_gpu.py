@@ -194,6 +194,42 @@ def test_ordered_launch_matches_the_oracle(ref_pool, oracle_mod, L, n, kw):
   g.close()
 
 
+@pytest.mark.parametrize('L,n,kw', [(8, 24, {}), (14, 6, {}), (20, 4, dict(resolution_factor=4))])
+def test_tail_staged_records_equal_the_staging_kernels(ref_pool, L, n, kw):
+  """The rocks' render records (csrc/stage.h) are made in the tail of the settle kernels (all three thread / point variants
+  here: 128 threads, 256 threads, 256 threads with two points per thread); `srl_k_stage` makes them for a handle whose
+  records are stale.  Two handles with the same seed, one of them told before every step that its bodies were moved
+  (`set_body_state` with nothing to set: the records are staged again by the kernel after the settle kernel): the records of
+  every placed rock, the observations and the rewards are equal bit for bit."""
+  from stackrl_amd import env as envs
+  a = envs.VecStackEnv(n_parallel=n, seed=13, pool=ref_pool, block=True, episode_length=L, **kw)
+  b = envs.VecStackEnv(n_parallel=n, seed=13, pool=ref_pool, block=True, episode_length=L, **kw)
+  a.reset(); b.reset()
+  for k in range(L + 2):
+    act = a.sample()
+    assert torch.equal(act, b.sample())
+    b.set_body_state()                       # marks b's records stale: srl_k_stage runs in its next step
+    (am, ao), ar, ad = a.step(act)
+    (bm, bo), br, bd = b.step(act)
+    assert torch.equal(am, bm) and torch.equal(ao, bo) and torch.equal(ar, br) and torch.equal(ad, bd), 'call {}'.format(k)
+    ra, rb = a.stage_records().view(np.int32), b.stage_records().view(np.int32)
+    nb = a.state()[1]
+    for e in range(n):
+      for r in range(int(nb[e])):
+        hdr = ra[e, r, :2]
+        nup, nsil = int(hdr[0, 2]), int(hdr[0, 3])
+        used = 10 + nup + nsil
+        assert np.array_equal(ra[e, r, :2], rb[e, r, :2]), 'call {} env {} rock {}: header'.format(k, e, r)
+        if int(hdr[1, 0]) > 0:               # (a rock outside the window has no tables)
+          assert np.array_equal(ra[e, r, 2:10], rb[e, r, 2:10]), 'call {} env {} rock {}: span / range tables'.format(k, e, r)
+          # the two lists are SETS per first item row (filled with LDS counters): compare them sorted
+          pa, pb_ = ra[e, r, 10:10 + nup, :3], rb[e, r, 10:10 + nup, :3]
+          sa, sb = ra[e, r, 10 + nup:used, :3], rb[e, r, 10 + nup:used, :3]
+          for x, y, what in ((pa, pb_, 'planes'), (sa, sb, 'sides')):
+            assert np.array_equal(x[np.lexsort(x.T)], y[np.lexsort(y.T)]), 'call {} env {} rock {}: {}'.format(k, e, r, what)
+  a.close(); b.close()
+
+
 @pytest.mark.parametrize('n', [2048, 5000, 10000])
 def test_ordered_launch_is_a_sorted_permutation_at_production_sizes(ref_pool, n):
   """The sizes the ordered launch switches itself on at (>= 2,048 envs: several pairs per thread of the sorting network;
