@@ -240,6 +240,7 @@ def test_ordered_launch_is_a_sorted_permutation_at_production_sizes(ref_pool, n)
   L = 3
   g = envs.VecStackEnv(n_parallel=n, seed=41, pool=ref_pool, block=True, episode_length=L)      # ordered by batch size
   g.reset()
+  g.kernel_times(); g.set_profiling(True)
   for k in range(2):
     a = g.sample()
     Hm, Om, _ = g.maps()                     # the state the keys are computed from
@@ -257,6 +258,10 @@ def test_ordered_launch_is_a_sorted_permutation_at_production_sizes(ref_pool, n)
       z = np.float32(np.max(np.where(o > 1e-4, Hm[e, u:u + 32, v:v + 32] + o, np.float32(0))))
       want = (~np.float32(z).view(np.uint32)) & np.uint32(0xffffffff)
       assert int(keys[e] >> np.uint64(32)) == int(want), 'env {}: key {} != release height {}'.format(e, keys[e] >> np.uint64(32), z)
+  # the two order kernels are timed on their own, not inside the settle kernel's figure: two launches per ordered step
+  ms, nl = g.kernel_times()
+  oms, onl = g.order_kernel_times()
+  assert int(nl[0]) == 2 and int(nl[1]) == 2 and int(nl[2]) == 0 and onl == 4 and 0.0 < oms < 10.0, (ms, nl, oms, onl)
   g.close()
 
 
