@@ -504,7 +504,7 @@ static inline int pixel_range(float lo, float hi, float inv_px, int res, int* i0
 }
 
 /* Which faces and outline sides a pixel consults (round 4; the kernels' ray cast visits a rock in items of ITEM_ROWS pixel
- * rows x 2 columns, csrc/render.hip srl_k_stage).  Along the vertical line through a pixel inside the outline the hull's top
+ * rows x 2 columns, csrc/stage.h stage_compute).  Along the vertical line through a pixel inside the outline the hull's top
  * is the face the line pierces, so the minimum over ALL up-facing planes equals the minimum over any subset that holds that
  * face — up to the last bit where two faces are coplanar within rounding, which is why the subset is part of the definition
  * and not an optimisation behind it:
