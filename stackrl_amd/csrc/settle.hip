@@ -747,7 +747,7 @@ __device__ __forceinline__ void point_turn(const Lds& L, Point& p, float& res) {
 // ballot.  The other waves skip the sweeps and wait at the barrier that ends the solve.
 template <bool WARM, int PP, bool SOLO, bool GB>
 __device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, GBody& gb, Point (&pp)[PP], int ncol, int gturns, int pturns,
-                                             int gslot, const int (&pslot)[PP], int gsweep) {
+                                             int gslot, const int (&pslot)[PP], int gsweep, int pturns_hi = 0) {
   // gslot / pslot: the turn a lane's point takes (ground: its index; colour phases: 4 * colour + index; -1: none), so
   // that a turn's guard is one compare
   // ground phase: the (up to 4) points of one body are consecutive lanes of one wave and take turns
@@ -765,8 +765,10 @@ __device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, GBody& gb
 #pragma unroll 1
   for (int c = 0; c < ncol; ++c) {
     if (!SOLO) __syncthreads();
+    const unsigned long long ptp = ((unsigned long long)(unsigned)pturns_hi << 32) | (unsigned)pturns;
+    const int pt = c < 21 ? (int)((ptp >> (3 * c)) & 7ull) : 4;     // this colour's turns (packed by substep)
 #pragma unroll 1
-    for (int i = 0; i < pturns; ++i) {
+    for (int i = 0; i < pt; ++i) {
 #pragma unroll
       for (int r = 0; r < PP; ++r)
         if (pslot[r] == 4 * c + i) point_turn<WARM, true>(L, pp[r], res);
@@ -942,6 +944,28 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
       for (int r = 0; r < PP; ++r) any |= pp[r].valid && pp[r].idx == i;
       if (__ballot(any)) pturns = i + 1;
     }
+    // Turns PER COLOUR (round 5), packed 3 bits each: 1 + the highest point index among this wave's points of that colour — a colour
+    // whose manifolds hold fewer points than the wave's fullest takes fewer turns (an empty turn costs a lone wave its loop control:
+    // +1 % at the headline shape, +3 % at 1,024 x 16, +7 % at 4,096 x 16, where there are more colours; profiles/r05_colour_turns_ab.txt).
+    // SRL_UNIFORM_TURNS: the wave's maximum for every colour, as until round 4 (A / B).
+    unsigned long long ptpack = 0ull;
+#ifndef SRL_UNIFORM_TURNS
+    for (int c = 0; c < ncol && c < 21; ++c) {
+      int t = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < PP; ++r) any |= pp[r].valid && pp[r].idx == i && pp[r].colour == c;
+        if (__ballot(any)) t = i + 1;
+      }
+      ptpack |= (unsigned long long)t << (3 * c);
+    }
+#else
+    for (int c = 0; c < 21; ++c) ptpack |= (unsigned long long)pturns << (3 * c);
+#endif
+    pturns = (int)(unsigned)(ptpack & 0xffffffffull);   // (the sweep takes the 64 bits through two ints)
+    const int pturns_hi = (int)(ptpack >> 32);
     const int gslot = gp.valid ? gp.idx : -1;
     int pslot[PP];
 #pragma unroll
@@ -951,20 +975,20 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
     if (solo) {
       int done = 0;
       if (tid < 64) {
-        solver_sweep<true, PP, PP == 1, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0);
+        solver_sweep<true, PP, PP == 1, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0, pturns_hi);
         for (int it = 0; it < P.c.solver_iterations; ++it) {
           done++;
-          if (!solver_sweep<false, PP, PP == 1, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0)) break;
+          if (!solver_sweep<false, PP, PP == 1, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0, pturns_hi)) break;
         }
         if (tid == 0) misc[M_CNT] = done;   // (M_CNT is free between the calls of newest_contacts)
       }
       __syncthreads();
       gsweep += misc[M_CNT];
     } else {
-      solver_sweep<true, PP, false, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0);
+      solver_sweep<true, PP, false, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0, pturns_hi);
       for (int it = 0; it < P.c.solver_iterations; ++it) {
         gsweep++;
-        if (!solver_sweep<false, PP, false, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, gsweep)) break;
+        if (!solver_sweep<false, PP, false, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, gsweep, pturns_hi)) break;
       }
     }
     // accumulated impulses back to the manifolds (warm start of the next sub-step)
