@@ -69,17 +69,17 @@ struct Lds {
   // the blob / scratch layout of DevParams, read once per kernel and kept in scalar registers (laundered through an
   // empty asm so that the compiler cannot re-load them from memory wherever they are used: a scalar load next to LDS
   // traffic shares its wait counter, and with one wave per SIMD nothing hides its latency)
-  int oX, oQ, oV, oW, oPX, oPQ, oMESH, oGM, oMAN, oSOP, oPOS, oCOL, oR, oIW, oAMIN, oAMAX, oBC, oWV, oLV, oMISC, oPAIR, vs3;
+  int oX, oQ, oV, oPX, oPQ, oMESH, oGM, oMAN, oSOP, oPOS, oCOL, oR, oIW, oAMIN, oAMAX, oBC, oWV, oLV, oMISC, oPAIR, vs3;
   __device__ __forceinline__ void init(float* sm_, const DevParams* P_) {
     sm = sm_; P = P_;
-    oX = P->OFF_X; oQ = P->OFF_Q; oV = P->OFF_V; oW = P->OFF_W; oPX = P->OFF_PX; oPQ = P->OFF_PQ; oMESH = P->OFF_MESH;
+    oX = P->OFF_X; oQ = P->OFF_Q; oV = P->OFF_V; oPX = P->OFF_PX; oPQ = P->OFF_PQ; oMESH = P->OFF_MESH;
     oGM = P->OFF_GM; oMAN = P->OFF_MAN; oSOP = P->OFF_SOP; oPOS = P->OFF_POS; oCOL = P->OFF_COL;
     const int blob = P->BLOB;
     oR = blob + P->S_R; oIW = blob + P->S_IW; oAMIN = blob + P->S_AMIN; oAMAX = blob + P->S_AMAX; oBC = blob + P->S_BC;
     oWV = blob + P->S_WV; oLV = blob + P->S_LV; oMISC = blob + P->S_MISC; oPAIR = blob + P->S_PAIR; vs3 = 3 * P->VS;
 #ifndef SRL_NO_LAUNDER
 #define SRL_KEEP(x) asm volatile("" : "+s"(x))
-    SRL_KEEP(oX); SRL_KEEP(oQ); SRL_KEEP(oV); SRL_KEEP(oW); SRL_KEEP(oPX); SRL_KEEP(oPQ); SRL_KEEP(oMESH); SRL_KEEP(oGM);
+    SRL_KEEP(oX); SRL_KEEP(oQ); SRL_KEEP(oV); SRL_KEEP(oPX); SRL_KEEP(oPQ); SRL_KEEP(oMESH); SRL_KEEP(oGM);
     SRL_KEEP(oMAN); SRL_KEEP(oSOP); SRL_KEEP(oPOS); SRL_KEEP(oCOL); SRL_KEEP(oR); SRL_KEEP(oIW); SRL_KEEP(oAMIN);
     SRL_KEEP(oAMAX); SRL_KEEP(oBC); SRL_KEEP(oWV); SRL_KEEP(oLV); SRL_KEEP(oMISC); SRL_KEEP(oPAIR); SRL_KEEP(vs3);
 #undef SRL_KEEP
@@ -87,8 +87,9 @@ struct Lds {
   }
   __device__ __forceinline__ float* X(int b) const { return sm + oX + 4 * b; }
   __device__ __forceinline__ float* Q(int b) const { return sm + oQ + 4 * b; }
-  __device__ __forceinline__ float* Vl(int b) const { return sm + oV + 4 * b; }
-  __device__ __forceinline__ float* Wl(int b) const { return sm + oW + 4 * b; }
+  // a body's velocities, interleaved: (v.x, w.x, v.y, w.y, v.z, w.z, -, -) — a (linear, angular) component pair is a register
+  // pair as it leaves LDS (one 16-byte and one 8-byte access per body), which is how the pair rows consume it (point_turn)
+  __device__ __forceinline__ float* VW(int b) const { return sm + oV + 8 * b; }
   __device__ __forceinline__ float* PX(int b) const { return sm + oPX + 4 * b; }
   __device__ __forceinline__ float* PQ(int b) const { return sm + oPQ + 4 * b; }
   __device__ __forceinline__ int* MESH() const { return (int*)(sm + oMESH); }
@@ -109,6 +110,21 @@ struct Lds {
   __device__ __forceinline__ int* PAIR() const { return (int*)(sm + oPAIR); }
   __device__ __forceinline__ void pair(int p, int& i, int& j) const { const int w = PAIR()[p]; i = w & 0xffff; j = w >> 16; }
 };
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 F2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32: one rounding per half
+
+__device__ __forceinline__ void ldvw(const Lds& L, int b, v3& v, v3& w) {
+  const float4 a = *(const float4*)L.VW(b);
+  const float2 c = *(const float2*)(L.VW(b) + 4);
+  v = V(a.x, a.z, c.x); w = V(a.y, a.w, c.y);
+}
+__device__ __forceinline__ v3 ldv(const Lds& L, int b) { const float* p = L.VW(b); return V(p[0], p[2], p[4]); }
+__device__ __forceinline__ void stvw(const Lds& L, int b, v3 v, v3 w) {
+  *(float4*)L.VW(b) = make_float4(v.x, w.x, v.y, w.y);
+  *(float2*)(L.VW(b) + 4) = make_float2(v.z, w.z);
+}
 
 // ------------------------------------------------------------------ episode reset (env.py:266-293)
 __device__ void goal_from_rng(const DevParams& P, uint32_t key, uint32_t episode, int32_t* rect) {
@@ -168,10 +184,12 @@ __device__ void env_reset(const DevParams& P, EnvHdr* h, int e) {
 __device__ __forceinline__ void body_frame(const Lds& L, int b) {
   const DevParams& P = *L.P;
   const float dt = P.c.sim_time_step;
-  v3 v = ld3(L.Vl(b)) * P.lin_damp;
-  v3 w = ld3(L.Wl(b)) * P.ang_damp;
+  v3 v, w;
+  ldvw(L, b, v, w);
+  v = v * P.lin_damp;
+  w = w * P.ang_damp;
   v.z = v.z - P.c.gravity * dt;
-  st3(L.Vl(b), v); st3(L.Wl(b), w);
+  stvw(L, b, v, w);
   const float* bc = L.BC(b);
   q4 q; q.x = L.Q(b)[0]; q.y = L.Q(b)[1]; q.z = L.Q(b)[2]; q.w = L.Q(b)[3];
   m3 R = quat_to_mat(q);
@@ -431,7 +449,6 @@ __device__ __forceinline__ void narrowphase_slot(const Lds& L, int sl, int gl) {
 // One solver row in precomputed form: direction d, ca = ra x d, aa = Ia ca (and cb, ab for body B),
 // k = effective mass denominator.  Same expression trees as the sequential definition.
 struct Row { v3 d, ca, aa, cb, ab; float rk, k; };   // k = effective mass denominator, rk = 1 / k
-struct Vel4 { v3 va, wa, vb, wb; };
 
 template <bool HAS_B>
 __device__ __forceinline__ Row make_row(v3 d, v3 ra, v3 rb, float ima, const m3& Ia, float imb, const m3& Ib) {
@@ -451,39 +468,54 @@ __device__ __forceinline__ Row make_row(v3 d, v3 ra, v3 rb, float ima, const m3&
   return r;
 }
 
-// res: running maximum of the rows' residuals |delta impulse x k| (Bullet: deltaImpulse / m_jacDiagABInv) — off the
-// velocities' dependency chain
-template <bool HAS_B>
-__device__ __forceinline__ void row_solve(const Row& r, float ima, float imb, Vel4& u, float target, float& acc,
-                                          float lo, float hi, float& res) {
-  float vrel = dot(r.d, u.va) + dot(r.ca, u.wa);
-  if (HAS_B) vrel = vrel - (dot(r.d, u.vb) + dot(r.cb, u.wb));
+// The pair rows in PAIR form (round 5).  A body's velocities leave LDS as the register pairs (v.c, w.c) (Lds::VW); a row's
+// constants are kept as the matching pairs — ka[c] = (d.c, ca.c), ua[c] = (d.c ima, aa.c) for body A, kb[c] = (d.c, cb.c),
+// ub[c] = (d.c (-imb), -ab.c) for body B — so that both dot products of a body are one chain of three packed operations, the
+// velocity update of a body three packed FMAs, and no register move stands between a read, the rows and the write-back.  (The
+// compiler's own pairing of row_solve — (va.c, vb.c), (wa.c, wb.c) across the two bodies — cost 23 moves and two sign flips per
+// turn of 89 vector instructions.)  The operations and their order are row_solve's: fma(-ab.c, dl, wb.c) = fma(ab.c, -dl, wb.c)
+// exactly (the product's sign is exact), the halves of a packed FMA round once each: bit-identical.
+struct PRow { f2 ka[3], kb[3], ua[3], ub[3]; float rk, k; };
+struct Vel2 { f2 a[3], b[3]; };   // [c] = (v.c, w.c) of body A / B
+
+__device__ __forceinline__ PRow pack_row(const Row& r, float ima, float imb) {
+  PRow q;
+  const v3 da = r.d * ima, db = r.d * (-imb);
+  q.ka[0] = F2(r.d.x, r.ca.x); q.ka[1] = F2(r.d.y, r.ca.y); q.ka[2] = F2(r.d.z, r.ca.z);
+  q.kb[0] = F2(r.d.x, r.cb.x); q.kb[1] = F2(r.d.y, r.cb.y); q.kb[2] = F2(r.d.z, r.cb.z);
+  q.ua[0] = F2(da.x, r.aa.x); q.ua[1] = F2(da.y, r.aa.y); q.ua[2] = F2(da.z, r.aa.z);
+  q.ub[0] = F2(db.x, -r.ab.x); q.ub[1] = F2(db.y, -r.ab.y); q.ub[2] = F2(db.z, -r.ab.z);
+  q.rk = r.rk; q.k = r.k;
+  return q;
+}
+
+__device__ __forceinline__ void prow_solve(const PRow& r, Vel2& u, float target, float& acc, float lo, float hi, float& res) {
+  const f2 sa = fma2(r.ka[0], u.a[0], fma2(r.ka[1], u.a[1], r.ka[2] * u.a[2]));   // (dot(d, va), dot(ca, wa))
+  const f2 sb = fma2(r.kb[0], u.b[0], fma2(r.kb[1], u.b[1], r.kb[2] * u.b[2]));   // (dot(d, vb), dot(cb, wb))
+  float ra = sa.x + sa.y;
+  asm("" : "+v"(ra));   // (kept from the vectoriser: paired with the sum below the two adds cost three moves and a packed add)
+  const float vrel = ra - (sb.x + sb.y);
   // (target - vrel) rk as one fused step and the linear impulses as (d m^-1) dl: the products that do not depend on the
   // velocities leave the dependency chain (10 dependent operations per row instead of 12; the oracle evaluates the same)
   float dl = fmaf(-vrel, r.rk, target * r.rk);
   // the accumulated impulse clamped to [lo, hi] as the median of the three (v_med3_f32; the oracle restates its zero
   // handling): one instruction on the solver's dependency chain instead of two compare / select pairs through VCC,
   // each of which costs a lone wave its wait states — 6.68 -> 6.02 ms per launch at the headline shape
-  float na = __builtin_amdgcn_fmed3f(acc + dl, lo, hi);
+  const float na = __builtin_amdgcn_fmed3f(acc + dl, lo, hi);
   dl = na - acc;
   acc = na;
+  // res: running maximum of the rows' residuals |delta impulse x k| (Bullet: deltaImpulse / m_jacDiagABInv) — off the
+  // velocities' dependency chain
   res = fmaxf(res, fabsf(dl * r.k));
-  u.va = madd(u.va, r.d * ima, dl);
-  u.wa = madd(u.wa, r.aa, dl);
-  if (HAS_B) {
-    u.vb = madd(u.vb, r.d * (-imb), dl);
-    u.wb = madd(u.wb, r.ab, -dl);
-  }
+  const f2 d2 = F2(dl, dl);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { u.a[c] = fma2(r.ua[c], d2, u.a[c]); u.b[c] = fma2(r.ub[c], d2, u.b[c]); }
 }
 
-template <bool HAS_B>
-__device__ __forceinline__ void row_apply(const Row& r, float ima, float imb, Vel4& u, float imp) {
-  u.va = madd(u.va, r.d * ima, imp);
-  u.wa = madd(u.wa, r.aa, imp);
-  if (HAS_B) {
-    u.vb = madd(u.vb, r.d * (-imb), imp);
-    u.wb = madd(u.wb, r.ab, -imp);
-  }
+__device__ __forceinline__ void prow_apply(const PRow& r, Vel2& u, float imp) {
+  const f2 d2 = F2(imp, imp);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { u.a[c] = fma2(r.ua[c], d2, u.a[c]); u.b[c] = fma2(r.ub[c], d2, u.b[c]); }
 }
 
 __device__ __forceinline__ float contact_target(const DevParams& P, float dist) {
@@ -494,7 +526,7 @@ __device__ __forceinline__ float contact_target(const DevParams& P, float dist) 
 
 // A contact point owned by one lane for the duration of a sub-step's solve
 struct Point {
-  Row n, t1, t2;
+  PRow n, t1, t2;
   float target, in, i1, i2, ima, imb, mu;
   int a, b;        // bodies (b < 0: ground)
   int colour;      // -1 = ground phase
@@ -572,8 +604,8 @@ __device__ __forceinline__ GPoint make_ground_point(const Lds& L, int b, int i) 
 template <bool WARM>
 __device__ __forceinline__ void ground_turn(const Lds& L, GPoint& p, float& res) {
   const float ws = L.P->c.warmstart;
-  const float4 a0 = *(const float4*)L.Vl(p.a), a1 = *(const float4*)L.Wl(p.a);
-  v3 v = V(a0.x, a0.y, a0.z), w = V(a1.x, a1.y, a1.z);
+  v3 v, w;
+  ldvw(L, p.a, v, w);
   if (WARM) {
     p.in = p.in * ws; p.i1 = p.i1 * ws; p.i2 = p.i2 * ws;
     grow_apply<2, 1>(p.n, p.ima, v, w, p.in);
@@ -585,7 +617,7 @@ __device__ __forceinline__ void ground_turn(const Lds& L, GPoint& p, float& res)
     grow_solve<1, -1>(p.t1, p.ima, v, w, 0.0f, p.i1, -lim, lim, res);
     grow_solve<0, 1>(p.t2, p.ima, v, w, 0.0f, p.i2, -lim, lim, res);
   }
-  *(float4*)L.Vl(p.a) = make_float4(v.x, v.y, v.z, 0.0f); *(float4*)L.Wl(p.a) = make_float4(w.x, w.y, w.z, 0.0f);
+  stvw(L, p.a, v, w);
 }
 
 // ---- the ground phase by BODY lanes (round 5).  The (up to 4) ground points of one body share that body's velocities and
@@ -599,7 +631,7 @@ struct GBody {
   float acc[SRL_GMAXP][3];   // accumulated impulses (normal, tangent 1, tangent 2) of the body's ground points
   float ima;
   int np, b;                 // points in the body's ground manifold (0: none / not a body lane)
-  float4 *pv, *pw;           // the body's linear / angular velocity in LDS
+  float* pvw;                // the body's velocities in LDS (Lds::VW)
   const float4* rec;         // its points' row constants
 };
 
@@ -653,8 +685,9 @@ __device__ __forceinline__ void ground_point(const float4* rec, GBody& gb, int i
 template <bool WARM>
 __device__ __forceinline__ void ground_body(const Lds& L, GBody& gb, float& res) {
   const float ws = L.P->c.warmstart;
-  const float4 a0 = *gb.pv, a1 = *gb.pw;
-  v3 v = V(a0.x, a0.y, a0.z), w = V(a1.x, a1.y, a1.z);
+  const float4 a0 = *(const float4*)gb.pvw;
+  const float2 a1 = *(const float2*)(gb.pvw + 4);
+  v3 v = V(a0.x, a0.z, a1.x), w = V(a0.y, a0.w, a1.y);
   const float4* rec = gb.rec;
   // The guards are nested: the points of a manifold are a prefix.  (Measured and dropped: the next point's record — or only its
   // first row's constants — requested before the current point is computed, pinned by an empty asm because the compiler sinks a
@@ -669,7 +702,7 @@ __device__ __forceinline__ void ground_body(const Lds& L, GBody& gb, float& res)
       if (gb.np > 3) ground_point<WARM>(rec, gb, 3, ws, v, w, res);
     }
   }
-  *gb.pv = make_float4(v.x, v.y, v.z, 0.0f); *gb.pw = make_float4(w.x, w.y, w.z, 0.0f);
+  *(float4*)gb.pvw = make_float4(v.x, w.x, v.y, w.y); *(float2*)(gb.pvw + 4) = make_float2(v.z, w.z);
 }
 
 __device__ __forceinline__ Point make_pair_point(const Lds& L, int sl, int i) {
@@ -694,42 +727,40 @@ __device__ __forceinline__ Point make_pair_point(const Lds& L, int sl, int i) {
   const v3 rb = mmul(Rb, ld3(q + 3));
   v3 n = ld3(q + 6), t1, t2;
   plane_space(n, t1, t2);
-  p.n = make_row<true>(n, ra, rb, p.ima, Ia, p.imb, Ib);
-  p.t1 = make_row<true>(t1, ra, rb, p.ima, Ia, p.imb, Ib);
-  p.t2 = make_row<true>(t2, ra, rb, p.ima, Ia, p.imb, Ib);
+  p.n = pack_row(make_row<true>(n, ra, rb, p.ima, Ia, p.imb, Ib), p.ima, p.imb);
+  p.t1 = pack_row(make_row<true>(t1, ra, rb, p.ima, Ia, p.imb, Ib), p.ima, p.imb);
+  p.t2 = pack_row(make_row<true>(t2, ra, rb, p.ima, Ia, p.imb, Ib), p.ima, p.imb);
   p.target = contact_target(P, q[9]);
   p.in = q[10]; p.i1 = q[11]; p.i2 = q[12];
   return p;
 }
 
 // one turn of a point: read the velocities of its bodies, three rows, write them back
-template <bool WARM, bool HAS_B>
+template <bool WARM>
 __device__ __forceinline__ void point_turn(const Lds& L, Point& p, float& res) {
   const float ws = L.P->c.warmstart;
-  Vel4 u;
-  {   // 16-byte LDS reads (vectors are stored with a stride of 4 words)
-    const float4 a0 = *(const float4*)L.Vl(p.a), a1 = *(const float4*)L.Wl(p.a);
-    u.va = V(a0.x, a0.y, a0.z); u.wa = V(a1.x, a1.y, a1.z);
-    if (HAS_B) {
-      const float4 b0 = *(const float4*)L.Vl(p.b), b1 = *(const float4*)L.Wl(p.b);
-      u.vb = V(b0.x, b0.y, b0.z); u.wb = V(b1.x, b1.y, b1.z);
-    } else { u.vb = V(0.0f, 0.0f, 0.0f); u.wb = V(0.0f, 0.0f, 0.0f); }
+  Vel2 u;
+  float* const pa = L.VW(p.a);
+  float* const pb = L.VW(p.b);
+  {
+    const float4 a0 = *(const float4*)pa, b0 = *(const float4*)pb;
+    const float2 a1 = *(const float2*)(pa + 4), b1 = *(const float2*)(pb + 4);
+    u.a[0] = F2(a0.x, a0.y); u.a[1] = F2(a0.z, a0.w); u.a[2] = F2(a1.x, a1.y);
+    u.b[0] = F2(b0.x, b0.y); u.b[1] = F2(b0.z, b0.w); u.b[2] = F2(b1.x, b1.y);
   }
   if (WARM) {
     p.in = p.in * ws; p.i1 = p.i1 * ws; p.i2 = p.i2 * ws;
-    row_apply<HAS_B>(p.n, p.ima, p.imb, u, p.in);
-    row_apply<HAS_B>(p.t1, p.ima, p.imb, u, p.i1);
-    row_apply<HAS_B>(p.t2, p.ima, p.imb, u, p.i2);
+    prow_apply(p.n, u, p.in);
+    prow_apply(p.t1, u, p.i1);
+    prow_apply(p.t2, u, p.i2);
   } else {
-    row_solve<HAS_B>(p.n, p.ima, p.imb, u, p.target, p.in, 0.0f, 1e30f, res);
+    prow_solve(p.n, u, p.target, p.in, 0.0f, 1e30f, res);
     const float lim = p.mu * p.in;
-    row_solve<HAS_B>(p.t1, p.ima, p.imb, u, 0.0f, p.i1, -lim, lim, res);
-    row_solve<HAS_B>(p.t2, p.ima, p.imb, u, 0.0f, p.i2, -lim, lim, res);
+    prow_solve(p.t1, u, 0.0f, p.i1, -lim, lim, res);
+    prow_solve(p.t2, u, 0.0f, p.i2, -lim, lim, res);
   }
-  *(float4*)L.Vl(p.a) = make_float4(u.va.x, u.va.y, u.va.z, 0.0f); *(float4*)L.Wl(p.a) = make_float4(u.wa.x, u.wa.y, u.wa.z, 0.0f);
-  if (HAS_B) {
-    *(float4*)L.Vl(p.b) = make_float4(u.vb.x, u.vb.y, u.vb.z, 0.0f); *(float4*)L.Wl(p.b) = make_float4(u.wb.x, u.wb.y, u.wb.z, 0.0f);
-  }
+  *(float4*)pa = make_float4(u.a[0].x, u.a[0].y, u.a[1].x, u.a[1].y); *(float2*)(pa + 4) = make_float2(u.a[2].x, u.a[2].y);
+  *(float4*)pb = make_float4(u.b[0].x, u.b[0].y, u.b[1].x, u.b[1].y); *(float2*)(pb + 4) = make_float2(u.b[2].x, u.b[2].y);
 }
 
 // gturns / pturns: the turns this wave needs in a ground / colour phase = 1 + the highest point index any of its lanes
@@ -771,7 +802,7 @@ __device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, GBody& gb
     for (int i = 0; i < pt; ++i) {
 #pragma unroll
       for (int r = 0; r < PP; ++r)
-        if (pslot[r] == 4 * c + i) point_turn<WARM, true>(L, pp[r], res);
+        if (pslot[r] == 4 * c + i) point_turn<WARM>(L, pp[r], res);
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -903,7 +934,7 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
     __syncthreads();   // every lane has read the pre-solve velocities' companions (R, Iw, manifolds)
     GBody gb;
     gb.np = 0; gb.b = 0; gb.ima = 0.0f;
-    gb.pv = (float4*)L.Vl(0); gb.pw = (float4*)L.Wl(0); gb.rec = cg_rec(L, 0, 0);
+    gb.pvw = L.VW(0); gb.rec = cg_rec(L, 0, 0);
 #pragma unroll
     for (int i = 0; i < SRL_GMAXP; ++i) { gb.acc[i][0] = 0.0f; gb.acc[i][1] = 0.0f; gb.acc[i][2] = 0.0f; }
     // The ground phase by body lanes (ground_body) in every variant but the four-wave one with one point per thread (9 - 16
@@ -921,7 +952,7 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
     if (tid < nb) {
       const float* g = L.GM(tid);
       gb.b = tid; gb.np = __float_as_int(g[0]); gb.ima = L.BC(tid)[0];
-      gb.pv = (float4*)L.Vl(tid); gb.pw = (float4*)L.Wl(tid); gb.rec = cg_rec(L, tid, 0);
+      gb.pvw = L.VW(tid); gb.rec = cg_rec(L, tid, 0);
 #pragma unroll
       for (int i = 0; i < SRL_GMAXP; ++i)
         if (i < gb.np) { gb.acc[i][0] = g[SRL_GM_IN + i]; gb.acc[i][1] = g[SRL_GM_T1 + i]; gb.acc[i][2] = g[SRL_GM_T2 + i]; }
@@ -1012,7 +1043,8 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
   const float dt = P.c.sim_time_step;
   if (tid < nb) {
     const int b = tid;
-    v3 v = ld3(L.Vl(b)), w = ld3(L.Wl(b));
+    v3 v, w;
+    ldvw(L, b, v, w);
     st3(L.X(b), madd(ld3(L.X(b)), v, dt));
     float* Q = L.Q(b);
     q4 q; q.x = Q[0]; q.y = Q[1]; q.z = Q[2]; q.w = Q[3];
@@ -1035,7 +1067,7 @@ __device__ __forceinline__ bool sim_stop(const Lds& L, int nb, int tid) {
   int* misc = L.MISC();
   bool moving = false;
   if (tid < nb) {
-    v3 v = ld3(L.Vl(tid));
+    v3 v = ldv(L, tid);
     moving = sqrtf(dot(v, v)) > L.P->c.velocity_threshold;
   }
   // the bodies are lanes of wave 0 (nb <= 32): one ballot, one LDS word, one barrier.  (__syncthreads_or reads the
@@ -1252,7 +1284,7 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
       st3(L.X(b), P.c.place_at_com ? pos : pos + mmul(quat_to_mat(q), V(mh.cx, mh.cy, mh.cz)));
       L.Q(b)[0] = q.x; L.Q(b)[1] = q.y; L.Q(b)[2] = q.z; L.Q(b)[3] = q.w;
     }
-    st3(L.Vl(b), V(0, 0, 0)); st3(L.Wl(b), V(0, 0, 0));
+    stvw(L, b, V(0, 0, 0), V(0, 0, 0));
     L.GM(b)[0] = __int_as_float(0);
   }
   if (mode == 0) nb += 1;
@@ -1294,7 +1326,7 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
   }
   for (;;) {
     if (phase == PH_SMOOTH) {
-      if (tid == 0) { st3(L.Vl(nb - 1), V(0, 0, 0)); st3(L.Wl(nb - 1), V(0, 0, 0)); }   // resetBaseVelocity
+      if (tid == 0) stvw(L, nb - 1, V(0, 0, 0), V(0, 0, 0));   // resetBaseVelocity
       __syncthreads();
     }
     substep<T, PP>(L, nb, tid, gsweep);

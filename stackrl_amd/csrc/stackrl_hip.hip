@@ -162,8 +162,8 @@ void layout(DevParams& P, int concurrent) {
   P.NP = L * (L - 1) / 2 > 0 ? L * (L - 1) / 2 : 1;
   int o = 0;
   // xyz vectors are stored with a stride of 4 words so that the kernels move them with 16-byte LDS accesses
-  P.OFF_V = o; o += 4 * L;
-  P.OFF_W = o; o += 4 * L;
+  // a body's velocities interleaved, 8 words per body: (v.x, w.x, v.y, w.y, v.z, w.z, -, -) — settle.hip Lds::VW
+  P.OFF_V = o; P.OFF_W = o + 1; o += 8 * L;
   P.OFF_X = o; o += 4 * L;
   P.OFF_Q = o; o += 4 * L;
   P.OFF_PX = o; o += 4 * L;
@@ -599,7 +599,7 @@ int srl_set_body_state(srl_env* env, const float* poses, const float* vel) {
       }
       if (vel) {
         const float* p = vel + ((size_t)i * SRL_MAX_BODIES + b) * 8;
-        for (int k = 0; k < 3; ++k) { gb[P.OFF_V + 4 * b + k] = p[k]; gb[P.OFF_W + 4 * b + k] = p[4 + k]; }
+        for (int k = 0; k < 3; ++k) { gb[P.OFF_V + 8 * b + 2 * k] = p[k]; gb[P.OFF_W + 8 * b + 2 * k] = p[4 + k]; }
       }
     }
   }
@@ -683,7 +683,7 @@ int srl_get_velocities(srl_env* env, float* vel) {
     const float* gb = blob.data() + (size_t)i * P.BLOB;
     float* p = vel + (size_t)i * SRL_MAX_BODIES * 8;
     for (int b = 0; b < h[i].nb; ++b)
-      for (int k = 0; k < 3; ++k) { p[b * 8 + k] = gb[P.OFF_V + 4 * b + k]; p[b * 8 + 4 + k] = gb[P.OFF_W + 4 * b + k]; }
+      for (int k = 0; k < 3; ++k) { p[b * 8 + k] = gb[P.OFF_V + 8 * b + 2 * k]; p[b * 8 + 4 + k] = gb[P.OFF_W + 8 * b + 2 * k]; }
   }
   return SRL_OK;
 }
