@@ -112,6 +112,7 @@ struct Lds {
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f2 F2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32: one rounding per half
 
@@ -664,10 +665,11 @@ __device__ __forceinline__ void grow_solve_t(v3 ca, v3 aa, float rk, float k, fl
   w = madd(w, aa, dl);
 }
 
+struct GRec { f4 q[7]; };   // one ground point's row constants (cg_store)
+
 template <bool WARM>
-__device__ __forceinline__ void ground_point(const float4* rec, GBody& gb, int i, float ws, v3& v, v3& w, float& res) {
-  const float4 q0 = rec[7 * i], q1 = rec[7 * i + 1], q2 = rec[7 * i + 2], q3 = rec[7 * i + 3], q4 = rec[7 * i + 4],
-               q5 = rec[7 * i + 5], q6 = rec[7 * i + 6];
+__device__ __forceinline__ void ground_point(const GRec& R, GBody& gb, int i, float ws, v3& v, v3& w, float& res) {
+  const f4 q0 = R.q[0], q1 = R.q[1], q2 = R.q[2], q3 = R.q[3], q4 = R.q[4], q5 = R.q[5], q6 = R.q[6];
   if (WARM) {
     gb.acc[i][0] = gb.acc[i][0] * ws; gb.acc[i][1] = gb.acc[i][1] * ws; gb.acc[i][2] = gb.acc[i][2] * ws;
     GRow g; g.rk = 0.0f; g.k = 0.0f;
@@ -682,24 +684,94 @@ __device__ __forceinline__ void ground_point(const float4* rec, GBody& gb, int i
   }
 }
 
-template <bool WARM>
+__device__ __forceinline__ GRec cg_load(const float4* rec, int i) {
+  GRec R;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { const float4 t = rec[7 * i + k]; R.q[k].x = t.x; R.q[k].y = t.y; R.q[k].z = t.z; R.q[k].w = t.w; }
+  return R;
+}
+
+// ---- the record of point i + 1 requested while point i is computed (AHEAD).  A plain read whose only use sits in the guarded
+// block of the next point is sunk into that block by the compiler (at IR level), a volatile one becomes a flat load with a
+// wait behind it, an empty asm that pins the value waits for it: so the reads and their waits are written out.  cg_request
+// issues the seven 16-byte reads of record I (and passes `tie`, an operand the current point's first operation needs, through,
+// so that the reads stand before that point's arithmetic); cg_arrive waits for everything in flight and passes the record and
+// `tie` (a result of the current point's last row) through, so that the wait stands behind that arithmetic and the next point's
+// in front of nothing it needs.  Every read is waited for in the block that issued it: no register is handed back to the
+// allocator with a read still in flight.  (The compiler's own wait counts do not know these reads; they can only wait longer.)
+template <int I>
+__device__ __forceinline__ void cg_request(unsigned a, GRec& R, float& tie) {
+  asm volatile(
+      "ds_read_b128 %0, %8 offset:%9\n\tds_read_b128 %1, %8 offset:%10\n\tds_read_b128 %2, %8 offset:%11\n\t"
+      "ds_read_b128 %3, %8 offset:%12\n\tds_read_b128 %4, %8 offset:%13\n\tds_read_b128 %5, %8 offset:%14\n\t"
+      "ds_read_b128 %6, %8 offset:%15"
+      : "=&v"(R.q[0]), "=&v"(R.q[1]), "=&v"(R.q[2]), "=&v"(R.q[3]), "=&v"(R.q[4]), "=&v"(R.q[5]), "=&v"(R.q[6]), "+v"(tie)
+      : "v"(a), "n"(112 * I), "n"(112 * I + 16), "n"(112 * I + 32), "n"(112 * I + 48), "n"(112 * I + 64), "n"(112 * I + 80),
+        "n"(112 * I + 96));
+}
+// the body's (v, w) and record 0 in one go (the compiler's own read of (v, w) would be waited for with a count that does not
+// know the records behind it: everything)
+__device__ __forceinline__ void cg_request_first(unsigned avw, unsigned a, f4& a0, f2& a1, GRec& R) {
+  asm volatile(
+      "ds_read_b128 %0, %9\n\tds_read_b64 %1, %9 offset:16\n\t"
+      "ds_read_b128 %2, %10\n\tds_read_b128 %3, %10 offset:16\n\tds_read_b128 %4, %10 offset:32\n\t"
+      "ds_read_b128 %5, %10 offset:48\n\tds_read_b128 %6, %10 offset:64\n\tds_read_b128 %7, %10 offset:80\n\t"
+      "ds_read_b128 %8, %10 offset:96"
+      : "=&v"(a0), "=&v"(a1), "=&v"(R.q[0]), "=&v"(R.q[1]), "=&v"(R.q[2]), "=&v"(R.q[3]), "=&v"(R.q[4]), "=&v"(R.q[5]), "=&v"(R.q[6])
+      : "v"(avw), "v"(a));
+}
+__device__ __forceinline__ void cg_arrive_first(f4& a0, f2& a1, GRec& R) {   // the next record's seven reads stay in flight
+  asm volatile("s_waitcnt lgkmcnt(7)"
+               : "+v"(a0), "+v"(a1), "+v"(R.q[0]), "+v"(R.q[1]), "+v"(R.q[2]), "+v"(R.q[3]), "+v"(R.q[4]), "+v"(R.q[5]), "+v"(R.q[6]));
+}
+template <int LEFT>   // LEFT: reads that may stay in flight (the record requested after this one)
+__device__ __forceinline__ void cg_arrive(GRec& R, float& tie) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(R.q[0]), "+v"(R.q[1]), "+v"(R.q[2]), "+v"(R.q[3]), "+v"(R.q[4]), "+v"(R.q[5]), "+v"(R.q[6]), "+v"(tie)
+               : "n"(LEFT));
+}
+
+template <bool WARM, bool AHEAD>
 __device__ __forceinline__ void ground_body(const Lds& L, GBody& gb, float& res) {
+  static_assert(SRL_CG_WORDS == 28, "cg_request reads seven float4 per record");
   const float ws = L.P->c.warmstart;
-  const float4 a0 = *(const float4*)gb.pvw;
-  const float2 a1 = *(const float2*)(gb.pvw + 4);
-  v3 v = V(a0.x, a0.z, a1.x), w = V(a0.y, a0.w, a1.y);
   const float4* rec = gb.rec;
-  // The guards are nested: the points of a manifold are a prefix.  (Measured and dropped: the next point's record — or only its
-  // first row's constants — requested before the current point is computed, pinned by an empty asm because the compiler sinks a
-  // read that only the guarded block uses into that block: 28 registers more spill 20 - 366 in the four variants; 8 registers
-  // more gain less at the headline shape than this form, +2.1 against +4.2 %: profiles/r05_experiment_log.md.)
+  v3 v, w;
+  // The guards are nested: the points of a manifold are a prefix.
   static_assert(SRL_GMAXP == 4, "four nested guards below");
-  ground_point<WARM>(rec, gb, 0, ws, v, w, res);        // (a body lane is called with np >= 1)
-  if (gb.np > 1) {
-    ground_point<WARM>(rec, gb, 1, ws, v, w, res);
-    if (gb.np > 2) {
-      ground_point<WARM>(rec, gb, 2, ws, v, w, res);
-      if (gb.np > 3) ground_point<WARM>(rec, gb, 3, ws, v, w, res);
+  if (!AHEAD) {
+    const float4 a0 = *(const float4*)gb.pvw;
+    const float2 a1 = *(const float2*)(gb.pvw + 4);
+    v = V(a0.x, a0.z, a1.x); w = V(a0.y, a0.w, a1.y);
+    ground_point<WARM>(cg_load(rec, 0), gb, 0, ws, v, w, res);        // (a body lane is called with np >= 1)
+    if (gb.np > 1) {
+      ground_point<WARM>(cg_load(rec, 1), gb, 1, ws, v, w, res);
+      if (gb.np > 2) {
+        ground_point<WARM>(cg_load(rec, 2), gb, 2, ws, v, w, res);
+        if (gb.np > 3) ground_point<WARM>(cg_load(rec, 3), gb, 3, ws, v, w, res);
+      }
+    }
+  } else {
+    const unsigned ra = (unsigned)(size_t)rec;   // the LDS byte address (the low word of the generic pointer)
+    GRec r0, r1, r2, r3;
+    f4 a0; f2 a1;
+    float none = 0.0f;
+    cg_request_first((unsigned)(size_t)gb.pvw, ra, a0, a1, r0);
+    cg_request<1>(ra, r1, none);
+    cg_arrive_first(a0, a1, r0);
+    v = V(a0.x, a0.z, a1.x); w = V(a0.y, a0.w, a1.y);
+    ground_point<WARM>(r0, gb, 0, ws, v, w, res);
+    cg_arrive<0>(r1, w.x);
+    if (gb.np > 1) {
+      cg_request<2>(ra, r2, w.z);
+      ground_point<WARM>(r1, gb, 1, ws, v, w, res);
+      cg_arrive<0>(r2, w.x);
+      if (gb.np > 2) {
+        cg_request<3>(ra, r3, w.z);
+        ground_point<WARM>(r2, gb, 2, ws, v, w, res);
+        cg_arrive<0>(r3, w.x);
+        if (gb.np > 3) ground_point<WARM>(r3, gb, 3, ws, v, w, res);
+      }
     }
   }
   *(float4*)gb.pvw = make_float4(v.x, w.x, v.y, w.y); *(float2*)(gb.pvw + 4) = make_float2(v.z, w.z);
@@ -776,7 +848,7 @@ __device__ __forceinline__ void point_turn(const Lds& L, Point& p, float& res) {
 // lanes, and manifold slots are handed out lowest first), so the sweep is wave 0's alone: the phases follow each other in
 // program order — the LDS serves one wave's accesses in order — without a single block barrier, and the residual is a
 // ballot.  The other waves skip the sweeps and wait at the barrier that ends the solve.
-template <bool WARM, int PP, bool SOLO, bool GB>
+template <bool WARM, int PP, bool SOLO, bool GB, bool GA>
 __device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, GBody& gb, Point (&pp)[PP], int ncol, int gturns, int pturns,
                                              int gslot, const int (&pslot)[PP], int gsweep, int pturns_hi = 0) {
   // gslot / pslot: the turn a lane's point takes (ground: its index; colour phases: 4 * colour + index; -1: none), so
@@ -790,7 +862,7 @@ __device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, GBody& gb
       __builtin_amdgcn_wave_barrier();
     }
   } else {
-    if (gb.np > 0) ground_body<WARM>(L, gb, res);
+    if (gb.np > 0) ground_body<WARM, !WARM && GA>(L, gb, res);
     __builtin_amdgcn_wave_barrier();
   }
 #pragma unroll 1
@@ -945,6 +1017,12 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
 #else
     constexpr bool GB = !(T == 256 && PP == 1);
 #endif
+    // the next ground point's record requested a point ahead (ground_body<AHEAD>): where the variant has the registers
+#ifndef SRL_GA_MASK
+#define SRL_GA_MASK 1
+#endif
+    constexpr bool GA = GB && ((T == 128 && PP == 1 && (SRL_GA_MASK & 1)) || (T == 128 && PP == 2 && (SRL_GA_MASK & 2)) ||
+                               (T == 256 && PP == 2 && (SRL_GA_MASK & 4)));
     if (GB) {
     // the rows' constants of every ground point to LDS (over the world vertices, which nothing reads before the next
     // sub-step rewrites them), for the body lanes (tid < nb: wave 0)
@@ -1006,20 +1084,20 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
     if (solo) {
       int done = 0;
       if (tid < 64) {
-        solver_sweep<true, PP, PP == 1, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0, pturns_hi);
+        solver_sweep<true, PP, PP == 1, GB, GA>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0, pturns_hi);
         for (int it = 0; it < P.c.solver_iterations; ++it) {
           done++;
-          if (!solver_sweep<false, PP, PP == 1, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0, pturns_hi)) break;
+          if (!solver_sweep<false, PP, PP == 1, GB, GA>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0, pturns_hi)) break;
         }
         if (tid == 0) misc[M_CNT] = done;   // (M_CNT is free between the calls of newest_contacts)
       }
       __syncthreads();
       gsweep += misc[M_CNT];
     } else {
-      solver_sweep<true, PP, false, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0, pturns_hi);
+      solver_sweep<true, PP, false, GB, GA>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0, pturns_hi);
       for (int it = 0; it < P.c.solver_iterations; ++it) {
         gsweep++;
-        if (!solver_sweep<false, PP, false, GB>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, gsweep, pturns_hi)) break;
+        if (!solver_sweep<false, PP, false, GB, GA>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, gsweep, pturns_hi)) break;
       }
     }
     // accumulated impulses back to the manifolds (warm start of the next sub-step)
