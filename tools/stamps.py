@@ -28,5 +28,9 @@ np2 = out[:, 8:].sum(0)
 slow = np.argmax(tot_sub)
 print('mean ns per sub-step by phase (all envs):')
 for nm, v in zip(names, per): print('  %-20s %8.0f ns  %5.1f%%' % (nm, v, 100 * v / per.sum()))
+ps = out[slow, :8] / tot_sub[slow] * 10.0
+print('slowest env (%d sub-steps), ns per sub-step by phase:' % tot_sub[slow])
+for nm, v in zip(names, ps): print('  %-20s %8.0f ns  %5.1f%%' % (nm, v, 100 * v / ps.sum()))
+print('  total %.1f us per sub-step' % (ps.sum() / 1e3))
 print('  total %.1f us; slowest env: %d sub-steps, %.2f ms' % (per.sum() / 1e3, tot_sub[slow], out[slow, :8].sum() * 1e-5))
 print('  slot-0 narrowphase per call: refresh %.0f ns, gjk %.0f ns, insert %.0f ns (%d calls, %.2f per sub-step)' % (10 * np2[0] / np2[3], 10 * np2[1] / np2[3], 10 * np2[2] / np2[3], np2[3], np2[3] / tot_sub.sum()))
