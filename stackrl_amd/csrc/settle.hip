@@ -1255,6 +1255,10 @@ __device__ __forceinline__ void step_body(const DevParams* __restrict__ Pp, cons
   int* misc = L.MISC();
   EnvHdr* h = &P.hdr[e];
   float* gblob = P.blob + (size_t)e * P.BLOB;
+#ifdef SRL_STAMPS
+  if ((threadIdx.x & 63) == 0 && threadIdx.x < 128)   // which CU / SIMD the env's waves run on (HW_REG_HW_ID = 4, HW_REG_XCC_ID = 20)
+    h->hwid[threadIdx.x >> 6] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
 
   if (tid == 0) {
     int mode;
