@@ -855,10 +855,19 @@ __device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, GBody& gb
   // that a turn's guard is one compare
   // ground phase: the (up to 4) points of one body are consecutive lanes of one wave and take turns
   float res = 0.0f;
+  // A turn's guard is a SCALAR mask: a point's index in its manifold is its lane & 3 (four consecutive lanes per body / per slot), so
+  // turn i of a phase is (the phase's lanes) & 0x1111... << i — `s_and_b64` + `s_and_saveexec_b64` on a uniform value
+  // (inverse ballot).  As a vector compare per turn inside a rolled loop the guard and the loop's backward branch cost a lone wave
+  // ≈ 75 cycles a turn (microbenchmark: compare -> VCC -> exec 32 cycles, a taken branch ≈ 32): the turns are unrolled, a
+  // phase ends at its first empty turn (the points of a manifold are a prefix).
+  constexpr unsigned long long T0 = 0x1111111111111111ull;
   if (!GB) {     // the points of a body as turns of point lanes (round 1 - 4; kept for the variant that loses with body lanes)
-#pragma unroll 1
-    for (int i = 0; i < gturns; ++i) {
-      if (gslot == i) ground_turn<WARM>(L, gp, res);
+    const unsigned long long gm = __ballot(gslot >= 0);
+#pragma unroll
+    for (int i = 0; i < SRL_GMAXP; ++i) {
+      const unsigned long long t = gm & (T0 << i);
+      if (t == 0) break;
+      if (__builtin_amdgcn_inverse_ballot_w64(t)) ground_turn<WARM>(L, gp, res);
       __builtin_amdgcn_wave_barrier();
     }
   } else {
@@ -868,13 +877,18 @@ __device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, GBody& gb
 #pragma unroll 1
   for (int c = 0; c < ncol; ++c) {
     if (!SOLO) __syncthreads();
-    const unsigned long long ptp = ((unsigned long long)(unsigned)pturns_hi << 32) | (unsigned)pturns;
-    const int pt = c < 21 ? (int)((ptp >> (3 * c)) & 7ull) : 4;     // this colour's turns (packed by substep)
-#pragma unroll 1
-    for (int i = 0; i < pt; ++i) {
+    unsigned long long mc[PP];
+#pragma unroll
+    for (int r = 0; r < PP; ++r) mc[r] = __ballot((pslot[r] >> 2) == c);   // (pslot = -1: no point)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned long long any = 0;
+#pragma unroll
+      for (int r = 0; r < PP; ++r) any |= mc[r] & (T0 << i);
+      if (any == 0) break;
 #pragma unroll
       for (int r = 0; r < PP; ++r)
-        if (pslot[r] == 4 * c + i) point_turn<WARM>(L, pp[r], res);
+        if (__builtin_amdgcn_inverse_ballot_w64(mc[r] & (T0 << i))) point_turn<WARM>(L, pp[r], res);
       __builtin_amdgcn_wave_barrier();
     }
   }

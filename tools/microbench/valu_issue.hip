@@ -38,6 +38,19 @@ TIMED(k_lds_handoff, "ds_write_b128 %3, v[10:13]\n ds_write_b64 %3, v[14:15] off
 TIMED(k_lds_read, "ds_read_b128 v[10:13], %3\n s_waitcnt lgkmcnt(0)\n v_add_f32 v14, v10, v11")
 TIMED(k_dpp_mov12, "v_mov_b32_dpp v10, v20 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v11, v21 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v12, v22 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v13, v23 row_shr:1 row_mask:0xf bank_mask:0xf")
 
+// control flow: a taken backward branch per iteration, and the exec-mask guard of a turn
+__global__ void k_loop_branch(unsigned long long* out, float* sink) {
+  float a = threadIdx.x * 1e-3f, b = 1.0001f, c = 1e-7f;
+  unsigned long long t0, t1; int n = N;
+  asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+  asm volatile("1:\n v_fmac_f32 %2, %0, %1\n s_add_i32 %3, %3, -1\n s_cmp_eq_u32 %3, 0\n s_cbranch_scc0 1b" : "+v"(a), "+v"(b), "+v"(c), "+s"(n) :: "scc");
+  asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+  if (threadIdx.x == 0) out[0] = t1 - t0;
+  sink[threadIdx.x] = a + b + c;
+}
+TIMED(k_guard, "v_subrev_co_u32 %3, vcc, 1, %3\n s_and_saveexec_b64 s[20:21], vcc\n v_fmac_f32 %2, %0, %1\n s_or_b64 exec, exec, s[20:21]")
+TIMED(k_guard_branch, "v_subrev_co_u32 %3, vcc, 1, %3\n s_and_saveexec_b64 s[20:21], vcc\n s_cbranch_execz 2f\n v_fmac_f32 %2, %0, %1\n2:\n s_or_b64 exec, exec, s[20:21]")
+
 int main() {
   unsigned long long* out; float* sink;
   hipMalloc(&out, 8); hipMalloc(&sink, 4096);
@@ -47,7 +60,8 @@ int main() {
     {"v_mov_b32 dependent", k_mov_dep, 1}, {"v_mov_b32 independent", k_mov_ind, 4},
     {"v_fmac_f32_dpp quad_perm independent", k_fmac_dpp_ind, 4}, {"v_fmac_f32_dpp quad_perm dependent", k_fmac_dpp_dep, 1}, {"v_fmac_f32 dependent", k_fmac_dep, 1},
     {"one pair-row-like chain (10 instr)", k_mix_row, 10}, {"LDS hand-off: write b128+b64, read back, wait, add (6 instr)", k_lds_handoff, 6},
-    {"ds_read_b128 + wait + add (3 instr)", k_lds_read, 3}, {"v_mov_b32_dpp row_shr:1 independent", k_dpp_mov12, 4}};
+    {"ds_read_b128 + wait + add (3 instr)", k_lds_read, 3}, {"loop: fmac + s_add + s_cmp + taken branch (per iteration)", k_loop_branch, 1},
+    {"guard: v_subrev_co + s_and_saveexec + fmac + s_or exec (per group)", k_guard, 1}, {"guard with s_cbranch_execz (mostly taken) (per group)", k_guard_branch, 1}, {"v_mov_b32_dpp row_shr:1 independent", k_dpp_mov12, 4}};
   for (auto& e : ks) {
     unsigned long long best = ~0ull;
     for (int r = 0; r < 5; ++r) {
