@@ -835,9 +835,9 @@ __device__ __forceinline__ void point_turn(const Lds& L, Point& p, float& res) {
   *(float4*)pb = make_float4(u.b[0].x, u.b[0].y, u.b[1].x, u.b[1].y); *(float2*)(pb + 4) = make_float2(u.b[2].x, u.b[2].y);
 }
 
-// gturns / pturns: the turns this wave needs in a ground / colour phase = 1 + the highest point index any of its lanes
-// holds (a turn no lane takes still costs a lone wave its loop control: 8 + 4 ncol empty turns per sweep were a third
-// of the sub-step's instructions)
+// A wave runs only the turns it has points for (a turn no lane takes still costs a lone wave its control flow: 8 + 4 ncol empty
+// turns per sweep were a third of the sub-step's instructions in round 1; rounds 2 - 5 counted the turns per phase / per colour,
+// now a phase ends at its first empty mask).
 // A sweep ends with a block barrier; before it every wave that still holds a row whose squared residual exceeds the
 // threshold writes the sweep's number `gsweep` (counted over the whole launch, so a stale word never matches) into the
 // LDS word of the sweep's parity; after the barrier every thread reads that word: `true` = some row has not converged
@@ -849,11 +849,9 @@ __device__ __forceinline__ void point_turn(const Lds& L, Point& p, float& res) {
 // program order — the LDS serves one wave's accesses in order — without a single block barrier, and the residual is a
 // ballot.  The other waves skip the sweeps and wait at the barrier that ends the solve.
 template <bool WARM, int PP, bool SOLO, bool GB, bool GA>
-__device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, GBody& gb, Point (&pp)[PP], int ncol, int gturns, int pturns,
-                                             int gslot, const int (&pslot)[PP], int gsweep, int pturns_hi = 0) {
-  // gslot / pslot: the turn a lane's point takes (ground: its index; colour phases: 4 * colour + index; -1: none), so
-  // that a turn's guard is one compare
-  // ground phase: the (up to 4) points of one body are consecutive lanes of one wave and take turns
+__device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, GBody& gb, Point (&pp)[PP], int ncol, int gslot,
+                                             const int (&pslot)[PP], int gsweep) {
+  // gslot / pslot: the turn a lane's point takes (ground: its index; colour phases: 4 * colour + index; -1: none)
   float res = 0.0f;
   // A turn's guard is a SCALAR mask: a point's index in its manifold is its lane & 3 (four consecutive lanes per body / per slot), so
   // turn i of a phase is (the phase's lanes) & 0x1111... << i — `s_and_b64` + `s_and_saveexec_b64` on a uniform value
@@ -1057,38 +1055,6 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
 #else
     const bool solo = PP == 1 && misc[M_SOLO] != 0;   // (the variants with two points per thread are out of registers as it is)
 #endif
-    int gturns = 0, pturns = 0;   // wave-uniform
-#pragma unroll
-    for (int i = 0; i < SRL_GMAXP; ++i) if (__ballot(gp.valid && gp.idx == i)) gturns = i + 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      bool any = false;
-#pragma unroll
-      for (int r = 0; r < PP; ++r) any |= pp[r].valid && pp[r].idx == i;
-      if (__ballot(any)) pturns = i + 1;
-    }
-    // Turns PER COLOUR (round 5), packed 3 bits each: 1 + the highest point index among this wave's points of that colour — a colour
-    // whose manifolds hold fewer points than the wave's fullest takes fewer turns (an empty turn costs a lone wave its loop control:
-    // +1 % at the headline shape, +3 % at 1,024 x 16, +7 % at 4,096 x 16, where there are more colours; profiles/r05_colour_turns_ab.txt).
-    // SRL_UNIFORM_TURNS: the wave's maximum for every colour, as until round 4 (A / B).
-    unsigned long long ptpack = 0ull;
-#ifndef SRL_UNIFORM_TURNS
-    for (int c = 0; c < ncol && c < 21; ++c) {
-      int t = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bool any = false;
-#pragma unroll
-        for (int r = 0; r < PP; ++r) any |= pp[r].valid && pp[r].idx == i && pp[r].colour == c;
-        if (__ballot(any)) t = i + 1;
-      }
-      ptpack |= (unsigned long long)t << (3 * c);
-    }
-#else
-    for (int c = 0; c < 21; ++c) ptpack |= (unsigned long long)pturns << (3 * c);
-#endif
-    pturns = (int)(unsigned)(ptpack & 0xffffffffull);   // (the sweep takes the 64 bits through two ints)
-    const int pturns_hi = (int)(ptpack >> 32);
     const int gslot = gp.valid ? gp.idx : -1;
     int pslot[PP];
 #pragma unroll
@@ -1098,22 +1064,30 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
     if (solo) {
       int done = 0;
       if (tid < 64) {
-        solver_sweep<true, PP, PP == 1, GB, GA>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0, pturns_hi);
+        solver_sweep<true, PP, PP == 1, GB, GA>(L, gp, gb, pp, ncol, gslot, pslot, 0);
         for (int it = 0; it < P.c.solver_iterations; ++it) {
           done++;
-          if (!solver_sweep<false, PP, PP == 1, GB, GA>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0, pturns_hi)) break;
+          if (!solver_sweep<false, PP, PP == 1, GB, GA>(L, gp, gb, pp, ncol, gslot, pslot, 0)) break;
         }
         if (tid == 0) misc[M_CNT] = done;   // (M_CNT is free between the calls of newest_contacts)
       }
       __syncthreads();
       gsweep += misc[M_CNT];
     } else {
-      solver_sweep<true, PP, false, GB, GA>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, 0, pturns_hi);
+      solver_sweep<true, PP, false, GB, GA>(L, gp, gb, pp, ncol, gslot, pslot, 0);
       for (int it = 0; it < P.c.solver_iterations; ++it) {
         gsweep++;
-        if (!solver_sweep<false, PP, false, GB, GA>(L, gp, gb, pp, ncol, gturns, pturns, gslot, pslot, gsweep, pturns_hi)) break;
+        if (!solver_sweep<false, PP, false, GB, GA>(L, gp, gb, pp, ncol, gslot, pslot, gsweep)) break;
       }
     }
+#ifdef SRL_STAMPS
+    if (tid == 0) {
+      EnvHdr* hh = &L.P->hdr[blockIdx.x];
+      bool anyp = false;
+      for (int r = 0; r < PP; ++r) anyp |= pp[r].valid;
+      hh->diag[0] += 1; hh->diag[1] += (__ballot(anyp) == 0ull); hh->diag[2] += ncol; hh->diag[3] += solo ? misc[M_CNT] : 0;
+    }
+#endif
     // accumulated impulses back to the manifolds (warm start of the next sub-step)
     if (!GB) {
       if (gp.valid) { float* g = L.GM(gp.a); g[SRL_GM_IN + gp.idx] = gp.in; g[SRL_GM_T1 + gp.idx] = gp.i1; g[SRL_GM_T2 + gp.idx] = gp.i2; }
