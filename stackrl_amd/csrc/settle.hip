@@ -49,7 +49,11 @@ __device__ __forceinline__ void srl_jitter_sync() {
 #define __syncthreads() srl_jitter_sync()
 #endif
 
-#define SRL_GJK_GROUP 32
+// lanes per manifold slot in the narrow phase: 32 in the 128-thread variant of <= 8 rocks, 16 where there are more slots than groups
+// (round 5, same box: 1,024 x 16 +1.6 %, 4,096 x 16 +2 %, the headline shape indifferent; bit-identical either way)
+#ifndef SRL_GJK_GROUP
+#define SRL_GJK_GROUP(T, PP) ((T) == 128 && (PP) == 1 ? 32 : 16)
+#endif
 
 // Bodies (i < j) of pair id p = j (j - 1) / 2 + i, computed when the kernel fills its LDS table.  (Until round 3 this
 // was a pair of process-wide __constant__ tables that every srl_create rewrote: device state shared by all handles.)
@@ -394,8 +398,9 @@ __device__ __forceinline__ void sat_faces(const DevParams& P, int mesh_a, const 
   dist = best;
 }
 
-// 16 lanes per slot: GJK runs in lock step on all of them (support scans split), the first lane maintains
+// G lanes per slot (SRL_GJK_GROUP): GJK runs in lock step on all of them (support scans split), the first lane maintains
 // the manifold
+template <int G>
 __device__ __forceinline__ void narrowphase_slot(const Lds& L, int sl, int gl) {
   const DevParams& P = *L.P;
   int pid = L.POS()[sl];
@@ -419,13 +424,13 @@ __device__ __forceinline__ void narrowphase_slot(const Lds& L, int sl, int gl) {
   v3 pa, pb, n; float d;
   int cache[3];
   cache[0] = __float_as_int(mp[56]); cache[1] = __float_as_int(mp[57]); cache[2] = __float_as_int(mp[58]);
-  int rc = gjk_distance<SRL_GJK_GROUP>(L.WV(a), na, L.WV(b), nb, axis, cache, (mg + mg) + thr, pa, pb, n, d, gl);
+  int rc = gjk_distance<G>(L.WV(a), na, L.WV(b), nb, axis, cache, (mg + mg) + thr, pa, pb, n, d, gl);
 #ifdef SRL_STAMPS
   if (threadIdx.x == 0) { long long _n2 = wall_clock64(); EnvHdr* hh = &L.P->hdr[blockIdx.x]; hh->stamps2[0] += _n1 - _n0; hh->stamps2[1] += _n2 - _n1; hh->stamps2[3] += 1; }
   long long _n3 = wall_clock64();
 #endif
   if (rc == 2) {   // every lane of the group got the same rc: the face scan is shared
-    sat_faces<SRL_GJK_GROUP>(P, __float_as_int(bca[7]), L.WV(a), na, __float_as_int(bcb[7]), L.WV(b), nb, pa, pb, n, d, gl);
+    sat_faces<G>(P, __float_as_int(bca[7]), L.WV(a), na, __float_as_int(bcb[7]), L.WV(b), nb, pa, pb, n, d, gl);
     if (gl != 0) return;
     rc = 1;
   } else {
@@ -994,11 +999,12 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
   }
   const int ncol = misc[M_NCOL];
   STAMP(3);
-  // (5) narrowphase: 16 lanes per slot
+  // (5) narrowphase: G lanes per slot
   {
-    const int gl = tid & (SRL_GJK_GROUP - 1);
-    for (int sl = tid / SRL_GJK_GROUP; sl < P.NS; sl += T / SRL_GJK_GROUP)
-      if (L.POS()[sl] >= 0) narrowphase_slot(L, sl, gl);
+    constexpr int G = SRL_GJK_GROUP(T, PP);
+    const int gl = tid & (G - 1);
+    for (int sl = tid / G; sl < P.NS; sl += T / G)
+      if (L.POS()[sl] >= 0) narrowphase_slot<G>(L, sl, gl);
   }
   __syncthreads();
   STAMP(4);
