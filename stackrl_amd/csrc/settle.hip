@@ -855,7 +855,7 @@ __device__ __forceinline__ void point_turn(const Lds& L, Point& p, float& res) {
 // ballot.  The other waves skip the sweeps and wait at the barrier that ends the solve.
 template <bool WARM, int PP, bool SOLO, bool GB, bool GA>
 __device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, GBody& gb, Point (&pp)[PP], int ncol, int gslot,
-                                             const int (&pslot)[PP], int gsweep) {
+                                             const int (&pslot)[PP], int gsweep, const unsigned long long (&cm)[2]) {
   // gslot / pslot: the turn a lane's point takes (ground: its index; colour phases: 4 * colour + index; -1: none)
   float res = 0.0f;
   // A turn's guard is a SCALAR mask: a point's index in its manifold is its lane & 3 (four consecutive lanes per body / per slot), so
@@ -877,8 +877,25 @@ __device__ __forceinline__ bool solver_sweep(const Lds& L, GPoint& gp, GBody& gb
     if (gb.np > 0) ground_body<WARM, !WARM && GA>(L, gb, res);
     __builtin_amdgcn_wave_barrier();
   }
+  int c0 = 0;
+#ifndef SRL_NO_COLOUR_MASKS
+  if (SOLO && PP == 1) {   // the first two colours from masks made once per sub-step, straight-line (no ballot, no loop branch per colour)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c >= ncol) break;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned long long t = cm[c] & (T0 << i);
+        if (t == 0) break;
+        if (__builtin_amdgcn_inverse_ballot_w64(t)) point_turn<WARM>(L, pp[0], res);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    c0 = 2;
+  }
+#endif
 #pragma unroll 1
-  for (int c = 0; c < ncol; ++c) {
+  for (int c = c0; c < ncol; ++c) {
     if (!SOLO) __syncthreads();
     unsigned long long mc[PP];
 #pragma unroll
@@ -1062,6 +1079,9 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
     const bool solo = PP == 1 && misc[M_SOLO] != 0;   // (the variants with two points per thread are out of registers as it is)
 #endif
     const int gslot = gp.valid ? gp.idx : -1;
+    // the lanes of the first two colours (solo sweeps: solver_sweep)
+    unsigned long long cm[2];
+    cm[0] = __ballot(pp[0].valid && pp[0].colour == 0); cm[1] = __ballot(pp[0].valid && pp[0].colour == 1);
     int pslot[PP];
 #pragma unroll
     for (int r = 0; r < PP; ++r) pslot[r] = pp[r].valid ? 4 * pp[r].colour + pp[r].idx : -1;
@@ -1070,20 +1090,20 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
     if (solo) {
       int done = 0;
       if (tid < 64) {
-        solver_sweep<true, PP, PP == 1, GB, GA>(L, gp, gb, pp, ncol, gslot, pslot, 0);
+        solver_sweep<true, PP, PP == 1, GB, GA>(L, gp, gb, pp, ncol, gslot, pslot, 0, cm);
         for (int it = 0; it < P.c.solver_iterations; ++it) {
           done++;
-          if (!solver_sweep<false, PP, PP == 1, GB, GA>(L, gp, gb, pp, ncol, gslot, pslot, 0)) break;
+          if (!solver_sweep<false, PP, PP == 1, GB, GA>(L, gp, gb, pp, ncol, gslot, pslot, 0, cm)) break;
         }
         if (tid == 0) misc[M_CNT] = done;   // (M_CNT is free between the calls of newest_contacts)
       }
       __syncthreads();
       gsweep += misc[M_CNT];
     } else {
-      solver_sweep<true, PP, false, GB, GA>(L, gp, gb, pp, ncol, gslot, pslot, 0);
+      solver_sweep<true, PP, false, GB, GA>(L, gp, gb, pp, ncol, gslot, pslot, 0, cm);
       for (int it = 0; it < P.c.solver_iterations; ++it) {
         gsweep++;
-        if (!solver_sweep<false, PP, false, GB, GA>(L, gp, gb, pp, ncol, gslot, pslot, gsweep)) break;
+        if (!solver_sweep<false, PP, false, GB, GA>(L, gp, gb, pp, ncol, gslot, pslot, gsweep, cm)) break;
       }
     }
 #ifdef SRL_STAMPS
