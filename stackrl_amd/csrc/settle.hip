@@ -1111,6 +1111,26 @@ __device__ __forceinline__ void substep(const Lds& L, int nb, int tid, int& gswe
       EnvHdr* hh = &L.P->hdr[blockIdx.x];
       bool anyp = false;
       for (int r = 0; r < PP; ++r) anyp |= pp[r].valid;
+      {   // pair turns of a sweep as scheduled (sum over colours of the fullest manifold) and as the longest dependency chain
+        int bl[SRL_MAX_BODIES]; for (int b = 0; b < SRL_MAX_BODIES; ++b) bl[b] = 0;
+        int lmax = 0, sumt = 0;
+        for (int c = 0; c < ncol; ++c) {
+          int mx = 0;
+          for (int sl = 0; sl < P.NS; ++sl) {
+            const int pid = L.POS()[sl];
+            if (pid < 0 || L.COL()[sl] != c) continue;
+            const int np = __float_as_int(L.MAN(sl)[0]);
+            if (np <= 0) continue;
+            int a, b; L.pair(pid, a, b);
+            const int st = bl[a] > bl[b] ? bl[a] : bl[b];
+            bl[a] = st + np; bl[b] = st + np;
+            if (st + np > lmax) lmax = st + np;
+            if (np > mx) mx = np;
+          }
+          sumt += mx;
+        }
+        hh->diag[4] += sumt; hh->diag[5] += lmax;
+      }
       hh->diag[0] += 1; hh->diag[1] += (__ballot(anyp) == 0ull); hh->diag[2] += ncol; hh->diag[3] += solo ? misc[M_CNT] : 0;
     }
 #endif

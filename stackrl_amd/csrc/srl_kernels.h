@@ -36,7 +36,7 @@ struct EnvHdr {
   long long stamps[8];          // diagnostic build only: accumulated wall-clock ticks per sub-step phase
   long long stamps2[4];         // narrowphase of slot 0: refresh, gjk, insert ticks, calls
   long long rstamps[8];         // render kernel phases
-  long long diag[4];            // sub-steps with a solve, of those without a pair point, colours summed, sweeps summed (tools/stamps.py)
+  long long diag[6];            // sub-steps with a solve, of those without a pair point, colours summed, sweeps summed, pair turns per sweep summed, and what a level schedule of the same rows would need (tools/stamps.py)
   long long hwid[2];            // HW_ID | XCC_ID << 32 of the settle workgroup's two first waves (tools/diag_placement.py)
 #endif
 };

@@ -788,12 +788,12 @@ int srl_debug_hwid(srl_env* env, long long* out) {   // [n][2]
   for (int i = 0; i < n; ++i) { out[2 * i] = h[i].hwid[0]; out[2 * i + 1] = h[i].hwid[1]; }
   return SRL_OK;
 }
-int srl_debug_diag(srl_env* env, long long* out) {   // [n][4]
+int srl_debug_diag(srl_env* env, long long* out) {   // [n][6]
   const int n = env->P.c.n_envs;
   HIP_TRY(hipDeviceSynchronize());
   std::vector<EnvHdr> h((size_t)n);
   HIP_TRY(hipMemcpy(h.data(), env->P.hdr, sizeof(EnvHdr) * (size_t)n, hipMemcpyDeviceToHost));
-  for (int i = 0; i < n; ++i) for (int k = 0; k < 4; ++k) out[4 * i + k] = h[i].diag[k];
+  for (int i = 0; i < n; ++i) for (int k = 0; k < 6; ++k) out[6 * i + k] = h[i].diag[k];
   return SRL_OK;
 }
 int srl_debug_rstamps(srl_env* env, long long* out, int reset) {

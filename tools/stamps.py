@@ -36,11 +36,11 @@ print('  total %.1f us; slowest env: %d sub-steps, %.2f ms' % (per.sum() / 1e3, 
 print('  slot-0 narrowphase per call: refresh %.0f ns, gjk %.0f ns, insert %.0f ns (%d calls, %.2f per sub-step)' % (10 * np2[0] / np2[3], 10 * np2[1] / np2[3], 10 * np2[2] / np2[3], np2[3], np2[3] / tot_sub.sum()))
 
 # per launch: is the slowest env's solve mostly ground phase?  (diag counters of the stamps build, cumulative over the L steps)
-dg = np.zeros((n, 4), np.int64)
+dg = np.zeros((n, 6), np.int64)
 lib.load().srl_debug_diag.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.load().srl_debug_diag(g._h, dg.ctypes.data_as(ctypes.c_void_p))
 order = np.argsort(-tot_sub)[:8]
 print('the eight envs with the most sub-steps: sub-steps, of those without a pair point in wave 0, mean colours, mean solo sweeps per sub-step')
 for i in order:
-  print('  env %4d: %5d sub-steps, %5.1f %% without pair points, %.2f colours, %.1f sweeps' % (i, dg[i, 0], 100.0 * dg[i, 1] / max(dg[i, 0], 1), dg[i, 2] / max(dg[i, 0], 1), dg[i, 3] / max(dg[i, 0], 1)))
-print('all envs: %.1f %% of sub-steps without pair points, %.2f colours, %.1f sweeps' % (100.0 * dg[:, 1].sum() / dg[:, 0].sum(), dg[:, 2].sum() / dg[:, 0].sum(), dg[:, 3].sum() / dg[:, 0].sum()))
+  print('  env %4d: %5d sub-steps, %5.1f %% without pair points, %.2f colours, %.1f sweeps, pair turns per sweep %.2f as scheduled / %.2f as the longest chain' % (i, dg[i, 0], 100.0 * dg[i, 1] / max(dg[i, 0], 1), dg[i, 2] / max(dg[i, 0], 1), dg[i, 3] / max(dg[i, 0], 1), dg[i, 4] / max(dg[i, 0], 1), dg[i, 5] / max(dg[i, 0], 1)))
+print('all envs: %.1f %% of sub-steps without pair points, %.2f colours, %.1f sweeps, pair turns per sweep %.2f / %.2f' % (100.0 * dg[:, 1].sum() / dg[:, 0].sum(), dg[:, 2].sum() / dg[:, 0].sum(), dg[:, 3].sum() / dg[:, 0].sum(), dg[:, 4].sum() / dg[:, 0].sum(), dg[:, 5].sum() / dg[:, 0].sum()))
